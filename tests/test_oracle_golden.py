@@ -1,0 +1,204 @@
+"""
+Pins oracle/mtm_oracle.py against (a) the hit lists printed by the reference's executed notebooks
+(real OpenCV 4.7.0) and (b) the outputs of the unmodified reference run in the build container
+with real skimage/scipy peak finders (tests/golden/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+
+import mtm_oracle as O
+import synth
+from helpers import (GOLDEN_DIR, assert_hits_equal, canon, coin_templates, hits_json, load_coins,
+                     load_golden)
+
+G = load_golden()
+REF = G["reference_run"]
+
+
+@pytest.fixture(scope="module")
+def coins():
+    return load_coins()
+
+
+def otsu_mask(small):
+    return ((small > G["otsu_threshold"]) * 255).astype(np.uint8)
+
+
+def test_notebook_G1_ccoeff_normed(coins):
+    small, _ = coin_templates(coins)
+    hits = O.match_templates([("small", small)], coins, method=5, score_threshold=0.5, maxOverlap=0)
+    # real cv2 is a float32-DFT away from exact arithmetic: 3.2e-6 observed, 1e-4 allowed
+    assert_hits_equal(hits, G["notebook_G1"]["hits"], tol=1e-4)
+
+
+def test_notebook_G2_ccorr_normed(coins):
+    small, _ = coin_templates(coins)
+    hits = O.match_templates([("testMask", small)], coins, method=3, score_threshold=0.8, maxOverlap=0)
+    assert_hits_equal(hits, G["notebook_G2"]["hits"], tol=1e-4)
+
+
+def test_notebook_G3_masked(coins):
+    small, _ = coin_templates(coins)
+    mask = otsu_mask(small)
+    assert int((mask > 0).sum()) == G["otsu_mask_count"] == 1082
+    hits = O.match_templates([("testMask", small, mask)], coins, method=3, score_threshold=0.8, maxOverlap=0)
+    assert_hits_equal(hits, G["notebook_G3"]["hits"], tol=1e-4)
+
+
+CALLS = {
+    "G1": lambda im, s, b: ([("small", s)], dict(score_threshold=0.5, method=5, maxOverlap=0)),
+    "testpy": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, maxOverlap=0)),
+    "tut1_two": lambda im, s, b: ([("small", s), ("large", b)], dict(score_threshold=0.4, method=5, maxOverlap=0)),
+    "sqdiff_normed": lambda im, s, b: ([("small", s), ("big", b)], dict(method=1, score_threshold=0.2, maxOverlap=0)),
+    "overlap025": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, maxOverlap=0.25)),
+    "nobj3": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, maxOverlap=0.25, N_object=3)),
+    "nobj1": lambda im, s, b: ([("small", s)], dict(method=5, N_object=1)),
+    "nobj1_sqdiff": lambda im, s, b: ([("big", b)], dict(method=1, N_object=1)),
+    "nobj0": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, N_object=0)),
+    "searchbox_exact": lambda im, s, b: ([("big", b)], dict(searchBox=(302, 14) + b.shape[::-1])),
+    "searchbox": lambda im, s, b: ([("small", s)], dict(score_threshold=0.5, maxOverlap=0, searchBox=(10, 20, 300, 200))),
+    "full_image": lambda im, s, b: ([("all", im)], dict()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CALLS))
+def test_reference_run_match_templates(coins, name):
+    small, big = coin_templates(coins)
+    templates, kw = CALLS[name](coins, small, big)
+    hits = O.match_templates(templates, coins, **kw)
+    # same arithmetic on both sides (the reference ran on this oracle's cv2 stand-in): what is
+    # being pinned here is peak finding (real skimage/scipy) and the NMS / orchestration logic.
+    if len(templates) > 1:
+        # equal scores from different templates: the reference's order is thread completion order
+        sc = [h[2] for h in hits]
+        assert all(a >= b for a, b in zip(sc, sc[1:])) or kw.get("method") == 1
+        assert_hits_equal(canon(hits), canon([(h[0], tuple(h[1]), h[2]) for h in REF[name]]), tol=1e-6)
+    else:
+        assert_hits_equal(hits, REF[name], tol=1e-6)
+
+
+def test_reference_run_1d_maps(coins):
+    tall = coins[:, 100:141]
+    wide = coins[50:90, :]
+    assert_hits_equal(canon(O.find_matches([("tall", tall)], coins, score_threshold=0.5)), REF["tall"], tol=1e-6)
+    assert_hits_equal(canon(O.find_matches([("wide", wide)], coins, score_threshold=0.5)), REF["wide"], tol=1e-6)
+
+
+def test_reference_run_uint16_float32(coins):
+    img16 = coins.astype(np.uint16) * 257
+    hits = O.match_templates([("small", img16[37:75, 80:121])], img16, score_threshold=0.5, method=5, maxOverlap=0)
+    assert_hits_equal(hits, REF["uint16"], tol=1e-6)
+    imgf = coins.astype(np.float32) / 255.0
+    hits = O.match_templates([("small", imgf[37:75, 80:121])], imgf, method=3, score_threshold=0.95, maxOverlap=0.1)
+    assert_hits_equal(hits, REF["float32_m3"], tol=1e-6)
+
+
+def test_reference_run_pre_nms_and_rgb(coins):
+    small, big = coin_templates(coins)
+    pre = O.find_matches([("small", small), ("big", big)], coins, score_threshold=0.3)
+    assert_hits_equal(canon(pre), REF["find_pre_nms"], tol=1e-6)
+    rgb = np.stack([coins, np.roll(coins, 3, axis=1), 255 - coins], axis=2)
+    hits = O.match_templates([("small", np.ascontiguousarray(rgb[37:75, 80:121]))], rgb, score_threshold=0.5, method=5, maxOverlap=0)
+    assert_hits_equal(hits, REF["rgb"], tol=1e-6)
+
+
+def test_nms_demo():
+    demo = [("1", (780, 350, 700, 480), 0.8), ("1", (806, 416, 716, 442), 0.6), ("1", (1074, 530, 680, 390), 0.4)]
+    out = O.NMS(demo, scoreThreshold=0.3, sortAscending=False, maxOverlap=0.5, N_object=2)
+    assert hits_json(out) == REF["nms_demo"]
+    assert [h[1] for h in out] == [demo[0][1], demo[2][1]]
+
+
+def test_score_map_fixtures(coins):
+    small, big = coin_templates(coins)
+    mask = otsu_mask(small)
+    rgb = np.stack([coins, np.roll(coins, 3, axis=1), 255 - coins], axis=2)
+    img16 = coins.astype(np.uint16) * 257
+    sub = np.load(GOLDEN_DIR + "/coins_maps_sub3.npz")
+    cases = {"small_m0_mask": (small, coins, 0, mask), "small_m3_mask": (small, coins, 3, mask),
+             "small_m0": (small, coins, 0, None),
+             "rgb_m5": (np.ascontiguousarray(rgb[37:75, 80:121]), rgb, 5, None),
+             "u16_m5": (img16[37:75, 80:121], img16, 5, None)}
+    for name, t in (("small", small), ("big", big)):
+        for m in (1, 2, 3, 4, 5):
+            cases["%s_m%d" % (name, m)] = (t, coins, m, None)
+    for key, (t, im, m, msk) in cases.items():
+        got = O.compute_score_map(t, im, m, mask=msk)
+        exp = sub[key]
+        np.testing.assert_allclose(got[::3, ::3], exp, rtol=1e-6, atol=1e-6, err_msg=key)
+        ck = G["map_checksums"][key]
+        assert list(got.shape) == ck["shape"]
+        assert abs(float(got.astype(np.float64).sum()) - ck["sum"]) <= 1e-6 * max(1.0, ck["abs_sum"])
+
+
+@pytest.mark.parametrize("name", sorted(G["synthetic"]))
+def test_synthetic_reference_runs(name):
+    case = G["synthetic"][name]
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case["kwargs"].items()}
+    img, units, plants = synth.make_workload(**kw)
+    assert int(img.astype(np.int64).sum()) == case["image_sum"]      # generator is reproducible
+    assert [[p[0], list(p[1]), p[2]] for p in plants] == case["plants"]
+    pre = O.find_matches(units, img, method=case["method"], score_threshold=case["score_threshold"])
+    assert_hits_equal(canon(pre), case["pre_nms"], tol=1e-6)
+    post = O.match_templates(units, img, method=case["method"], score_threshold=case["score_threshold"], maxOverlap=0.25)
+    assert_hits_equal(canon(post), case["post_nms"], tol=1e-6)
+    if not kw.get("masked"):
+        # every plant is recovered at its exact location
+        found = {(h[0], tuple(h[1])) for h in hits_json(post)}
+        assert {(p[0], tuple(p[1])) for p in plants} <= found
+
+
+def test_direct_and_fft_correlation_agree():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (90, 120), dtype=np.uint8)
+    t = img[10:42, 30:70].copy()
+    for m in range(6):
+        a = O.match_template(img, t, m, corr="direct")
+        b = O.match_template(img, t, m, corr="fft")
+        assert np.array_equal(a, b), m      # uint8: both paths are exact integers -> bit-identical
+    mask = (rng.integers(0, 2, t.shape) * 255).astype(np.uint8)
+    for m in (0, 3):
+        assert np.array_equal(O.match_template(img, t, m, mask=mask, corr="direct"),
+                              O.match_template(img, t, m, mask=mask, corr="fft"))
+    f = rng.random((60, 70)).astype(np.float32)
+    tf = f[5:25, 7:33].copy()
+    for m in range(6):
+        np.testing.assert_allclose(O.match_template(f, tf, m, corr="direct"), O.match_template(f, tf, m, corr="fft"),
+                                   rtol=1e-5, atol=1e-5)
+
+
+def test_guards_flat_and_constant():
+    img = np.full((40, 50), 7, dtype=np.uint8)
+    img[20:, :] = 9
+    t = np.full((8, 8), 7, dtype=np.uint8)
+    # constant template: CCOEFF_NORMED map is all ones (templNorm < DBL_EPSILON)
+    assert np.all(O.match_template(img, t, 5) == 1.0)
+    t2 = img[16:24, 10:18].copy()
+    m5 = O.match_template(img, t2, 5)
+    assert np.all(m5[:8] == 0.0)        # flat windows: t = 0 -> 0
+    assert m5[16, 10] == pytest.approx(1.0, abs=1e-6)
+    m1 = O.match_template(img, t2, 1)
+    assert m1[16, 10] == 0.0
+
+
+def test_min_max_loc_first_occurrence():
+    a = np.array([[1, 5, 5], [0, 0, 5]], dtype=np.float32)
+    assert O.min_max_loc(a) == (0.0, 5.0, (0, 1), (1, 0))
+
+
+def test_find_peaks_1d_semantics():
+    assert O.find_peaks_1d(np.array([0, 1, 0, 2, 2, 2, 0, 3], dtype=np.float32), 0.5) == [1, 4]
+    assert O.find_peaks_1d(np.array([3, 1, 0], dtype=np.float32), 0.0) == []
+    assert O.find_peaks_1d(np.array([0, 1, 1, 0], dtype=np.float32), 1.0) == [1]
+
+
+def test_peak_plateau_and_trivial():
+    a = np.zeros((6, 6), np.float32)
+    assert O.peak_local_max_2d(a + 1, 0.5) == []            # every pixel equals its local max
+    a[2, 2] = a[2, 3] = 0.9
+    assert sorted(O.peak_local_max_2d(a, 0.5)) == [[2, 2], [2, 3]]   # all plateau pixels returned
+    assert O.peak_local_max_2d(a, 0.9) == []                # strict >
+    b = -np.ones((5, 5), np.float32)
+    b[0, 0] = -0.1
+    assert O.peak_local_max_2d(b, -0.5, "constant") == []   # skimage<=0.18: zero padding wins at the border
+    assert O.peak_local_max_2d(b, -0.5, "nearest") == [[0, 0]]
