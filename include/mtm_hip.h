@@ -1,0 +1,166 @@
+/*
+ * mtm_hip.h - C ABI of libmtm_hip.so, the MI355X (gfx950) implementation of the
+ * Multi-Template-Matching hot path.
+ *
+ * The reference (multi-template-matching/MultiTemplateMatching-Python) has no FFI of its own: it
+ * is pure Python calling OpenCV / scikit-image / scipy.  The boundary this library sits behind is
+ * therefore the set of third-party calls on the reference's hot path; each entry point below
+ * names the reference call site(s) it replaces (file:line in the reference tree).  The Python
+ * host layer (multitemplatematching-python_amd/MTM) binds these with ctypes and re-exposes the
+ * reference's module-level API unchanged; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative MTM_E_* code;
+ *     mtm_last_error() returns a thread-local message for the last failure on this thread.
+ *   - the caller owns every host buffer for the duration of a call; the library owns all device
+ *     memory, freed in mtm_ctx_destroy().
+ *   - images are row-major, (rows, cols) or (rows, cols, chans) interleaved, with an explicit row
+ *     stride in bytes (numpy views with contiguous pixels are passed without a copy).
+ *   - a context is bound to one GPU and is single-caller (not re-entrant); calls block until
+ *     their results are on the host unless documented otherwise.
+ */
+#ifndef MTM_HIP_H
+#define MTM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTM_ABI_VERSION 1
+
+/* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
+#define MTM_U8  0
+#define MTM_F32 1
+
+/* OpenCV's TemplateMatchModes values, used as raw ints by the reference
+ * (MTM/__init__.py:56,95,247 defaults; :78,:216,:227,:232 comparisons) */
+#define MTM_TM_SQDIFF        0
+#define MTM_TM_SQDIFF_NORMED 1
+#define MTM_TM_CCORR         2
+#define MTM_TM_CCORR_NORMED  3
+#define MTM_TM_CCOEFF        4
+#define MTM_TM_CCOEFF_NORMED 5
+
+/* peak extraction mode */
+#define MTM_PEAKS_LOCAL  0   /* MTM/__init__.py:231-235: local maxima (methods 2-5) / minima (0,1) */
+#define MTM_PEAKS_GLOBAL 1   /* MTM/__init__.py:225-230: N_object == 1, cv2.minMaxLoc              */
+
+/* 3x3 maximum-filter border rule of skimage.feature.peak_local_max */
+#define MTM_BORDER_CONSTANT 0  /* skimage <= 0.18: pad with 0 */
+#define MTM_BORDER_NEAREST  1  /* newer skimage: replicate the edge */
+
+/* kernel selection for the uint8 score-map path (mtm_set_option MTM_OPT_KERNEL) */
+#define MTM_KERNEL_AUTO  0
+#define MTM_KERNEL_NAIVE 1   /* one thread per output pixel, scalar loop: the in-library cross-check */
+#define MTM_KERNEL_DOT4  2   /* LDS-tiled sliding window on v_dot4_u32_u8 */
+#define MTM_KERNEL_MFMA  3   /* implicit-GEMM sliding window on v_mfma_i32_32x32x32_i8 */
+
+#define MTM_OPT_KERNEL      1
+#define MTM_OPT_PEAK_BORDER 2
+#define MTM_OPT_HIT_CAPACITY 3
+#define MTM_OPT_DOT4_VARIANT 4  /* register-blocking variant of the dot4 kernel (tuning) */
+
+/* error codes */
+#define MTM_OK            0
+#define MTM_E_INVALID    -1  /* bad argument */
+#define MTM_E_HIP        -2  /* a HIP runtime call failed (message has the hipError string) */
+#define MTM_E_NO_DEVICE  -3  /* no usable GPU */
+#define MTM_E_STATE      -4  /* call order: image / templates not set */
+#define MTM_E_OVERFLOW   -5  /* output buffer too small; *n_out holds the required capacity */
+#define MTM_E_COMM       -6  /* RCCL failure */
+
+typedef struct mtm_ctx mtm_ctx;
+
+/* One template ("unit": a template, or a rotation/scale variant the caller appended to
+ * listTemplates).  mask == NULL for no mask; a mask has the template's shape and dtype
+ * (the policy of MTM/__init__.py:76-88 is applied by the host layer before this call). */
+typedef struct mtm_templ {
+    const void* px;
+    const void* mask;
+    int32_t rows, cols, chans, dtype;
+    int64_t row_stride;       /* bytes */
+    int64_t mask_row_stride;  /* bytes */
+} mtm_templ;
+
+/* One detection: the record MTM builds at MTM/__init__.py:241 (label replaced by the template's
+ * index in the list).  24 bytes; also the record exchanged between ranks. */
+typedef struct mtm_hit {
+    int32_t templ_idx;
+    int32_t x, y, w, h;
+    float   score;
+} mtm_hit;
+
+/* timing of the last mtm_find_matches call, measured with HIP events on the context's stream */
+typedef struct mtm_timing {
+    float total_ms;      /* first kernel launch -> last kernel done                      */
+    float score_ms;      /* window statistics + score-map kernels                        */
+    float peaks_ms;      /* peak-extraction kernels                                      */
+    float ncc_kernel_ms; /* the dominant score-map kernel(s) alone                        */
+    int32_t ncc_launches;
+    int32_t kernel_used; /* MTM_KERNEL_* actually dispatched for the uint8 path           */
+    int64_t n_hits;
+} mtm_timing;
+
+/* ---- device / context ------------------------------------------------------------------- */
+int         mtm_abi_version(void);
+int         mtm_device_count(void);                 /* 0 when no GPU is visible */
+const char* mtm_last_error(void);
+int         mtm_ctx_create(mtm_ctx** out, int device_id);
+void        mtm_ctx_destroy(mtm_ctx* ctx);
+int         mtm_set_option(mtm_ctx* ctx, int option, int64_t value);
+
+/* ---- inputs ------------------------------------------------------------------------------ */
+/* Upload the search image (already cropped to searchBox by the host layer, MTM/__init__.py:140-144)
+ * and build its integral images.  Replaces the per-template image handling inside
+ * cv2.matchTemplate (MTM/__init__.py:92). */
+int mtm_set_image(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
+                  int64_t row_stride_bytes);
+
+/* Upload all templates of one matchTemplates/findMatches call and fix the method.  Template
+ * statistics (cv::meanStdDev) are computed here.  Replaces the per-template arguments of
+ * cv2.matchTemplate (MTM/__init__.py:92). */
+int mtm_set_templates(mtm_ctx* ctx, const mtm_templ* templs, int n_templ, int method);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* cv2.matchTemplate(image, template, method, mask) for template `templ_idx`
+ * (MTM/__init__.py:92, via computeScoreMap :56-92): float32 (rows-h+1, cols-w+1) to host memory. */
+int mtm_score_map(mtm_ctx* ctx, int templ_idx, float* out, int64_t out_row_stride_bytes);
+
+/* The per-template pipeline of _multi_compute (MTM/__init__.py:222-241) for every template set by
+ * mtm_set_templates, batched: score maps, then either local extrema above/below `score_threshold`
+ * (skimage peak_local_max / scipy find_peaks semantics, :22-53) or the global extremum
+ * (cv2.minMaxLoc, :226).  Hits come back ordered by template index, then descending quality, then
+ * row-major position; coordinates are relative to the uploaded image.  The threshold is the
+ * python float of the reference call; it is narrowed to float32 for the comparison with the
+ * float32 map exactly as numpy does.  On MTM_E_OVERFLOW *n_out is the capacity needed. */
+int mtm_find_matches(mtm_ctx* ctx, int mode, double score_threshold,
+                     mtm_hit* out, int64_t capacity, int64_t* n_out);
+
+int mtm_get_timing(mtm_ctx* ctx, mtm_timing* out);
+
+/* cv2.dnn.NMSBoxes as MTM.NMS uses it (MTM/NMS.py:73-82): keep hits with score > threshold
+ * (float32, strict), stable sort by descending score, greedy IoU suppression with
+ * overlap <= max_overlap, optional truncation to n_object (-1 = no limit).  `ascending` applies
+ * the 1-score transform of MTM/NMS.py:73-75.  Host code (C++), no GPU needed.
+ * keep[] receives indices into hits[]; capacity of keep must be >= n. */
+int mtm_nms(const mtm_hit* hits, int64_t n, double score_threshold, int ascending,
+            int64_t n_object, double max_overlap, int32_t* keep, int64_t* n_keep);
+
+/* ---- multi-GPU: one process per GPU, templates sharded across ranks (north_star) ------------ */
+/* RCCL all-gather of per-rank hit lists over xGMI.  The 128-byte unique id is created on rank 0
+ * and distributed by the caller's bootstrap (torch.distributed store, MPI, a file...). */
+#define MTM_COMM_ID_BYTES 128
+int mtm_comm_unique_id(void* id_out /* MTM_COMM_ID_BYTES */);
+int mtm_comm_init(mtm_ctx* ctx, const void* id, int n_ranks, int rank);
+/* all-gather: every rank contributes n_local hits; out receives the concatenation in rank order.
+ * counts_out[n_ranks] receives the per-rank counts.  Collective call. */
+int mtm_comm_allgather_hits(mtm_ctx* ctx, const mtm_hit* local, int64_t n_local,
+                            mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out);
+int mtm_comm_destroy(mtm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTM_HIP_H */

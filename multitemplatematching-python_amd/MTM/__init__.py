@@ -1,0 +1,268 @@
+"""
+Multi-Template-Matching on MI355X: drop-in for the reference package's module-level API.
+
+Same functions, arguments, defaults, exceptions and warnings as the reference
+(``MTM/__init__.py:56`` computeScoreMap, ``:95`` findMatches, ``:247`` matchTemplates,
+``MTM/NMS.py:20`` NMS), but the arithmetic - cv2.matchTemplate, skimage peak_local_max / scipy
+find_peaks, cv2.minMaxLoc, cv2.dnn.NMSBoxes - runs in libmtm_hip.so (hand-written HIP kernels
+for gfx950 behind the C ABI of include/mtm_hip.h, bound with ctypes).  All templates of a call
+are batched into a few launches instead of one thread-pool task per template
+(reference ``MTM/__init__.py:172-175``).
+
+No OpenCV, scikit-image, scipy or PyTorch on this path, and no CPU fallback: a missing library or
+GPU raises.
+"""
+import warnings
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .NMS import NMS, Hit
+from .version import __version__
+
+__all__ = ["NMS", "Hit", "matchTemplates", "findMatches", "computeScoreMap", "drawBoxesOnRGB",
+           "drawBoxesOnGray", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
+           "TM_CCOEFF", "TM_CCOEFF_NORMED", "__version__"]
+
+# OpenCV's TemplateMatchModes values: the reference takes them from cv2 (defaults at
+# MTM/__init__.py:56, :95, :247); the drop-in defines them itself.
+TM_SQDIFF, TM_SQDIFF_NORMED, TM_CCORR, TM_CCORR_NORMED, TM_CCOEFF, TM_CCOEFF_NORMED = range(6)
+
+BBox = Tuple[int, int, int, int]            # (x, y, width, height), x,y = top left corner
+TemplateTuple = Tuple[str, np.ndarray, Optional[np.ndarray]]
+
+_MSG_MASK_METHOD = ("Template matching method not compatible with use of mask (only 0/TM_SQDIFF or "
+                    "3/TM_CCORR_NORMED).\n-> Ignoring mask.")
+_MSG_MASK_SHAPE = "Mask does not have the same dimension or bit depth than the template.\n-> Ignoring mask."
+_MSG_MASK_UNSUPPORTED = ("Template matching method not supporting the use of Mask. "
+                         "Use 0/TM_SQDIFF or 3/TM_CCORR_NORMED.")
+
+
+def _apply_pixel_policy(template, image, method, mask):
+    """dtype and mask policy of the reference's computeScoreMap (MTM/__init__.py:67-88).
+    Returns (template, image, mask) ready for the library."""
+    if template.dtype == "float64" or image.dtype == "float64":
+        raise ValueError("64-bit images not supported, max 32-bit")
+
+    # only 8-bit/8-bit stays 8-bit; every other combination is matched in float32
+    if not (template.dtype == "uint8" and image.dtype == "uint8"):
+        template = np.float32(template)
+        image = np.float32(image)
+        if mask is not None:
+            mask = np.float32(mask)
+
+    if mask is not None:
+        if method not in (0, 3):
+            mask = None
+            warnings.warn(_MSG_MASK_METHOD)
+        elif not (mask.shape == template.shape and mask.dtype == template.dtype):
+            mask = None
+            warnings.warn(_MSG_MASK_SHAPE)
+    return template, image, mask
+
+
+def _check_opencv_preconditions(template, image):
+    """What cv2.matchTemplate itself would reject (cv2.error in the reference)."""
+    if template.ndim not in (2, 3) or image.ndim not in (2, 3):
+        raise ValueError("image and template must be 2-D (grayscale) or 3-D (rows, cols, channels) arrays")
+    tc = 1 if template.ndim == 2 else template.shape[2]
+    ic = 1 if image.ndim == 2 else image.shape[2]
+    if tc != ic:
+        raise ValueError("image and template must have the same number of channels")
+    if ic > 4:
+        raise ValueError("at most 4 channels are supported")
+    if template.shape[0] > image.shape[0] or template.shape[1] > image.shape[1]:
+        raise ValueError("template is larger than the image")
+
+
+def computeScoreMap(template: np.ndarray, image: np.ndarray, method: int = TM_CCOEFF_NORMED, mask=None):
+    """
+    Score map of one template over an image (reference MTM/__init__.py:56-92).
+
+    The template must not be larger than the image.  A mask of the template's shape and dtype
+    restricts the comparison to part of the template (methods 0/TM_SQDIFF and 3/TM_CCORR_NORMED
+    only).  Anything that is not uint8/uint8 is matched in float32; float64 raises.
+
+    Returns a float32 array of shape (H - h + 1, W - w + 1).
+    """
+    template, image, mask = _apply_pixel_policy(template, image, method, mask)
+    _check_opencv_preconditions(template, image)
+    ctx = _lib.default_context()
+    with ctx.lock:
+        ctx.set_image(image)
+        ctx.set_templates([(template, mask)], method)
+        return ctx.score_map(0, (image.shape[0] - template.shape[0] + 1, image.shape[1] - template.shape[1] + 1))
+
+
+def _validate_search(listTemplates, image, N_object, searchBox):
+    """Argument checks of the reference's findMatches, in its order (MTM/__init__.py:129-167).
+    Returns (cropped image, xOffset, yOffset)."""
+    if N_object != float("inf") and not isinstance(N_object, int):
+        raise TypeError("N_object must be an integer")
+
+    if image.shape[0] == 0:
+        raise ValueError("Image has a height of 0.")
+    if image.shape[1] == 0:
+        raise ValueError("Image has a width of 0.")
+
+    if searchBox is not None:
+        xOffset, yOffset, searchWidth, searchHeight = searchBox
+        image = image[yOffset: yOffset + searchHeight, xOffset: xOffset + searchWidth]
+    else:
+        xOffset = yOffset = 0
+
+    for index, tempTuple in enumerate(listTemplates):
+        if not isinstance(tempTuple, tuple) or len(tempTuple) < 2:
+            raise ValueError("listTemplates should be a list of tuples as ('name','array') or ('name', 'array', 'mask')")
+        tempName, tempImage = tempTuple[0], tempTuple[1]
+        if tempImage.shape[0] == 0:
+            raise ValueError(f"Template '{tempName}' has a height of 0.")
+        if tempImage.shape[1] == 0:
+            raise ValueError(f"Template '{tempName}' has a width of 0.")
+        fits = all(t <= i for t, i in zip(tempImage.shape, image.shape))
+        if not fits:
+            where = "searchBox" if (searchBox is not None) else "image"
+            raise ValueError("Template '{}' at index {} in the list of templates is larger than {}.".format(tempName, index, where))
+    return image, xOffset, yOffset
+
+
+def _raw_matches(listTemplates, image, method, N_object, score_threshold, context=None):
+    """Batched equivalent of one _multi_compute per template (MTM/__init__.py:179-244).
+    Returns a structured array of hits (template index, box relative to `image`, score) ordered by
+    template index, then descending quality, then row-major position."""
+    units = []       # (index, template, image-as-matched, mask)
+    for index, tempTuple in enumerate(listTemplates):
+        template = tempTuple[1]
+        mask = None
+        if len(tempTuple) >= 3:
+            if method in (0, 3):
+                mask = tempTuple[2]
+            else:
+                warnings.warn(_MSG_MASK_UNSUPPORTED)
+        t, im, m = _apply_pixel_policy(template, image, method, mask)
+        _check_opencv_preconditions(t, im)
+        units.append((index, t, im, m))
+
+    ctx = context or _lib.default_context()
+    mode = _lib.PEAKS_GLOBAL if N_object == 1 else _lib.PEAKS_LOCAL
+    parts = []
+    with ctx.lock:
+        # the pixel policy is per template: group the units by the dtype their match runs in
+        for code in ("uint8", "float32"):
+            group = [u for u in units if u[2].dtype == code]
+            if not group:
+                continue
+            ctx.set_image(group[0][2])
+            ctx.set_templates([(u[1], u[3]) for u in group], method)
+            hits = ctx.find_matches(mode, score_threshold).copy()
+            hits["templ_idx"] = np.asarray([u[0] for u in group], dtype=np.int32)[hits["templ_idx"]]
+            parts.append(hits)
+    if not parts:
+        return np.zeros(0, dtype=_lib.HIT_DTYPE)
+    hits = parts[0] if len(parts) == 1 else np.concatenate(parts)
+    if len(parts) > 1:
+        hits = hits[np.argsort(hits["templ_idx"], kind="stable")]
+    return hits
+
+
+def _to_hit_list(raw, listTemplates, xOffset, yOffset):
+    labels = [t[0] for t in listTemplates]
+    return [(labels[int(r["templ_idx"])], (int(r["x"]) + xOffset, int(r["y"]) + yOffset, int(r["w"]), int(r["h"])),
+             np.float32(r["score"])) for r in raw]
+
+
+def findMatches(listTemplates: Sequence[TemplateTuple], image: np.ndarray, method: int = TM_CCOEFF_NORMED,
+                N_object=float("inf"), score_threshold: float = 0.5, searchBox: Optional[BBox] = None) -> List[Hit]:
+    """
+    All template locations satisfying the score threshold, before Non-Maxima Suppression
+    (reference MTM/__init__.py:95-177).
+
+    - listTemplates  : list of tuples (label, template[, mask]); template grayscale or RGB numpy
+                       array, mask of the template's shape and dtype (methods 0 and 3 only)
+    - image          : grayscale or RGB numpy array of the same bit depth and channel count
+    - method         : one of the OpenCV template matching methods 0..5 (default 5)
+    - N_object       : int or float("inf"); 1 returns the global extremum of every template
+    - score_threshold: local maxima above it (minima below it for methods 0/1) are returned
+    - searchBox      : optional (x, y, width, height) region of the image to search
+
+    Returns a list of hits ``(label, (x, y, width, height), score)``.  Hits come grouped by
+    template in list order, each group by descending quality (the reference's cross-template
+    order is the completion order of its worker threads).
+    """
+    image, xOffset, yOffset = _validate_search(listTemplates, image, N_object, searchBox)
+    raw = _raw_matches(listTemplates, image, method, N_object, score_threshold)
+    return _to_hit_list(raw, listTemplates, xOffset, yOffset)
+
+
+def matchTemplates(listTemplates: List[TemplateTuple], image: np.ndarray, method: int = TM_CCOEFF_NORMED,
+                   N_object=float("inf"), score_threshold: float = 0.5, maxOverlap: float = 0.25,
+                   searchBox: Optional[BBox] = None) -> List[Hit]:
+    """
+    Search each template in the image and return the best N_object locations that do not overlap
+    more than maxOverlap (reference MTM/__init__.py:247-296).
+
+    - method     : 1..5 (0/TM_SQDIFF is rejected: no NMS for an unbounded difference score)
+    - maxOverlap : float in [0, 1], maximal Intersection-over-Union between two returned boxes
+    Other arguments as in findMatches.
+
+    Returns a list of hits ``(label, (x, y, width, height), score)``:
+        N_object == 1   -> the best match, whatever its score
+        N_object < inf  -> up to N_object best matches that passed the NMS
+        N_object == inf -> every match that passed the NMS
+    """
+    if maxOverlap < 0 or maxOverlap > 1:
+        raise ValueError("Maximal overlap between bounding box is in range [0-1]")
+
+    listHits = findMatches(listTemplates, image, method, N_object, score_threshold, searchBox)
+
+    if method == 0:     # as in the reference, only after the search ran (MTM/__init__.py:291)
+        raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
+
+    sortAscending = (method == 1)
+    return NMS(listHits, score_threshold, sortAscending, N_object, maxOverlap)
+
+
+# ---------------------------------------------------------------------------------------------
+# drawing helpers (reference MTM/__init__.py:299-391), numpy only
+# ---------------------------------------------------------------------------------------------
+def _draw_boxes(canvas, listHit, boxThickness, color):
+    H, W = canvas.shape[:2]
+    t = max(int(boxThickness), 1)
+    # cv2.rectangle draws a line of thickness t centred on the box outline
+    lo, hi = (t - 1) // 2, t // 2
+    for _, (x, y, w, h), _ in listHit:
+        x0, y0, x1, y1 = int(x), int(y), int(x + w), int(y + h)
+        for (ya, yb, xa, xb) in ((y0 - lo, y0 + hi + 1, x0 - lo, x1 + hi + 1), (y1 - lo, y1 + hi + 1, x0 - lo, x1 + hi + 1),
+                                 (y0 - lo, y1 + hi + 1, x0 - lo, x0 + hi + 1), (y0 - lo, y1 + hi + 1, x1 - lo, x1 + hi + 1)):
+            ya, yb, xa, xb = max(ya, 0), min(yb, H), max(xa, 0), min(xb, W)
+            if ya < yb and xa < xb:
+                canvas[ya:yb, xa:xb] = color
+    return canvas
+
+
+def drawBoxesOnRGB(image: np.ndarray, listHit: Sequence[Hit], boxThickness: int = 2,
+                   boxColor: Tuple[int, int, int] = (255, 255, 00), showLabel: bool = False,
+                   labelColor=(255, 255, 0), labelScale=0.5) -> np.ndarray:
+    """Return an RGB copy of the image with the hit boxes drawn (reference MTM/__init__.py:299-343).
+    Label text needs a font rasteriser (cv2.putText in the reference) and is not drawn."""
+    if image.ndim == 2:
+        out = np.stack([image] * 3, axis=2)
+    else:
+        out = image.copy()
+    if showLabel:
+        warnings.warn("drawBoxesOnRGB: label text is not rendered by the MI355X drop-in (no cv2.putText).")
+    return _draw_boxes(out, listHit, boxThickness, np.asarray(boxColor, dtype=out.dtype))
+
+
+def drawBoxesOnGray(image: np.ndarray, listHit: Sequence[Hit], boxThickness: int = 2, boxColor: int = 255,
+                    showLabel: bool = False, labelColor: int = 255, labelScale=0.5) -> np.ndarray:
+    """Return a grayscale copy of the image with the hit boxes drawn (reference MTM/__init__.py:346-391)."""
+    if image.ndim == 3:
+        # cv2.COLOR_RGB2GRAY weights
+        out = np.rint(image[..., 0] * 0.299 + image[..., 1] * 0.587 + image[..., 2] * 0.114).astype(image.dtype)
+    else:
+        out = image.copy()
+    if showLabel:
+        warnings.warn("drawBoxesOnGray: label text is not rendered by the MI355X drop-in (no cv2.putText).")
+    return _draw_boxes(out, listHit, boxThickness, boxColor)

@@ -1,0 +1,273 @@
+"""
+ctypes binding of libmtm_hip.so (C ABI: include/mtm_hip.h).
+
+There is NO CPU fallback: if the library cannot be loaded, or no GPU is visible when a context is
+requested, the call fails loudly.  The oracle under oracle/ is test infrastructure and is never
+imported from here.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtm_hip.so")
+
+MTM_U8, MTM_F32 = 0, 1
+PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1
+BORDER_CONSTANT, BORDER_NEAREST = 0, 1
+KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
+OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT = 1, 2, 3, 4
+E_OVERFLOW = -5
+COMM_ID_BYTES = 128
+
+
+class MtmTempl(ctypes.Structure):
+    _fields_ = [("px", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("chans", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("row_stride", ctypes.c_int64), ("mask_row_stride", ctypes.c_int64)]
+
+
+class MtmHit(ctypes.Structure):
+    _fields_ = [("templ_idx", ctypes.c_int32), ("x", ctypes.c_int32), ("y", ctypes.c_int32),
+                ("w", ctypes.c_int32), ("h", ctypes.c_int32), ("score", ctypes.c_float)]
+
+
+class MtmTiming(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_float), ("score_ms", ctypes.c_float),
+                ("peaks_ms", ctypes.c_float), ("ncc_kernel_ms", ctypes.c_float),
+                ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
+                ("n_hits", ctypes.c_int64)]
+
+
+HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),
+                      ("score", "<f4")])
+assert HIT_DTYPE.itemsize == ctypes.sizeof(MtmHit) == 24
+
+# every symbol include/mtm_hip.h declares: (restype, argtypes)
+_P = ctypes.POINTER
+SYMBOLS = {
+    "mtm_abi_version": (ctypes.c_int, []),
+    "mtm_device_count": (ctypes.c_int, []),
+    "mtm_last_error": (ctypes.c_char_p, []),
+    "mtm_ctx_create": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_int]),
+    "mtm_ctx_destroy": (None, [ctypes.c_void_p]),
+    "mtm_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "mtm_set_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "mtm_set_templates": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTempl), ctypes.c_int, ctypes.c_int]),
+    "mtm_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
+    "mtm_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                        ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_get_timing": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTiming)]),
+    "mtm_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
+                               ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, _P(ctypes.c_int64)]),
+    "mtm_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtm_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mtm_comm_allgather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                               _P(ctypes.c_int64)]),
+    "mtm_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class MtmError(RuntimeError):
+    """A libmtm_hip call failed (message from mtm_last_error)."""
+
+
+def load():
+    """Load libmtm_hip.so and declare every prototype.  Raises if the library is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MtmError(
+                "libmtm_hip.so is not built (%s). Build it with "
+                "`python multitemplatematching-python_amd/build.py` (needs hipcc); this package has "
+                "no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)       # ctypes releases the GIL during every call
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mtm_abi_version() != 1:
+            raise MtmError("libmtm_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mtm_last_error()
+        raise MtmError("%s failed (%d): %s" % (what or "libmtm_hip call", rc, (msg or b"").decode()))
+
+
+def _pixel_rows(a):
+    """Return (array_kept_alive, pointer, row_stride_bytes) for a (rows, cols[, C]) array whose
+    rows have contiguous pixels; anything else (e.g. a transposed view) is copied."""
+    item = a.itemsize
+    ok = a.strides[-1] == item and (a.ndim == 2 or a.strides[1] == a.shape[2] * item)
+    if a.ndim == 3 and a.shape[2] == 1:
+        ok = ok or a.strides[1] == item
+    if not ok or a.strides[0] < a.shape[1] * (a.shape[2] if a.ndim == 3 else 1) * item or not a.flags.aligned:
+        a = np.ascontiguousarray(a)
+    return a, a.ctypes.data, a.strides[0]
+
+
+def _dtype_code(a):
+    if a.dtype == np.uint8:
+        return MTM_U8
+    if a.dtype == np.float32:
+        return MTM_F32
+    raise MtmError("libmtm_hip takes uint8 or float32 pixels (got %s)" % a.dtype)
+
+
+class Context:
+    """One GPU context (single caller: guarded by a lock)."""
+
+    def __init__(self, device=None):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get("MTM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            n = lib.mtm_device_count()
+            if n > 0:
+                device %= n
+        h = ctypes.c_void_p()
+        check(lib.mtm_ctx_create(ctypes.byref(h), int(device)), "mtm_ctx_create")
+        self._lib = lib
+        self._h = h
+        self.device = device
+        self.lock = threading.RLock()
+        self._keep = []
+        k = os.environ.get("MTM_KERNEL")
+        if k:
+            self.set_option(OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[k.lower()])
+        b = os.environ.get("MTM_PEAK_BORDER")
+        if b:
+            self.set_option(OPT_PEAK_BORDER, {"constant": 0, "nearest": 1}[b.lower()])
+
+    def close(self):
+        if self._h:
+            self._lib.mtm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def set_option(self, opt, value):
+        check(self._lib.mtm_set_option(self._h, int(opt), int(value)), "mtm_set_option")
+
+    def set_image(self, image):
+        a, ptr, stride = _pixel_rows(image)
+        chans = 1 if a.ndim == 2 else a.shape[2]
+        check(self._lib.mtm_set_image(self._h, ptr, a.shape[0], a.shape[1], chans, _dtype_code(a), stride),
+              "mtm_set_image")
+
+    def set_templates(self, templates, method):
+        """templates: list of (array, mask_or_None) with identical dtype policy already applied."""
+        n = len(templates)
+        arr = (MtmTempl * max(n, 1))()
+        keep = []
+        for i, (t, m) in enumerate(templates):
+            t, tp, ts = _pixel_rows(t)
+            keep.append(t)
+            arr[i].px = tp
+            arr[i].rows, arr[i].cols = t.shape[0], t.shape[1]
+            arr[i].chans = 1 if t.ndim == 2 else t.shape[2]
+            arr[i].dtype = _dtype_code(t)
+            arr[i].row_stride = ts
+            if m is not None:
+                m, mp, ms = _pixel_rows(m)
+                keep.append(m)
+                arr[i].mask = mp
+                arr[i].mask_row_stride = ms
+            else:
+                arr[i].mask = None
+                arr[i].mask_row_stride = 0
+        check(self._lib.mtm_set_templates(self._h, arr, n, int(method)), "mtm_set_templates")
+
+    def score_map(self, idx, shape):
+        out = np.empty(shape, dtype=np.float32)
+        check(self._lib.mtm_score_map(self._h, int(idx), out.ctypes.data, out.strides[0]), "mtm_score_map")
+        return out
+
+    def find_matches(self, mode, score_threshold):
+        cap = 4096
+        while True:
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            n = ctypes.c_int64(0)
+            rc = self._lib.mtm_find_matches(self._h, int(mode), float(score_threshold), out.ctypes.data, cap,
+                                            ctypes.byref(n))
+            if rc == E_OVERFLOW:
+                cap = int(n.value) + 16
+                continue
+            check(rc, "mtm_find_matches")
+            return out[:n.value]
+
+    def timing(self):
+        t = MtmTiming()
+        check(self._lib.mtm_get_timing(self._h, ctypes.byref(t)), "mtm_get_timing")
+        return {f: getattr(t, f) for f, _ in MtmTiming._fields_}
+
+    # ---- RCCL hit exchange ------------------------------------------------------------------
+    def comm_init(self, uid, n_ranks, rank):
+        buf = (ctypes.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        check(self._lib.mtm_comm_init(self._h, buf, int(n_ranks), int(rank)), "mtm_comm_init")
+        self.n_ranks = n_ranks
+
+    def allgather_hits(self, local):
+        local = np.ascontiguousarray(local, dtype=HIT_DTYPE)
+        cap = max(1024, 4 * len(local) * self.n_ranks)
+        while True:
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            counts = np.zeros(self.n_ranks, dtype=np.int64)
+            n = ctypes.c_int64(0)
+            rc = self._lib.mtm_comm_allgather_hits(self._h, local.ctypes.data, len(local), out.ctypes.data, cap,
+                                                   counts.ctypes.data, ctypes.byref(n))
+            if rc == E_OVERFLOW:
+                cap = int(n.value) + 16
+                continue
+            check(rc, "mtm_comm_allgather_hits")
+            return out[:n.value], counts
+
+
+def comm_unique_id():
+    buf = (ctypes.c_char * COMM_ID_BYTES)()
+    check(load().mtm_comm_unique_id(buf), "mtm_comm_unique_id")
+    return bytes(buf)
+
+
+def nms_indices(boxes, scores, score_threshold, max_overlap, ascending=False, n_object=-1):
+    """cv2.dnn.NMSBoxes through the C ABI (host code, works without a GPU)."""
+    n = len(boxes)
+    hits = np.zeros(n, dtype=HIT_DTYPE)
+    if n:
+        b = np.asarray(boxes, dtype=np.int64).reshape(n, 4)
+        hits["x"], hits["y"], hits["w"], hits["h"] = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+        hits["score"] = np.asarray(scores, dtype=np.float32)
+    keep = np.empty(max(n, 1), dtype=np.int32)
+    m = ctypes.c_int64(0)
+    check(load().mtm_nms(hits.ctypes.data, n, float(score_threshold), int(bool(ascending)), int(n_object),
+                         float(max_overlap), keep.ctypes.data, ctypes.byref(m)), "mtm_nms")
+    return keep[:m.value]
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            _default_ctx = Context()
+        return _default_ctx

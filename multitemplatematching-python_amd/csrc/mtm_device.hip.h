@@ -1,0 +1,632 @@
+// Device kernels of libmtm_hip.so (gfx950 / CDNA4 only).  Included once, by mtm_hip.hip.
+//
+// Score-map arithmetic: the sliding dot products are exact (uint32/uint64 integers for uint8
+// pixels, float64 FMA chains for float32 pixels); the normalisation epilogue is evaluated in
+// float64 in the operation order of OpenCV's common_matchTemplate (the arithmetic behind the
+// cv2.matchTemplate call at reference MTM/__init__.py:92) as restated in oracle/mtm_oracle.py, and
+// the result is stored as float32.  This TU is compiled with -ffp-contract=off: every FMA below is
+// explicit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#include "mtm_kernels.h"
+#include "../../include/mtm_hip.h"
+
+namespace mtm {
+
+// ---------------------------------------------------------------------------------------------
+// image layout conversion: interleaved rows -> planar, padded, (u8 +) f32
+// ---------------------------------------------------------------------------------------------
+__global__ void planarize_u8_kernel(const uint8_t* __restrict__ raw, int rows, int cols, int chans,
+                                    uint8_t* __restrict__ u8, int u8_pitch, long long u8_plane,
+                                    float* __restrict__ f32, int f32_pitch, long long f32_plane) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const uint8_t* p = raw + ((size_t)y * cols + x) * chans;
+    for (int c = 0; c < chans; ++c) {
+        const uint8_t v = p[c];
+        u8[c * u8_plane + (size_t)y * u8_pitch + x] = v;
+        f32[c * f32_plane + (size_t)y * f32_pitch + x] = (float)v;
+    }
+}
+
+__global__ void planarize_f32_kernel(const float* __restrict__ raw, int rows, int cols, int chans,
+                                     float* __restrict__ f32, int f32_pitch, long long f32_plane) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float* p = raw + ((size_t)y * cols + x) * chans;
+    for (int c = 0; c < chans; ++c) f32[c * f32_plane + (size_t)y * f32_pitch + x] = p[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// window statistics: separable box sums (exact integers for uint8 sources)
+//   pass 1: hs1[c][y][x] = sum_{dx<w} I_c[y][x+dx],  hs2 likewise for I^2      (all image rows)
+//   pass 2: vertical sums over h rows + the per-pixel, template-independent part of the
+//           normalisation (window sums per channel, sum of squares, sqrt(diff2) with the
+//           flat-window guard).
+// ---------------------------------------------------------------------------------------------
+constexpr int kHsumSeg = 16;
+
+template <typename AccT>
+__global__ void hsum_kernel(const float* __restrict__ img, int pitch, long long plane, int rows,
+                            int w, int ow, AccT* __restrict__ hs1, AccT* __restrict__ hs2,
+                            int hs_pitch, long long hs_plane) {
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * kHsumSeg;
+    const int y = blockIdx.y;
+    const int c = blockIdx.z;
+    if (x0 >= ow || y >= rows) return;
+    const float* row = img + c * plane + (size_t)y * pitch;
+    AccT s1 = 0, s2 = 0;
+    for (int dx = 0; dx < w; ++dx) {
+        const AccT v = (AccT)row[x0 + dx];
+        s1 += v;
+        s2 += v * v;
+    }
+    AccT* o1 = hs1 + c * hs_plane + (size_t)y * hs_pitch;
+    AccT* o2 = hs2 + c * hs_plane + (size_t)y * hs_pitch;
+    for (int k = 0; k < kHsumSeg; ++k) {
+        const int x = x0 + k;
+        if (x >= ow) break;
+        o1[x] = s1;
+        o2[x] = s2;
+        const AccT vn = (AccT)row[x + w];   // padded image: always readable
+        const AccT vo = (AccT)row[x];
+        s1 += vn - vo;                      // uint32: modular arithmetic, exact
+        s2 += vn * vn - vo * vo;
+    }
+}
+
+constexpr int kVsumBand = 32;
+
+template <typename AccT, typename SumT>
+__global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __restrict__ hs2,
+                                  int hs_pitch, long long hs_plane, int chans, int h, int oh, int ow,
+                                  double inv_area, int num_type, int want_sq,
+                                  double* __restrict__ t0, double* __restrict__ t1,
+                                  double* __restrict__ t2, double* __restrict__ t3,
+                                  double* __restrict__ sum2, double* __restrict__ sq, int pitch) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = blockIdx.y * kVsumBand;
+    if (x >= ow || y0 >= oh) return;
+    double* tp[kMaxChans] = {t0, t1, t2, t3};
+    SumT s1[kMaxChans], s2[kMaxChans];
+    // all channel loops are unrolled over kMaxChans with a guard: no dynamically indexed
+    // private arrays (they would go to scratch)
+#pragma unroll
+    for (int c = 0; c < kMaxChans; ++c) {
+        s1[c] = 0;
+        s2[c] = 0;
+        if (c < chans) {
+            SumT a = 0, b = 0;
+            const AccT* p1 = hs1 + c * hs_plane + (size_t)y0 * hs_pitch + x;
+            const AccT* p2 = hs2 + c * hs_plane + (size_t)y0 * hs_pitch + x;
+            for (int dy = 0; dy < h; ++dy) {
+                a += (SumT)p1[(size_t)dy * hs_pitch];
+                b += (SumT)p2[(size_t)dy * hs_pitch];
+            }
+            s1[c] = a;
+            s2[c] = b;
+        }
+    }
+    const int y1 = min(y0 + kVsumBand, oh);
+    for (int y = y0; y < y1; ++y) {
+        double wnd_mean2 = 0.0, wnd_sum2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < kMaxChans; ++c) {
+            if (c < chans) {
+                const double t = (double)s1[c];
+                if (num_type == 1) {
+                    wnd_mean2 += t * t;
+                    tp[c][(size_t)y * pitch + x] = t;
+                }
+                wnd_sum2 += (double)s2[c];
+            }
+        }
+        wnd_mean2 *= inv_area;
+        sum2[(size_t)y * pitch + x] = wnd_sum2;
+        if (want_sq) {
+            const double diff2 = fmax(wnd_sum2 - wnd_mean2, 0.0);
+            const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * wnd_sum2);
+            sq[(size_t)y * pitch + x] = small ? 0.0 : sqrt(diff2);
+        }
+        if (y + 1 < y1) {
+#pragma unroll
+            for (int c = 0; c < kMaxChans; ++c) {
+                if (c < chans) {
+                    const size_t o = c * hs_plane + x;
+                    s1[c] += (SumT)hs1[o + (size_t)(y + h) * hs_pitch] - (SumT)hs1[o + (size_t)y * hs_pitch];
+                    s2[c] += (SumT)hs2[o + (size_t)(y + h) * hs_pitch] - (SumT)hs2[o + (size_t)y * hs_pitch];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// normalisation epilogue (common_matchTemplate / matchTemplateMask), float64 -> float32
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float finish_unmasked(int method, double corr, const StatPlanes& st,
+                                                 size_t sidx, const TemplDev& T, int chans) {
+    if (T.all_ones) return 1.0f;
+    if (method == MTM_TM_CCORR) return (float)corr;
+    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    const bool normed = (method == MTM_TM_SQDIFF_NORMED) || (method == MTM_TM_CCORR_NORMED) ||
+                        (method == MTM_TM_CCOEFF_NORMED);
+    double num = corr;
+    if (num_type == 1) {
+#pragma unroll
+        for (int c = 0; c < kMaxChans; ++c)
+            if (c < chans) num -= st.t[c][sidx] * T.mean[c];
+    } else if (num_type == 2) {
+        num = st.sum2[sidx] - 2.0 * num + T.templ_sum2;
+        num = fmax(num, 0.0);
+    }
+    if (normed) {
+        const double t = st.sq[sidx] * T.templ_norm;
+        const double an = fabs(num);
+        if (an < t) num = num / t;
+        else if (an < t * 1.125) num = (num > 0.0) ? 1.0 : -1.0;
+        else num = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
+    }
+    return (float)num;
+}
+
+__device__ __forceinline__ float finish_masked(int method, double c_i_tm2, double c_i2_m2,
+                                               const TemplDev& T) {
+    const double tms = T.templ2_mask2_sum;
+    double res;
+    switch (method) {
+        case MTM_TM_SQDIFF:        res = -2.0 * c_i_tm2 + c_i2_m2 + tms; break;
+        case MTM_TM_SQDIFF_NORMED: res = (-2.0 * c_i_tm2 + c_i2_m2 + tms) / sqrt(tms * c_i2_m2); break;
+        case MTM_TM_CCORR:         res = c_i_tm2; break;
+        default:                   res = c_i_tm2 / sqrt(tms * c_i2_m2); break;   // TM_CCORR_NORMED
+    }
+    return (float)res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NAIVE score-map kernel: one thread per output pixel, float64 FMA chain over the window.
+// Generic (uint8 or float32 pixels, masks, any size); it is the in-library cross-check for the
+// tiled kernels and the fallback for shapes they do not take.
+// ---------------------------------------------------------------------------------------------
+__global__ void ncc_naive_kernel(ImageDev img, const TemplDev* __restrict__ td,
+                                 const int* __restrict__ tlist, const double* __restrict__ weights,
+                                 StatPlanes st, int method, int masked, float* __restrict__ maps) {
+    const int t = tlist[blockIdx.z];
+    const TemplDev T = td[t];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= T.ow || y >= T.oh) return;
+    const int h = T.rows, w = T.cols;
+    double c1 = 0.0, c2 = 0.0;
+    for (int c = 0; c < img.chans; ++c) {
+        const float* ip = img.f32 + c * img.f32_plane + (size_t)y * img.f32_pitch + x;
+        const double* k1 = weights + T.k1_off + (size_t)c * h * w;
+        const double* k2 = masked ? (weights + T.k2_off + (size_t)c * h * w) : nullptr;
+        double a1 = 0.0, a2 = 0.0;
+        for (int dy = 0; dy < h; ++dy) {
+            const float* r = ip + (size_t)dy * img.f32_pitch;
+            for (int dx = 0; dx < w; ++dx) {
+                const double v = (double)r[dx];
+                a1 = fma(v, k1[dy * w + dx], a1);
+                if (masked) a2 = fma(v * v, k2[dy * w + dx], a2);
+            }
+        }
+        c1 += a1;
+        c2 += a2;
+    }
+    float out;
+    if (masked) out = finish_masked(method, c1, c2, T);
+    else out = finish_unmasked(method, c1, st, (size_t)y * st.pitch + x, T, img.chans);
+    maps[T.map_off + (size_t)y * T.map_pitch + x] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TILED float64 score-map kernel for float32 pixels and for masked templates.
+// Block = 32x8 threads; every thread owns 4 consecutive outputs of one row; the image tile is
+// staged in LDS as float32, the template weights (float64) are wave-uniform scalar loads.
+// ---------------------------------------------------------------------------------------------
+constexpr int kF64ChunkH = 16, kF64ChunkW = 32;
+constexpr int kF64BX = 128, kF64BY = 8;
+constexpr int kF64LdsPitch = kF64BX + kF64ChunkW + 4;   // floats, multiple of 4
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void ncc_f64_kernel(ImageDev img, const TemplDev* __restrict__ td,
+                                                      const int* __restrict__ tlist,
+                                                      const double* __restrict__ weights,
+                                                      StatPlanes st, int method,
+                                                      float* __restrict__ maps, int ntx) {
+    __shared__ __attribute__((aligned(16))) float tile[(kF64BY + kF64ChunkH - 1) * kF64LdsPitch];
+    const int t = tlist[blockIdx.y];
+    const TemplDev T = td[t];
+    const int h = T.rows, w = T.cols;
+    const int txi = blockIdx.x % ntx, tyi = blockIdx.x / ntx;
+    const int tx0 = txi * kF64BX, ty0 = tyi * kF64BY;
+    if (tx0 >= T.ow || ty0 >= T.oh) return;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    double acc1[4] = {0, 0, 0, 0}, acc2[4] = {0, 0, 0, 0};
+    double tot1[4] = {0, 0, 0, 0}, tot2[4] = {0, 0, 0, 0};
+
+    for (int c = 0; c < img.chans; ++c) {
+        const float* plane = img.f32 + c * img.f32_plane;
+        const double* k1 = weights + T.k1_off + (size_t)c * h * w;
+        const double* k2 = MASKED ? (weights + T.k2_off + (size_t)c * h * w) : nullptr;
+        for (int cy0 = 0; cy0 < h; cy0 += kF64ChunkH) {
+            const int ch = min(kF64ChunkH, h - cy0);
+            for (int cx0 = 0; cx0 < w; cx0 += kF64ChunkW) {
+                const int cw = min(kF64ChunkW, w - cx0);
+                __syncthreads();
+                // stage (ch + BY - 1) rows x (BX + 32 + 4) floats, as float4
+                const int nrow = ch + kF64BY - 1;
+                constexpr int q4 = kF64LdsPitch / 4;
+                for (int idx = threadIdx.x; idx < nrow * q4; idx += 256) {
+                    const int r = idx / q4, q = idx - r * q4;
+                    const float4 v = *reinterpret_cast<const float4*>(
+                        plane + (size_t)(ty0 + cy0 + r) * img.f32_pitch + tx0 + cx0 + 4 * q);
+                    *reinterpret_cast<float4*>(&tile[r * kF64LdsPitch + 4 * q]) = v;
+                }
+                __syncthreads();
+                for (int dy = 0; dy < ch; ++dy) {
+                    const float* lrow = &tile[(ly + dy) * kF64LdsPitch + 4 * lx];
+                    const double* kr1 = k1 + (size_t)(cy0 + dy) * w + cx0;
+                    const double* kr2 = MASKED ? (k2 + (size_t)(cy0 + dy) * w + cx0) : nullptr;
+                    float4 cur = *reinterpret_cast<const float4*>(lrow);
+                    for (int dx4 = 0; dx4 < cw; dx4 += 4) {
+                        const float4 nxt = *reinterpret_cast<const float4*>(lrow + dx4 + 4);
+                        const double v[8] = {(double)cur.x, (double)cur.y, (double)cur.z, (double)cur.w,
+                                             (double)nxt.x, (double)nxt.y, (double)nxt.z, (double)nxt.w};
+                        double v2[8];
+                        if (MASKED) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v2[i] = v[i] * v[i];
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            if (dx4 + s < cw) {
+                                const double ka = kr1[dx4 + s];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc1[k] = fma(v[k + s], ka, acc1[k]);
+                                if (MASKED) {
+                                    const double kb = kr2[dx4 + s];
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) acc2[k] = fma(v2[k + s], kb, acc2[k]);
+                                }
+                            }
+                        }
+                        cur = nxt;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tot1[k] += acc1[k]; acc1[k] = 0.0;
+            tot2[k] += acc2[k]; acc2[k] = 0.0;
+        }
+    }
+    const int y = ty0 + ly;
+    if (y >= T.oh) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = tx0 + 4 * lx + k;
+        if (x >= T.ow) continue;
+        float out;
+        if (MASKED) out = finish_masked(method, tot1[k], tot2[k], T);
+        else out = finish_unmasked(method, tot1[k], st, (size_t)y * st.pitch + x, T, img.chans);
+        maps[T.map_off + (size_t)y * T.map_pitch + x] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DOT4 score-map kernel: the uint8 hot path on the vector ALU.
+//
+//   * work-group = 256 threads as 32 (x) x 8 (y); a thread owns PX consecutive output columns x
+//     PY consecutive output rows for NT templates: PX*PY*NT uint32 accumulators in registers;
+//     output tile = (32*PX) x (8*PY) pixels.
+//   * the image tile (tile + template chunk halo) is staged once in LDS as dwords and reused for
+//     all NT templates and all PY rows; a lane walks a tile row one dword at a time and forms
+//     its byte-shifted windows with v_alignbyte_b32 (3 per dword).
+//   * template rows are wave-uniform: they are read with scalar loads (s_load_dword*) straight
+//     into SGPRs and used as the scalar operand of v_dot4_u32_u8: no VGPRs, no LDS bandwidth.
+//   * templates larger than 64x64 are processed in 64x64 chunks (image tile re-staged per chunk),
+//     so LDS use is bounded (<= 31 KB) for any template size.
+//   * sums are exact: a chunk's partial sum is < 2^32; WIDE folds it into uint64 totals.
+//   * epilogue in float64 (finish_unmasked), float32 store.
+//
+// Packed template layout (host: pack_template_dot4): per template, per channel, per chunk
+// (cy, cx): (kDotChunk + 2*kDotPadRows) rows of kDotChunk bytes, zero filled, template row dy of
+// the chunk at packed row dy + kDotPadRows: rows that fall outside the chunk multiply by zero, so
+// the PY-row register blocking needs no conditionals.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDotChunk = 64;
+constexpr int kDotPadRows = 3;                                   // supports PY <= 4
+constexpr int kDotPackRows = kDotChunk + 2 * kDotPadRows;
+constexpr int kDotChunkBytes = kDotPackRows * kDotChunk;
+
+struct DotParams {
+    const uint8_t* img;     // planar padded u8
+    int pitch;              // bytes
+    long long plane;
+    int chans;
+    int h, w;               // template size of this class
+    int oh, ow;
+    int ncy, ncx;           // chunk grid of the packed templates
+    int n_list;             // templates in this launch
+    int ntx, nty;           // output tile grid
+    int nchunks;            // ceil(n_list / NT)
+    int n_work;             // ntx * nty * nchunks
+    int method;
+};
+
+template <int PX, int PY, int NT, bool WIDE>
+__global__ __launch_bounds__(256) void ncc_dot4_kernel(DotParams p, const TemplDev* __restrict__ td,
+                                                       const int* __restrict__ tlist,
+                                                       const uint8_t* __restrict__ packs,
+                                                       StatPlanes st, float* __restrict__ maps) {
+    constexpr int BX = 32 * PX, BY = 8 * PY;
+    constexpr int PXD = PX / 4;
+    constexpr int LP = BX / 4 + kDotChunk / 4 + 1;          // LDS row pitch in dwords
+    constexpr int LROWS = kDotChunk + BY - 1;
+    constexpr int EPAD = 256 + 32 / PX;                     // epilogue LDS pitch: conflict-free
+    constexpr int ELDS = PX * PY * EPAD * (WIDE ? 2 : 1);
+    constexpr int LDS_DW = (LROWS * LP > ELDS) ? LROWS * LP : ELDS;
+    __shared__ uint32_t tile[LDS_DW];
+
+    // XCD-aware work mapping: block b runs on XCD b % 8; give each XCD a contiguous range of work
+    // items (tile-major, template-chunk-minor) so the template chunks of one image tile hit the
+    // same L2.
+    const int per_xcd = (p.n_work + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= p.n_work) return;
+    const int chunk = wid % p.nchunks;
+    const int tile_id = wid / p.nchunks;
+    const int txi = tile_id % p.ntx, tyi = tile_id / p.ntx;
+    const int tx0 = txi * BX, ty0 = tyi * BY;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+
+    // wave-uniform template indices / packed bases of this chunk (tail entries repeat the last)
+    int tidx[NT];
+    const uint32_t* tbase[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int li = min(chunk * NT + t, p.n_list - 1);
+        tidx[t] = tlist[li];
+        tbase[t] = reinterpret_cast<const uint32_t*>(packs + td[tidx[t]].pack_off);
+    }
+
+    uint32_t acc[NT][PY][PX];
+    unsigned long long tot[WIDE ? NT : 1][WIDE ? PY : 1][WIDE ? PX : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < PY; ++r)
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                acc[t][r][k] = 0u;
+                if (WIDE) tot[t][r][k] = 0ull;
+            }
+
+    const int w4 = (p.w + 3) & ~3;
+    for (int c = 0; c < p.chans; ++c) {
+        const uint8_t* plane = p.img + c * p.plane;
+        for (int cyi = 0; cyi < p.ncy; ++cyi) {
+            const int cy0 = cyi * kDotChunk;
+            const int ch = min(kDotChunk, p.h - cy0);
+            for (int cxi = 0; cxi < p.ncx; ++cxi) {
+                const int cx0 = cxi * kDotChunk;
+                const int cw4 = min(kDotChunk, w4 - cx0) >> 2;      // dwords per template row
+                const int chunk_dw = ((c * p.ncy + cyi) * p.ncx + cxi) * (kDotChunkBytes / 4);
+                // ---- stage the image tile: (ch + BY - 1) rows x (BX/4 + cw4 + 1) dwords
+                __syncthreads();
+                {
+                    const int nrow = ch + BY - 1;
+                    const int ncol = BX / 4 + cw4 + 1;
+                    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+                    for (int cc = col; cc < ncol; cc += 64) {
+                        const uint8_t* g = plane + (size_t)(ty0 + cy0) * p.pitch + tx0 + cx0 + 4 * cc;
+                        for (int r = r0; r < nrow; r += 4)
+                            tile[r * LP + cc] = *reinterpret_cast<const uint32_t*>(g + (size_t)r * p.pitch);
+                    }
+                }
+                __syncthreads();
+                // ---- accumulate: walk the tile rows this thread's PY output rows touch
+                const int nj = ch + PY - 1;
+                for (int j = 0; j < nj; ++j) {
+                    const uint32_t* lrow = &tile[(ly * PY + j) * LP + lx * PXD];
+                    uint32_t d[PXD + 1];
+#pragma unroll
+                    for (int q = 0; q < PXD; ++q) d[q] = lrow[q];
+                    // packed template row of output row r at tile row j: (j - r) + kDotPadRows
+                    const int prow0 = chunk_dw + (j + kDotPadRows) * (kDotChunk / 4);
+#pragma unroll 4
+                    for (int s = 0; s < cw4; ++s) {
+                        d[PXD] = lrow[s + PXD];
+                        uint32_t win[PX];
+#pragma unroll
+                        for (int q = 0; q < PXD; ++q) {
+                            win[4 * q + 0] = d[q];
+                            win[4 * q + 1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+                            win[4 * q + 2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+                            win[4 * q + 3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+                        }
+#pragma unroll
+                        for (int r = 0; r < PY; ++r) {
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const uint32_t tw = tbase[t][prow0 - r * (kDotChunk / 4) + s];
+#pragma unroll
+                                for (int k = 0; k < PX; ++k)
+                                    acc[t][r][k] = __builtin_amdgcn_udot4(win[k], tw, acc[t][r][k], false);
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < PXD; ++q) d[q] = d[q + 1];
+                    }
+                }
+                if (WIDE) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < PY; ++r)
+#pragma unroll
+                            for (int k = 0; k < PX; ++k) {
+                                tot[t][r][k] += acc[t][r][k];
+                                acc[t][r][k] = 0u;
+                            }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue.  The accumulators of one template at a time go through LDS (transposed), so
+    // that the float64 normalisation runs as ONE rolled loop per template (small code) in which
+    // consecutive lanes own consecutive output columns: coalesced statistics loads and map stores.
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();        // the tile (or the previous template's values) is no longer read
+#pragma unroll
+        for (int r = 0; r < PY; ++r)
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                const int slot = (r * PX + k) * EPAD + threadIdx.x;
+                if (WIDE) {
+                    tile[slot] = (uint32_t)tot[t][r][k];
+                    tile[PX * PY * EPAD + slot] = (uint32_t)(tot[t][r][k] >> 32);
+                } else {
+                    tile[slot] = acc[t][r][k];
+                }
+            }
+        __syncthreads();
+        if (chunk * NT + t >= p.n_list) continue;      // wave-uniform
+        const TemplDev T = td[tidx[t]];
+        float* mbase = maps + T.map_off;
+        for (int i = 0; i < PX * PY; ++i) {
+            const int idx = i * 256 + threadIdx.x;
+            const int cc = idx % BX, rr = idx / BX;                 // pixel inside the tile
+            const int slot = ((rr % PY) * PX + (cc % PX)) * EPAD + (rr / PY) * 32 + (cc / PX);
+            const int x = tx0 + cc, y = ty0 + rr;
+            if (x < p.ow && y < p.oh) {
+                double corr;
+                if (WIDE) corr = (double)(((unsigned long long)tile[PX * PY * EPAD + slot] << 32) | tile[slot]);
+                else corr = (double)tile[slot];
+                mbase[(size_t)y * T.map_pitch + x] =
+                    finish_unmasked(p.method, corr, st, (size_t)y * st.pitch + x, T, p.chans);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// peak extraction: skimage.feature.peak_local_max(map, threshold_abs=thr, exclude_border=False)
+// on a 2-D map (reference MTM/__init__.py:45): pixel == max of its 3x3 neighbourhood and
+// pixel > thr.  mode_min evaluates it on the negated map (MTM/__init__.py:51-53).  Candidates are
+// appended to a global hit buffer; `nontrivial[t]` records that some pixel differs from its local
+// max (skimage returns no peak at all for a map where none does).
+// ---------------------------------------------------------------------------------------------
+constexpr int kPkTW = 64, kPkTH = 16;
+
+__global__ __launch_bounds__(256) void peaks_kernel(const float* __restrict__ maps,
+                                                    const TemplDev* __restrict__ td,
+                                                    const int* __restrict__ tlist, int mode_min,
+                                                    float thr, int border, mtm_hit* __restrict__ hits,
+                                                    unsigned long long cap,
+                                                    unsigned long long* __restrict__ counter,
+                                                    int* __restrict__ nontrivial) {
+    __shared__ float tile[(kPkTH + 2) * (kPkTW + 2)];
+    const int t = tlist[blockIdx.z];
+    const TemplDev T = td[t];
+    const int tx0 = blockIdx.x * kPkTW, ty0 = blockIdx.y * kPkTH;
+    if (tx0 >= T.ow || ty0 >= T.oh) return;
+    const float* m = maps + T.map_off;
+    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+    for (int idx = threadIdx.x; idx < (kPkTH + 2) * (kPkTW + 2); idx += 256) {
+        const int ly = idx / (kPkTW + 2), lx = idx - ly * (kPkTW + 2);
+        const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+        float v = padv;
+        if (gy >= 0 && gy < T.oh && gx >= 0 && gx < T.ow) {
+            v = m[(size_t)gy * T.map_pitch + gx];
+            if (mode_min) v = -v;
+        }
+        tile[idx] = v;
+    }
+    __syncthreads();
+    const float thr2 = mode_min ? -thr : thr;
+    const int px = threadIdx.x & 63, py0 = threadIdx.x >> 6;
+    int nontriv = 0;
+#pragma unroll
+    for (int i = 0; i < kPkTH / 4; ++i) {
+        const int py = py0 + 4 * i;
+        const int gx = tx0 + px, gy = ty0 + py;
+        if (gx >= T.ow || gy >= T.oh) continue;
+        const float* c = &tile[(py + 1) * (kPkTW + 2) + px + 1];
+        const float v = c[0];
+        float mx = fmaxf(fmaxf(c[-(kPkTW + 2) - 1], c[-(kPkTW + 2)]), c[-(kPkTW + 2) + 1]);
+        mx = fmaxf(mx, fmaxf(c[-1], c[1]));
+        mx = fmaxf(mx, fmaxf(fmaxf(c[(kPkTW + 2) - 1], c[kPkTW + 2]), c[(kPkTW + 2) + 1]));
+        mx = fmaxf(mx, v);
+        if (!(v == mx)) nontriv = 1;
+        else if (v > thr2) {
+            const unsigned long long slot = atomicAdd(counter, 1ull);
+            if (slot < cap) {
+                mtm_hit hrec;
+                hrec.templ_idx = t;
+                hrec.x = gx;
+                hrec.y = gy;
+                hrec.w = T.cols;
+                hrec.h = T.rows;
+                hrec.score = mode_min ? -v : v;
+                hits[slot] = hrec;
+            }
+        }
+    }
+    if (__syncthreads_or(nontriv) && threadIdx.x == 0) nontrivial[t] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// global extremum: cv2.minMaxLoc (reference MTM/__init__.py:226): first occurrence in row-major
+// order wins ties.  One packed 64-bit key per (template, min|max): high word = order-preserving
+// image of the float, low word = ~index, combined with atomicMax.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_order(float v) {
+    if (v == 0.0f) v = 0.0f;     // -0 -> +0
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void extremum_kernel(const float* __restrict__ maps,
+                                                       const TemplDev* __restrict__ td, int n_blocks_per_map,
+                                                       unsigned long long* __restrict__ best) {
+    const int t = blockIdx.y;
+    const TemplDev T = td[t];
+    const long long n = (long long)T.oh * T.ow;
+    const float* m = maps + T.map_off;
+    unsigned long long kmax = 0ull, kmin = 0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)n_blocks_per_map * 256) {
+        const int y = (int)(i / T.ow), x = (int)(i - (long long)y * T.ow);
+        const float v = m[(size_t)y * T.map_pitch + x];
+        if (v != v) continue;   // NaN never wins
+        const uint32_t o = float_order(v);
+        const uint32_t ri = 0xFFFFFFFFu - (uint32_t)i;
+        const unsigned long long a = ((unsigned long long)o << 32) | ri;
+        const unsigned long long b = ((unsigned long long)(~o) << 32) | ri;
+        kmax = a > kmax ? a : kmax;
+        kmin = b > kmin ? b : kmin;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_down(kmax, off);
+        const unsigned long long b = __shfl_down(kmin, off);
+        kmax = a > kmax ? a : kmax;
+        kmin = b > kmin ? b : kmin;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kmax) atomicMax(&best[2 * t], kmax);
+        if (kmin) atomicMax(&best[2 * t + 1], kmin);
+    }
+}
+
+}  // namespace mtm

@@ -1,0 +1,940 @@
+// libmtm_hip.so - context, launch logic and the GPU entry points of include/mtm_hip.h.
+// gfx950 (MI355X / CDNA4) only; built by multitemplatematching-python_amd/build.py with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "mtm_device.hip.h"
+#include "mtm_internal.h"
+
+using namespace mtm;
+
+#define HIPC(expr)                                                                          \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            return MTM_E_HIP;                                                               \
+        }                                                                                   \
+    } while (0)
+
+#define MTMC(expr)                                                                          \
+    do {                                                                                    \
+        int r_ = (expr);                                                                    \
+        if (r_ != MTM_OK) return r_;                                                        \
+    } while (0)
+
+namespace {
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MTM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = round_up(bytes + bytes / 8, 256);
+        HIPC(hipMalloc(&p, want));
+        cap = want;
+        return MTM_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct HostTempl {
+    int rows = 0, cols = 0, chans = 0, dtype = 0;
+    bool masked = false;
+    std::vector<double> px;     // planar [C][h][w]
+    std::vector<double> mask;   // planar weights (binarised for uint8 masks) or empty
+    TemplStats st;
+    int cls = -1;
+};
+
+struct SizeClass {
+    int h = 0, w = 0;
+    bool masked = false;
+    bool all_u8 = true;
+    std::vector<int> members;
+    int tlist_off = 0;          // offset into the device tlist array
+};
+
+// dot4 kernel variants
+struct DotVariant {
+    int px, py, nt;
+    bool wide;
+    void (*fn)(DotParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*);
+};
+#define DOTV(PX, PY, NT, W) {PX, PY, NT, W, ncc_dot4_kernel<PX, PY, NT, W>}
+const DotVariant kDotVariants[] = {
+    DOTV(4, 4, 4, false),   // 0: default
+    DOTV(4, 4, 2, false),   // 1
+    DOTV(8, 2, 4, false),   // 2
+    DOTV(8, 4, 2, false),   // 3
+    DOTV(4, 2, 4, false),   // 4
+    DOTV(8, 2, 2, false),   // 5
+    DOTV(4, 2, 8, false),   // 6
+    DOTV(4, 2, 2, true),    // 7: uint64 totals for templates with C*w*h*255^2 >= 2^32
+};
+constexpr int kDotWideVariant = 7;
+constexpr int kNumDotVariants = sizeof(kDotVariants) / sizeof(kDotVariants[0]);
+
+}  // namespace
+
+struct mtm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
+
+    // image
+    bool have_image = false;
+    int rows = 0, cols = 0, chans = 0, dtype = 0;
+    int u8_pitch = 0, f32_pitch = 0, rows_alloc = 0;
+    DevBuf raw, u8, f32;
+
+    // templates
+    bool have_templ = false;
+    bool placed = false;
+    int method = MTM_TM_CCOEFF_NORMED;
+    std::vector<HostTempl> templs;
+    std::vector<SizeClass> classes;
+    std::vector<TemplDev> td_host;
+    std::vector<int> tlist_host;
+    std::vector<int> list2d;        // templates with a 2-D score map
+    int list2d_off = 0;
+    size_t maps_floats = 0;
+    DevBuf td, tlist, weights, packs, maps, hs1, hs2, stats, hits, counters;
+
+    // options
+    int opt_kernel = MTM_KERNEL_AUTO;
+    int opt_border = MTM_BORDER_CONSTANT;
+    int64_t hit_cap = 1 << 18;
+    int dot_variant = 0;
+
+    mtm_timing timing{};
+
+    // RCCL
+    void* rccl_lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    DevBuf comm_send, comm_recv;
+};
+
+namespace {
+
+ImageDev image_dev(const mtm_ctx* c) {
+    ImageDev d;
+    d.u8 = c->u8.as<uint8_t>();
+    d.f32 = c->f32.as<float>();
+    d.rows = c->rows;
+    d.cols = c->cols;
+    d.chans = c->chans;
+    d.u8_pitch = c->u8_pitch;
+    d.f32_pitch = c->f32_pitch;
+    d.u8_plane = (long long)c->u8_pitch * c->rows_alloc;
+    d.f32_plane = (long long)c->f32_pitch * c->rows_alloc;
+    return d;
+}
+
+// Packs one uint8 template for ncc_dot4_kernel (layout documented in mtm_device.hip.h).
+size_t dot_pack_bytes(int h, int w, int chans) {
+    const int w4 = (w + 3) & ~3;
+    const int ncy = (h + kDotChunk - 1) / kDotChunk, ncx = (w4 + kDotChunk - 1) / kDotChunk;
+    return (size_t)chans * ncy * ncx * kDotChunkBytes;
+}
+
+void pack_template_dot4(const HostTempl& t, uint8_t* out) {
+    const int h = t.rows, w = t.cols;
+    const int w4 = (w + 3) & ~3;
+    const int ncy = (h + kDotChunk - 1) / kDotChunk, ncx = (w4 + kDotChunk - 1) / kDotChunk;
+    std::memset(out, 0, dot_pack_bytes(h, w, t.chans));
+    for (int c = 0; c < t.chans; ++c)
+        for (int cy = 0; cy < ncy; ++cy)
+            for (int cx = 0; cx < ncx; ++cx) {
+                uint8_t* chunk = out + ((size_t)(c * ncy + cy) * ncx + cx) * kDotChunkBytes;
+                const int ch = std::min(kDotChunk, h - cy * kDotChunk);
+                const int cw = std::min(kDotChunk, w - cx * kDotChunk);
+                for (int dy = 0; dy < ch; ++dy)
+                    for (int dx = 0; dx < cw; ++dx)
+                        chunk[(dy + kDotPadRows) * kDotChunk + dx] =
+                            (uint8_t)t.px[((size_t)c * h + cy * kDotChunk + dy) * w + cx * kDotChunk + dx];
+            }
+}
+
+int place_templates(mtm_ctx* c) {
+    if (!c->have_image || !c->have_templ) {
+        set_error("set the image and the templates first");
+        return MTM_E_STATE;
+    }
+    if (c->placed) return MTM_OK;
+    const int n = (int)c->templs.size();
+    c->td_host.assign(n, TemplDev{});
+    size_t map_off = 0, w_off = 0, p_off = 0;
+    const bool img_u8 = c->dtype == MTM_U8;
+    for (int i = 0; i < n; ++i) {
+        const HostTempl& t = c->templs[i];
+        if (t.chans != c->chans) {
+            set_error("template " + std::to_string(i) + " has a different channel count than the image");
+            return MTM_E_INVALID;
+        }
+        if (t.rows > c->rows || t.cols > c->cols) {
+            set_error("template " + std::to_string(i) + " is larger than the image");
+            return MTM_E_INVALID;
+        }
+        TemplDev& d = c->td_host[i];
+        for (int k = 0; k < kMaxChans; ++k) d.mean[k] = t.st.mean[k];
+        d.templ_norm = t.st.templ_norm;
+        d.templ_sum2 = t.st.templ_sum2;
+        d.templ2_mask2_sum = t.st.templ2_mask2_sum;
+        d.all_ones = t.st.all_ones;
+        d.rows = t.rows;
+        d.cols = t.cols;
+        d.oh = c->rows - t.rows + 1;
+        d.ow = c->cols - t.cols + 1;
+        d.map_pitch = (int)round_up((size_t)d.ow, 4);
+        d.map_off = (long long)map_off;
+        map_off += (size_t)d.map_pitch * d.oh;
+        const size_t plane = (size_t)t.chans * t.rows * t.cols;
+        d.k1_off = (long long)w_off;
+        w_off += plane;
+        if (t.masked) {
+            d.k2_off = (long long)w_off;
+            w_off += plane;
+        } else {
+            d.k2_off = -1;
+        }
+        if (img_u8 && t.dtype == MTM_U8 && !t.masked) {
+            d.pack_off = (long long)p_off;
+            p_off += dot_pack_bytes(t.rows, t.cols, t.chans);
+        } else {
+            d.pack_off = -1;
+        }
+    }
+    c->maps_floats = map_off;
+    // weights (float64): K1 = T (or T*M^2), K2 = M^2
+    std::vector<double> wts(w_off);
+    std::vector<uint8_t> packs(p_off);
+    for (int i = 0; i < n; ++i) {
+        const HostTempl& t = c->templs[i];
+        const TemplDev& d = c->td_host[i];
+        const size_t plane = (size_t)t.chans * t.rows * t.cols;
+        if (t.masked) {
+            for (size_t k = 0; k < plane; ++k) {
+                const double m2 = t.mask[k] * t.mask[k];
+                wts[d.k1_off + k] = t.px[k] * m2;
+                wts[d.k2_off + k] = m2;
+            }
+        } else {
+            std::copy(t.px.begin(), t.px.end(), wts.begin() + d.k1_off);
+        }
+        if (d.pack_off >= 0) pack_template_dot4(t, packs.data() + d.pack_off);
+    }
+    // template lists: one per class, then the list of templates with a 2-D score map
+    c->tlist_host.clear();
+    for (SizeClass& sc : c->classes) {
+        sc.tlist_off = (int)c->tlist_host.size();
+        c->tlist_host.insert(c->tlist_host.end(), sc.members.begin(), sc.members.end());
+    }
+    c->list2d.clear();
+    for (int i = 0; i < n; ++i)
+        if (c->td_host[i].oh > 1 && c->td_host[i].ow > 1) c->list2d.push_back(i);
+    c->list2d_off = (int)c->tlist_host.size();
+    c->tlist_host.insert(c->tlist_host.end(), c->list2d.begin(), c->list2d.end());
+
+    MTMC(c->td.ensure(sizeof(TemplDev) * n));
+    MTMC(c->tlist.ensure(sizeof(int) * std::max<size_t>(1, c->tlist_host.size())));
+    MTMC(c->weights.ensure(sizeof(double) * std::max<size_t>(1, w_off)));
+    MTMC(c->packs.ensure(std::max<size_t>(4, p_off)));
+    MTMC(c->maps.ensure(sizeof(float) * std::max<size_t>(4, map_off)));
+    HIPC(hipMemcpyAsync(c->td.p, c->td_host.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
+    if (!c->tlist_host.empty())
+        HIPC(hipMemcpyAsync(c->tlist.p, c->tlist_host.data(), sizeof(int) * c->tlist_host.size(),
+                            hipMemcpyHostToDevice, c->stream));
+    if (w_off) HIPC(hipMemcpyAsync(c->weights.p, wts.data(), sizeof(double) * w_off, hipMemcpyHostToDevice, c->stream));
+    if (p_off) HIPC(hipMemcpyAsync(c->packs.p, packs.data(), p_off, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
+    c->placed = true;
+    return MTM_OK;
+}
+
+// Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
+int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
+    const int h = sc.h, w = sc.w;
+    const int oh = c->rows - h + 1, ow = c->cols - w + 1;
+    const int method = c->method;
+    StatPlanes st{};
+    st.pitch = (int)round_up((size_t)ow, 4);
+    *out = st;
+    if (sc.masked || method == MTM_TM_CCORR) return MTM_OK;   // no statistics needed
+    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED ||
+                        method == MTM_TM_CCOEFF_NORMED;
+    const size_t plane = (size_t)st.pitch * oh;
+    MTMC(c->stats.ensure(sizeof(double) * plane * (kMaxChans + 2)));
+    double* base = c->stats.as<double>();
+    double* tp[kMaxChans];
+    for (int k = 0; k < kMaxChans; ++k) tp[k] = base + plane * k;
+    double* sum2 = base + plane * kMaxChans;
+    double* sq = base + plane * (kMaxChans + 1);
+    const int hs_pitch = st.pitch;
+    const long long hs_plane = (long long)hs_pitch * c->rows;
+    const bool u8 = c->dtype == MTM_U8;
+    const size_t esz = u8 ? sizeof(uint32_t) : sizeof(double);
+    MTMC(c->hs1.ensure(esz * hs_plane * c->chans));
+    MTMC(c->hs2.ensure(esz * hs_plane * c->chans));
+    const ImageDev img = image_dev(c);
+    const dim3 g1((ow + 256 * kHsumSeg - 1) / (256 * kHsumSeg), c->rows, c->chans);
+    const dim3 g2((ow + 255) / 256, (oh + kVsumBand - 1) / kVsumBand);
+    const double inv_area = 1.0 / ((double)h * (double)w);
+    if (u8) {
+        hipLaunchKernelGGL(hsum_kernel<uint32_t>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
+                           img.f32_plane, c->rows, w, ow, c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(),
+                           hs_pitch, hs_plane);
+        hipLaunchKernelGGL((vsum_stats_kernel<uint32_t, unsigned long long>), g2, dim3(256), 0, c->stream,
+                           c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
+                           ow, inv_area, num_type, normed ? 1 : 0, tp[0], tp[1], tp[2], tp[3], sum2, sq,
+                           st.pitch);
+    } else {
+        hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
+                           img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
+                           hs_plane);
+        hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream,
+                           c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
+                           inv_area, num_type, normed ? 1 : 0, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
+    }
+    HIPC(hipGetLastError());
+    for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
+    st.sum2 = sum2;
+    st.sq = sq;
+    *out = st;
+    return MTM_OK;
+}
+
+// Score maps of `n_list` templates of class `sc` (device list at tlist + list_off).
+int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const StatPlanes& st) {
+    const int h = sc.h, w = sc.w;
+    const int oh = c->rows - h + 1, ow = c->cols - w + 1;
+    const ImageDev img = image_dev(c);
+    const int* tl = c->tlist.as<int>() + list_off;
+    const TemplDev* td = c->td.as<TemplDev>();
+    float* maps = c->maps.as<float>();
+    const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
+    int kernel = c->opt_kernel;
+    if (kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) kernel = MTM_KERNEL_DOT4;
+    if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;   // -> tiled float64
+
+    // timing events around the dominant kernel
+    if ((int)c->ncc_ev.size() <= c->timing.ncc_launches) {
+        hipEvent_t a, b;
+        HIPC(hipEventCreate(&a));
+        HIPC(hipEventCreate(&b));
+        c->ncc_ev.emplace_back(a, b);
+    }
+    auto& evp = c->ncc_ev[c->timing.ncc_launches];
+    HIPC(hipEventRecord(evp.first, c->stream));
+
+    if (kernel == MTM_KERNEL_NAIVE) {
+        const dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4, n_list);
+        hipLaunchKernelGGL(ncc_naive_kernel, grd, blk, 0, c->stream, img, td, tl, c->weights.as<double>(), st,
+                           c->method, sc.masked ? 1 : 0, maps);
+        c->timing.kernel_used = MTM_KERNEL_NAIVE;
+    } else if (kernel == MTM_KERNEL_DOT4) {
+        const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
+        const DotVariant& v = kDotVariants[wide ? kDotWideVariant : c->dot_variant];
+        DotParams p{};
+        p.img = img.u8;
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = c->chans;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        const int w4 = (w + 3) & ~3;
+        p.ncy = (h + kDotChunk - 1) / kDotChunk;
+        p.ncx = (w4 + kDotChunk - 1) / kDotChunk;
+        p.n_list = n_list;
+        p.ntx = (ow + 32 * v.px - 1) / (32 * v.px);
+        p.nty = (oh + 8 * v.py - 1) / (8 * v.py);
+        p.nchunks = (n_list + v.nt - 1) / v.nt;
+        p.n_work = p.ntx * p.nty * p.nchunks;
+        p.method = c->method;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, c->stream, p, td, tl, c->packs.as<uint8_t>(), st, maps);
+        c->timing.kernel_used = MTM_KERNEL_DOT4;
+    } else {
+        const int ntx = (ow + kF64BX - 1) / kF64BX, nty = (oh + kF64BY - 1) / kF64BY;
+        const dim3 grd(ntx * nty, n_list);
+        if (sc.masked)
+            hipLaunchKernelGGL(ncc_f64_kernel<true>, grd, dim3(256), 0, c->stream, img, td, tl,
+                               c->weights.as<double>(), st, c->method, maps, ntx);
+        else
+            hipLaunchKernelGGL(ncc_f64_kernel<false>, grd, dim3(256), 0, c->stream, img, td, tl,
+                               c->weights.as<double>(), st, c->method, maps, ntx);
+        if (c->timing.kernel_used == 0) c->timing.kernel_used = MTM_KERNEL_AUTO;
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(evp.second, c->stream));
+    c->timing.ncc_launches++;
+    return MTM_OK;
+}
+
+int run_score_all(mtm_ctx* c) {
+    for (const SizeClass& sc : c->classes) {
+        StatPlanes st;
+        MTMC(launch_stats(c, sc, &st));
+        MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st));
+    }
+    return MTM_OK;
+}
+
+int collect_ncc_time(mtm_ctx* c) {
+    float total = 0.f;
+    for (int i = 0; i < c->timing.ncc_launches; ++i) {
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, c->ncc_ev[i].first, c->ncc_ev[i].second));
+        total += ms;
+    }
+    c->timing.ncc_kernel_ms = total;
+    return MTM_OK;
+}
+
+inline float decode_order(uint32_t o) {
+    const uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float v;
+    std::memcpy(&v, &b, 4);
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mtm_ctx_create(mtm_ctx** out, int device_id) {
+    if (!out) {
+        set_error("mtm_ctx_create: null output");
+        return MTM_E_INVALID;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (libmtm_hip has no CPU fallback)");
+        return MTM_E_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        set_error("device id out of range");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(device_id));
+    mtm_ctx* c = new mtm_ctx();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        set_error(std::string("context creation: ") + hipGetErrorString(e));
+        delete c;
+        return MTM_E_HIP;
+    }
+    if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
+        const int k = std::atoi(v);
+        if (k >= 0 && k < kNumDotVariants && !kDotVariants[k].wide) c->dot_variant = k;
+    }
+    *out = c;
+    return MTM_OK;
+}
+
+void mtm_ctx_destroy(mtm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    mtm_comm_destroy(c);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->maps, &c->hs1,
+                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->comm_send, &c->comm_recv})
+        b->release();
+    for (auto& p : c->ncc_ev) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
+    if (!c) return MTM_E_INVALID;
+    switch (option) {
+        case MTM_OPT_KERNEL:
+            if (value < MTM_KERNEL_AUTO || value > MTM_KERNEL_MFMA) break;
+            c->opt_kernel = (int)value;
+            return MTM_OK;
+        case MTM_OPT_PEAK_BORDER:
+            if (value != MTM_BORDER_CONSTANT && value != MTM_BORDER_NEAREST) break;
+            c->opt_border = (int)value;
+            return MTM_OK;
+        case MTM_OPT_HIT_CAPACITY:
+            if (value < 1) break;
+            c->hit_cap = value;
+            return MTM_OK;
+        case MTM_OPT_DOT4_VARIANT:
+            if (value < 0 || value >= kNumDotVariants || kDotVariants[value].wide) break;
+            c->dot_variant = (int)value;
+            return MTM_OK;
+        default: break;
+    }
+    set_error("mtm_set_option: bad option or value");
+    return MTM_E_INVALID;
+}
+
+int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
+                  int64_t row_stride_bytes) {
+    if (!c || !px || rows <= 0 || cols <= 0 || chans < 1 || chans > kMaxChans ||
+        (dtype != MTM_U8 && dtype != MTM_F32)) {
+        set_error("mtm_set_image: bad arguments (1..4 channels, uint8 or float32)");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    const size_t esz = dtype == MTM_U8 ? 1 : 4;
+    const size_t tight = (size_t)cols * chans * esz;
+    if (row_stride_bytes < (int64_t)tight) {
+        set_error("mtm_set_image: row stride smaller than a row");
+        return MTM_E_INVALID;
+    }
+    MTMC(c->raw.ensure(tight * rows));
+    HIPC(hipMemcpy2DAsync(c->raw.p, tight, px, (size_t)row_stride_bytes, tight, rows, hipMemcpyHostToDevice,
+                          c->stream));
+    c->rows_alloc = rows + kPadRows;
+    c->u8_pitch = (int)round_up((size_t)cols + kPadCols, 64);
+    c->f32_pitch = (int)round_up((size_t)cols + kPadCols, 64);
+    const size_t f32_bytes = sizeof(float) * c->f32_pitch * c->rows_alloc * chans;
+    MTMC(c->f32.ensure(f32_bytes));
+    HIPC(hipMemsetAsync(c->f32.p, 0, f32_bytes, c->stream));
+    const dim3 grd((cols + 255) / 256, rows);
+    if (dtype == MTM_U8) {
+        const size_t u8_bytes = (size_t)c->u8_pitch * c->rows_alloc * chans;
+        MTMC(c->u8.ensure(u8_bytes));
+        HIPC(hipMemsetAsync(c->u8.p, 0, u8_bytes, c->stream));
+        hipLaunchKernelGGL(planarize_u8_kernel, grd, dim3(256), 0, c->stream, c->raw.as<uint8_t>(), rows, cols,
+                           chans, c->u8.as<uint8_t>(), c->u8_pitch, (long long)c->u8_pitch * c->rows_alloc,
+                           c->f32.as<float>(), c->f32_pitch, (long long)c->f32_pitch * c->rows_alloc);
+    } else {
+        hipLaunchKernelGGL(planarize_f32_kernel, grd, dim3(256), 0, c->stream, c->raw.as<float>(), rows, cols,
+                           chans, c->f32.as<float>(), c->f32_pitch, (long long)c->f32_pitch * c->rows_alloc);
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));
+    if (rows != c->rows || cols != c->cols || chans != c->chans || dtype != c->dtype) c->placed = false;
+    c->rows = rows;
+    c->cols = cols;
+    c->chans = chans;
+    c->dtype = dtype;
+    c->have_image = true;
+    return MTM_OK;
+}
+
+int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int method) {
+    if (!c || n_templ < 0 || (n_templ > 0 && !templs) || method < 0 || method > 5) {
+        set_error("mtm_set_templates: bad arguments");
+        return MTM_E_INVALID;
+    }
+    std::vector<HostTempl> hts((size_t)n_templ);
+    for (int i = 0; i < n_templ; ++i) {
+        const mtm_templ& s = templs[i];
+        if (!s.px || s.rows <= 0 || s.cols <= 0 || s.chans < 1 || s.chans > kMaxChans ||
+            (s.dtype != MTM_U8 && s.dtype != MTM_F32)) {
+            set_error("mtm_set_templates: bad template " + std::to_string(i));
+            return MTM_E_INVALID;
+        }
+        HostTempl& t = hts[i];
+        t.rows = s.rows;
+        t.cols = s.cols;
+        t.chans = s.chans;
+        t.dtype = s.dtype;
+        t.masked = s.mask != nullptr;
+        const size_t plane = (size_t)s.rows * s.cols;
+        t.px.resize(plane * s.chans);
+        if (t.masked) t.mask.resize(plane * s.chans);
+        for (int y = 0; y < s.rows; ++y) {
+            const uint8_t* rp = (const uint8_t*)s.px + (size_t)y * s.row_stride;
+            const uint8_t* mp = t.masked ? (const uint8_t*)s.mask + (size_t)y * s.mask_row_stride : nullptr;
+            for (int x = 0; x < s.cols; ++x)
+                for (int k = 0; k < s.chans; ++k) {
+                    const size_t src = (size_t)x * s.chans + k;
+                    const size_t dst = (size_t)k * plane + (size_t)y * s.cols + x;
+                    if (s.dtype == MTM_U8) {
+                        t.px[dst] = (double)rp[src];
+                        // CV_8U masks are binary masks (matchTemplateMask)
+                        if (mp) t.mask[dst] = mp[src] > 0 ? 1.0 : 0.0;
+                    } else {
+                        t.px[dst] = (double)((const float*)rp)[src];
+                        if (mp) t.mask[dst] = (double)((const float*)mp)[src];
+                    }
+                }
+        }
+        t.st = compute_templ_stats(t.px.data(), t.masked ? t.mask.data() : nullptr, t.rows, t.cols, t.chans,
+                                   method, s.dtype == MTM_U8);
+    }
+    // size classes, in order of first appearance
+    std::vector<SizeClass> classes;
+    std::map<std::tuple<int, int, bool>, int> index;
+    for (int i = 0; i < n_templ; ++i) {
+        const auto key = std::make_tuple(hts[i].rows, hts[i].cols, hts[i].masked);
+        auto it = index.find(key);
+        if (it == index.end()) {
+            SizeClass sc;
+            sc.h = hts[i].rows;
+            sc.w = hts[i].cols;
+            sc.masked = hts[i].masked;
+            it = index.emplace(key, (int)classes.size()).first;
+            classes.push_back(sc);
+        }
+        SizeClass& sc = classes[it->second];
+        sc.members.push_back(i);
+        sc.all_u8 = sc.all_u8 && hts[i].dtype == MTM_U8;
+        hts[i].cls = it->second;
+    }
+    c->templs.swap(hts);
+    c->classes.swap(classes);
+    c->method = method;
+    c->have_templ = true;
+    c->placed = false;
+    return MTM_OK;
+}
+
+int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_bytes) {
+    if (!c || !out) {
+        set_error("mtm_score_map: bad arguments");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    MTMC(place_templates(c));
+    if (templ_idx < 0 || templ_idx >= (int)c->templs.size()) {
+        set_error("mtm_score_map: template index out of range");
+        return MTM_E_INVALID;
+    }
+    const TemplDev& d = c->td_host[templ_idx];
+    if (out_row_stride_bytes < (int64_t)(sizeof(float) * d.ow)) {
+        set_error("mtm_score_map: output row stride too small");
+        return MTM_E_INVALID;
+    }
+    const SizeClass& sc = c->classes[c->templs[templ_idx].cls];
+    // position of the template inside its class list
+    int pos = 0;
+    while (sc.members[pos] != templ_idx) ++pos;
+    c->timing = mtm_timing{};
+    StatPlanes st;
+    MTMC(launch_stats(c, sc, &st));
+    MTMC(launch_ncc(c, sc, sc.tlist_off + pos, 1, st));
+    HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off,
+                          sizeof(float) * d.map_pitch, sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    MTMC(collect_ncc_time(c));
+    return MTM_OK;
+}
+
+int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                     int64_t* n_out) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) ||
+        (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
+        set_error("mtm_find_matches: bad arguments");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    MTMC(place_templates(c));
+    const int n = (int)c->templs.size();
+    const bool mode_min = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_SQDIFF_NORMED;
+    // numpy compares the float32 map with the python-float threshold in float32
+    const float thr = (float)score_threshold;
+    c->timing = mtm_timing{};
+    std::vector<mtm_hit> hits;
+
+    HIPC(hipEventRecord(c->ev[0], c->stream));
+    MTMC(run_score_all(c));
+    HIPC(hipEventRecord(c->ev[1], c->stream));
+
+    if (mode == MTM_PEAKS_GLOBAL) {
+        MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
+        HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
+        if (n > 0) {
+            const int nb = 256;
+            hipLaunchKernelGGL(extremum_kernel, dim3(nb, n), dim3(256), 0, c->stream, c->maps.as<float>(),
+                               c->td.as<TemplDev>(), nb, c->counters.as<unsigned long long>());
+            HIPC(hipGetLastError());
+        }
+        HIPC(hipEventRecord(c->ev[2], c->stream));
+        std::vector<unsigned long long> best(2 * (size_t)std::max(1, n));
+        HIPC(hipMemcpyAsync(best.data(), c->counters.p, sizeof(unsigned long long) * 2 * std::max(1, n),
+                            hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        for (int t = 0; t < n; ++t) {
+            const unsigned long long key = best[2 * t + (mode_min ? 1 : 0)];
+            const TemplDev& d = c->td_host[t];
+            uint32_t o = (uint32_t)(key >> 32);
+            if (mode_min) o = ~o;
+            const uint32_t idx = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu)) : 0u;
+            mtm_hit hrec;
+            hrec.templ_idx = t;
+            hrec.x = (int)(idx % (uint32_t)d.ow);
+            hrec.y = (int)(idx / (uint32_t)d.ow);
+            hrec.w = d.cols;
+            hrec.h = d.rows;
+            hrec.score = key ? decode_order(o) : NAN;
+            hits.push_back(hrec);
+        }
+    } else {
+        // ---- 2-D maps: peaks kernel with a growing hit buffer
+        const int n2d = (int)c->list2d.size();
+        MTMC(c->counters.ensure(sizeof(unsigned long long) + sizeof(int) * std::max(1, n)));
+        unsigned long long count = 0;
+        std::vector<int> nontrivial((size_t)std::max(1, n), 0);
+        for (int attempt = 0; attempt < 2 && n2d > 0; ++attempt) {
+            MTMC(c->hits.ensure(sizeof(mtm_hit) * (size_t)c->hit_cap));
+            HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) + sizeof(int) * n, c->stream));
+            int max_oh = 0, max_ow = 0;
+            for (int t : c->list2d) {
+                max_oh = std::max(max_oh, c->td_host[t].oh);
+                max_ow = std::max(max_ow, c->td_host[t].ow);
+            }
+            const dim3 grd((max_ow + kPkTW - 1) / kPkTW, (max_oh + kPkTH - 1) / kPkTH, n2d);
+            unsigned long long* counter = c->counters.as<unsigned long long>();
+            int* flags = reinterpret_cast<int*>(counter + 1);
+            hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
+                               c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
+                               c->opt_border, c->hits.as<mtm_hit>(), (unsigned long long)c->hit_cap, counter,
+                               flags);
+            HIPC(hipGetLastError());
+            if (attempt == 0) HIPC(hipEventRecord(c->ev[2], c->stream));
+            HIPC(hipMemcpyAsync(&count, counter, sizeof(count), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipMemcpyAsync(nontrivial.data(), flags, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            if ((int64_t)count <= c->hit_cap) break;
+            c->hit_cap = (int64_t)count + 1024;     // grow and rerun the compaction pass
+        }
+        if (n2d == 0) HIPC(hipEventRecord(c->ev[2], c->stream));
+        if (count > 0) {
+            hits.resize((size_t)count);
+            HIPC(hipMemcpyAsync(hits.data(), c->hits.p, sizeof(mtm_hit) * (size_t)count, hipMemcpyDeviceToHost,
+                                c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            // skimage: a map in which every pixel equals its local maximum has no peaks at all
+            hits.erase(std::remove_if(hits.begin(), hits.end(),
+                                      [&](const mtm_hit& h) { return nontrivial[h.templ_idx] == 0; }),
+                       hits.end());
+        }
+        // ---- 1x1 and 1-D maps (MTM/__init__.py:25-41) on the host
+        for (int t = 0; t < n; ++t) {
+            const TemplDev& d = c->td_host[t];
+            if (d.oh > 1 && d.ow > 1) continue;
+            const int len = std::max(d.oh, d.ow);
+            std::vector<float> line((size_t)len);
+            HIPC(hipMemcpy2DAsync(line.data(), sizeof(float) * (d.oh == 1 ? len : 1),
+                                  c->maps.as<float>() + d.map_off, sizeof(float) * d.map_pitch,
+                                  sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            std::vector<int> pk;
+            if (len == 1) {
+                const float v = mode_min ? -line[0] : line[0];
+                if (v >= (mode_min ? -thr : thr)) pk.push_back(0);
+            } else {
+                pk = find_peaks_1d(line.data(), len, 1, mode_min ? -thr : thr, mode_min);
+            }
+            for (int i : pk) {
+                mtm_hit hrec;
+                hrec.templ_idx = t;
+                hrec.x = d.oh == 1 ? i : 0;
+                hrec.y = d.oh == 1 ? 0 : i;
+                hrec.w = d.cols;
+                hrec.h = d.rows;
+                hrec.score = line[(size_t)i];
+                hits.push_back(hrec);
+            }
+        }
+        // deterministic order: template, then descending quality, then row-major position
+        std::sort(hits.begin(), hits.end(), [&](const mtm_hit& a, const mtm_hit& b) {
+            if (a.templ_idx != b.templ_idx) return a.templ_idx < b.templ_idx;
+            const float qa = mode_min ? -a.score : a.score, qb = mode_min ? -b.score : b.score;
+            if (qa != qb) return qa > qb;
+            if (a.y != b.y) return a.y < b.y;
+            return a.x < b.x;
+        });
+    }
+    HIPC(hipEventRecord(c->ev[3], c->stream));
+    HIPC(hipEventSynchronize(c->ev[3]));
+    HIPC(hipEventElapsedTime(&c->timing.score_ms, c->ev[0], c->ev[1]));
+    HIPC(hipEventElapsedTime(&c->timing.peaks_ms, c->ev[1], c->ev[2]));
+    HIPC(hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[2]));
+    MTMC(collect_ncc_time(c));
+    c->timing.n_hits = (int64_t)hits.size();
+    *n_out = (int64_t)hits.size();
+    if ((int64_t)hits.size() > capacity) {
+        set_error("mtm_find_matches: output capacity too small");
+        return MTM_E_OVERFLOW;
+    }
+    if (!hits.empty()) std::memcpy(out, hits.data(), sizeof(mtm_hit) * hits.size());
+    return MTM_OK;
+}
+
+int mtm_get_timing(mtm_ctx* c, mtm_timing* out) {
+    if (!c || !out) return MTM_E_INVALID;
+    *out = c->timing;
+    return MTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RCCL hit exchange.  librccl is loaded lazily so that the library itself has no link-time
+// dependency on it (single-GPU users never touch it).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.lib) return MTM_OK;
+    void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        set_error(std::string("cannot load librccl.so: ") + dlerror());
+        return MTM_E_COMM;
+    }
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        set_error("librccl.so lacks an expected symbol");
+        dlclose(lib);
+        return MTM_E_COMM;
+    }
+    g_rccl.lib = lib;
+    return MTM_OK;
+}
+
+#define NCCLC(expr)                                                                         \
+    do {                                                                                    \
+        ncclResult_t r_ = (expr);                                                           \
+        if (r_ != ncclSuccess) {                                                            \
+            set_error(std::string(#expr) + ": " +                                           \
+                      (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error"));  \
+            return MTM_E_COMM;                                                              \
+        }                                                                                   \
+    } while (0)
+}  // namespace
+
+int mtm_comm_unique_id(void* id_out) {
+    if (!id_out) return MTM_E_INVALID;
+    static_assert(sizeof(ncclUniqueId) == MTM_COMM_ID_BYTES, "unique id size");
+    MTMC(load_rccl());
+    ncclUniqueId id;
+    NCCLC(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return MTM_OK;
+}
+
+int mtm_comm_init(mtm_ctx* c, const void* id, int n_ranks, int rank) {
+    if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        set_error("mtm_comm_init: bad arguments");
+        return MTM_E_INVALID;
+    }
+    MTMC(load_rccl());
+    HIPC(hipSetDevice(c->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCLC(g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank));
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    return MTM_OK;
+}
+
+int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, mtm_hit* out,
+                            int64_t capacity, int64_t* counts_out, int64_t* n_out) {
+    if (!c || !c->comm || n_local < 0 || (n_local > 0 && !local) || !counts_out || !n_out) {
+        set_error("mtm_comm_allgather_hits: bad arguments or communicator not initialised");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    const int R = c->n_ranks;
+    // 1) counts
+    MTMC(c->comm_send.ensure(sizeof(long long)));
+    MTMC(c->comm_recv.ensure(sizeof(long long) * R));
+    long long mine = n_local;
+    HIPC(hipMemcpyAsync(c->comm_send.p, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, 1, ncclInt64, c->comm, c->stream));
+    std::vector<long long> counts((size_t)R);
+    HIPC(hipMemcpyAsync(counts.data(), c->comm_recv.p, sizeof(long long) * R, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    long long total = 0, mx = 0;
+    for (int r = 0; r < R; ++r) {
+        counts_out[r] = counts[r];
+        total += counts[r];
+        mx = std::max(mx, counts[r]);
+    }
+    *n_out = total;
+    if (total > capacity) {
+        set_error("mtm_comm_allgather_hits: output capacity too small");
+        return MTM_E_OVERFLOW;   // every rank sees the same counts, so every rank returns here
+    }
+    if (mx == 0) return MTM_OK;
+    // 2) fixed-size padded records (24 B each), one all-gather over xGMI
+    const size_t slot = sizeof(mtm_hit) * (size_t)mx;
+    MTMC(c->comm_send.ensure(slot));
+    MTMC(c->comm_recv.ensure(slot * R));
+    HIPC(hipMemsetAsync(c->comm_send.p, 0, slot, c->stream));
+    if (n_local)
+        HIPC(hipMemcpyAsync(c->comm_send.p, local, sizeof(mtm_hit) * (size_t)n_local, hipMemcpyHostToDevice,
+                            c->stream));
+    NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream));
+    std::vector<uint8_t> all(slot * R);
+    HIPC(hipMemcpyAsync(all.data(), c->comm_recv.p, slot * R, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    int64_t o = 0;
+    for (int r = 0; r < R; ++r) {
+        std::memcpy(out + o, all.data() + slot * r, sizeof(mtm_hit) * (size_t)counts[r]);
+        o += counts[r];
+    }
+    return MTM_OK;
+}
+
+int mtm_comm_destroy(mtm_ctx* c) {
+    if (!c) return MTM_E_INVALID;
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    c->n_ranks = 1;
+    c->rank = 0;
+    return MTM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Host-only parts of libmtm_hip.so: error string, template statistics, 1-D peak finding and the
+// NMS.  Nothing here touches the GPU, so these entry points also work on a machine without one
+// (the CPU test-suite exercises mtm_nms through the C ABI).
+#include <algorithm>
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+#include <numeric>
+
+#include "mtm_internal.h"
+
+namespace mtm {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+// ---------------------------------------------------------------------------------------------
+// Template constants.  Follows OpenCV's common_matchTemplate (the arithmetic behind the
+// cv2.matchTemplate call at reference MTM/__init__.py:92) in the operation order that
+// oracle/mtm_oracle.py::match_template uses, so that both sides round identically.
+// ---------------------------------------------------------------------------------------------
+TemplStats compute_templ_stats(const double* px, const double* mask, int rows, int cols, int chans,
+                               int method, bool integer) {
+    TemplStats st;
+    const double n = (double)rows * (double)cols;
+    st.inv_area = 1.0 / ((double)rows * (double)cols);
+    const size_t plane = (size_t)rows * cols;
+
+    if (mask != nullptr) {
+        // matchTemplateMask: templ2_mask2_sum = norm(templ.mul(mask), NORM_L2SQR)
+        double s = 0.0;
+        for (int c = 0; c < chans; ++c)
+            for (size_t i = 0; i < plane; ++i) {
+                const double v = px[c * plane + i] * mask[c * plane + i];
+                s += v * v;
+            }
+        st.templ2_mask2_sum = s;
+        return st;
+    }
+
+    double mean[4] = {0, 0, 0, 0}, sdv[4] = {0, 0, 0, 0};
+    for (int c = 0; c < chans && c < 4; ++c) {
+        double s = 0.0, sq = 0.0;
+        if (integer) {
+            long long is = 0, isq = 0;
+            for (size_t i = 0; i < plane; ++i) {
+                const long long v = (long long)px[c * plane + i];
+                is += v;
+                isq += v * v;
+            }
+            s = (double)is;
+            sq = (double)isq;
+        } else {
+            for (size_t i = 0; i < plane; ++i) {
+                const double v = px[c * plane + i];
+                s += v;
+                sq += v * v;
+            }
+        }
+        mean[c] = s / n;
+        const double var = sq / n - mean[c] * mean[c];
+        sdv[c] = std::sqrt(std::max(var, 0.0));
+    }
+    if (method == MTM_TM_CCORR) return st;
+    const int num_type = (method == MTM_TM_CCORR || method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    for (int c = 0; c < 4; ++c) st.mean[c] = mean[c];
+    if (method != MTM_TM_CCOEFF) {
+        double templ_norm = 0.0;
+        for (int c = 0; c < chans && c < 4; ++c) templ_norm += sdv[c] * sdv[c];
+        if (templ_norm < DBL_EPSILON && method == MTM_TM_CCOEFF_NORMED) {
+            st.all_ones = 1;
+            return st;
+        }
+        double msum = 0.0;
+        for (int c = 0; c < chans && c < 4; ++c) msum += mean[c] * mean[c];
+        double templ_sum2 = templ_norm + msum;
+        if (num_type != 1) {
+            for (int c = 0; c < 4; ++c) st.mean[c] = 0.0;
+            templ_norm = templ_sum2;
+        }
+        templ_sum2 /= st.inv_area;
+        templ_norm = std::sqrt(templ_norm);
+        templ_norm /= std::sqrt(st.inv_area);
+        st.templ_norm = templ_norm;
+        st.templ_sum2 = templ_sum2;
+    }
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scipy.signal.find_peaks(x, height=height)[0], the 1-D branch of MTM._findLocalMax_
+// (reference MTM/__init__.py:33-41): strict local maxima, a plateau yields its middle sample,
+// end points are never peaks, the height test is >=.  `negate` evaluates it on -x
+// (MTM._findLocalMin_, :51-53).
+// ---------------------------------------------------------------------------------------------
+std::vector<int> find_peaks_1d(const float* x, int n, int stride, float height, bool negate) {
+    std::vector<int> peaks;
+    auto at = [&](int i) { const float v = x[(size_t)i * stride]; return negate ? -v : v; };
+    int i = 1;
+    const int i_max = n - 1;
+    while (i < i_max) {
+        if (at(i - 1) < at(i)) {
+            int ahead = i + 1;
+            while (ahead < i_max && at(ahead) == at(i)) ++ahead;
+            if (at(ahead) < at(i)) {
+                const int left = i, right = ahead - 1;
+                const int mid = (left + right) / 2;
+                if (at(mid) >= height) peaks.push_back(mid);
+                i = ahead;
+            }
+        }
+        ++i;
+    }
+    return peaks;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv2.dnn.NMSBoxes (OpenCV dnn/nms.cpp + nms.inl.hpp) as called at reference MTM/NMS.py:78.
+// ---------------------------------------------------------------------------------------------
+static inline float rect_overlap(const mtm_hit& a, const mtm_hit& b) {
+    // 1.f - (float)jaccardDistance(a, b) for Rect_<int>
+    const long long aa = (long long)a.w * a.h, ab = (long long)b.w * b.h;
+    if (aa + ab <= 0) return 1.0f;
+    const int x1 = std::max(a.x, b.x), y1 = std::max(a.y, b.y);
+    const int x2 = std::min(a.x + a.w, b.x + b.w), y2 = std::min(a.y + a.h, b.y + b.h);
+    const int iw = x2 - x1, ih = y2 - y1;
+    const double aab = (iw > 0 && ih > 0) ? (double)((long long)iw * ih) : 0.0;
+    const double dist = 1.0 - aab / ((double)aa + (double)ab - aab);
+    return 1.0f - (float)dist;
+}
+
+void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_threshold,
+               float nms_threshold, std::vector<int32_t>& keep) {
+    std::vector<int32_t> cand;
+    cand.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+        if (scores[i] > score_threshold) cand.push_back((int32_t)i);
+    std::stable_sort(cand.begin(), cand.end(),
+                     [&](int32_t a, int32_t b) { return scores[a] > scores[b]; });
+    keep.clear();
+    for (int32_t idx : cand) {
+        bool ok = true;
+        for (size_t k = 0; k < keep.size() && ok; ++k)
+            ok = rect_overlap(hits[idx], hits[keep[k]]) <= nms_threshold;
+        if (ok) keep.push_back(idx);
+    }
+}
+
+}  // namespace mtm
+
+extern "C" {
+
+const char* mtm_last_error(void) { return mtm::g_last_error.c_str(); }
+
+int mtm_abi_version(void) { return MTM_ABI_VERSION; }
+
+int mtm_nms(const mtm_hit* hits, int64_t n, double score_threshold, int ascending,
+            int64_t n_object, double max_overlap, int32_t* keep, int64_t* n_keep) {
+    if (n < 0 || (n > 0 && (hits == nullptr || keep == nullptr)) || n_keep == nullptr) {
+        mtm::set_error("mtm_nms: bad arguments");
+        return MTM_E_INVALID;
+    }
+    std::vector<float> scores((size_t)n);
+    // MTM/NMS.py:73-75: scores are np.float32, so 1-score is a float32 subtraction; the threshold
+    // is a python float, transformed in double and narrowed by the cv2 binding.
+    for (int64_t i = 0; i < n; ++i) scores[i] = ascending ? (1.0f - hits[i].score) : hits[i].score;
+    const float thr = (float)(ascending ? (1.0 - score_threshold) : score_threshold);
+    std::vector<int32_t> kept;
+    mtm::nms_boxes(hits, n, scores.data(), thr, (float)max_overlap, kept);
+    int64_t m = (int64_t)kept.size();
+    if (n_object >= 0 && m > n_object) m = n_object;   // MTM/NMS.py:81-82
+    for (int64_t i = 0; i < m; ++i) keep[i] = kept[(size_t)i];
+    *n_keep = m;
+    return MTM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// Internal declarations shared by the host-only translation unit (mtm_host.cpp) and the HIP
+// translation unit (mtm_hip.hip).  Not part of the ABI.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mtm_hip.h"
+
+namespace mtm {
+
+void set_error(const std::string& msg);   // thread-local message behind mtm_last_error()
+
+// cv::meanStdDev + the template constants of OpenCV's common_matchTemplate, in the same
+// operation order as oracle/mtm_oracle.py::match_template (so that both sides round alike).
+struct TemplStats {
+    double mean[4] = {0, 0, 0, 0};   // templMean per channel (zeroed when numType != 1)
+    double templ_norm = 0;           // sqrt(templNorm) / sqrt(invArea)
+    double templ_sum2 = 0;           // templSum2 / invArea
+    double inv_area = 0;
+    int all_ones = 0;                // TM_CCOEFF_NORMED with a constant template: map == 1
+    double templ2_mask2_sum = 0;     // masked path: sum((T*M)^2)
+};
+
+// px: planar float64 copies of the template (and mask weights, or nullptr), chans planes of
+// rows*cols each.  `integer` = values are exact integers (uint8 source).
+TemplStats compute_templ_stats(const double* px, const double* mask, int rows, int cols, int chans,
+                               int method, bool integer);
+
+// scipy.signal.find_peaks(x, height=h)[0]
+std::vector<int> find_peaks_1d(const float* x, int n, int stride, float height, bool negate);
+
+// float32-faithful restatement of cv2.dnn.NMSBoxes as called by MTM.NMS
+void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_threshold,
+               float nms_threshold, std::vector<int32_t>& keep);
+
+}  // namespace mtm

@@ -1,0 +1,49 @@
+// Device-side data structures shared by the kernels and the launcher (mtm_hip.hip).
+#pragma once
+#include <cstdint>
+
+namespace mtm {
+
+constexpr int kMaxChans = 4;
+
+// Padding of the planar device image so that tile staging never needs bounds checks:
+// every kernel may read up to kPadCols bytes right of / kPadRows rows below the image.
+constexpr int kPadCols = 512;
+constexpr int kPadRows = 160;
+
+// Per-template constants (device copy).  Mirrors mtm::TemplStats plus placement.
+struct TemplDev {
+    double mean[kMaxChans];
+    double templ_norm;
+    double templ_sum2;
+    double templ2_mask2_sum;
+    long long map_off;      // float offset of this template's score map in the map arena
+    long long k1_off;       // double offset of K1 (T, or T*M^2) in the weight arena, planar [C][h][w]
+    long long k2_off;       // double offset of K2 (M^2) or -1
+    long long pack_off;     // byte offset of the dot4-packed template in the pack arena, or -1
+    int all_ones;
+    int rows, cols;         // h, w
+    int map_pitch;          // floats per score-map row on the device (multiple of 4)
+    int oh, ow;             // score-map size
+    int pad_;
+};
+
+// Window statistics planes of one size class (all double, pitch = stat_pitch elements).
+struct StatPlanes {
+    const double* t[kMaxChans];   // window sums per channel (numType == 1 only)
+    const double* sum2;           // sum over channels of window sum of squares
+    const double* sq;             // sqrt(diff2), or 0 where the window is flat (normed only)
+    int pitch;
+};
+
+struct ImageDev {
+    const uint8_t* u8;     // planar, padded (u8 images only)
+    const float* f32;      // planar, padded
+    int rows, cols, chans;
+    int u8_pitch;          // bytes per row
+    int f32_pitch;         // floats per row
+    long long u8_plane;    // bytes per plane
+    long long f32_plane;   // floats per plane
+};
+
+}  // namespace mtm

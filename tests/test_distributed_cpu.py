@@ -1,0 +1,83 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the units, exchange hit records with the
+'torch' backend of MTM.distributed.HitExchange and run the global NMS; the result must equal the
+single-process pipeline.  The GPU step is replaced by the oracle (tests may use it) because this
+container has no GPU; the RCCL backend itself is exercised by bench.py --gpus N on the GPU node."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (os.path.join(ROOT, "multitemplatematching-python_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    import mtm_oracle as O
+    import synth
+    from MTM import _lib
+    from MTM.distributed import HitExchange, matchTemplates_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        img, units, _ = synth.make_workload(seed=9, image_hw=(260, 420), n_base=5, templ=24)
+        units.append(("big", np.ascontiguousarray(img[10:70, 20:90])))      # unequal costs
+
+        def find_local(sub, image):
+            hits = O.find_matches(sub, image, 5, float("inf"), 0.4)
+            names = [s[0] for s in sub]
+            out = np.zeros(len(hits), dtype=_lib.HIT_DTYPE)
+            for i, h in enumerate(hits):
+                out[i] = (names.index(h[0]), h[1][0], h[1][1], h[1][2], h[1][3], h[2])
+            return out
+
+        ex = HitExchange("torch", rank, world)
+        got = matchTemplates_sharded(units, img, ex, score_threshold=0.4, maxOverlap=0.25, find_local=find_local)
+        q.put((rank, [(h[0], tuple(h[1]), float(h[2])) for h in got]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_units_lpt():
+    from MTM.distributed import shard_units
+    costs = [16, 1, 1, 1, 4, 4, 9, 2]
+    shards = shard_units(costs, 3)
+    assert sorted(i for s in shards for i in s) == list(range(8))
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert max(loads) == 16 and min(loads) >= 10
+    assert shard_units([1.0] * 8, 4) == [[0, 4], [1, 5], [2, 6], [3, 7]]
+    assert shard_units([], 2) == [[], []]
+
+
+def test_two_rank_gloo_matches_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mtm_oracle as O
+    import synth
+    img, units, _ = synth.make_workload(seed=9, image_hw=(260, 420), n_base=5, templ=24)
+    units.append(("big", np.ascontiguousarray(img[10:70, 20:90])))
+    exp = O.match_templates(units, img, score_threshold=0.4, maxOverlap=0.25)
+    key = lambda h: (-float(h[2]), h[0], tuple(h[1]))    # noqa: E731
+    assert sorted(res[0], key=key) == sorted([(h[0], tuple(h[1]), float(h[2])) for h in exp], key=key)

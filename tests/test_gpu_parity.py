@@ -1,0 +1,355 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): every test drives the HIP kernels through the
+C ABI (ctypes) and checks them against the CPU oracle on the same inputs, against the committed
+golden fixtures, and - at BASELINE.json sizes - through size-independent properties.
+
+Tolerance for score maps: |ours - oracle| <= 1e-4 * max(1, |oracle|) (north_star).  The uint8
+path is exact integer arithmetic with a float64 epilogue in the oracle's operation order, so it is
+in fact held to 1e-6 here.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import mtm_oracle as O
+import synth
+from helpers import (assert_hits_equal, canon, coin_templates, hits_json, load_coins, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+G = load_golden()
+REF = G["reference_run"]
+KERNELS = {"naive": 1, "dot4": 2, "auto": 0}
+
+
+@pytest.fixture(scope="module")
+def mtm():
+    import build as mtm_build
+    mtm_build.build()
+    import MTM
+    assert MTM._lib.load().mtm_device_count() >= 1, "no GPU visible to libmtm_hip"
+    return MTM
+
+
+@pytest.fixture(scope="module")
+def ctx(mtm):
+    return mtm._lib.default_context()
+
+
+@pytest.fixture(scope="module")
+def coins():
+    return load_coins()
+
+
+def set_kernel(ctx, name):
+    ctx.set_option(1, KERNELS[name])
+
+
+def map_close(got, exp, tol=1e-4):
+    assert got.shape == exp.shape and got.dtype == np.float32
+    err = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+    bound = tol * np.maximum(1.0, np.abs(exp.astype(np.float64)))
+    bad = err > bound
+    assert not bad.any(), "max err %.3g at %s" % (err.max(), np.unravel_index(np.argmax(err), err.shape))
+    return float(err.max())
+
+
+def otsu_mask(small):
+    return ((small > G["otsu_threshold"]) * 255).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# score maps
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["naive", "dot4"])
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
+def test_score_map_coins_u8(mtm, ctx, coins, method, kernel):
+    set_kernel(ctx, kernel)
+    try:
+        for t in coin_templates(coins):
+            got = mtm.computeScoreMap(t, coins, method)
+            exp = O.compute_score_map(t, coins, method)
+            map_close(got, exp, tol=1e-6)
+    finally:
+        set_kernel(ctx, "auto")
+
+
+@pytest.mark.parametrize("method", [0, 3])
+def test_score_map_masked(mtm, coins, method):
+    small, _ = coin_templates(coins)
+    mask = otsu_mask(small)
+    got = mtm.computeScoreMap(small, coins, method, mask=mask)
+    exp = O.compute_score_map(small, coins, method, mask=mask)
+    map_close(got, exp, tol=1e-6)
+    # float32 image + float32 weights mask
+    imf = coins.astype(np.float32) / 255
+    wm = np.linspace(0, 1, small.size, dtype=np.float32).reshape(small.shape)
+    got = mtm.computeScoreMap(imf[37:75, 80:121], imf, method, mask=wm)
+    exp = O.compute_score_map(imf[37:75, 80:121], imf, method, mask=wm)
+    map_close(got, exp, tol=1e-5)
+
+
+@pytest.mark.parametrize("method", [1, 3, 5])
+def test_score_map_float32_uint16_rgb(mtm, ctx, coins, method):
+    img16 = coins.astype(np.uint16) * 257
+    map_close(mtm.computeScoreMap(img16[37:75, 80:121], img16, method),
+              O.compute_score_map(img16[37:75, 80:121], img16, method), tol=1e-5)
+    imf = coins.astype(np.float32) / 255.0
+    map_close(mtm.computeScoreMap(imf[14:73, 302:367], imf, method),
+              O.compute_score_map(imf[14:73, 302:367], imf, method), tol=1e-5)
+    rgb = np.stack([coins, np.roll(coins, 3, axis=1), 255 - coins], axis=2)
+    t = np.ascontiguousarray(rgb[37:75, 80:121])
+    for kernel in ("naive", "dot4"):
+        set_kernel(ctx, kernel)
+        try:
+            map_close(mtm.computeScoreMap(t, rgb, method), O.compute_score_map(t, rgb, method), tol=1e-6)
+        finally:
+            set_kernel(ctx, "auto")
+
+
+def test_score_map_golden_fixture(mtm, coins):
+    """HIP path against the committed fixture (reference run), not just against the live oracle."""
+    small, big = coin_templates(coins)
+    from helpers import GOLDEN_DIR
+    sub = np.load(GOLDEN_DIR + "/coins_maps_sub3.npz")
+    for name, t in (("small", small), ("big", big)):
+        for m in (1, 2, 3, 4, 5):
+            got = mtm.computeScoreMap(t, coins, m)
+            np.testing.assert_allclose(got[::3, ::3], sub["%s_m%d" % (name, m)], rtol=1e-5, atol=1e-5)
+    got = mtm.computeScoreMap(small, coins, 3, mask=otsu_mask(small))
+    np.testing.assert_allclose(got[::3, ::3], sub["small_m3_mask"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,tshape", [((200, 300), (100, 70)), ((150, 333), (33, 129)), ((400, 400), (300, 260)),
+                                          ((97, 131), (97, 10)), ((97, 131), (5, 131)), ((64, 64), (64, 64)),
+                                          ((70, 90), (1, 1)), ((300, 500), (130, 3))])
+def test_score_map_shapes(mtm, ctx, shape, tshape):
+    """chunked templates (> 64), widths not multiple of 4, uint64 accumulation (300x260), 1-D and
+    1x1 maps, template == image."""
+    img = synth.rand_u8(11, 1, shape)
+    y0, x0 = (shape[0] - tshape[0]) // 2, (shape[1] - tshape[1]) // 3
+    t = np.ascontiguousarray(img[y0:y0 + tshape[0], x0:x0 + tshape[1]])
+    for method in (1, 3, 5):
+        exp = O.compute_score_map(t, img, method)
+        for kernel in ("naive", "dot4"):
+            set_kernel(ctx, kernel)
+            try:
+                map_close(mtm.computeScoreMap(t, img, method), exp, tol=1e-6)
+            finally:
+                set_kernel(ctx, "auto")
+
+
+def test_guards(mtm):
+    img = np.full((40, 50), 7, dtype=np.uint8)
+    img[20:, :] = 9
+    t = np.full((8, 8), 7, dtype=np.uint8)
+    assert np.all(mtm.computeScoreMap(t, img, 5) == 1.0)       # constant template
+    t2 = img[16:24, 10:18].copy()
+    for m in (1, 3, 5):
+        got, exp = mtm.computeScoreMap(t2, img, m), O.compute_score_map(t2, img, m)
+        assert np.array_equal(got, exp), m                      # flat windows, saturation branches
+    black = np.zeros((30, 30), np.uint8)
+    assert np.array_equal(mtm.computeScoreMap(black[:5, :5], black, 1), O.compute_score_map(black[:5, :5], black, 1))
+
+
+def test_dot4_variants_agree(mtm, ctx):
+    img, units, _ = synth.make_workload(seed=21, image_hw=(300, 700), n_base=7, templ=48)
+    ctx.set_image(img)
+    ctx.set_templates([(u[1], None) for u in units], 5)
+    shape = (300 - 48 + 1, 700 - 48 + 1)
+    set_kernel(ctx, "naive")
+    base = [ctx.score_map(i, shape) for i in range(len(units))]
+    set_kernel(ctx, "dot4")
+    try:
+        for v in range(7):
+            ctx.set_option(4, v)
+            # batched path (all templates in one launch) through find_matches, then single maps
+            hits = ctx.find_matches(0, 0.5)
+            assert len(hits) == 4 * len(units), (v, len(hits))
+            for i in range(len(units)):
+                assert np.array_equal(ctx.score_map(i, shape), base[i]), (v, i)
+    finally:
+        ctx.set_option(4, 0)
+        set_kernel(ctx, "auto")
+
+
+# ------------------------------------------------------------------------------------------------
+# full API against the golden fixtures
+# ------------------------------------------------------------------------------------------------
+def test_notebook_goldens(mtm, coins):
+    small, _ = coin_templates(coins)
+    assert_hits_equal(mtm.matchTemplates([("small", small)], coins, score_threshold=0.5, method=5, maxOverlap=0),
+                      G["notebook_G1"]["hits"], tol=1e-4)
+    assert_hits_equal(mtm.matchTemplates([("testMask", small)], coins, method=3, score_threshold=0.8, maxOverlap=0),
+                      G["notebook_G2"]["hits"], tol=1e-4)
+    assert_hits_equal(mtm.matchTemplates([("testMask", small, otsu_mask(small))], coins, method=3, score_threshold=0.8, maxOverlap=0),
+                      G["notebook_G3"]["hits"], tol=1e-4)
+
+
+CALLS = {
+    "G1": lambda im, s, b: ([("small", s)], dict(score_threshold=0.5, method=5, maxOverlap=0)),
+    "testpy": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, maxOverlap=0)),
+    "tut1_two": lambda im, s, b: ([("small", s), ("large", b)], dict(score_threshold=0.4, method=5, maxOverlap=0)),
+    "sqdiff_normed": lambda im, s, b: ([("small", s), ("big", b)], dict(method=1, score_threshold=0.2, maxOverlap=0)),
+    "overlap025": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, maxOverlap=0.25)),
+    "nobj3": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, maxOverlap=0.25, N_object=3)),
+    "nobj1": lambda im, s, b: ([("small", s)], dict(method=5, N_object=1)),
+    "nobj1_sqdiff": lambda im, s, b: ([("big", b)], dict(method=1, N_object=1)),
+    "nobj0": lambda im, s, b: ([("small", s), ("big", b)], dict(score_threshold=0.3, method=5, N_object=0)),
+    "searchbox_exact": lambda im, s, b: ([("big", b)], dict(searchBox=(302, 14) + b.shape[::-1])),
+    "searchbox": lambda im, s, b: ([("small", s)], dict(score_threshold=0.5, maxOverlap=0, searchBox=(10, 20, 300, 200))),
+    "full_image": lambda im, s, b: ([("all", im)], dict()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CALLS))
+def test_reference_run_match_templates(mtm, coins, name):
+    small, big = coin_templates(coins)
+    templates, kw = CALLS[name](coins, small, big)
+    hits = mtm.matchTemplates(templates, coins, **kw)
+    if len(templates) > 1:
+        assert_hits_equal(canon(hits), canon([(h[0], tuple(h[1]), h[2]) for h in REF[name]]), tol=1e-5)
+    else:
+        assert_hits_equal(hits, REF[name], tol=1e-5)
+    assert all(isinstance(h[2], np.float32) and isinstance(h[1][0], int) for h in hits)
+
+
+def test_reference_run_misc(mtm, coins):
+    small, big = coin_templates(coins)
+    tall, wide = coins[:, 100:141], coins[50:90, :]
+    assert_hits_equal(canon(mtm.findMatches([("tall", tall)], coins, score_threshold=0.5)), REF["tall"], tol=1e-5)
+    assert_hits_equal(canon(mtm.findMatches([("wide", wide)], coins, score_threshold=0.5)), REF["wide"], tol=1e-5)
+    img16 = coins.astype(np.uint16) * 257
+    assert_hits_equal(mtm.matchTemplates([("small", img16[37:75, 80:121])], img16, score_threshold=0.5, method=5, maxOverlap=0),
+                      REF["uint16"], tol=1e-5)
+    imgf = coins.astype(np.float32) / 255.0
+    assert_hits_equal(mtm.matchTemplates([("small", imgf[37:75, 80:121])], imgf, method=3, score_threshold=0.95, maxOverlap=0.1),
+                      REF["float32_m3"], tol=1e-5)
+    assert_hits_equal(canon(mtm.findMatches([("small", small), ("big", big)], coins, score_threshold=0.3)),
+                      REF["find_pre_nms"], tol=1e-5)
+    rgb = np.stack([coins, np.roll(coins, 3, axis=1), 255 - coins], axis=2)
+    assert_hits_equal(mtm.matchTemplates([("small", np.ascontiguousarray(rgb[37:75, 80:121]))], rgb, score_threshold=0.5, method=5, maxOverlap=0),
+                      REF["rgb"], tol=1e-5)
+
+
+def test_method0_raises_after_compute(mtm, coins):
+    small, _ = coin_templates(coins)
+    with pytest.raises(ValueError, match="The method TM_SQDIFF is not supported"):
+        mtm.matchTemplates([("small", small)], coins, method=0)
+    # findMatches with method 0 works (local minima of the raw difference)
+    got = mtm.findMatches([("small", small)], coins, method=0, score_threshold=1e6)
+    exp = O.find_matches([("small", small)], coins, method=0, score_threshold=1e6)
+    assert_hits_equal(got, hits_json(exp), tol=1e-5)
+
+
+def test_mask_warnings(mtm, coins):
+    small, _ = coin_templates(coins)
+    mask = otsu_mask(small)
+    with pytest.warns(UserWarning, match="not supporting the use of Mask"):
+        a = mtm.matchTemplates([("s", small, mask)], coins, method=5, maxOverlap=0)
+    assert_hits_equal(a, [["s"] + h[1:] for h in REF["G1"]], tol=1e-5)
+    with pytest.warns(UserWarning, match="same dimension or bit depth"):
+        mtm.computeScoreMap(small, coins, 3, mask=mask[:-1])
+    with pytest.warns(UserWarning, match="not compatible with use of mask"):
+        mtm.computeScoreMap(small, coins, 5, mask=mask)
+
+
+@pytest.mark.parametrize("name", sorted(G["synthetic"]))
+def test_synthetic_reference_runs(mtm, name):
+    case = G["synthetic"][name]
+    kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in case["kwargs"].items()}
+    img, units, plants = synth.make_workload(**kw)
+    pre = mtm.findMatches(units, img, method=case["method"], score_threshold=case["score_threshold"])
+    assert_hits_equal(canon(pre), case["pre_nms"], tol=1e-5)
+    post = mtm.matchTemplates(units, img, method=case["method"], score_threshold=case["score_threshold"], maxOverlap=0.25)
+    assert_hits_equal(canon(post), case["post_nms"], tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# peak extraction details
+# ------------------------------------------------------------------------------------------------
+def test_peaks_vs_oracle_low_threshold(mtm, ctx, coins):
+    """Thousands of peaks, plateaus (saturated +-1 scores), both border rules, minima and maxima,
+    and the growing device hit buffer."""
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    for border, code in (("constant", 0), ("nearest", 1)):
+        ctx.set_option(2, code)
+        ctx.set_option(3, 64)          # tiny device hit buffer: forces the grow-and-rerun path
+        try:
+            for method, thr in ((5, -0.5), (5, 0.05), (3, 0.6), (1, 0.9), (1, 0.05)):
+                got = mtm.findMatches(lt, coins, method=method, score_threshold=thr)
+                exp = O.find_matches(lt, coins, method=method, score_threshold=thr, border=border)
+                assert len(got) > 20
+                assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+        finally:
+            ctx.set_option(2, 0)
+            ctx.set_option(3, 1 << 18)
+
+
+def test_peaks_trivial_and_plateau(mtm):
+    img = np.zeros((60, 80), np.uint8)
+    img[20:30, 30:40] = 200
+    t = np.zeros((10, 10), np.uint8)
+    t[:, :] = 200
+    t[0, 0] = 0
+    for method, thr in ((3, 0.5), (5, 0.5), (1, 0.5)):
+        got = mtm.findMatches([("t", t)], img, method=method, score_threshold=thr)
+        exp = O.find_matches([("t", t)], img, method=method, score_threshold=thr)
+        assert_hits_equal(canon(got), canon(exp), tol=1e-6)
+    # constant template + method 5 -> all-ones map -> "trivial image": no peaks at all
+    assert mtm.findMatches([("c", np.full((5, 5), 9, np.uint8))], img, method=5, score_threshold=0.5) == []
+
+
+def test_global_extremum_first_occurrence(mtm):
+    img = np.zeros((50, 70), np.uint8)
+    for (y, x) in ((7, 9), (7, 40), (30, 9)):
+        img[y:y + 6, x:x + 6] = synth.rand_u8(5, 0, (6, 6))
+    t = img[7:13, 9:15].copy()
+    for method in (1, 3, 5):
+        got = mtm.findMatches([("t", t)], img, method=method, N_object=1)
+        exp = O.find_matches([("t", t)], img, method=method, N_object=1)
+        assert_hits_equal(got, hits_json(exp), tol=1e-6)
+        assert got[0][1][:2] == (9, 7)      # three exact copies: the first in row-major order wins
+    blank = np.full((20, 20), 3, np.uint8)
+    got = mtm.findMatches([("b", blank[:4, :4])], blank, method=3, N_object=1)
+    assert got[0][1] == (0, 0, 4, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: oracle on cfg2, properties on cfg3-sized input
+# ------------------------------------------------------------------------------------------------
+def test_cfg2_full_size_against_oracle(mtm):
+    img, units, plants = synth.make_config("cfg2")
+    got = mtm.matchTemplates(units, img, score_threshold=0.5)
+    exp = O.match_templates(units, img, score_threshold=0.5)
+    assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+    assert {(p[0], p[1]) for p in plants} == {(h[0], h[1]) for h in got}
+    m = mtm.computeScoreMap(units[3][1], img, 5)
+    map_close(m, O.compute_score_map(units[3][1], img, 5), tol=1e-6)
+
+
+def test_cfg3_size_properties(mtm, ctx):
+    img, units, plants = synth.make_config("cfg3")
+    hits = mtm.matchTemplates(units, img, score_threshold=0.5)
+    found = {(h[0], h[1]): float(h[2]) for h in hits}
+    assert set(found) == {(p[0], p[1]) for p in plants}          # every plant, nothing else
+    for p in plants:
+        if p[2] == 0:
+            assert found[(p[0], p[1])] == 1.0                     # exact copies score exactly 1
+        else:
+            assert 0.6 < found[(p[0], p[1])] < 0.99
+    assert hits == mtm.matchTemplates(units, img, score_threshold=0.5)     # idempotent
+    sc = [h[2] for h in hits]
+    assert all(a >= b for a, b in zip(sc, sc[1:]))                # sorted by descending score
+    # rot90 symmetry: matching the rotated image with the rotated templates gives rotated boxes
+    img_r = np.ascontiguousarray(np.rot90(img))
+    units_r = [(u[0], np.ascontiguousarray(np.rot90(u[1]))) for u in units[:16]]
+    a = mtm.matchTemplates(units[:16], img, score_threshold=0.5)
+    b = mtm.matchTemplates(units_r, img_r, score_threshold=0.5)
+    W = img.shape[1]
+    rot = sorted((h[0], (h[1][1], W - h[1][0] - h[1][2], h[1][3], h[1][2]), round(float(h[2]), 5)) for h in a)
+    assert rot == sorted((h[0], h[1], round(float(h[2]), 5)) for h in b)
+    t = ctx.timing()
+    assert t["kernel_used"] == 2 and t["ncc_launches"] >= 1

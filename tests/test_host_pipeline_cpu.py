@@ -1,0 +1,98 @@
+"""The Python host layer (dtype policy, unit grouping, searchBox offsets, hit construction, NMS
+hand-off) exercised on CPU with a stand-in context whose kernels are the oracle.  This checks the
+host logic only; the HIP kernels are checked by tests/test_gpu_parity.py on the GPU box."""
+import threading
+
+import numpy as np
+import pytest
+
+import mtm_oracle as O
+from helpers import assert_hits_equal, canon, coin_templates, load_coins, load_golden
+
+REF = load_golden()["reference_run"]
+
+
+class OracleContext:
+    """Implements the _lib.Context surface the host layer uses, on the oracle."""
+
+    def __init__(self, hit_dtype):
+        self.lock = threading.RLock()
+        self.hit_dtype = hit_dtype
+
+    def set_image(self, image):
+        self.image = image
+
+    def set_templates(self, templates, method):
+        self.templates, self.method = templates, method
+
+    def score_map(self, idx, shape):
+        t, m = self.templates[idx]
+        out = O.match_template(self.image, t, self.method, mask=m)
+        assert out.shape == tuple(shape)
+        return out
+
+    def find_matches(self, mode, thr):
+        rows = []
+        for i, (t, m) in enumerate(self.templates):
+            cmap = O.match_template(self.image, t, self.method, mask=m)
+            if mode == 1:
+                _, _, mn, mx = O.min_max_loc(cmap)
+                peaks = [mn[::-1]] if self.method in (0, 1) else [mx[::-1]]
+            elif self.method in (0, 1):
+                peaks = O.find_local_min(cmap, thr)
+            else:
+                peaks = O.find_local_max(cmap, thr)
+            rows += [(i, int(p[1]), int(p[0]), t.shape[1], t.shape[0], cmap[tuple(p)]) for p in peaks]
+        return np.array(rows, dtype=self.hit_dtype) if rows else np.zeros(0, dtype=self.hit_dtype)
+
+
+@pytest.fixture()
+def mtm(monkeypatch):
+    import build as mtm_build
+    mtm_build.build()
+    import MTM
+    monkeypatch.setattr(MTM._lib, "_default_ctx", OracleContext(MTM._lib.HIT_DTYPE))
+    return MTM
+
+
+def test_pipeline_against_reference_runs(mtm):
+    coins = load_coins()
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    assert_hits_equal(mtm.matchTemplates([("small", small)], coins, score_threshold=0.5, method=5, maxOverlap=0), REF["G1"], tol=1e-6)
+    assert_hits_equal(canon(mtm.matchTemplates(lt, coins, score_threshold=0.3, method=5, maxOverlap=0)),
+                      canon([(h[0], tuple(h[1]), h[2]) for h in REF["testpy"]]), tol=1e-6)
+    assert_hits_equal(canon(mtm.matchTemplates(lt, coins, method=1, score_threshold=0.2, maxOverlap=0)),
+                      canon([(h[0], tuple(h[1]), h[2]) for h in REF["sqdiff_normed"]]), tol=1e-6)
+    assert_hits_equal(mtm.matchTemplates([("small", small)], coins, score_threshold=0.5, maxOverlap=0, searchBox=(10, 20, 300, 200)),
+                      REF["searchbox"], tol=1e-6)
+    assert_hits_equal(mtm.matchTemplates([("small", small)], coins, method=5, N_object=1), REF["nobj1"], tol=1e-6)
+    assert mtm.matchTemplates(lt, coins, score_threshold=0.3, method=5, N_object=0) == []
+    img16 = coins.astype(np.uint16) * 257
+    assert_hits_equal(mtm.matchTemplates([("small", img16[37:75, 80:121])], img16, score_threshold=0.5, method=5, maxOverlap=0),
+                      REF["uint16"], tol=1e-6)
+    assert_hits_equal(canon(mtm.findMatches(lt, coins, score_threshold=0.3)), REF["find_pre_nms"], tol=1e-6)
+    with pytest.raises(ValueError, match="TM_SQDIFF is not supported"):
+        mtm.matchTemplates([("small", small)], coins, method=0)
+
+
+def test_mixed_dtype_units_are_grouped(mtm):
+    """The pixel policy is per template (MTM/__init__.py:71): a float32 template next to a uint8
+    one is matched in float32 against the float32 image, the uint8 one stays 8-bit."""
+    coins = load_coins()
+    small, big = coin_templates(coins)
+    lt = [("f", small.astype(np.float32)), ("u", big), ("f2", big.astype(np.uint16))]
+    got = mtm.findMatches(lt, coins, score_threshold=0.5)
+    exp = O.find_matches(lt, coins, score_threshold=0.5)
+    assert_hits_equal(got, [[h[0], list(h[1]), float(h[2])] for h in exp], tol=1e-6)
+    assert [h[0] for h in got] == sorted([h[0] for h in got], key=["f", "u", "f2"].index)
+
+
+def test_score_map_and_types(mtm):
+    coins = load_coins()
+    small, _ = coin_templates(coins)
+    m = mtm.computeScoreMap(small, coins)
+    assert m.dtype == np.float32 and m.shape == (266, 344)
+    hits = mtm.matchTemplates([("small", small)], coins, maxOverlap=0)
+    assert isinstance(hits, list) and isinstance(hits[0], tuple) and isinstance(hits[0][2], np.float32)
+    assert all(type(v) is int for v in hits[0][1])
