@@ -85,7 +85,7 @@ constexpr int kVsumBand = 32;
 template <typename AccT, typename SumT>
 __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __restrict__ hs2,
                                   int hs_pitch, long long hs_plane, int chans, int h, int oh, int ow,
-                                  double inv_area, int num_type, int want_sq,
+                                  double inv_area, int num_type, int want_sq, int want_t,
                                   double* __restrict__ t0, double* __restrict__ t1,
                                   double* __restrict__ t2, double* __restrict__ t3,
                                   double* __restrict__ sum2, double* __restrict__ sq, int pitch) {
@@ -119,10 +119,8 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
         for (int c = 0; c < kMaxChans; ++c) {
             if (c < chans) {
                 const double t = (double)s1[c];
-                if (num_type == 1) {
-                    wnd_mean2 += t * t;
-                    tp[c][(size_t)y * pitch + x] = t;
-                }
+                if (num_type == 1) wnd_mean2 += t * t;
+                if (want_t) tp[c][(size_t)y * pitch + x] = t;
                 wnd_sum2 += (double)s2[c];
             }
         }

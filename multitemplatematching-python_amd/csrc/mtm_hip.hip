@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mtm_device.hip.h"
+#include "mtm_mfma.hip.h"
 #include "mtm_internal.h"
 
 using namespace mtm;
@@ -74,6 +75,9 @@ struct SizeClass {
     bool all_u8 = true;
     std::vector<int> members;
     int tlist_off = 0;          // offset into the device tlist array
+    bool mfma_ok = false;       // packed for ncc_mfma_kernel
+    long long apack_off = 0;    // byte offset of this class's A packs in the apack arena
+    long long group_bytes = 0;
 };
 
 // dot4 kernel variants
@@ -121,13 +125,14 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, maps, hs1, hs2, stats, hits, counters;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
     int opt_border = MTM_BORDER_CONSTANT;
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
+    int auto_kernel = MTM_KERNEL_DOT4;   // what MTM_KERNEL_AUTO resolves to for uint8 classes
 
     mtm_timing timing{};
 
@@ -179,6 +184,36 @@ void pack_template_dot4(const HostTempl& t, uint8_t* out) {
             }
 }
 
+// A-operand packs of ncc_mfma_kernel for one size class: per group of 16 templates (list order),
+// [channel][template row][64-tap block][lane = 16*q + i][16 bytes]: lane (i, q) holds taps
+// 64*b + 16*q .. +15 of template i, biased to int8 (T ^ 0x80); taps beyond the template width and
+// templates beyond the list are 0 (the signed zero), so they add nothing.
+constexpr int kMfmaMaxW = 256;
+bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
+    return c->dtype == MTM_U8 && sc.all_u8 && !sc.masked && sc.w <= kMfmaMaxW &&
+           (long long)c->chans * sc.w * sc.h <= 131071;
+}
+long long mfma_group_bytes(int h, int w, int chans) { return (long long)chans * h * ((w + 63) / 64) * 1024; }
+int mfma_groups_alloc(int n) { return (((n + 15) / 16) + 1) & ~1; }     // multiple of MB = 2
+
+void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, chans = c->chans;
+    const long long gb = mfma_group_bytes(h, w, chans);
+    std::memset(out, 0, (size_t)gb * mfma_groups_alloc((int)sc.members.size()));
+    for (size_t li = 0; li < sc.members.size(); ++li) {
+        const HostTempl& t = c->templs[sc.members[li]];
+        uint8_t* g = out + (li / 16) * gb;
+        const int i = (int)(li % 16);
+        for (int ch = 0; ch < chans; ++ch)
+            for (int dy = 0; dy < h; ++dy)
+                for (int dx = 0; dx < w; ++dx) {
+                    const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
+                    const uint8_t v = (uint8_t)t.px[((size_t)ch * h + dy) * w + dx];
+                    g[((((size_t)ch * h + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                }
+    }
+}
+
 int place_templates(mtm_ctx* c) {
     if (!c->have_image || !c->have_templ) {
         set_error("set the image and the templates first");
@@ -205,6 +240,12 @@ int place_templates(mtm_ctx* c) {
         d.templ_sum2 = t.st.templ_sum2;
         d.templ2_mask2_sum = t.st.templ2_mask2_sum;
         d.all_ones = t.st.all_ones;
+        {
+            double sum_t = 0.0;      // exact: integers
+            if (t.dtype == MTM_U8 && !t.masked)
+                for (double v : t.px) sum_t += v;
+            d.mfma_k = 128.0 * sum_t - 16384.0 * (double)t.rows * (double)t.cols * (double)t.chans;
+        }
         d.rows = t.rows;
         d.cols = t.cols;
         d.oh = c->rows - t.rows + 1;
@@ -247,6 +288,18 @@ int place_templates(mtm_ctx* c) {
         }
         if (d.pack_off >= 0) pack_template_dot4(t, packs.data() + d.pack_off);
     }
+    // int8 MFMA packs, per eligible class
+    size_t a_off = 0;
+    for (SizeClass& sc : c->classes) {
+        sc.mfma_ok = mfma_class_ok(c, sc);
+        if (!sc.mfma_ok) continue;
+        sc.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
+        sc.apack_off = (long long)a_off;
+        a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
+    }
+    std::vector<uint8_t> apacks(a_off);
+    for (const SizeClass& sc : c->classes)
+        if (sc.mfma_ok) pack_class_mfma(c, sc, apacks.data() + sc.apack_off);
     // template lists: one per class, then the list of templates with a 2-D score map
     c->tlist_host.clear();
     for (SizeClass& sc : c->classes) {
@@ -263,6 +316,8 @@ int place_templates(mtm_ctx* c) {
     MTMC(c->tlist.ensure(sizeof(int) * std::max<size_t>(1, c->tlist_host.size())));
     MTMC(c->weights.ensure(sizeof(double) * std::max<size_t>(1, w_off)));
     MTMC(c->packs.ensure(std::max<size_t>(4, p_off)));
+    MTMC(c->apacks.ensure(std::max<size_t>(16, a_off)));
+    if (a_off) HIPC(hipMemcpyAsync(c->apacks.p, apacks.data(), a_off, hipMemcpyHostToDevice, c->stream));
     MTMC(c->maps.ensure(sizeof(float) * std::max<size_t>(4, map_off)));
     HIPC(hipMemcpyAsync(c->td.p, c->td_host.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
     if (!c->tlist_host.empty())
@@ -283,7 +338,8 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     StatPlanes st{};
     st.pitch = (int)round_up((size_t)ow, 4);
     *out = st;
-    if (sc.masked || method == MTM_TM_CCORR) return MTM_OK;   // no statistics needed
+    const bool want_t_always = sc.mfma_ok && c->opt_kernel != MTM_KERNEL_NAIVE && c->opt_kernel != MTM_KERNEL_DOT4;
+    if (sc.masked || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // no statistics needed
     const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
                        : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
     const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED ||
@@ -304,6 +360,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     const ImageDev img = image_dev(c);
     const dim3 g1((ow + 256 * kHsumSeg - 1) / (256 * kHsumSeg), c->rows, c->chans);
     const dim3 g2((ow + 255) / 256, (oh + kVsumBand - 1) / kVsumBand);
+    const int want_t = (num_type == 1 || want_t_always) ? 1 : 0;
     const double inv_area = 1.0 / ((double)h * (double)w);
     if (u8) {
         hipLaunchKernelGGL(hsum_kernel<uint32_t>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
@@ -311,7 +368,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
                            hs_pitch, hs_plane);
         hipLaunchKernelGGL((vsum_stats_kernel<uint32_t, unsigned long long>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
-                           ow, inv_area, num_type, normed ? 1 : 0, tp[0], tp[1], tp[2], tp[3], sum2, sq,
+                           ow, inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq,
                            st.pitch);
     } else {
         hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
@@ -319,7 +376,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
                            hs_plane);
         hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
-                           inv_area, num_type, normed ? 1 : 0, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
+                           inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
     }
     HIPC(hipGetLastError());
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
@@ -330,7 +387,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
 }
 
 // Score maps of `n_list` templates of class `sc` (device list at tlist + list_off).
-int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const StatPlanes& st) {
+int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const StatPlanes& st, int only_li = -1) {
     const int h = sc.h, w = sc.w;
     const int oh = c->rows - h + 1, ow = c->cols - w + 1;
     const ImageDev img = image_dev(c);
@@ -339,7 +396,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     float* maps = c->maps.as<float>();
     const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
     int kernel = c->opt_kernel;
-    if (kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) kernel = MTM_KERNEL_DOT4;
+    if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
+    if (kernel == MTM_KERNEL_MFMA && !sc.mfma_ok) kernel = MTM_KERNEL_DOT4;
     if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;   // -> tiled float64
 
     // timing events around the dominant kernel
@@ -357,6 +415,50 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         hipLaunchKernelGGL(ncc_naive_kernel, grd, blk, 0, c->stream, img, td, tl, c->weights.as<double>(), st,
                            c->method, sc.masked ? 1 : 0, maps);
         c->timing.kernel_used = MTM_KERNEL_NAIVE;
+    } else if (kernel == MTM_KERNEL_MFMA) {
+        // the MFMA kernel works on whole 16-template groups of the class list; a single-template
+        // request (mtm_score_map) computes its group and stores only that template
+        const int n_all = (int)sc.members.size();
+        const int mb = n_all > 16 ? 2 : 1;
+        MfmaParams p{};
+        p.img = img.u8;
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = c->chans;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nb = (w + 63) / 64;
+        p.n_list = n_all;
+        p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+        p.nyb = (oh + kMfRows - 1) / kMfRows;
+        p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
+        p.method = c->method;
+        p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.group_bytes = sc.group_bytes;
+        p.only_li = only_li;
+        int tg0 = 0;
+        if (only_li >= 0) {          // one template: just its group
+            tg0 = only_li / (16 * mb);
+            p.ntg = 1;
+        }
+        p.n_work = p.nseg * p.nyb * p.ntg;
+        const size_t lds = std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
+                                            (size_t)kMfRows * kMfEpiBytesPerWave);
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
+        // with a group offset the kernel's list positions must stay class-relative: shift the list
+        // pointer and the counts instead (positions inside the kernel are relative to tg0)
+        p.n_list = n_all - tg0 * 16 * mb;
+        if (only_li >= 0) p.only_li = only_li - tg0 * 16 * mb;
+        const int* tl_k = tl_class + tg0 * 16 * mb;
+        if (mb == 2)
+            hipLaunchKernelGGL(ncc_mfma_kernel<2>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        else
+            hipLaunchKernelGGL(ncc_mfma_kernel<1>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
         const DotVariant& v = kDotVariants[wide ? kDotWideVariant : c->dot_variant];
@@ -459,6 +561,10 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         delete c;
         return MTM_E_HIP;
     }
+    if (const char* v = std::getenv("MTM_AUTO_KERNEL")) {
+        if (!std::strcmp(v, "mfma")) c->auto_kernel = MTM_KERNEL_MFMA;
+        if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
+    }
     if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
         const int k = std::atoi(v);
         if (k >= 0 && k < kNumDotVariants && !kDotVariants[k].wide) c->dot_variant = k;
@@ -472,7 +578,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     (void)hipSetDevice(c->device);
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->maps, &c->hs1,
+    for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
                       &c->hs2, &c->stats, &c->hits, &c->counters, &c->comm_send, &c->comm_recv})
         b->release();
     for (auto& p : c->ncc_ev) {
@@ -648,7 +754,7 @@ int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_
     c->timing = mtm_timing{};
     StatPlanes st;
     MTMC(launch_stats(c, sc, &st));
-    MTMC(launch_ncc(c, sc, sc.tlist_off + pos, 1, st));
+    MTMC(launch_ncc(c, sc, sc.tlist_off + pos, 1, st, pos));
     HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off,
                           sizeof(float) * d.map_pitch, sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost,
                           c->stream));

@@ -1,0 +1,225 @@
+// MFMA score-map kernel: the uint8 sliding-window correlation as an implicit GEMM on the int8
+// matrix cores (v_mfma_i32_16x16x64_i8), exact integer arithmetic.
+//
+//   out[t][y][x] = sum_{dy,dx} I[y+dy][x+dx] * T[t][dy][dx]           (uint8 x uint8)
+//
+// Signed operands: the matrix cores multiply int8, so both operands are biased by -128
+// (I' = I ^ 0x80, T' = T ^ 0x80) and the exact correlation is recovered in the epilogue from the
+// window sum S1 the statistics pass already provides:
+//   sum I*T = sum I'*T' + 128*S1 + 128*sum(T) - 16384*w*h*C
+// |sum I'T'| <= 16384*w*h*C must fit int32: the launcher only takes w*h*C <= 131071.
+//
+// GEMM mapping (one v_mfma_i32_16x16x64_i8 = 16 templates x 16 pixels x 64 taps):
+//   A (16 x 64)  = one 64-tap template-row segment of 16 templates; lane (i = lane&15, q = lane>>4)
+//                  holds taps 16q..16q+15 of template i: 16 contiguous bytes, pre-packed on the host
+//                  in exactly this order (coalesced 1 KiB global_load_dwordx4 per operand).
+//   B (64 x 16)  = the matching image bytes of 16 output pixels; lane (j = lane&15, q) holds
+//                  I'[y+dy][x_j + 16q .. +15].
+//   The pairing only relies on A and B using the same (q, byte) slot for the same tap.
+//   The 16 pixels of one MFMA are 16 apart: x_j = x0 + 16 j + c, "phase" c = 0..15.  All 16 phases
+//   of a lane read the SAME 32 bytes of LDS (two aligned 16-byte chunks j+q and j+q+1), shifted by
+//   c bytes: 2 ds_read_b128 + 21 v_alignbyte_b32 feed 16*MB MFMAs.  A wave therefore owns
+//   256 consecutive output pixels of one row for 16*MB templates (64*MB accumulator registers).
+//   * work-group = 4 waves = 4 consecutive output rows of the same 256-pixel segment, sharing one
+//     LDS image tile (biased to int8 while staging); template rows beyond 64 are processed in
+//     64-row chunks (tile re-staged), widths beyond 64 in 64-tap blocks.
+//   * epilogue: accumulators go through LDS (transposed) so that consecutive lanes own consecutive
+//     output columns - coalesced statistics loads and score-map stores - then the float64
+//     normalisation shared with the other kernels (finish_unmasked).
+#pragma once
+#include "mtm_device.hip.h"
+
+namespace mtm {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kMfSeg = 256;          // output pixels per wave (16 phases x 16 columns)
+constexpr int kMfRows = 4;           // output rows per work-group (one per wave)
+constexpr int kMfChunkH = 64;        // template rows per LDS tile
+constexpr int kMfEpiPitch = 12;      // dwords per pixel in the epilogue buffer (8 used)
+constexpr int kMfEpiBytesPerWave = kMfSeg * kMfEpiPitch * 4;
+
+struct MfmaParams {
+    const uint8_t* img;      // planar padded u8
+    int pitch;
+    long long plane;
+    int chans;
+    int h, w;
+    int oh, ow;
+    int nb;                  // 64-tap blocks per template row: ceil(w / 64)
+    int n_list;              // templates of this class (list order = pack order)
+    int nseg, nyb, ntg;      // work grid: x segments, row blocks, template groups (of 16*MB)
+    int n_work;
+    int method;
+    int lds_pitch;           // bytes per LDS tile row: (16 + 4*nb + 1) * 16
+    long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
+    int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
+};
+
+// One K step: 16 phases x MB template groups, operands already in registers.
+template <int MB>
+__device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, const v4i qb, const v4i (&a)[MB]) {
+    const int W[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    // phases with a whole-dword shift: no VALU work
+#pragma unroll
+    for (int cq = 0; cq < 4; ++cq) {
+        const v4i bv = {W[cq], W[cq + 1], W[cq + 2], W[cq + 3]};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            acc[mb][4 * cq] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mb], bv, acc[mb][4 * cq], 0, 0, 0);
+    }
+    // byte shifts 1..3: 7 v_alignbyte_b32 serve four phases each
+#pragma unroll
+    for (int cr = 1; cr < 4; ++cr) {
+        int E[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) E[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)W[m + 1], (uint32_t)W[m], cr);
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) {
+            const v4i bv = {E[cq], E[cq + 1], E[cq + 2], E[cq + 3]};
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                acc[mb][4 * cq + cr] =
+                    __builtin_amdgcn_mfma_i32_16x16x64_i8(a[mb], bv, acc[mb][4 * cq + cr], 0, 0, 0);
+        }
+    }
+}
+
+template <int MB>
+__global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
+                                                          const int* __restrict__ tlist,
+                                                          const uint8_t* __restrict__ apack,
+                                                          StatPlanes st, float* __restrict__ maps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+
+    const int per_xcd = (p.n_work + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= p.n_work) return;
+    const int tg = wid % p.ntg;
+    const int rest = wid / p.ntg;
+    const int seg = rest % p.nseg, yb = rest / p.nseg;
+    const int x0 = seg * kMfSeg, y0 = yb * kMfRows;
+
+    v4i acc[MB][16];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[mb][c] = v4i{0, 0, 0, 0};
+
+    const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
+    const int tile_dw_per_row = p.lds_pitch >> 2;
+
+    for (int c = 0; c < p.chans; ++c) {
+        const uint8_t* plane = p.img + c * p.plane;
+        for (int cy0 = 0; cy0 < p.h; cy0 += kMfChunkH) {
+            const int ch = min(kMfChunkH, p.h - cy0);
+            // ---- stage (ch + 3) image rows, biased to int8
+            __syncthreads();
+            {
+                const int nrow = ch + kMfRows - 1;
+                uint32_t* tile32 = reinterpret_cast<uint32_t*>(smem);
+                for (int idx = threadIdx.x; idx < nrow * tile_dw_per_row; idx += 256) {
+                    const int r = idx / tile_dw_per_row, d = idx - r * tile_dw_per_row;
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(
+                        plane + (size_t)(y0 + cy0 + r) * p.pitch + x0 + 4 * d);
+                    tile32[idx] = v ^ 0x80808080u;
+                }
+            }
+            __syncthreads();
+            // ---- K loop: template rows of this chunk x 64-tap blocks, software pipelined with two
+            // register sets: the operands of the next step (2 LDS chunks + MB packed template rows)
+            // are requested before the 16*MB MFMAs of the current step issue.  sched_barrier keeps
+            // the compiler from sinking the requests below the MFMAs.
+            const uint8_t* aptr = apack_g + ((size_t)(c * p.h + cy0) * p.nb) * 1024;   // + ks * 1024
+            const uint8_t* lbase = smem + wave * p.lds_pitch + (j + q) * 16;
+            const int nsteps = ch * p.nb;
+            int nb_i = 0;                       // 64-tap block of the step last requested
+            int loff = 0;                       // its LDS offset: dy * lds_pitch + b * 64
+            int req = 0;                        // index of the step last requested
+            v4i qa0, qb0, qa1, qb1, a0[MB], a1[MB];
+#define MTM_MF_ADVANCE()                                            \
+            if (req + 1 < nsteps) {                                 \
+                ++req;                                              \
+                aptr += 1024;                                       \
+                if (++nb_i == p.nb) {                               \
+                    nb_i = 0;                                       \
+                    loff += p.lds_pitch - (p.nb - 1) * 64;          \
+                } else {                                            \
+                    loff += 64;                                     \
+                }                                                   \
+            }
+#define MTM_MF_LOAD(QA, QB, A)                                                          \
+            QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
+            QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
+                A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
+            MTM_MF_LOAD(qa0, qb0, a0)
+            for (int ks = 0; ks < nsteps; ks += 2) {
+                MTM_MF_ADVANCE()
+                MTM_MF_LOAD(qa1, qb1, a1)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step<MB>(acc, qa0, qb0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                MTM_MF_ADVANCE()
+                MTM_MF_LOAD(qa0, qb0, a0)
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < nsteps) mfma_step<MB>(acc, qa1, qb1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef MTM_MF_ADVANCE
+#undef MTM_MF_LOAD
+        }
+    }
+
+    // ---- epilogue: per wave, 8 templates at a time through LDS ([pixel][8 templates] int32).
+    // The stage loop is rolled (one copy of the float64 normalisation in the binary); the
+    // accumulator block of a stage is selected by a wave-uniform switch with static indices.
+    const int y = y0 + wave;
+    int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
+#pragma unroll 1
+    for (int stage = 0; stage < 2 * MB; ++stage) {
+        const int mb = stage >> 1, round = stage & 1;
+        __syncthreads();          // tile / previous stage no longer read
+        if ((q >> 1) == round) {
+            int* dst = &epi[(16 * j) * kMfEpiPitch + 4 * (q & 1)];
+            if (mb == 0) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) *reinterpret_cast<v4i*>(dst + c * kMfEpiPitch) = acc[0][c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) *reinterpret_cast<v4i*>(dst + c * kMfEpiPitch) = acc[MB - 1][c];
+            }
+        }
+        __syncthreads();
+        if (y >= p.oh) continue;
+#pragma unroll 1
+        for (int s8 = 0; s8 < 8; ++s8) {
+            // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
+            // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
+            const int li = (tg * MB + mb) * 16 + 8 * round + s8;
+            if (li >= p.n_list) break;                                  // wave-uniform
+            if (p.only_li >= 0 && li != p.only_li) continue;
+            const TemplDev T = td[tlist[li]];
+            float* orow = maps + T.map_off + (size_t)y * T.map_pitch;
+            const double kfix = T.mfma_k;
+#pragma unroll 1
+            for (int it = 0; it < kMfSeg / 64; ++it) {
+                const int xl = it * 64 + lane;
+                const int x = x0 + xl;
+                if (x < p.ow) {
+                    const size_t sidx = (size_t)y * st.pitch + x;
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < kMaxChans; ++cc)
+                        if (cc < p.chans) s1 += st.t[cc][sidx];
+                    const double corr = ((double)epi[xl * kMfEpiPitch + s8] + 128.0 * s1) + kfix;
+                    orow[x] = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mtm

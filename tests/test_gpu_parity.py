@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 G = load_golden()
 REF = G["reference_run"]
-KERNELS = {"naive": 1, "dot4": 2, "auto": 0}
+KERNELS = {"naive": 1, "dot4": 2, "mfma": 3, "auto": 0}
 
 
 @pytest.fixture(scope="module")
@@ -62,7 +62,7 @@ def otsu_mask(small):
 # ------------------------------------------------------------------------------------------------
 # score maps
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["naive", "dot4"])
+@pytest.mark.parametrize("kernel", ["naive", "dot4", "mfma"])
 @pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])
 def test_score_map_coins_u8(mtm, ctx, coins, method, kernel):
     set_kernel(ctx, kernel)
@@ -100,7 +100,7 @@ def test_score_map_float32_uint16_rgb(mtm, ctx, coins, method):
               O.compute_score_map(imf[14:73, 302:367], imf, method), tol=1e-5)
     rgb = np.stack([coins, np.roll(coins, 3, axis=1), 255 - coins], axis=2)
     t = np.ascontiguousarray(rgb[37:75, 80:121])
-    for kernel in ("naive", "dot4"):
+    for kernel in ("naive", "dot4", "mfma"):
         set_kernel(ctx, kernel)
         try:
             map_close(mtm.computeScoreMap(t, rgb, method), O.compute_score_map(t, rgb, method), tol=1e-6)
@@ -132,7 +132,7 @@ def test_score_map_shapes(mtm, ctx, shape, tshape):
     t = np.ascontiguousarray(img[y0:y0 + tshape[0], x0:x0 + tshape[1]])
     for method in (1, 3, 5):
         exp = O.compute_score_map(t, img, method)
-        for kernel in ("naive", "dot4"):
+        for kernel in ("naive", "dot4", "mfma"):
             set_kernel(ctx, kernel)
             try:
                 map_close(mtm.computeScoreMap(t, img, method), exp, tol=1e-6)
@@ -154,10 +154,10 @@ def test_guards(mtm):
 
 
 def test_dot4_variants_agree(mtm, ctx):
-    img, units, _ = synth.make_workload(seed=21, image_hw=(300, 700), n_base=7, templ=48)
+    img, units, _ = synth.make_workload(seed=21, image_hw=(400, 900), n_base=7, templ=48)
     ctx.set_image(img)
     ctx.set_templates([(u[1], None) for u in units], 5)
-    shape = (300 - 48 + 1, 700 - 48 + 1)
+    shape = (400 - 48 + 1, 900 - 48 + 1)
     set_kernel(ctx, "naive")
     base = [ctx.score_map(i, shape) for i in range(len(units))]
     set_kernel(ctx, "dot4")
@@ -169,9 +169,45 @@ def test_dot4_variants_agree(mtm, ctx):
             assert len(hits) == 4 * len(units), (v, len(hits))
             for i in range(len(units)):
                 assert np.array_equal(ctx.score_map(i, shape), base[i]), (v, i)
+        set_kernel(ctx, "mfma")
+        hits = ctx.find_matches(0, 0.5)
+        assert len(hits) == 4 * len(units) and ctx.timing()["kernel_used"] == 3
+        for i in range(len(units)):
+            assert np.array_equal(ctx.score_map(i, shape), base[i]), ("mfma", i)
     finally:
         ctx.set_option(4, 0)
         set_kernel(ctx, "auto")
+
+
+@pytest.mark.parametrize("n_templ,side,method", [(37, 24, 5), (16, 40, 3), (17, 33, 1), (70, 16, 5)])
+def test_mfma_template_groups(mtm, ctx, n_templ, side, method):
+    """MFMA kernel: 16-template groups (MB = 1 and 2), partial last group, several groups, sizes
+    that are not multiples of 16/64; batched hits and single maps against the naive kernel."""
+    img = synth.rand_u8(31, 0, (260, 610))
+    rng = np.random.default_rng(n_templ)
+    units = []
+    for i in range(n_templ):
+        y, x = int(rng.integers(0, 260 - side)), int(rng.integers(0, 610 - side))
+        units.append(("t%d" % i, np.ascontiguousarray(img[y:y + side, x:x + side])))
+    thr = {5: 0.6, 3: 0.95, 1: 0.2}[method]
+    res = {}
+    for kernel in ("naive", "mfma", "dot4"):
+        set_kernel(ctx, kernel)
+        try:
+            res[kernel] = mtm.findMatches(units, img, method=method, score_threshold=thr)
+            if kernel != "naive":
+                for i in (0, n_templ // 2, n_templ - 1):
+                    set_kernel(ctx, "naive")
+                    a = mtm.computeScoreMap(units[i][1], img, method)
+                    set_kernel(ctx, kernel)
+                    b = mtm.computeScoreMap(units[i][1], img, method)
+                    assert np.array_equal(a, b), (kernel, i)
+        finally:
+            set_kernel(ctx, "auto")
+    assert len(res["naive"]) >= n_templ
+    assert res["mfma"] == res["naive"] and res["dot4"] == res["naive"]
+    exp = O.find_matches(units[:3], img, method=method, score_threshold=thr)
+    assert_hits_equal([h for h in res["mfma"] if h[0] in ("t0", "t1", "t2")], hits_json(exp), tol=1e-6)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -352,4 +388,13 @@ def test_cfg3_size_properties(mtm, ctx):
     rot = sorted((h[0], (h[1][1], W - h[1][0] - h[1][2], h[1][3], h[1][2]), round(float(h[2]), 5)) for h in a)
     assert rot == sorted((h[0], h[1], round(float(h[2]), 5)) for h in b)
     t = ctx.timing()
-    assert t["kernel_used"] == 2 and t["ncc_launches"] >= 1
+    assert t["kernel_used"] in (2, 3) and t["ncc_launches"] >= 1
+    # the MFMA and dot4 kernels produce the same hits at full size
+    res = {}
+    for kernel in ("dot4", "mfma"):
+        set_kernel(ctx, kernel)
+        try:
+            res[kernel] = mtm.matchTemplates(units, img, score_threshold=0.5)
+        finally:
+            set_kernel(ctx, "auto")
+    assert res["dot4"] == res["mfma"] == hits
