@@ -444,8 +444,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.ntg = 1;
         }
         p.n_work = p.nseg * p.nyb * p.ntg;
-        const size_t lds = std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
-                                            (size_t)kMfRows * kMfEpiBytesPerWave);
+        const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
+                                                  (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
+        p.tc_off = (int)lds_main;
+        const size_t lds = lds_main + sizeof(MfTemplConst) * 32;
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
@@ -454,10 +456,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.n_list = n_all - tg0 * 16 * mb;
         if (only_li >= 0) p.only_li = only_li - tg0 * 16 * mb;
         const int* tl_k = tl_class + tg0 * 16 * mb;
-        if (mb == 2)
-            hipLaunchKernelGGL(ncc_mfma_kernel<2>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
-        else
-            hipLaunchKernelGGL(ncc_mfma_kernel<1>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        const bool c1 = c->chans == 1;
+        auto fn = mb == 2 ? (c1 ? ncc_mfma_kernel<2, true> : ncc_mfma_kernel<2, false>)
+                          : (c1 ? ncc_mfma_kernel<1, true> : ncc_mfma_kernel<1, false>);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
         c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;

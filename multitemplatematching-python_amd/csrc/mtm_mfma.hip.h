@@ -54,7 +54,45 @@ struct MfmaParams {
     int lds_pitch;           // bytes per LDS tile row: (16 + 4*nb + 1) * 16
     long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
+    int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
 };
+
+// Per-template constants staged in LDS once per work-group (the epilogue reads them with LDS
+// broadcasts instead of dependent scalar loads per template).
+struct MfTemplConst {
+    double mean[kMaxChans];
+    double templ_norm, templ_sum2, mfma_k;
+    long long map_off;
+    int map_pitch, all_ones;
+};
+
+// finish_unmasked on values already in registers (same arithmetic, same order).
+__device__ __forceinline__ float finish_vals(int method, double corr, const double (&t)[kMaxChans], double sum2,
+                                             double sq, const MfTemplConst& T, int chans) {
+    if (T.all_ones) return 1.0f;
+    if (method == MTM_TM_CCORR) return (float)corr;
+    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    const bool normed = (method == MTM_TM_SQDIFF_NORMED) || (method == MTM_TM_CCORR_NORMED) ||
+                        (method == MTM_TM_CCOEFF_NORMED);
+    double num = corr;
+    if (num_type == 1) {
+#pragma unroll
+        for (int c = 0; c < kMaxChans; ++c)
+            if (c < chans) num -= t[c] * T.mean[c];
+    } else if (num_type == 2) {
+        num = sum2 - 2.0 * num + T.templ_sum2;
+        num = fmax(num, 0.0);
+    }
+    if (normed) {
+        const double tt = sq * T.templ_norm;
+        const double an = fabs(num);
+        if (an < tt) num = num / tt;
+        else if (an < tt * 1.125) num = (num > 0.0) ? 1.0 : -1.0;
+        else num = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
+    }
+    return (float)num;
+}
 
 // One K step: 16 phases x MB template groups, operands already in registers.
 template <int MB>
@@ -85,7 +123,7 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
     }
 }
 
-template <int MB>
+template <int MB, bool C1>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
@@ -107,6 +145,25 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[mb][c] = v4i{0, 0, 0, 0};
+
+    // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
+    MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
+    if (threadIdx.x < 16 * MB) {
+        const int li = tg * MB * 16 + threadIdx.x;
+        if (li < p.n_list) {
+            const TemplDev& T = td[tlist[li]];
+            MfTemplConst k;
+#pragma unroll
+            for (int cc = 0; cc < kMaxChans; ++cc) k.mean[cc] = T.mean[cc];
+            k.templ_norm = T.templ_norm;
+            k.templ_sum2 = T.templ_sum2;
+            k.mfma_k = T.mfma_k;
+            k.map_off = T.map_off;
+            k.map_pitch = T.map_pitch;
+            k.all_ones = T.all_ones;
+            tcl[threadIdx.x] = k;
+        }
+    }
 
     const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
     const int tile_dw_per_row = p.lds_pitch >> 2;
@@ -174,10 +231,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     }
 
     // ---- epilogue: per wave, 8 templates at a time through LDS ([pixel][8 templates] int32).
-    // The stage loop is rolled (one copy of the float64 normalisation in the binary); the
-    // accumulator block of a stage is selected by a wave-uniform switch with static indices.
+    // The per-pixel statistics of the wave's 256 pixels are loaded ONCE into registers (they do
+    // not depend on the template); per-template constants come from LDS.  The stage loop is rolled
+    // (one copy of the float64 normalisation in the binary); the accumulator block of a stage is
+    // selected by a wave-uniform branch with static register indices.
     const int y = y0 + wave;
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
+    double pt[C1 ? 4 : 1][kMaxChans], psum2[C1 ? 4 : 1], psq[C1 ? 4 : 1];
+    if (C1 && y < p.oh) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int x = min(x0 + it * 64 + lane, p.ow - 1);
+            const size_t sidx = (size_t)y * st.pitch + x;
+            pt[it][0] = st.t[0][sidx];
+            pt[it][1] = pt[it][2] = pt[it][3] = 0.0;
+            psum2[it] = st.sum2[sidx];
+            psq[it] = st.sq[sidx];
+        }
+    }
 #pragma unroll 1
     for (int stage = 0; stage < 2 * MB; ++stage) {
         const int mb = stage >> 1, round = stage & 1;
@@ -198,24 +269,36 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         for (int s8 = 0; s8 < 8; ++s8) {
             // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
             // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
-            const int li = (tg * MB + mb) * 16 + 8 * round + s8;
-            if (li >= p.n_list) break;                                  // wave-uniform
+            const int lt = mb * 16 + 8 * round + s8;            // template inside this work item
+            const int li = tg * MB * 16 + lt;
+            if (li >= p.n_list) break;                          // wave-uniform
             if (p.only_li >= 0 && li != p.only_li) continue;
-            const TemplDev T = td[tlist[li]];
+            const MfTemplConst T = tcl[lt];
             float* orow = maps + T.map_off + (size_t)y * T.map_pitch;
-            const double kfix = T.mfma_k;
-#pragma unroll 1
+#pragma unroll
             for (int it = 0; it < kMfSeg / 64; ++it) {
                 const int xl = it * 64 + lane;
                 const int x = x0 + xl;
                 if (x < p.ow) {
-                    const size_t sidx = (size_t)y * st.pitch + x;
-                    double s1 = 0.0;
+                    const int a32 = epi[xl * kMfEpiPitch + s8];
+                    float out;
+                    if (C1) {
+                        const double corr = ((double)a32 + 128.0 * pt[it][0]) + T.mfma_k;
+                        out = finish_vals(p.method, corr, pt[it], psum2[it], psq[it], T, 1);
+                    } else {
+                        const size_t sidx = (size_t)y * st.pitch + x;
+                        double tv[kMaxChans] = {0.0, 0.0, 0.0, 0.0};
+                        double s1 = 0.0;
 #pragma unroll
-                    for (int cc = 0; cc < kMaxChans; ++cc)
-                        if (cc < p.chans) s1 += st.t[cc][sidx];
-                    const double corr = ((double)epi[xl * kMfEpiPitch + s8] + 128.0 * s1) + kfix;
-                    orow[x] = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
+                        for (int cc = 0; cc < kMaxChans; ++cc)
+                            if (cc < p.chans) {
+                                tv[cc] = st.t[cc][sidx];
+                                s1 += tv[cc];
+                            }
+                        const double corr = ((double)a32 + 128.0 * s1) + T.mfma_k;
+                        out = finish_vals(p.method, corr, tv, st.sum2[sidx], st.sq[sidx], T, p.chans);
+                    }
+                    orow[x] = out;
                 }
             }
         }
