@@ -80,6 +80,69 @@ __global__ void hsum_kernel(const float* __restrict__ img, int pitch, long long 
     }
 }
 
+// Horizontal box sums of one uint8 image row per work-group, through inclusive prefix sums held in
+// LDS (uint32, exact): fully coalesced global reads and writes.  Element i of the row is owned by
+// thread i % 256 in round i / 256; each round is a 256-wide block scan (wave shuffles + one LDS
+// exchange) plus the carry of the previous rounds.  Used for uint8 images up to 8191 columns; the
+// generic hsum_kernel above covers the rest.
+__global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict__ img, int pitch, long long plane,
+                                                      int cols, int w, int ow, uint32_t* __restrict__ hs1,
+                                                      uint32_t* __restrict__ hs2, int hs_pitch, long long hs_plane) {
+    extern __shared__ uint32_t pre[];            // P1[cols + 1], P2[cols + 1]
+    __shared__ uint32_t wsum[2][4];
+    uint32_t* P1 = pre;
+    uint32_t* P2 = pre + cols + 1;
+    const int y = blockIdx.x, c = blockIdx.y;
+    const uint8_t* row = img + c * plane + (size_t)y * pitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        P1[0] = 0;
+        P2[0] = 0;
+    }
+    uint32_t carry1 = 0, carry2 = 0;
+    for (int base = 0; base < cols; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < cols ? row[i] : 0u;
+        uint32_t a = v, b = v * v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ua = __shfl_up(a, off), ub = __shfl_up(b, off);
+            if (lane >= off) {
+                a += ua;
+                b += ub;
+            }
+        }
+        if (lane == 63) {
+            wsum[0][wave] = a;
+            wsum[1][wave] = b;
+        }
+        __syncthreads();
+        uint32_t oa = carry1, ob = carry2, ta = 0, tb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < wave) {
+                oa += wsum[0][k];
+                ob += wsum[1][k];
+            }
+            ta += wsum[0][k];
+            tb += wsum[1][k];
+        }
+        if (i < cols) {
+            P1[i + 1] = a + oa;
+            P2[i + 1] = b + ob;
+        }
+        carry1 += ta;
+        carry2 += tb;
+        __syncthreads();
+    }
+    uint32_t* o1 = hs1 + c * hs_plane + (size_t)y * hs_pitch;
+    uint32_t* o2 = hs2 + c * hs_plane + (size_t)y * hs_pitch;
+    for (int x = threadIdx.x; x < ow; x += 256) {
+        o1[x] = P1[x + w] - P1[x];
+        o2[x] = P2[x + w] - P2[x];
+    }
+}
+
 constexpr int kVsumBand = 32;
 
 template <typename AccT, typename SumT>
@@ -526,7 +589,46 @@ __global__ __launch_bounds__(256) void ncc_dot4_kernel(DotParams p, const TemplD
 // appended to a global hit buffer; `nontrivial[t]` records that some pixel differs from its local
 // max (skimage returns no peak at all for a map where none does).
 // ---------------------------------------------------------------------------------------------
-constexpr int kPkTW = 64, kPkTH = 16;
+// One wave owns a strip of 256 columns x kPkRows rows and walks it top to bottom: per row one
+// coalesced float4 load per lane (4 pixels), the horizontal neighbours come from the adjacent
+// lanes by shuffle (strip edges: two scalar loads), three rows of horizontal 3-maxima stay in
+// registers.  A work-group is 4 such strips stacked vertically.
+constexpr int kPkCols = 256, kPkRows = 32;
+
+__device__ __forceinline__ void peaks_load_row(const float* __restrict__ m, int pitch, int oh, int ow, int y, int xb,
+                                               int lane, bool mode_min, float padv, float (&v)[4], float& hl,
+                                               float& hr) {
+    // v[k] = value of pixel (y, xb + k); hl / hr = pixels xb - 1 and xb + 4; everything outside the
+    // map is the pad value
+    if (y < 0 || y >= oh) {
+        v[0] = v[1] = v[2] = v[3] = hl = hr = padv;
+        return;
+    }
+    const float* r = m + (size_t)y * pitch;
+    if (xb + 3 < ow) {
+        const float4 q4 = *reinterpret_cast<const float4*>(r + xb);
+        v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (xb + k < ow) ? r[xb + k] : padv;
+    }
+    if (mode_min) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (xb + k < ow) ? -v[k] : padv;
+    }
+    // neighbours across lanes
+    const float left = __shfl_up(v[3], 1), right = __shfl_down(v[0], 1);
+    hl = left;
+    hr = right;
+    if (lane == 0) {
+        const int x = xb - 1;
+        hl = (x >= 0) ? (mode_min ? -r[x] : r[x]) : padv;
+    }
+    if (lane == 63) {
+        const int x = xb + 4;
+        hr = (x < ow) ? (mode_min ? -r[x] : r[x]) : padv;
+    }
+}
 
 __global__ __launch_bounds__(256) void peaks_kernel(const float* __restrict__ maps,
                                                     const TemplDev* __restrict__ td,
@@ -535,50 +637,62 @@ __global__ __launch_bounds__(256) void peaks_kernel(const float* __restrict__ ma
                                                     unsigned long long cap,
                                                     unsigned long long* __restrict__ counter,
                                                     int* __restrict__ nontrivial) {
-    __shared__ float tile[(kPkTH + 2) * (kPkTW + 2)];
     const int t = tlist[blockIdx.z];
     const TemplDev T = td[t];
-    const int tx0 = blockIdx.x * kPkTW, ty0 = blockIdx.y * kPkTH;
-    if (tx0 >= T.ow || ty0 >= T.oh) return;
-    const float* m = maps + T.map_off;
-    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
-    for (int idx = threadIdx.x; idx < (kPkTH + 2) * (kPkTW + 2); idx += 256) {
-        const int ly = idx / (kPkTW + 2), lx = idx - ly * (kPkTW + 2);
-        const int gy = ty0 + ly - 1, gx = tx0 + lx - 1;
-        float v = padv;
-        if (gy >= 0 && gy < T.oh && gx >= 0 && gx < T.ow) {
-            v = m[(size_t)gy * T.map_pitch + gx];
-            if (mode_min) v = -v;
-        }
-        tile[idx] = v;
-    }
-    __syncthreads();
-    const float thr2 = mode_min ? -thr : thr;
-    const int px = threadIdx.x & 63, py0 = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xs = blockIdx.x * kPkCols;
+    const int y0 = (blockIdx.y * 4 + wave) * kPkRows;
     int nontriv = 0;
+    if (xs < T.ow && y0 < T.oh) {
+        const float* m = maps + T.map_off;
+        const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+        const float thr2 = mode_min ? -thr : thr;
+        const int xb = xs + 4 * lane;
+        // hm_*[k] = max over columns xb+k-1 .. xb+k+1 of one row; c_* = the row's own values
+        float va[4], vb[4], vc[4], hl, hr;
+        float hm_a[4], hm_b[4], hm_c[4];
+        auto hmax = [](const float (&v)[4], float hl, float hr, float (&h)[4]) {
+            h[0] = fmaxf(fmaxf(hl, v[0]), v[1]);
+            h[1] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+            h[2] = fmaxf(fmaxf(v[1], v[2]), v[3]);
+            h[3] = fmaxf(fmaxf(v[2], v[3]), hr);
+        };
+        peaks_load_row(m, T.map_pitch, T.oh, T.ow, y0 - 1, xb, lane, mode_min, padv, va, hl, hr);
+        hmax(va, hl, hr, hm_a);
+        peaks_load_row(m, T.map_pitch, T.oh, T.ow, y0, xb, lane, mode_min, padv, vb, hl, hr);
+        hmax(vb, hl, hr, hm_b);
+        const int y1 = min(y0 + kPkRows, T.oh);
+        for (int y = y0; y < y1; ++y) {
+            peaks_load_row(m, T.map_pitch, T.oh, T.ow, y + 1, xb, lane, mode_min, padv, vc, hl, hr);
+            hmax(vc, hl, hr, hm_c);
 #pragma unroll
-    for (int i = 0; i < kPkTH / 4; ++i) {
-        const int py = py0 + 4 * i;
-        const int gx = tx0 + px, gy = ty0 + py;
-        if (gx >= T.ow || gy >= T.oh) continue;
-        const float* c = &tile[(py + 1) * (kPkTW + 2) + px + 1];
-        const float v = c[0];
-        float mx = fmaxf(fmaxf(c[-(kPkTW + 2) - 1], c[-(kPkTW + 2)]), c[-(kPkTW + 2) + 1]);
-        mx = fmaxf(mx, fmaxf(c[-1], c[1]));
-        mx = fmaxf(mx, fmaxf(fmaxf(c[(kPkTW + 2) - 1], c[kPkTW + 2]), c[(kPkTW + 2) + 1]));
-        mx = fmaxf(mx, v);
-        if (!(v == mx)) nontriv = 1;
-        else if (v > thr2) {
-            const unsigned long long slot = atomicAdd(counter, 1ull);
-            if (slot < cap) {
-                mtm_hit hrec;
-                hrec.templ_idx = t;
-                hrec.x = gx;
-                hrec.y = gy;
-                hrec.w = T.cols;
-                hrec.h = T.rows;
-                hrec.score = mode_min ? -v : v;
-                hits[slot] = hrec;
+            for (int k = 0; k < 4; ++k) {
+                const int x = xb + k;
+                if (x < T.ow) {
+                    const float v = vb[k];
+                    const float mx = fmaxf(fmaxf(hm_a[k], hm_b[k]), hm_c[k]);
+                    if (!(v == mx)) {
+                        nontriv = 1;
+                    } else if (v > thr2) {
+                        const unsigned long long slot = atomicAdd(counter, 1ull);
+                        if (slot < cap) {
+                            mtm_hit hrec;
+                            hrec.templ_idx = t;
+                            hrec.x = x;
+                            hrec.y = y;
+                            hrec.w = T.cols;
+                            hrec.h = T.rows;
+                            hrec.score = mode_min ? -v : v;
+                            hits[slot] = hrec;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vb[k] = vc[k];
+                hm_a[k] = hm_b[k];
+                hm_b[k] = hm_c[k];
             }
         }
     }

@@ -132,7 +132,7 @@ struct mtm_ctx {
     int opt_border = MTM_BORDER_CONSTANT;
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
-    int auto_kernel = MTM_KERNEL_DOT4;   // what MTM_KERNEL_AUTO resolves to for uint8 classes
+    int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};
 
@@ -338,7 +338,8 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     StatPlanes st{};
     st.pitch = (int)round_up((size_t)ow, 4);
     *out = st;
-    const bool want_t_always = sc.mfma_ok && c->opt_kernel != MTM_KERNEL_NAIVE && c->opt_kernel != MTM_KERNEL_DOT4;
+    const int resolved = c->opt_kernel == MTM_KERNEL_AUTO ? c->auto_kernel : c->opt_kernel;
+    const bool want_t_always = sc.mfma_ok && resolved == MTM_KERNEL_MFMA;
     if (sc.masked || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // no statistics needed
     const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
                        : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
@@ -363,9 +364,14 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     const int want_t = (num_type == 1 || want_t_always) ? 1 : 0;
     const double inv_area = 1.0 / ((double)h * (double)w);
     if (u8) {
-        hipLaunchKernelGGL(hsum_kernel<uint32_t>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
-                           img.f32_plane, c->rows, w, ow, c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(),
-                           hs_pitch, hs_plane);
+        if (c->cols <= 8191)
+            hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
+                               c->stream, img.u8, img.u8_pitch, img.u8_plane, c->cols, w, ow, c->hs1.as<uint32_t>(),
+                               c->hs2.as<uint32_t>(), hs_pitch, hs_plane);
+        else
+            hipLaunchKernelGGL(hsum_kernel<uint32_t>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
+                               img.f32_plane, c->rows, w, ow, c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(),
+                               hs_pitch, hs_plane);
         hipLaunchKernelGGL((vsum_stats_kernel<uint32_t, unsigned long long>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
                            ow, inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq,
@@ -828,7 +834,7 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
                 max_oh = std::max(max_oh, c->td_host[t].oh);
                 max_ow = std::max(max_ow, c->td_host[t].ow);
             }
-            const dim3 grd((max_ow + kPkTW - 1) / kPkTW, (max_oh + kPkTH - 1) / kPkTH, n2d);
+            const dim3 grd((max_ow + kPkCols - 1) / kPkCols, (max_oh + 4 * kPkRows - 1) / (4 * kPkRows), n2d);
             unsigned long long* counter = c->counters.as<unsigned long long>();
             int* flags = reinterpret_cast<int*>(counter + 1);
             hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
