@@ -132,6 +132,7 @@ struct mtm_ctx {
     int opt_border = MTM_BORDER_CONSTANT;
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
+    int mfma_dbg = 0;
     int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};
@@ -444,6 +445,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
         p.group_bytes = sc.group_bytes;
         p.only_li = only_li;
+        p.dbg = c->mfma_dbg;
         int tg0 = 0;
         if (only_li >= 0) {          // one template: just its group
             tg0 = only_li / (16 * mb);
@@ -573,6 +575,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         if (!std::strcmp(v, "mfma")) c->auto_kernel = MTM_KERNEL_MFMA;
         if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
     }
+    if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
         const int k = std::atoi(v);
         if (k >= 0 && k < kNumDotVariants && !kDotVariants[k].wide) c->dot_variant = k;

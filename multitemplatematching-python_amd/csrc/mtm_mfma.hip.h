@@ -55,6 +55,8 @@ struct MfmaParams {
     long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
     int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
+    int dbg;                 // profiling probes (MTM_MFMA_DBG): 1 cheap epilogue, 2 no epilogue, 4 frozen A
+                             // pointer, 8 no MFMA; results are only valid with dbg == 0
 };
 
 // Per-template constants staged in LDS once per work-group (the epilogue reads them with LDS
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #define MTM_MF_ADVANCE()                                            \
             if (req + 1 < nsteps) {                                 \
                 ++req;                                              \
-                aptr += 1024;                                       \
+                if (!(p.dbg & 4)) aptr += 1024;                     \
                 if (++nb_i == p.nb) {                               \
                     nb_i = 0;                                       \
                     loff += p.lds_pitch - (p.nb - 1) * 64;          \
@@ -217,12 +219,16 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 MTM_MF_ADVANCE()
                 MTM_MF_LOAD(qa1, qb1, a1)
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_step<MB>(acc, qa0, qb0, a0);
+                if (!(p.dbg & 8)) mfma_step<MB>(acc, qa0, qb0, a0);
+                else acc[0][0] += qa0 + qb0 + a0[0] + a0[MB - 1];
                 __builtin_amdgcn_sched_barrier(0);
                 MTM_MF_ADVANCE()
                 MTM_MF_LOAD(qa0, qb0, a0)
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks + 1 < nsteps) mfma_step<MB>(acc, qa1, qb1, a1);
+                if (ks + 1 < nsteps) {
+                    if (!(p.dbg & 8)) mfma_step<MB>(acc, qa1, qb1, a1);
+                    else acc[0][1] += qa1 + qb1 + a1[0] + a1[MB - 1];
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef MTM_MF_ADVANCE
@@ -237,6 +243,15 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // selected by a wave-uniform branch with static register indices.
     const int y = y0 + wave;
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
+    if (p.dbg & 2) {            // probe: no epilogue (keep the accumulators observable)
+        int sum = 0;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sum += acc[mb][c].x ^ acc[mb][c].y ^ acc[mb][c].z ^ acc[mb][c].w;
+        if (sum == 0x7fffffff) maps[0] = 1.0f;
+        return;
+    }
     double pt[C1 ? 4 : 1][kMaxChans], psum2[C1 ? 4 : 1], psq[C1 ? 4 : 1];
     if (C1 && y < p.oh) {
 #pragma unroll
@@ -282,7 +297,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 if (x < p.ow) {
                     const int a32 = epi[xl * kMfEpiPitch + s8];
                     float out;
-                    if (C1) {
+                    if (p.dbg & 1) {
+                        out = (float)a32;
+                    } else if (C1) {
                         const double corr = ((double)a32 + 128.0 * pt[it][0]) + T.mfma_k;
                         out = finish_vals(p.method, corr, pt[it], psum2[it], psq[it], T, 1);
                     } else {
