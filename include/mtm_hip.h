@@ -61,6 +61,8 @@ extern "C" {
 #define MTM_OPT_PEAK_BORDER 2
 #define MTM_OPT_HIT_CAPACITY 3
 #define MTM_OPT_DOT4_VARIANT 4  /* register-blocking variant of the dot4 kernel (tuning) */
+#define MTM_OPT_EXACT_DIV 5     /* 1: IEEE division in the MFMA epilogue (bit-identical to the other kernels);
+                                   0 (default): reciprocal multiplies, <= 1 ulp(float32) on ~1e-8 of the pixels */
 
 /* error codes */
 #define MTM_OK            0

@@ -125,7 +125,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -133,6 +133,11 @@ struct mtm_ctx {
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
     int mfma_dbg = 0;
+    int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
+    int mfma_persistent = 1;
+    int mfma_stagger = -1;     // < 0: automatic
+    int mfma_stagger_mode = 0;
+    int mfma_per_cu = 2;
     int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};
@@ -455,7 +460,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
-        const size_t lds = lds_main + sizeof(MfTemplConst) * 32;
+        const size_t lds = lds_main + sizeof(MfTemplConst) * 32 + 16;
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
@@ -464,10 +469,34 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.n_list = n_all - tg0 * 16 * mb;
         if (only_li >= 0) p.only_li = only_li - tg0 * 16 * mb;
         const int* tl_k = tl_class + tg0 * 16 * mb;
-        const bool c1 = c->chans == 1;
-        auto fn = mb == 2 ? (c1 ? ncc_mfma_kernel<2, true> : ncc_mfma_kernel<2, false>)
-                          : (c1 ? ncc_mfma_kernel<1, true> : ncc_mfma_kernel<1, false>);
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
+#define MTM_MF_ROW(MB, X) {ncc_mfma_kernel<MB, -1, X>, ncc_mfma_kernel<MB, 0, X>, ncc_mfma_kernel<MB, 1, X>, \
+                          ncc_mfma_kernel<MB, 2, X>, ncc_mfma_kernel<MB, 3, X>, ncc_mfma_kernel<MB, 4, X>,  \
+                          ncc_mfma_kernel<MB, 5, X>}
+        static const MfmaFn kMfmaFns[2][2][7] = {{MTM_MF_ROW(1, false), MTM_MF_ROW(2, false)},
+                                                 {MTM_MF_ROW(1, true), MTM_MF_ROW(2, true)}};
+#undef MTM_MF_ROW
+        const MfmaFn fn = kMfmaFns[c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
+        // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        p.persistent = c->mfma_persistent;
+        int grid_launch = grid;
+        if (p.persistent) {
+            int per_cu = 0;
+            HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+            hipDeviceProp_t prop;
+            HIPC(hipGetDeviceProperties(&prop, c->device));
+            per_cu = std::max(1, std::min(per_cu, c->mfma_per_cu));
+            p.stagger_mode = c->mfma_stagger_mode;
+            grid_launch = std::min(p.n_work, per_cu * prop.multiProcessorCount);
+            // one main loop is chans*h*nb*16*MB MFMAs of 16 cycles; s_sleep(127) is ~8128 cycles
+            const double main_cycles = (double)c->chans * h * p.nb * 16.0 * mb * 16.0;
+            p.stagger_sleeps = c->mfma_stagger >= 0 ? c->mfma_stagger : (int)(0.75 * main_cycles / 8128.0 + 0.5);
+            HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
+        }
+        hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
+                           c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
@@ -576,6 +605,11 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
     }
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
+    if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_STAGGER_MODE")) c->mfma_stagger_mode = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_PER_CU")) c->mfma_per_cu = std::atoi(v);
     if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
         const int k = std::atoi(v);
         if (k >= 0 && k < kNumDotVariants && !kDotVariants[k].wide) c->dot_variant = k;
@@ -590,7 +624,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
-                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->comm_send, &c->comm_recv})
+                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->comm_send, &c->comm_recv})
         b->release();
     for (auto& p : c->ncc_ev) {
         (void)hipEventDestroy(p.first);
@@ -616,6 +650,9 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
         case MTM_OPT_HIT_CAPACITY:
             if (value < 1) break;
             c->hit_cap = value;
+            return MTM_OK;
+        case MTM_OPT_EXACT_DIV:
+            c->exact_div = value ? 1 : 0;
             return MTM_OK;
         case MTM_OPT_DOT4_VARIANT:
             if (value < 0 || value >= kNumDotVariants || kDotVariants[value].wide) break;

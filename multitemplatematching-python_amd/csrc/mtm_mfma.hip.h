@@ -36,8 +36,14 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kMfSeg = 256;          // output pixels per wave (16 phases x 16 columns)
 constexpr int kMfRows = 4;           // output rows per work-group (one per wave)
 constexpr int kMfChunkH = 64;        // template rows per LDS tile
-constexpr int kMfEpiPitch = 12;      // dwords per pixel in the epilogue buffer (8 used)
-constexpr int kMfEpiBytesPerWave = kMfSeg * kMfEpiPitch * 4;
+// Epilogue buffer of one wave: [8 templates][kMfEpiPitch] int32.  Pixel column xl = 16 j + c is
+// stored at physical column 16 j + ((c + 4 * ((j >> 1) & 3)) & 15): 4-pixel groups stay contiguous
+// and 16-byte aligned (one ds_read_b128 per lane and template, conflict-free), while the
+// phase-strided ds_write_b32 of the MFMA C/D layout (lane = pixel column j) are at most 2-way
+// conflicting, which costs nothing for 4-byte LDS stores.  Pitch = 4 (mod 8) dwords.
+constexpr int kMfEpiPitch = 260;
+constexpr int kMfEpiBytesPerWave = 8 * kMfEpiPitch * 4;
+__device__ __forceinline__ int mf_epi_rot(int j) { return 4 * ((j >> 1) & 3); }
 
 struct MfmaParams {
     const uint8_t* img;      // planar padded u8
@@ -55,6 +61,10 @@ struct MfmaParams {
     long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
     int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
+    int persistent;          // 1: work items are pulled from *work_counter (grid = resident blocks)
+    int stagger_sleeps;      // s_sleep(127) count of the second block on a CU before its first item
+    int stagger_mode;        // how "second block on a CU" is guessed: 0 per-CU arrival counter (HW_ID),
+                             // 1 upper half of the grid, 2 bit 3 of the block index
     int dbg;                 // profiling probes (MTM_MFMA_DBG): 1 cheap epilogue, 2 no epilogue, 4 frozen A
                              // pointer, 8 no MFMA; results are only valid with dbg == 0
 };
@@ -64,13 +74,19 @@ struct MfmaParams {
 struct MfTemplConst {
     double mean[kMaxChans];
     double templ_norm, templ_sum2, mfma_k;
+    double rtempl_norm;      // 1 / templ_norm (0 when templ_norm == 0)
     long long map_off;
     int map_pitch, all_ones;
 };
 
-// finish_unmasked on values already in registers (same arithmetic, same order).
-__device__ __forceinline__ float finish_vals(int method, double corr, const double (&t)[kMaxChans], double sum2,
+// finish_unmasked on values already in registers (same arithmetic, same order).  METHOD >= 0 fixes
+// the matching method at compile time: the per-output code is then branch-free apart from the
+// data-dependent normalisation cases (the runtime-method version spends most of its time in
+// wave-uniform scalar branches).
+template <int METHOD>
+__device__ __forceinline__ float finish_vals(int method_rt, double corr, const double (&t)[kMaxChans], double sum2,
                                              double sq, const MfTemplConst& T, int chans) {
+    const int method = METHOD >= 0 ? METHOD : method_rt;
     if (T.all_ones) return 1.0f;
     if (method == MTM_TM_CCORR) return (float)corr;
     const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
@@ -89,11 +105,35 @@ __device__ __forceinline__ float finish_vals(int method, double corr, const doub
     if (normed) {
         const double tt = sq * T.templ_norm;
         const double an = fabs(num);
-        if (an < tt) num = num / tt;
-        else if (an < tt * 1.125) num = (num > 0.0) ? 1.0 : -1.0;
-        else num = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
+        const double other = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
+        const double sat = (an < tt * 1.125) ? ((num > 0.0) ? 1.0 : -1.0) : other;
+        num = (an < tt) ? num / tt : sat;
     }
     return (float)num;
+}
+
+// Lean single-channel epilogue with the method fixed at compile time.  Same quantities and the same
+// case analysis as finish_unmasked / OpenCV's common_matchTemplate; the exact integer correlation is
+// rebuilt from the biased MFMA accumulator (a32 + 128*S1 + K, all exact in float64).  EXACT_DIV keeps
+// the IEEE division num / t (bit-identical to the other kernels and to the oracle); otherwise the
+// quotient is num * (1/sq) * (1/templ_norm) with both reciprocals correctly rounded: <= 2 ulp(double)
+// from the exact quotient, i.e. the float32 result differs in the last bit for ~1e-8 of the pixels.
+template <int METHOD, bool EXACT_DIV>
+__device__ __forceinline__ float finish_lean(int a32, double s1, double p1, double sum2, double sq, double rsq,
+                                             const MfTemplConst& T) {
+    constexpr bool normed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
+                            METHOD == MTM_TM_CCOEFF_NORMED;
+    const double corr = (double)a32 + (p1 + T.mfma_k);
+    double num = corr;
+    if (METHOD == MTM_TM_CCOEFF || METHOD == MTM_TM_CCOEFF_NORMED) num = corr - s1 * T.mean[0];
+    if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
+    if (!normed) return (float)num;
+    const double tt = sq * T.templ_norm;
+    const double an = fabs(num);
+    const float qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
+    const float satf = (num > 0.0) ? 1.0f : -1.0f;
+    const float other = (METHOD == MTM_TM_SQDIFF_NORMED) ? 1.0f : 0.0f;
+    return (an < tt) ? qf : ((an < tt * 1.125) ? satf : other);
 }
 
 // One K step: 16 phases x MB template groups, operands already in registers.
@@ -125,18 +165,53 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
     }
 }
 
-template <int MB, bool C1>
+// METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
+// count, runtime method).
+template <int MB, int METHOD, bool EXACT_DIV>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
-                                                          StatPlanes st, float* __restrict__ maps) {
+                                                          StatPlanes st, float* __restrict__ maps,
+                                                          unsigned int* __restrict__ sched) {
+    constexpr bool C1 = METHOD >= 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
 
+    // ---- scheduling.  Persistent mode: the grid is the number of co-resident work-groups and
+    // items are pulled from an atomic counter (sched[0]).  The MFMA main loop and the float64
+    // epilogue of an item use different pipes; two work-groups that share a CU overlap them only
+    // if they are out of phase, so the second work-group to arrive on a CU (per-CU arrival counter
+    // sched[1 + cu]) sleeps for about one main loop before its first item.  Placement only
+    // affects speed, never results.
+    int* s_item = reinterpret_cast<int*>(smem + p.tc_off + 32 * (int)sizeof(MfTemplConst));
+    if (p.persistent) {
+        if (threadIdx.x == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+            const unsigned cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            int late = (int)(atomicAdd(&sched[1 + cu], 1u) & 1u);
+            if (p.stagger_mode == 1) late = blockIdx.x >= (gridDim.x >> 1);
+            if (p.stagger_mode == 2) late = (blockIdx.x >> 3) & 1;
+            s_item[1] = late;
+        }
+        __syncthreads();
+        if (s_item[1])
+            for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int per_xcd = (p.n_work + 7) >> 3;
-    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (wid >= p.n_work) return;
+    for (int iter = 0;; ++iter) {
+    int wid;
+    if (p.persistent) {
+        __syncthreads();                       // previous item fully done (s_item / LDS reuse)
+        if (threadIdx.x == 0) s_item[0] = (int)atomicAdd(&sched[0], 1u);
+        __syncthreads();
+        wid = s_item[0];
+    } else {
+        if (iter > 0) break;
+        wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    }
+    if (wid >= p.n_work) break;
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
@@ -160,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.templ_norm = T.templ_norm;
             k.templ_sum2 = T.templ_sum2;
             k.mfma_k = T.mfma_k;
+            k.rtempl_norm = T.templ_norm > 0.0 ? 1.0 / T.templ_norm : 0.0;
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
@@ -236,11 +312,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
 
-    // ---- epilogue: per wave, 8 templates at a time through LDS ([pixel][8 templates] int32).
-    // The per-pixel statistics of the wave's 256 pixels are loaded ONCE into registers (they do
-    // not depend on the template); per-template constants come from LDS.  The stage loop is rolled
-    // (one copy of the float64 normalisation in the binary); the accumulator block of a stage is
-    // selected by a wave-uniform branch with static register indices.
+    // ---- epilogue: per wave, 8 templates at a time through LDS ([8 templates][pixel] int32).
+    // A lane owns 4 consecutive pixels: their statistics are loaded ONCE into registers (they do
+    // not depend on the template), per-template constants come from LDS, every (lane, template)
+    // pair is one ds_read_b128, four normalisations and one float4 store.  The stage loop is
+    // rolled (one copy of the float64 normalisation in the binary).  The buffer of a wave is
+    // private to it: LDS executes a wave's instructions in order, so no work-group barrier is
+    // needed between the stages.
     const int y = y0 + wave;
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
     if (p.dbg & 2) {            // probe: no epilogue (keep the accumulators observable)
@@ -250,59 +328,72 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
             for (int c = 0; c < 16; ++c) sum += acc[mb][c].x ^ acc[mb][c].y ^ acc[mb][c].z ^ acc[mb][c].w;
         if (sum == 0x7fffffff) maps[0] = 1.0f;
-        return;
+        continue;
     }
-    double pt[C1 ? 4 : 1][kMaxChans], psum2[C1 ? 4 : 1], psq[C1 ? 4 : 1];
+    constexpr bool kNeedSum2 = METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED;
+    constexpr bool kNormed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
+                             METHOD == MTM_TM_CCOEFF_NORMED;
+    const int xq = x0 + 4 * lane;                       // first of this lane's 4 pixels
+    double ps1[C1 ? 4 : 1], pp1[C1 ? 4 : 1], psum2[C1 ? 4 : 1], psq[C1 ? 4 : 1], prsq[C1 ? 4 : 1];
     if (C1 && y < p.oh) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int x = min(x0 + it * 64 + lane, p.ow - 1);
+        for (int i = 0; i < 4; ++i) {
+            const int x = min(xq + i, p.ow - 1);
             const size_t sidx = (size_t)y * st.pitch + x;
-            pt[it][0] = st.t[0][sidx];
-            pt[it][1] = pt[it][2] = pt[it][3] = 0.0;
-            psum2[it] = st.sum2[sidx];
-            psq[it] = st.sq[sidx];
+            ps1[i] = st.t[0][sidx];
+            pp1[i] = 128.0 * ps1[i];
+            psum2[i] = kNeedSum2 ? st.sum2[sidx] : 0.0;
+            psq[i] = kNormed ? st.sq[sidx] : 0.0;
+            prsq[i] = (kNormed && !EXACT_DIV && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
         }
     }
+    __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+    const int rd_off = 16 * (lane >> 2) + ((4 * (lane & 3) + mf_epi_rot(lane >> 2)) & 15);
 #pragma unroll 1
     for (int stage = 0; stage < 2 * MB; ++stage) {
         const int mb = stage >> 1, round = stage & 1;
-        __syncthreads();          // tile / previous stage no longer read
         if ((q >> 1) == round) {
-            int* dst = &epi[(16 * j) * kMfEpiPitch + 4 * (q & 1)];
-            if (mb == 0) {
+            // registers e = 0..3 of phase c hold templates 4 (q & 1) + e of this stage, pixel 16 j + c
+            int* dst = &epi[(4 * (q & 1)) * kMfEpiPitch + 16 * j];
+            const int rot = mf_epi_rot(j);
+            auto put = [&](const v4i (&blk)[16]) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) *reinterpret_cast<v4i*>(dst + c * kMfEpiPitch) = acc[0][c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) *reinterpret_cast<v4i*>(dst + c * kMfEpiPitch) = acc[MB - 1][c];
-            }
+                for (int c = 0; c < 16; ++c) {
+                    const int col = (c + rot) & 15;
+                    dst[0 * kMfEpiPitch + col] = blk[c].x;
+                    dst[1 * kMfEpiPitch + col] = blk[c].y;
+                    dst[2 * kMfEpiPitch + col] = blk[c].z;
+                    dst[3 * kMfEpiPitch + col] = blk[c].w;
+                }
+            };
+            if (mb == 0) put(acc[0]);
+            else put(acc[MB - 1]);
         }
-        __syncthreads();
-        if (y >= p.oh) continue;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS writes above, reads below
+        __builtin_amdgcn_wave_barrier();
+        if (y < p.oh && xq < p.ow) {
 #pragma unroll 1
-        for (int s8 = 0; s8 < 8; ++s8) {
-            // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
-            // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
-            const int lt = mb * 16 + 8 * round + s8;            // template inside this work item
-            const int li = tg * MB * 16 + lt;
-            if (li >= p.n_list) break;                          // wave-uniform
-            if (p.only_li >= 0 && li != p.only_li) continue;
-            const MfTemplConst T = tcl[lt];
-            float* orow = maps + T.map_off + (size_t)y * T.map_pitch;
+            for (int s8 = 0; s8 < 8; ++s8) {
+                // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
+                // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
+                const int lt = mb * 16 + 8 * round + s8;            // template inside this work item
+                const int li = tg * MB * 16 + lt;
+                if (li >= p.n_list) break;                          // wave-uniform
+                if (p.only_li >= 0 && li != p.only_li) continue;
+                const MfTemplConst T = tcl[lt];
+                const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
+                const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+                float out[4];
 #pragma unroll
-            for (int it = 0; it < kMfSeg / 64; ++it) {
-                const int xl = it * 64 + lane;
-                const int x = x0 + xl;
-                if (x < p.ow) {
-                    const int a32 = epi[xl * kMfEpiPitch + s8];
-                    float out;
+                for (int i = 0; i < 4; ++i) {
                     if (p.dbg & 1) {
-                        out = (float)a32;
+                        out[i] = (float)a32[i];
                     } else if (C1) {
-                        const double corr = ((double)a32 + 128.0 * pt[it][0]) + T.mfma_k;
-                        out = finish_vals(p.method, corr, pt[it], psum2[it], psq[it], T, 1);
+                        out[i] = T.all_ones ? 1.0f
+                                            : finish_lean<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(
+                                                  a32[i], ps1[i], pp1[i], psum2[i], psq[i], prsq[i], T);
                     } else {
+                        const int x = min(xq + i, p.ow - 1);
                         const size_t sidx = (size_t)y * st.pitch + x;
                         double tv[kMaxChans] = {0.0, 0.0, 0.0, 0.0};
                         double s1 = 0.0;
@@ -312,14 +403,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 tv[cc] = st.t[cc][sidx];
                                 s1 += tv[cc];
                             }
-                        const double corr = ((double)a32 + 128.0 * s1) + T.mfma_k;
-                        out = finish_vals(p.method, corr, tv, st.sum2[sidx], st.sq[sidx], T, p.chans);
+                        const double corr = ((double)a32[i] + 128.0 * s1) + T.mfma_k;
+                        out[i] = finish_vals<-1>(p.method, corr, tv, st.sum2[sidx], st.sq[sidx], T, p.chans);
                     }
-                    orow[x] = out;
+                }
+                float* orow = maps + T.map_off + (size_t)y * T.map_pitch + xq;
+                if (xq + 3 < p.ow) {
+                    *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (xq + i < p.ow) orow[i] = out[i];
                 }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below
+        __builtin_amdgcn_wave_barrier();
     }
+    }   // work-item loop
 }
 
 }  // namespace mtm

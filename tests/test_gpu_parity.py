@@ -55,6 +55,24 @@ def map_close(got, exp, tol=1e-4):
     return float(err.max())
 
 
+def set_exact(ctx, on):
+    """MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-identical to the other kernels)."""
+    ctx.set_option(5, 1 if on else 0)
+
+
+def ulp_close(a, b, tol=1.2e-7):
+    """float32 maps equal up to the last bit of values <= 1 (the default MFMA epilogue multiplies by
+    correctly rounded reciprocals instead of dividing)."""
+    assert a.shape == b.shape
+    err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    assert float(err.max()) <= tol * max(1.0, float(np.abs(b).max())), float(err.max())
+
+
+def hits_close(a, b, tol=2e-7):
+    assert [(h[0], h[1]) for h in a] == [(h[0], h[1]) for h in b]
+    assert all(abs(float(x[2]) - float(y[2])) <= tol * max(1.0, abs(float(y[2]))) for x, y in zip(a, b))
+
+
 def otsu_mask(small):
     return ((small > G["otsu_threshold"]) * 255).astype(np.uint8)
 
@@ -146,9 +164,18 @@ def test_guards(mtm):
     t = np.full((8, 8), 7, dtype=np.uint8)
     assert np.all(mtm.computeScoreMap(t, img, 5) == 1.0)       # constant template
     t2 = img[16:24, 10:18].copy()
+    ctx = mtm._lib.default_context()
     for m in (1, 3, 5):
-        got, exp = mtm.computeScoreMap(t2, img, m), O.compute_score_map(t2, img, m)
-        assert np.array_equal(got, exp), m                      # flat windows, saturation branches
+        exp = O.compute_score_map(t2, img, m)
+        set_exact(ctx, True)
+        try:
+            assert np.array_equal(mtm.computeScoreMap(t2, img, m), exp), m     # exact mode: bit-identical
+        finally:
+            set_exact(ctx, False)
+        got = mtm.computeScoreMap(t2, img, m)
+        ulp_close(got, exp)
+        special = (exp == 0.0) | (np.abs(exp) == 1.0)               # flat windows, saturation branches
+        assert np.array_equal(got[special], exp[special]), m
     black = np.zeros((30, 30), np.uint8)
     assert np.array_equal(mtm.computeScoreMap(black[:5, :5], black, 1), O.compute_score_map(black[:5, :5], black, 1))
 
@@ -173,9 +200,14 @@ def test_dot4_variants_agree(mtm, ctx):
         hits = ctx.find_matches(0, 0.5)
         assert len(hits) == 4 * len(units) and ctx.timing()["kernel_used"] == 3
         for i in range(len(units)):
-            assert np.array_equal(ctx.score_map(i, shape), base[i]), ("mfma", i)
+            ulp_close(ctx.score_map(i, shape), base[i])
+        set_exact(ctx, True)
+        for i in range(len(units)):
+            assert np.array_equal(ctx.score_map(i, shape), base[i]), ("mfma exact", i)
+        set_exact(ctx, False)
     finally:
         ctx.set_option(4, 0)
+        set_exact(ctx, False)
         set_kernel(ctx, "auto")
 
 
@@ -191,21 +223,27 @@ def test_mfma_template_groups(mtm, ctx, n_templ, side, method):
         units.append(("t%d" % i, np.ascontiguousarray(img[y:y + side, x:x + side])))
     thr = {5: 0.6, 3: 0.95, 1: 0.2}[method]
     res = {}
-    for kernel in ("naive", "mfma", "dot4"):
-        set_kernel(ctx, kernel)
+    for kernel in ("naive", "mfma", "dot4", "mfma_exact"):
+        set_kernel(ctx, kernel.split("_")[0])
+        set_exact(ctx, kernel.endswith("exact"))
         try:
             res[kernel] = mtm.findMatches(units, img, method=method, score_threshold=thr)
             if kernel != "naive":
                 for i in (0, n_templ // 2, n_templ - 1):
                     set_kernel(ctx, "naive")
                     a = mtm.computeScoreMap(units[i][1], img, method)
-                    set_kernel(ctx, kernel)
+                    set_kernel(ctx, kernel.split("_")[0])
                     b = mtm.computeScoreMap(units[i][1], img, method)
-                    assert np.array_equal(a, b), (kernel, i)
+                    if kernel == "mfma":
+                        ulp_close(b, a)
+                    else:
+                        assert np.array_equal(a, b), (kernel, i)
         finally:
+            set_exact(ctx, False)
             set_kernel(ctx, "auto")
     assert len(res["naive"]) >= n_templ
-    assert res["mfma"] == res["naive"] and res["dot4"] == res["naive"]
+    assert res["mfma_exact"] == res["naive"] and res["dot4"] == res["naive"]
+    hits_close(res["mfma"], res["naive"])
     exp = O.find_matches(units[:3], img, method=method, score_threshold=thr)
     assert_hits_equal([h for h in res["mfma"] if h[0] in ("t0", "t1", "t2")], hits_json(exp), tol=1e-6)
 
@@ -376,7 +414,7 @@ def test_cfg3_size_properties(mtm, ctx):
             assert found[(p[0], p[1])] == 1.0                     # exact copies score exactly 1
         else:
             assert 0.6 < found[(p[0], p[1])] < 0.99
-    assert hits == mtm.matchTemplates(units, img, score_threshold=0.5)     # idempotent
+    assert hits == mtm.matchTemplates(units, img, score_threshold=0.5)     # idempotent, deterministic
     sc = [h[2] for h in hits]
     assert all(a >= b for a, b in zip(sc, sc[1:]))                # sorted by descending score
     # rot90 symmetry: matching the rotated image with the rotated templates gives rotated boxes
@@ -397,4 +435,5 @@ def test_cfg3_size_properties(mtm, ctx):
             res[kernel] = mtm.matchTemplates(units, img, score_threshold=0.5)
         finally:
             set_kernel(ctx, "auto")
-    assert res["dot4"] == res["mfma"] == hits
+    assert res["mfma"] == hits
+    hits_close(sorted(res["dot4"], key=lambda h: (h[0], h[1])), sorted(hits, key=lambda h: (h[0], h[1])))

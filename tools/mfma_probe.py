@@ -15,7 +15,11 @@ for i in range(5):
     ctx.find_matches(0, 0.5); t = ctx.timing(); best = min(best, t["ncc_kernel_ms"])
 print(json.dumps(dict(dbg=int(os.environ.get("MTM_MFMA_DBG", "0")), ncc_ms=round(best, 3), peaks_ms=round(t["peaks_ms"], 3), score_ms=round(t["score_ms"], 3))))
 ''' % ROOT
-for dbg in (0, 1, 2, 4, 6, 8, 10, 14):
-    env = dict(os.environ, MTM_MFMA_DBG=str(dbg), MTM_KERNEL="mfma")
+runs = [dict()]
+for mode in ("0", "1", "2"):
+    for st in ("50", "200"):
+        runs.append(dict(MTM_MFMA_STAGGER_MODE=mode, MTM_MFMA_STAGGER=st))
+for extra in runs:
+    env = dict(os.environ, MTM_KERNEL="mfma", **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
-    print(r.stdout.strip() or r.stderr[-300:], flush=True)
+    print(json.dumps(extra), r.stdout.strip() or r.stderr[-300:], flush=True)
