@@ -85,6 +85,18 @@ def algorithmic_macs(img, units):
     return m
 
 
+def pmc_traffic(kernel_used, config, world):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE, WRITE_SIZE; collected separately, see tools/pmc_run.sh), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            table = json.load(f)
+        key = "%s/%s/n%d" % ({2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(kernel_used, "?"), config, world)
+        return table.get(key)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(img, units, method, thr, n_sample):
     """The oracle (kind 'port') on a bounded sample of the same workload, thread pool over
     templates with round(cpu_count/2) workers like the reference (MTM/__init__.py:172)."""
@@ -184,6 +196,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # PCIe-inclusive: one full MTM.matchTemplates call, numpy arrays in -> hit list out (never `value`)
+    e2e_ms = None
+    if world == 1:
+        _lib._default_ctx = ctx
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            MTM.matchTemplates(units, img, method=method, score_threshold=thr, maxOverlap=0.25)
+            ts.append((time.perf_counter() - t1) * 1e3)
+        e2e_ms = float(np.median(ts))
+
     # sanity: the timed path found every planted template
     found = {(h[0], h[1]) for h in hits}
     planted_ok = all((p[0], p[1]) in found for p in plants) if method == 5 else True
@@ -206,7 +229,7 @@ def main():
                        "max_overlap": 0.25, "parallelism": "units sharded over %d rank(s), RCCL all-gather of hits" % world,
                        "timed_region": "score maps + peaks + D2H hits + all-gather + NMS; image/templates resident in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(tinfo["kernel_used"], args.config, world),
                          "kernel": {1: "ncc_naive_kernel", 2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(tinfo["kernel_used"], "ncc_f64_kernel"),
                          "kernel_ms_per_launch": round(kms, 4), "launches_per_step": launches,
                          "algorithmic_bytes_per_launch": int(bytes_launch),
@@ -217,6 +240,8 @@ def main():
                                  "achieved_tmacs vs the dot4 / i8-MFMA peak is the meaningful utilisation"},
             "gpu_ms": {"kernels_total": round(float(np.mean(total_ms)), 4), "ncc_kernel": round(float(np.mean(kernel_ms)), 4)},
             "hits": len(hits), "planted_found": bool(planted_ok),
+            "e2e_call_ms": None if e2e_ms is None else round(e2e_ms, 3),
+            "e2e_call_mpx_corr_s": None if e2e_ms is None else round(px * len(units) / e2e_ms / 1e3, 1),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)

@@ -166,6 +166,24 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
     return hits
 
 
+def _nms_raw(raw, scoreThreshold, sortAscending, N_object, maxOverlap):
+    """MTM.NMS.NMS (reference MTM/NMS.py:53-84) evaluated on the raw hit array: same decisions on the
+    same float32 scores, but Python tuples are only built for the hits that survive."""
+    if len(raw) <= 1:
+        return raw
+    if N_object == 1:       # python max()/min(): the first best hit wins ties
+        i = int(np.argmin(raw["score"])) if sortAscending else int(np.argmax(raw["score"]))
+        return raw[i:i + 1]
+    scores = raw["score"]
+    if sortAscending:
+        scores = np.float32(1) - scores          # np.float32 scores: 1 - score is a float32 subtraction
+        scoreThreshold = 1 - scoreThreshold
+    idx = _lib.nms_hits(raw, scores, scoreThreshold, maxOverlap)
+    if N_object != float("inf"):
+        idx = idx[:N_object]
+    return raw[idx]
+
+
 def _to_hit_list(raw, listTemplates, xOffset, yOffset):
     labels = [t[0] for t in listTemplates]
     return [(labels[int(r["templ_idx"])], (int(r["x"]) + xOffset, int(r["y"]) + yOffset, int(r["w"]), int(r["h"])),
@@ -214,13 +232,15 @@ def matchTemplates(listTemplates: List[TemplateTuple], image: np.ndarray, method
     if maxOverlap < 0 or maxOverlap > 1:
         raise ValueError("Maximal overlap between bounding box is in range [0-1]")
 
-    listHits = findMatches(listTemplates, image, method, N_object, score_threshold, searchBox)
+    image_s, xOffset, yOffset = _validate_search(listTemplates, image, N_object, searchBox)
+    raw = _raw_matches(listTemplates, image_s, method, N_object, score_threshold)
 
     if method == 0:     # as in the reference, only after the search ran (MTM/__init__.py:291)
         raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
 
     sortAscending = (method == 1)
-    return NMS(listHits, score_threshold, sortAscending, N_object, maxOverlap)
+    kept = _nms_raw(raw, score_threshold, sortAscending, N_object, maxOverlap)
+    return _to_hit_list(kept, listTemplates, xOffset, yOffset)
 
 
 # ---------------------------------------------------------------------------------------------

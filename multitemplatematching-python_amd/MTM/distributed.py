@@ -86,11 +86,10 @@ def merge_and_nms(raw_all: np.ndarray, listTemplates, method, N_object, score_th
                   xOffset=0, yOffset=0):
     """Global NMS over the gathered hits; identical on every rank.  The gathered list is first put
     in the single-process order (template index, then the per-template order each rank produced)."""
+    from . import _nms_raw, _to_hit_list
     raw_all = raw_all[np.argsort(raw_all["templ_idx"], kind="stable")]
-    labels = [t[0] for t in listTemplates]
-    hits = [(labels[int(r["templ_idx"])], (int(r["x"]) + xOffset, int(r["y"]) + yOffset, int(r["w"]), int(r["h"])),
-             np.float32(r["score"])) for r in raw_all]
-    return NMS(hits, score_threshold, method == 1, N_object, maxOverlap)
+    kept = _nms_raw(raw_all, score_threshold, method == 1, N_object, maxOverlap)
+    return _to_hit_list(kept, listTemplates, xOffset, yOffset)
 
 
 def matchTemplates_sharded(listTemplates, image, exchange: HitExchange, method=5, N_object=float("inf"),

@@ -699,6 +699,46 @@ __global__ __launch_bounds__(256) void peaks_kernel(const float* __restrict__ ma
     if (__syncthreads_or(nontriv) && threadIdx.x == 0) nontrivial[t] = 1;
 }
 
+// Second half of the fused peak extraction: the score-map kernel has appended every pixel above the
+// threshold to `cands`; a candidate is a peak iff it equals the maximum of its 3x3 neighbourhood
+// (same border rule and minima handling as peaks_kernel).  tcount[t] counts the peaks of template t:
+// tcount[t] == oh*ow means every pixel equals its local maximum, i.e. skimage's "trivial image".
+__global__ __launch_bounds__(256) void verify_peaks_kernel(const float* __restrict__ maps,
+                                                           const TemplDev* __restrict__ td, int mode_min,
+                                                           int border, const mtm_hit* __restrict__ cands,
+                                                           const unsigned long long* __restrict__ cand_count,
+                                                           unsigned long long cand_cap, mtm_hit* __restrict__ hits,
+                                                           unsigned long long hit_cap,
+                                                           unsigned long long* __restrict__ hit_count,
+                                                           int* __restrict__ tcount) {
+    const unsigned long long n = min(*cand_count, cand_cap);
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtm_hit c = cands[i];
+    const TemplDev T = td[c.templ_idx];
+    const float* m = maps + T.map_off;
+    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+    const float v = mode_min ? -c.score : c.score;
+    float mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = c.y + dy, xx = c.x + dx;
+            float nv = padv;
+            if (yy >= 0 && yy < T.oh && xx >= 0 && xx < T.ow) {
+                nv = m[(size_t)yy * T.map_pitch + xx];
+                if (mode_min) nv = -nv;
+            }
+            mx = fmaxf(mx, nv);
+        }
+    if (v == mx) {
+        const unsigned long long slot = atomicAdd(hit_count, 1ull);
+        if (slot < hit_cap) hits[slot] = c;
+        atomicAdd(&tcount[c.templ_idx], 1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // global extremum: cv2.minMaxLoc (reference MTM/__init__.py:226): first occurrence in row-major
 // order wins ties.  One packed 64-bit key per (template, min|max): high word = order-preserving

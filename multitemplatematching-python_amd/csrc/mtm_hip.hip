@@ -125,7 +125,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -133,6 +133,11 @@ struct mtm_ctx {
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
     int mfma_dbg = 0;
+    int fuse_peaks = 1;        // MTM_FUSE_PEAKS: candidates from the MFMA epilogue + verify kernel
+    // candidate emission of the current launch sequence (set by mtm_find_matches)
+    bool cand_on = false;
+    bool cand_min = false;
+    float cand_thr = 0.f;
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
     int mfma_persistent = 1;
     int mfma_stagger = -1;     // < 0: automatic
@@ -451,6 +456,12 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.group_bytes = sc.group_bytes;
         p.only_li = only_li;
         p.dbg = c->mfma_dbg;
+        p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.cand_min = c->cand_min ? 1 : 0;
+        p.cand_thr = c->cand_thr;
+        p.cand_cap = (unsigned long long)c->hit_cap;
+        p.cand_counter = c->cands.as<unsigned long long>();
+        p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         int tg0 = 0;
         if (only_li >= 0) {          // one template: just its group
             tg0 = only_li / (16 * mb);
@@ -539,6 +550,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     return MTM_OK;
 }
 
+int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
+    const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
+    int kernel = c->opt_kernel;
+    if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
+    if (kernel == MTM_KERNEL_MFMA && !sc.mfma_ok) kernel = MTM_KERNEL_DOT4;
+    if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;
+    return kernel;
+}
+
 int run_score_all(mtm_ctx* c) {
     for (const SizeClass& sc : c->classes) {
         StatPlanes st;
@@ -605,6 +625,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
     }
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
+    if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
@@ -624,7 +645,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
-                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->comm_send, &c->comm_recv})
+                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->cands, &c->comm_send, &c->comm_recv})
         b->release();
     for (auto& p : c->ncc_ev) {
         (void)hipEventDestroy(p.first);
@@ -827,9 +848,22 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
     c->timing = mtm_timing{};
     std::vector<mtm_hit> hits;
 
+    // fused peak candidates: only when every class runs the MFMA kernel
+    bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
+    for (const SizeClass& sc : c->classes) fused = fused && resolved_kernel(c, sc) == MTM_KERNEL_MFMA;
+    c->cand_on = false;
+    if (fused) {
+        MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
+        HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        c->cand_on = true;
+        c->cand_min = mode_min;
+        c->cand_thr = mode_min ? -thr : thr;
+    }
+
     HIPC(hipEventRecord(c->ev[0], c->stream));
     MTMC(run_score_all(c));
     HIPC(hipEventRecord(c->ev[1], c->stream));
+    c->cand_on = false;
 
     if (mode == MTM_PEAKS_GLOBAL) {
         MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
@@ -861,43 +895,90 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
             hits.push_back(hrec);
         }
     } else {
-        // ---- 2-D maps: peaks kernel with a growing hit buffer
+        // ---- 2-D maps.  One device buffer holds [64-bit counter | per-template ints | hit records];
+        // the header and the first kHitPrefetch records come back in ONE copy.
+        // Fused path: the score-map kernel already appended every pixel above the threshold to the
+        // candidate list; verify_peaks_kernel keeps the 3x3 local maxima.  If the candidate list
+        // overflowed (dense maps), or on any non-MFMA class, the full peaks_kernel pass runs instead.
         const int n2d = (int)c->list2d.size();
-        MTMC(c->counters.ensure(sizeof(unsigned long long) + sizeof(int) * std::max(1, n)));
+        constexpr size_t kHitPrefetch = 1024;
+        const size_t hdr_bytes = round_up(2 * sizeof(unsigned long long) + sizeof(int) * (size_t)std::max(1, n), 16);
         unsigned long long count = 0;
-        std::vector<int> nontrivial((size_t)std::max(1, n), 0);
-        for (int attempt = 0; attempt < 2 && n2d > 0; ++attempt) {
-            MTMC(c->hits.ensure(sizeof(mtm_hit) * (size_t)c->hit_cap));
-            HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) + sizeof(int) * n, c->stream));
-            int max_oh = 0, max_ow = 0;
-            for (int t : c->list2d) {
-                max_oh = std::max(max_oh, c->td_host[t].oh);
-                max_ow = std::max(max_ow, c->td_host[t].ow);
+        std::vector<int> tflags((size_t)std::max(1, n), 0);
+        std::vector<uint8_t> host_buf;
+        bool use_fused = fused;
+        for (int attempt = 0; attempt < 3 && n2d > 0; ++attempt) {
+            MTMC(c->hits.ensure(hdr_bytes + sizeof(mtm_hit) * (size_t)c->hit_cap));
+            uint8_t* dbase = c->hits.as<uint8_t>();
+            HIPC(hipMemsetAsync(dbase, 0, hdr_bytes, c->stream));
+            unsigned long long* counter = reinterpret_cast<unsigned long long*>(dbase);
+            int* flags = reinterpret_cast<int*>(counter + 2);
+            mtm_hit* dhits = reinterpret_cast<mtm_hit*>(dbase + hdr_bytes);
+            if (use_fused) {
+                // counter[1] <- candidate count (for the overflow check on the host)
+                HIPC(hipMemcpyAsync(counter + 1, c->cands.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                    c->stream));
+                const unsigned blocks = (unsigned)((c->hit_cap + 255) / 256);
+                hipLaunchKernelGGL(verify_peaks_kernel, dim3(std::min(blocks, 4096u)), dim3(256), 0, c->stream,
+                                   c->maps.as<float>(), c->td.as<TemplDev>(), mode_min ? 1 : 0, c->opt_border,
+                                   reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16),
+                                   c->cands.as<unsigned long long>(),
+                                   (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256), dhits,
+                                   (unsigned long long)c->hit_cap, counter, flags);
+            } else {
+                int max_oh = 0, max_ow = 0;
+                for (int t : c->list2d) {
+                    max_oh = std::max(max_oh, c->td_host[t].oh);
+                    max_ow = std::max(max_ow, c->td_host[t].ow);
+                }
+                const dim3 grd((max_ow + kPkCols - 1) / kPkCols, (max_oh + 4 * kPkRows - 1) / (4 * kPkRows), n2d);
+                hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
+                                   c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
+                                   c->opt_border, dhits, (unsigned long long)c->hit_cap, counter, flags);
             }
-            const dim3 grd((max_ow + kPkCols - 1) / kPkCols, (max_oh + 4 * kPkRows - 1) / (4 * kPkRows), n2d);
-            unsigned long long* counter = c->counters.as<unsigned long long>();
-            int* flags = reinterpret_cast<int*>(counter + 1);
-            hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
-                               c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
-                               c->opt_border, c->hits.as<mtm_hit>(), (unsigned long long)c->hit_cap, counter,
-                               flags);
             HIPC(hipGetLastError());
-            if (attempt == 0) HIPC(hipEventRecord(c->ev[2], c->stream));
-            HIPC(hipMemcpyAsync(&count, counter, sizeof(count), hipMemcpyDeviceToHost, c->stream));
-            HIPC(hipMemcpyAsync(nontrivial.data(), flags, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipEventRecord(c->ev[2], c->stream));
+            const size_t first = std::min<size_t>(kHitPrefetch, (size_t)c->hit_cap);
+            host_buf.resize(hdr_bytes + sizeof(mtm_hit) * first);
+            HIPC(hipMemcpyAsync(host_buf.data(), dbase, host_buf.size(), hipMemcpyDeviceToHost, c->stream));
             HIPC(hipStreamSynchronize(c->stream));
-            if ((int64_t)count <= c->hit_cap) break;
+            unsigned long long ncand = 0;
+            std::memcpy(&count, host_buf.data(), sizeof(count));
+            std::memcpy(&ncand, host_buf.data() + sizeof(count), sizeof(ncand));
+            std::memcpy(tflags.data(), host_buf.data() + 2 * sizeof(count), sizeof(int) * n);
+            if (use_fused && (int64_t)ncand > std::min<int64_t>(c->hit_cap, 4096LL * 256)) {
+                use_fused = false;                  // dense maps: candidate list overflowed
+                continue;
+            }
+            if ((int64_t)count <= c->hit_cap) {
+                hits.resize((size_t)count);
+                const size_t got = std::min<size_t>((size_t)count, first);
+                if (got) std::memcpy(hits.data(), host_buf.data() + hdr_bytes, sizeof(mtm_hit) * got);
+                if (count > got) {
+                    HIPC(hipMemcpyAsync(hits.data() + got, dhits + got, sizeof(mtm_hit) * ((size_t)count - got),
+                                        hipMemcpyDeviceToHost, c->stream));
+                    HIPC(hipStreamSynchronize(c->stream));
+                }
+                break;
+            }
             c->hit_cap = (int64_t)count + 1024;     // grow and rerun the compaction pass
+            use_fused = false;
         }
-        if (n2d == 0) HIPC(hipEventRecord(c->ev[2], c->stream));
-        if (count > 0) {
-            hits.resize((size_t)count);
-            HIPC(hipMemcpyAsync(hits.data(), c->hits.p, sizeof(mtm_hit) * (size_t)count, hipMemcpyDeviceToHost,
-                                c->stream));
+        if (n2d == 0) {
+            HIPC(hipEventRecord(c->ev[2], c->stream));
             HIPC(hipStreamSynchronize(c->stream));
-            // skimage: a map in which every pixel equals its local maximum has no peaks at all
+        }
+        if (!hits.empty()) {
+            // skimage: a map in which every pixel equals its local maximum has no peaks at all.
+            // peaks_kernel: tflags[t] = "some pixel differs from its local max";
+            // fused path:   tflags[t] = number of peaks of t (all pixels <=> trivial).
             hits.erase(std::remove_if(hits.begin(), hits.end(),
-                                      [&](const mtm_hit& h) { return nontrivial[h.templ_idx] == 0; }),
+                                      [&](const mtm_hit& h) {
+                                          const TemplDev& d = c->td_host[h.templ_idx];
+                                          if (d.oh <= 1 || d.ow <= 1) return true;   // 1-D / 1x1 maps: host path below
+                                          if (use_fused) return (long long)tflags[h.templ_idx] == (long long)d.oh * d.ow;
+                                          return tflags[h.templ_idx] == 0;
+                                      }),
                        hits.end());
         }
         // ---- 1x1 and 1-D maps (MTM/__init__.py:25-41) on the host
@@ -937,8 +1018,7 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
             return a.x < b.x;
         });
     }
-    HIPC(hipEventRecord(c->ev[3], c->stream));
-    HIPC(hipEventSynchronize(c->ev[3]));
+    HIPC(hipEventSynchronize(c->ev[2]));       // already complete: every path above synchronised the stream
     HIPC(hipEventElapsedTime(&c->timing.score_ms, c->ev[0], c->ev[1]));
     HIPC(hipEventElapsedTime(&c->timing.peaks_ms, c->ev[1], c->ev[2]));
     HIPC(hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[2]));

@@ -65,6 +65,15 @@ struct MfmaParams {
     int stagger_sleeps;      // s_sleep(127) count of the second block on a CU before its first item
     int stagger_mode;        // how "second block on a CU" is guessed: 0 per-CU arrival counter (HW_ID),
                              // 1 upper half of the grid, 2 bit 3 of the block index
+    // fused peak candidates (mtm_find_matches, local-extrema mode): every output with
+    // (cand_min ? -v : v) > cand_thr is appended to cand_hits; verify_peaks_kernel then keeps the
+    // ones that are 3x3 local maxima.  Replaces a full re-read of all score maps.
+    mtm_hit* cand_hits;
+    unsigned long long* cand_counter;
+    unsigned long long cand_cap;
+    float cand_thr;
+    int cand_min;
+    int cand_on;
     int dbg;                 // profiling probes (MTM_MFMA_DBG): 1 cheap epilogue, 2 no epilogue, 4 frozen A
                              // pointer, 8 no MFMA; results are only valid with dbg == 0
 };
@@ -405,6 +414,31 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             }
                         const double corr = ((double)a32[i] + 128.0 * s1) + T.mfma_k;
                         out[i] = finish_vals<-1>(p.method, corr, tv, st.sum2[sidx], st.sq[sidx], T, p.chans);
+                    }
+                }
+                if (p.cand_on) {
+                    unsigned m = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = p.cand_min ? -out[i] : out[i];
+                        if (xq + i < p.ow && v > p.cand_thr) m |= 1u << i;
+                    }
+                    if (m) {                      // rare
+                        const int tglob = tlist[li];
+                        for (int i = 0; i < 4; ++i)
+                            if ((m >> i) & 1u) {
+                                const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+                                if (slot < p.cand_cap) {
+                                    mtm_hit hrec;
+                                    hrec.templ_idx = tglob;
+                                    hrec.x = xq + i;
+                                    hrec.y = y;
+                                    hrec.w = p.w;
+                                    hrec.h = p.h;
+                                    hrec.score = out[i];
+                                    p.cand_hits[slot] = hrec;
+                                }
+                            }
                     }
                 }
                 float* orow = maps + T.map_off + (size_t)y * T.map_pitch + xq;
