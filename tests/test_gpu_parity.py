@@ -437,3 +437,35 @@ def test_cfg3_size_properties(mtm, ctx):
             set_kernel(ctx, "auto")
     assert res["mfma"] == hits
     hits_close(sorted(res["dot4"], key=lambda h: (h[0], h[1])), sorted(hits, key=lambda h: (h[0], h[1])))
+
+
+# ------------------------------------------------------------------------------------------------
+# RCCL hit exchange (single rank: exercises dlopen(librccl), unique id, comm init, both all-gathers)
+# ------------------------------------------------------------------------------------------------
+def test_rccl_allgather_single_rank(mtm):
+    from MTM import _lib
+    ctx = _lib.Context(0)
+    try:
+        ctx.comm_init(_lib.comm_unique_id(), 1, 0)
+        hits = np.zeros(5, dtype=_lib.HIT_DTYPE)
+        hits["templ_idx"] = np.arange(5)
+        hits["x"] = 7
+        hits["score"] = np.linspace(0, 1, 5, dtype=np.float32)
+        out, counts = ctx.allgather_hits(hits)
+        assert list(counts) == [5] and np.array_equal(out, hits)
+        out, counts = ctx.allgather_hits(hits[:0])
+        assert list(counts) == [0] and len(out) == 0
+    finally:
+        ctx.close()
+
+
+def test_sharded_api_single_rank(mtm, coins):
+    """matchTemplates_sharded with the RCCL exchange at world size 1 == matchTemplates."""
+    from MTM import _lib
+    from MTM.distributed import HitExchange, matchTemplates_sharded
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    ex = HitExchange("rccl", 0, 1, context=_lib.default_context())
+    a = matchTemplates_sharded(lt, coins, ex, score_threshold=0.3, maxOverlap=0.25)
+    b = mtm.matchTemplates(lt, coins, score_threshold=0.3, maxOverlap=0.25)
+    assert a == b
