@@ -133,6 +133,8 @@ struct mtm_ctx {
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
     int mfma_dbg = 0;
+    int n_cus = 0;
+    std::map<std::pair<const void*, size_t>, int> occupancy_cache;
     int fuse_peaks = 1;        // MTM_FUSE_PEAKS: candidates from the MFMA epilogue + verify kernel
     // candidate emission of the current launch sequence (set by mtm_find_matches)
     bool cand_on = false;
@@ -494,13 +496,23 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.persistent = c->mfma_persistent;
         int grid_launch = grid;
         if (p.persistent) {
+            // residency query, cached per (kernel, LDS size): both calls are slow on the host
             int per_cu = 0;
-            HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
-            hipDeviceProp_t prop;
-            HIPC(hipGetDeviceProperties(&prop, c->device));
+            const auto key = std::make_pair(reinterpret_cast<const void*>(fn), lds);
+            auto it = c->occupancy_cache.find(key);
+            if (it == c->occupancy_cache.end()) {
+                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+                it = c->occupancy_cache.emplace(key, per_cu).first;
+            }
+            per_cu = it->second;
+            if (c->n_cus == 0) {
+                hipDeviceProp_t prop;
+                HIPC(hipGetDeviceProperties(&prop, c->device));
+                c->n_cus = prop.multiProcessorCount;
+            }
             per_cu = std::max(1, std::min(per_cu, c->mfma_per_cu));
             p.stagger_mode = c->mfma_stagger_mode;
-            grid_launch = std::min(p.n_work, per_cu * prop.multiProcessorCount);
+            grid_launch = std::min(p.n_work, per_cu * c->n_cus);
             // one main loop is chans*h*nb*16*MB MFMAs of 16 cycles; s_sleep(127) is ~8128 cycles
             const double main_cycles = (double)c->chans * h * p.nb * 16.0 * mb * 16.0;
             p.stagger_sleeps = c->mfma_stagger >= 0 ? c->mfma_stagger : (int)(0.75 * main_cycles / 8128.0 + 0.5);

@@ -471,3 +471,102 @@ def match_templates(listTemplates, image, method=TM_CCOEFF_NORMED, N_object=floa
     if method == 0:
         raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
     return NMS(hits, score_threshold, method == 1, N_object, maxOverlap)
+
+
+# --------------------------------------------------------------------------------------------
+# CPU baseline port ("what OpenCV + a thread pool does"), used by bench.py's cpu_baseline leg only.
+# --------------------------------------------------------------------------------------------
+class FastPipeline:
+    """A throughput-oriented CPU restatement of the reference pipeline for uint8 images and
+    TM_CCOEFF_NORMED / TM_CCORR_NORMED / TM_SQDIFF_NORMED, structured like OpenCV's implementation:
+    the sliding dot product comes from a float32 DFT (cv::crossCorr uses a float32 DFT for 8-bit
+    input - this is where cv2's ~3e-6 deviation from exact arithmetic comes from), the window sums
+    from float64 integral images, the normalisation from one float64 pass, the peaks from
+    scipy.ndimage.maximum_filter as skimage does.  The image spectrum and the window statistics of a
+    template size are computed once and shared by all templates (more than cv2 shares).
+    Thread-safe: one instance is used from a thread pool with one task per template, as the
+    reference does (MTM/__init__.py:172-175).  Checked against the exact oracle in
+    tests/test_oracle_golden.py::test_fast_pipeline_matches_exact_oracle (1e-4)."""
+
+    def __init__(self, image):
+        import threading
+        try:
+            import scipy.fft as _fft
+            self._fft = _fft
+        except ImportError:          # numpy's pocketfft computes in float64
+            self._fft = np.fft
+        self.image = np.asarray(image)
+        assert self.image.dtype == np.uint8 and self.image.ndim == 2
+        H, W = self.image.shape
+        self.fshape = (_next_fast(H), _next_fast(W))
+        self.spec = self._fft.rfft2(self.image.astype(np.float32), s=self.fshape)
+        f64 = self.image.astype(np.float64)
+        self.ii1 = np.zeros((H + 1, W + 1))
+        self.ii2 = np.zeros((H + 1, W + 1))
+        self.ii1[1:, 1:] = np.cumsum(np.cumsum(f64, axis=1), axis=0)
+        self.ii2[1:, 1:] = np.cumsum(np.cumsum(f64 * f64, axis=1), axis=0)
+        self._stats = {}
+        self._lock = threading.Lock()
+
+    def _window_stats(self, h, w):
+        with self._lock:
+            st = self._stats.get((h, w))
+        if st is None:
+            H, W = self.image.shape
+            def box(ii):
+                return ii[:H - h + 1, :W - w + 1] - ii[:H - h + 1, w:] - ii[h:, :W - w + 1] + ii[h:, w:]
+            s1, s2 = box(self.ii1), box(self.ii2)
+            st = (s1, s2)
+            with self._lock:
+                self._stats[(h, w)] = st
+        return st
+
+    def score_map(self, templ, method=TM_CCOEFF_NORMED):
+        H, W = self.image.shape
+        h, w = templ.shape
+        g = self._fft.rfft2(templ.astype(np.float32)[::-1, ::-1], s=self.fshape)
+        corr = self._fft.irfft2(self.spec * g, s=self.fshape)[h - 1:H, w - 1:W].astype(np.float64)
+        s1, s2 = self._window_stats(h, w)
+        inv_area = 1.0 / (h * w)
+        mean, sdv = _templ_mean_sdv(_as3d(templ), True)
+        var = sdv[0] * sdv[0]
+        if method == TM_CCOEFF_NORMED:
+            if var < DBL_EPSILON:
+                return np.ones(corr.shape, np.float32)
+            num = corr - s1 * mean[0]
+            diff2 = np.maximum(s2 - s1 * s1 * inv_area, 0.0)
+            tnorm = math.sqrt(var) / math.sqrt(inv_area)
+            other = 0.0
+        else:
+            tsum2 = (var + mean[0] * mean[0]) / inv_area
+            num = corr if method == TM_CCORR_NORMED else np.maximum(s2 - 2.0 * corr + tsum2, 0.0)
+            diff2 = s2
+            tnorm = math.sqrt(var + mean[0] * mean[0]) / math.sqrt(inv_area)
+            other = 1.0 if method == TM_SQDIFF_NORMED else 0.0
+        t = np.sqrt(diff2)
+        t[diff2 <= np.minimum(0.5, 10.0 * FLT_EPSILON * s2)] = 0.0
+        t *= tnorm
+        an = np.abs(num)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = num / t
+        sat = an >= t
+        out[sat] = np.where(an[sat] < 1.125 * t[sat], np.where(num[sat] > 0, 1.0, -1.0), other)
+        return out.astype(np.float32)
+
+    def find(self, name, templ, method, score_threshold):
+        """One _multi_compute task: score map + local maxima (minima for SQDIFF_NORMED) + hits."""
+        m = self.score_map(templ, method)
+        v = -m if method == TM_SQDIFF_NORMED else m
+        thr = -score_threshold if method == TM_SQDIFF_NORMED else score_threshold
+        try:
+            import scipy.ndimage as ndi
+            mx = ndi.maximum_filter(v, size=3, mode="constant")
+        except ImportError:
+            mx = _max_filter_3x3(v, "constant")
+        is_max = v == mx
+        if is_max.all():
+            return []
+        rows, cols = np.nonzero(is_max & (v > thr))
+        order = np.argsort(-v[rows, cols].astype(np.float64), kind="stable")
+        th, tw = templ.shape
+        return [(name, (int(cols[i]), int(rows[i]), tw, th), m[rows[i], cols[i]]) for i in order]

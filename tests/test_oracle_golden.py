@@ -202,3 +202,21 @@ def test_peak_plateau_and_trivial():
     b[0, 0] = -0.1
     assert O.peak_local_max_2d(b, -0.5, "constant") == []   # skimage<=0.18: zero padding wins at the border
     assert O.peak_local_max_2d(b, -0.5, "nearest") == [[0, 0]]
+
+
+def test_fast_pipeline_matches_exact_oracle(coins):
+    """The cpu_baseline port (float32 DFT, like cv2) agrees with the exact oracle within 1e-4 and
+    finds the same hits on the notebook case."""
+    small, big = coin_templates(coins)
+    fp = O.FastPipeline(coins)
+    for t in (small, big):
+        for m in (1, 3, 5):
+            np.testing.assert_allclose(fp.score_map(t, m), O.match_template(coins, t, m), rtol=1e-4, atol=1e-4)
+    hits = fp.find("small", small, 5, 0.5)
+    exp = O.find_matches([("small", small)], coins, 5, float("inf"), 0.5)
+    assert [(h[0], h[1]) for h in hits] == [(h[0], h[1]) for h in exp]
+    img, units, _ = synth.make_workload(seed=2, image_hw=(360, 640), n_base=4, templ=32)
+    fp = O.FastPipeline(img)
+    got = [h for u in units for h in fp.find(u[0], u[1], 5, 0.5)]
+    exp = O.find_matches(units, img, 5, float("inf"), 0.5)
+    assert [(h[0], h[1]) for h in got] == [(h[0], h[1]) for h in exp]
