@@ -140,6 +140,10 @@ int mtm_score_map(mtm_ctx* ctx, int templ_idx, float* out, int64_t out_row_strid
 int mtm_find_matches(mtm_ctx* ctx, int mode, double score_threshold,
                      mtm_hit* out, int64_t capacity, int64_t* n_out);
 
+/* The hit list of the last mtm_find_matches call again, without recomputing anything: the way to
+ * collect the result after MTM_E_OVERFLOW told the caller the capacity it needs. */
+int mtm_last_hits(mtm_ctx* ctx, mtm_hit* out, int64_t capacity, int64_t* n_out);
+
 int mtm_get_timing(mtm_ctx* ctx, mtm_timing* out);
 
 /* cv2.dnn.NMSBoxes as MTM.NMS uses it (MTM/NMS.py:73-82): keep hits with score > threshold

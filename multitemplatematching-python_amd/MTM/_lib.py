@@ -61,6 +61,7 @@ SYMBOLS = {
     "mtm_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
     "mtm_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                         ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_get_timing": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTiming)]),
     "mtm_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
                                ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, _P(ctypes.c_int64)]),
@@ -202,16 +203,16 @@ class Context:
 
     def find_matches(self, mode, score_threshold):
         cap = 4096
-        while True:
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_find_matches(self._h, int(mode), float(score_threshold), out.ctypes.data, cap,
+                                        ctypes.byref(n))
+        if rc == E_OVERFLOW:        # the result stays in the context: fetch it, do not recompute
+            cap = int(n.value)
             out = np.empty(cap, dtype=HIT_DTYPE)
-            n = ctypes.c_int64(0)
-            rc = self._lib.mtm_find_matches(self._h, int(mode), float(score_threshold), out.ctypes.data, cap,
-                                            ctypes.byref(n))
-            if rc == E_OVERFLOW:
-                cap = int(n.value) + 16
-                continue
-            check(rc, "mtm_find_matches")
-            return out[:n.value]
+            rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        check(rc, "mtm_find_matches")
+        return out[:n.value]
 
     def timing(self):
         t = MtmTiming()

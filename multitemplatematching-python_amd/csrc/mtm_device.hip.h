@@ -399,6 +399,10 @@ __global__ __launch_bounds__(256) void ncc_f64_kernel(ImageDev img, const TemplD
 //   * sums are exact: a chunk's partial sum is < 2^32; WIDE folds it into uint64 totals.
 //   * epilogue in float64 (finish_unmasked), float32 store.
 //
+// MASKSQ variant: the packed "template" is a binary mask (bytes 0xFF / 0x00) and the inner operation is
+// dot4(window & mask, window): the masked sum of squares  sum I^2 * M  that OpenCV's matchTemplateMask
+// needs, exact in uint32; written as float64 into the statistics plane `sumsq_out`.
+//
 // Packed template layout (host: pack_template_dot4): per template, per channel, per chunk
 // (cy, cx): (kDotChunk + 2*kDotPadRows) rows of kDotChunk bytes, zero filled, template row dy of
 // the chunk at packed row dy + kDotPadRows: rows that fall outside the chunk multiply by zero, so
@@ -422,9 +426,10 @@ struct DotParams {
     int nchunks;            // ceil(n_list / NT)
     int n_work;             // ntx * nty * nchunks
     int method;
+    double* sumsq_out;      // MASKSQ: destination plane (pitch = st.pitch) of sum I^2 * M
 };
 
-template <int PX, int PY, int NT, bool WIDE>
+template <int PX, int PY, int NT, bool WIDE, bool MASKSQ = false>
 __global__ __launch_bounds__(256) void ncc_dot4_kernel(DotParams p, const TemplDev* __restrict__ td,
                                                        const int* __restrict__ tlist,
                                                        const uint8_t* __restrict__ packs,
@@ -522,7 +527,8 @@ __global__ __launch_bounds__(256) void ncc_dot4_kernel(DotParams p, const TemplD
                                 const uint32_t tw = tbase[t][prow0 - r * (kDotChunk / 4) + s];
 #pragma unroll
                                 for (int k = 0; k < PX; ++k)
-                                    acc[t][r][k] = __builtin_amdgcn_udot4(win[k], tw, acc[t][r][k], false);
+                                    acc[t][r][k] = MASKSQ ? __builtin_amdgcn_udot4(win[k] & tw, win[k], acc[t][r][k], false)
+                                                          : __builtin_amdgcn_udot4(win[k], tw, acc[t][r][k], false);
                             }
                         }
 #pragma unroll
@@ -575,8 +581,11 @@ __global__ __launch_bounds__(256) void ncc_dot4_kernel(DotParams p, const TemplD
                 double corr;
                 if (WIDE) corr = (double)(((unsigned long long)tile[PX * PY * EPAD + slot] << 32) | tile[slot]);
                 else corr = (double)tile[slot];
-                mbase[(size_t)y * T.map_pitch + x] =
-                    finish_unmasked(p.method, corr, st, (size_t)y * st.pitch + x, T, p.chans);
+                if (MASKSQ)      // "template" = binary mask bytes (0xFF / 0): sum over the window of I^2 * M
+                    p.sumsq_out[(size_t)y * st.pitch + x] = corr;
+                else
+                    mbase[(size_t)y * T.map_pitch + x] =
+                        finish_unmasked(p.method, corr, st, (size_t)y * st.pitch + x, T, p.chans);
             }
         }
     }

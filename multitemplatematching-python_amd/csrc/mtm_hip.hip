@@ -76,6 +76,9 @@ struct SizeClass {
     std::vector<int> members;
     int tlist_off = 0;          // offset into the device tlist array
     bool mfma_ok = false;       // packed for ncc_mfma_kernel
+    bool masked_int = false;    // masked class on the integer path: binary uint8 mask shared by all members
+    unsigned long long mask_hash = 0;
+    long long mask_pack_off = -1;   // dot4 pack of the mask bytes (0xFF / 0) in the pack arena
     long long apack_off = 0;    // byte offset of this class's A packs in the apack arena
     long long group_bytes = 0;
 };
@@ -125,7 +128,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -148,6 +151,7 @@ struct mtm_ctx {
     int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};
+    std::vector<mtm_hit> last_hits;     // result of the last mtm_find_matches (for mtm_last_hits)
 
     // RCCL
     void* rccl_lib = nullptr;
@@ -203,8 +207,11 @@ void pack_template_dot4(const HostTempl& t, uint8_t* out) {
 // templates beyond the list are 0 (the signed zero), so they add nothing.
 constexpr int kMfmaMaxW = 256;
 bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
-    return c->dtype == MTM_U8 && sc.all_u8 && !sc.masked && sc.w <= kMfmaMaxW &&
-           (long long)c->chans * sc.w * sc.h <= 131071;
+    if (!(c->dtype == MTM_U8 && sc.all_u8 && sc.w <= kMfmaMaxW && (long long)c->chans * sc.w * sc.h <= 131071))
+        return false;
+    // masked: single channel, sum I^2*M must fit the uint32 dot4 accumulator (w*h*255^2 < 2^32)
+    if (sc.masked) return c->chans == 1 && (long long)sc.w * sc.h <= 66051;
+    return true;
 }
 long long mfma_group_bytes(int h, int w, int chans) { return (long long)chans * h * ((w + 63) / 64) * 1024; }
 int mfma_groups_alloc(int n) { return (((n + 15) / 16) + 1) & ~1; }     // multiple of MB = 2
@@ -221,7 +228,8 @@ void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
             for (int dy = 0; dy < h; ++dy)
                 for (int dx = 0; dx < w; ++dx) {
                     const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
-                    const uint8_t v = (uint8_t)t.px[((size_t)ch * h + dy) * w + dx];
+                    const size_t k = ((size_t)ch * h + dy) * w + dx;
+                    const uint8_t v = (uint8_t)(t.masked ? t.px[k] * t.mask[k] : t.px[k]);   // masked: T*M, M in {0,1}
                     g[((((size_t)ch * h + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
                 }
     }
@@ -255,8 +263,8 @@ int place_templates(mtm_ctx* c) {
         d.all_ones = t.st.all_ones;
         {
             double sum_t = 0.0;      // exact: integers
-            if (t.dtype == MTM_U8 && !t.masked)
-                for (double v : t.px) sum_t += v;
+            if (t.dtype == MTM_U8)
+                for (size_t k = 0; k < t.px.size(); ++k) sum_t += t.masked ? t.px[k] * t.mask[k] : t.px[k];
             d.mfma_k = 128.0 * sum_t - 16384.0 * (double)t.rows * (double)t.cols * (double)t.chans;
         }
         d.rows = t.rows;
@@ -283,6 +291,15 @@ int place_templates(mtm_ctx* c) {
         }
     }
     c->maps_floats = map_off;
+    // masked classes on the integer path: one dot4 pack of the (shared, binary) mask bytes per class
+    for (SizeClass& sc : c->classes) {
+        sc.masked_int = sc.masked && mfma_class_ok(c, sc);
+        sc.mask_pack_off = -1;
+        if (sc.masked_int) {
+            sc.mask_pack_off = (long long)p_off;
+            p_off += dot_pack_bytes(sc.h, sc.w, 1);
+        }
+    }
     // weights (float64): K1 = T (or T*M^2), K2 = M^2
     std::vector<double> wts(w_off);
     std::vector<uint8_t> packs(p_off);
@@ -301,6 +318,12 @@ int place_templates(mtm_ctx* c) {
         }
         if (d.pack_off >= 0) pack_template_dot4(t, packs.data() + d.pack_off);
     }
+    for (const SizeClass& sc : c->classes)
+        if (sc.masked_int) {
+            HostTempl mk = c->templs[sc.members[0]];
+            for (size_t k = 0; k < mk.px.size(); ++k) mk.px[k] = mk.mask[k] > 0.0 ? 255.0 : 0.0;
+            pack_template_dot4(mk, packs.data() + sc.mask_pack_off);
+        }
     // int8 MFMA packs, per eligible class
     size_t a_off = 0;
     for (SizeClass& sc : c->classes) {
@@ -343,6 +366,8 @@ int place_templates(mtm_ctx* c) {
     return MTM_OK;
 }
 
+int resolved_kernel(const mtm_ctx* c, const SizeClass& sc);
+
 // Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
 int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     const int h = sc.h, w = sc.w;
@@ -351,13 +376,14 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     StatPlanes st{};
     st.pitch = (int)round_up((size_t)ow, 4);
     *out = st;
-    const int resolved = c->opt_kernel == MTM_KERNEL_AUTO ? c->auto_kernel : c->opt_kernel;
-    const bool want_t_always = sc.mfma_ok && resolved == MTM_KERNEL_MFMA;
-    if (sc.masked || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // no statistics needed
-    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
+    const bool want_t_always = resolved_kernel(c, sc) == MTM_KERNEL_MFMA;
+    const bool masked_mfma = sc.masked && want_t_always;
+    if ((sc.masked && !masked_mfma) || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // none needed
+    const int num_type = masked_mfma ? 0
+                       : (method == MTM_TM_CCORR_NORMED) ? 0
                        : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
-    const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED ||
-                        method == MTM_TM_CCOEFF_NORMED;
+    const bool normed = !masked_mfma && (method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED ||
+                                         method == MTM_TM_CCOEFF_NORMED);
     const size_t plane = (size_t)st.pitch * oh;
     MTMC(c->stats.ensure(sizeof(double) * plane * (kMaxChans + 2)));
     double* base = c->stats.as<double>();
@@ -401,6 +427,42 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
     st.sum2 = sum2;
     st.sq = sq;
+    if (masked_mfma) {
+        // sum I^2 * M over every window: dot4 kernel with the mask bytes as the "template", into the
+        // sum2 plane (overwrites the unmasked window sum of squares, which the masked path never uses)
+        const DotVariant v = {4, 4, 1, false, ncc_dot4_kernel<4, 4, 1, false, true>};
+        DotParams p{};
+        p.img = img.u8;
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = 1;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        const int w4 = (w + 3) & ~3;
+        p.ncy = (h + kDotChunk - 1) / kDotChunk;
+        p.ncx = (w4 + kDotChunk - 1) / kDotChunk;
+        p.n_list = 1;
+        p.ntx = (ow + 32 * v.px - 1) / (32 * v.px);
+        p.nty = (oh + 8 * v.py - 1) / (8 * v.py);
+        p.nchunks = 1;
+        p.n_work = p.ntx * p.nty;
+        p.method = method;
+        p.sumsq_out = sum2;
+        // the kernel addresses its single template through td[tlist[0]].pack_off: point a scratch
+        // TemplDev at the class's mask pack (only pack_off is read on the MASKSQ path)
+        TemplDev mk = c->td_host[sc.members[0]];
+        mk.pack_off = sc.mask_pack_off;
+        MTMC(c->mask_td.ensure(sizeof(TemplDev) + sizeof(int)));
+        HIPC(hipMemcpyAsync(c->mask_td.p, &mk, sizeof(TemplDev), hipMemcpyHostToDevice, c->stream));
+        HIPC(hipMemsetAsync(c->mask_td.as<uint8_t>() + sizeof(TemplDev), 0, sizeof(int), c->stream));
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, c->stream, p, c->mask_td.as<TemplDev>(),
+                           reinterpret_cast<const int*>(c->mask_td.as<uint8_t>() + sizeof(TemplDev)),
+                           c->packs.as<uint8_t>(), st, c->maps.as<float>());
+        HIPC(hipGetLastError());
+    }
     *out = st;
     return MTM_OK;
 }
@@ -416,7 +478,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
     int kernel = c->opt_kernel;
     if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
-    if (kernel == MTM_KERNEL_MFMA && !sc.mfma_ok) kernel = MTM_KERNEL_DOT4;
+    if (kernel == MTM_KERNEL_MFMA && (!sc.mfma_ok || (sc.masked && c->method > 3))) kernel = MTM_KERNEL_DOT4;
     if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;   // -> tiled float64
 
     // timing events around the dominant kernel
@@ -483,13 +545,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         if (only_li >= 0) p.only_li = only_li - tg0 * 16 * mb;
         const int* tl_k = tl_class + tg0 * 16 * mb;
         using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
-#define MTM_MF_ROW(MB, X) {ncc_mfma_kernel<MB, -1, X>, ncc_mfma_kernel<MB, 0, X>, ncc_mfma_kernel<MB, 1, X>, \
-                          ncc_mfma_kernel<MB, 2, X>, ncc_mfma_kernel<MB, 3, X>, ncc_mfma_kernel<MB, 4, X>,  \
-                          ncc_mfma_kernel<MB, 5, X>}
-        static const MfmaFn kMfmaFns[2][2][7] = {{MTM_MF_ROW(1, false), MTM_MF_ROW(2, false)},
-                                                 {MTM_MF_ROW(1, true), MTM_MF_ROW(2, true)}};
+#define MTM_MF_ROW(MB, X, M) {ncc_mfma_kernel<MB, -1, X, false>, ncc_mfma_kernel<MB, 0, X, M>, ncc_mfma_kernel<MB, 1, X, M>, \
+                             ncc_mfma_kernel<MB, 2, X, M>, ncc_mfma_kernel<MB, 3, X, M>, ncc_mfma_kernel<MB, 4, X, false>,  \
+                             ncc_mfma_kernel<MB, 5, X, false>}
+        static const MfmaFn kMfmaFns[2][2][2][7] = {
+            {{MTM_MF_ROW(1, false, false), MTM_MF_ROW(2, false, false)}, {MTM_MF_ROW(1, true, false), MTM_MF_ROW(2, true, false)}},
+            {{MTM_MF_ROW(1, false, true), MTM_MF_ROW(2, false, true)}, {MTM_MF_ROW(1, true, true), MTM_MF_ROW(2, true, true)}}};
 #undef MTM_MF_ROW
-        const MfmaFn fn = kMfmaFns[c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
+        // masked classes reach here only with methods 0..3 and one channel (mfma_class_ok)
+        const MfmaFn fn = kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
         // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
@@ -566,7 +630,7 @@ int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
     const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
     int kernel = c->opt_kernel;
     if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
-    if (kernel == MTM_KERNEL_MFMA && !sc.mfma_ok) kernel = MTM_KERNEL_DOT4;
+    if (kernel == MTM_KERNEL_MFMA && (!sc.mfma_ok || (sc.masked && c->method > 3))) kernel = MTM_KERNEL_DOT4;
     if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;
     return kernel;
 }
@@ -657,7 +721,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
-                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->cands, &c->comm_send, &c->comm_recv})
+                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->cands, &c->mask_td, &c->comm_send, &c->comm_recv})
         b->release();
     for (auto& p : c->ncc_ev) {
         (void)hipEventDestroy(p.first);
@@ -787,15 +851,26 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
     }
     // size classes, in order of first appearance
     std::vector<SizeClass> classes;
-    std::map<std::tuple<int, int, bool>, int> index;
+    // masked templates only share a class (and its masked window statistics) when their masks are equal
+    auto mask_hash = [](const HostTempl& t) {
+        unsigned long long hsh = 1469598103934665603ull;
+        for (double v : t.mask) {
+            unsigned long long bits;
+            std::memcpy(&bits, &v, 8);
+            hsh = (hsh ^ bits) * 1099511628211ull;
+        }
+        return t.masked ? hsh : 0ull;
+    };
+    std::map<std::tuple<int, int, bool, unsigned long long>, int> index;
     for (int i = 0; i < n_templ; ++i) {
-        const auto key = std::make_tuple(hts[i].rows, hts[i].cols, hts[i].masked);
+        const auto key = std::make_tuple(hts[i].rows, hts[i].cols, hts[i].masked, mask_hash(hts[i]));
         auto it = index.find(key);
         if (it == index.end()) {
             SizeClass sc;
             sc.h = hts[i].rows;
             sc.w = hts[i].cols;
             sc.masked = hts[i].masked;
+            sc.mask_hash = std::get<3>(key);
             it = index.emplace(key, (int)classes.size()).first;
             classes.push_back(sc);
         }
@@ -1037,11 +1112,26 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
     MTMC(collect_ncc_time(c));
     c->timing.n_hits = (int64_t)hits.size();
     *n_out = (int64_t)hits.size();
-    if ((int64_t)hits.size() > capacity) {
-        set_error("mtm_find_matches: output capacity too small");
+    c->last_hits.swap(hits);
+    if ((int64_t)c->last_hits.size() > capacity) {
+        set_error("mtm_find_matches: output capacity too small (fetch the result with mtm_last_hits)");
         return MTM_E_OVERFLOW;
     }
-    if (!hits.empty()) std::memcpy(out, hits.data(), sizeof(mtm_hit) * hits.size());
+    if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
+    return MTM_OK;
+}
+
+int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        set_error("mtm_last_hits: bad arguments");
+        return MTM_E_INVALID;
+    }
+    *n_out = (int64_t)c->last_hits.size();
+    if ((int64_t)c->last_hits.size() > capacity) {
+        set_error("mtm_last_hits: output capacity too small");
+        return MTM_E_OVERFLOW;
+    }
+    if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
     return MTM_OK;
 }
 

@@ -84,6 +84,7 @@ struct MfTemplConst {
     double mean[kMaxChans];
     double templ_norm, templ_sum2, mfma_k;
     double rtempl_norm;      // 1 / templ_norm (0 when templ_norm == 0)
+    double tms, rsqrt_tms;   // masked templates: sum((T*M)^2) and its inverse square root
     long long map_off;
     int map_pitch, all_ones;
 };
@@ -145,6 +146,19 @@ __device__ __forceinline__ float finish_lean(int a32, double s1, double p1, doub
     return (an < tt) ? qf : ((an < tt * 1.125) ? satf : other);
 }
 
+// Masked templates (OpenCV's matchTemplateMask, binary uint8 mask, reference MTM/__init__.py:78,:216):
+// c1 = sum I*(T*M) comes from the MFMA accumulator exactly like an unmasked correlation (the packed
+// template is T*M), c2 = sum I^2*M from the MASKSQ dot4 pass.  No guards, as in OpenCV: 0/0 is NaN.
+template <int METHOD, bool EXACT_DIV>
+__device__ __forceinline__ float finish_lean_masked(int a32, double p1, double c2, double rsqrt_c2,
+                                                    const MfTemplConst& T) {
+    const double c1 = (double)a32 + (p1 + T.mfma_k);
+    if (METHOD == MTM_TM_CCORR) return (float)c1;
+    if (METHOD == MTM_TM_SQDIFF) return (float)(-2.0 * c1 + c2 + T.tms);
+    const double num = (METHOD == MTM_TM_SQDIFF_NORMED) ? (-2.0 * c1 + c2 + T.tms) : c1;
+    return EXACT_DIV ? (float)(num / sqrt(T.tms * c2)) : (float)(num * (rsqrt_c2 * T.rsqrt_tms));
+}
+
 // One K step: 16 phases x MB template groups, operands already in registers.
 template <int MB>
 __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, const v4i qb, const v4i (&a)[MB]) {
@@ -176,7 +190,7 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
-template <int MB, int METHOD, bool EXACT_DIV>
+template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
@@ -245,6 +259,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.templ_sum2 = T.templ_sum2;
             k.mfma_k = T.mfma_k;
             k.rtempl_norm = T.templ_norm > 0.0 ? 1.0 / T.templ_norm : 0.0;
+            k.tms = T.templ2_mask2_sum;
+            k.rsqrt_tms = 1.0 / sqrt(T.templ2_mask2_sum);
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
@@ -339,9 +355,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if (sum == 0x7fffffff) maps[0] = 1.0f;
         continue;
     }
-    constexpr bool kNeedSum2 = METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED;
-    constexpr bool kNormed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
-                             METHOD == MTM_TM_CCOEFF_NORMED;
+    constexpr bool kNeedSum2 = MASKED || METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED;
+    constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
+                                         METHOD == MTM_TM_CCOEFF_NORMED);
+    constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
     const int xq = x0 + 4 * lane;                       // first of this lane's 4 pixels
     double ps1[C1 ? 4 : 1], pp1[C1 ? 4 : 1], psum2[C1 ? 4 : 1], psq[C1 ? 4 : 1], prsq[C1 ? 4 : 1];
     if (C1 && y < p.oh) {
@@ -354,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             psum2[i] = kNeedSum2 ? st.sum2[sidx] : 0.0;
             psq[i] = kNormed ? st.sq[sidx] : 0.0;
             prsq[i] = (kNormed && !EXACT_DIV && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+            if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
         }
     }
     __syncthreads();              // every wave is done reading the image tile: the buffers alias it
@@ -397,6 +415,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 for (int i = 0; i < 4; ++i) {
                     if (p.dbg & 1) {
                         out[i] = (float)a32[i];
+                    } else if (C1 && MASKED) {
+                        out[i] = finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[i], pp1[i], psum2[i],
+                                                                                         prsq[i], T);
                     } else if (C1) {
                         out[i] = T.all_ones ? 1.0f
                                             : finish_lean<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(

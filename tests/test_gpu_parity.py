@@ -469,3 +469,46 @@ def test_sharded_api_single_rank(mtm, coins):
     a = matchTemplates_sharded(lt, coins, ex, score_threshold=0.3, maxOverlap=0.25)
     b = mtm.matchTemplates(lt, coins, score_threshold=0.3, maxOverlap=0.25)
     assert a == b
+
+
+# ------------------------------------------------------------------------------------------------
+# masked uint8 templates on the integer path (MFMA for sum I*(T*M), dot4 for sum I^2*M)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", [0, 1, 2, 3])
+def test_masked_integer_path(mtm, ctx, method):
+    img = synth.rand_u8(77, 0, (230, 410))
+    rng = np.random.default_rng(5)
+    disc = synth._disc_mask(37)
+    other = ((rng.integers(0, 3, (37, 37)) > 0) * 255).astype(np.uint8)
+    templs = []
+    for i in range(19):                      # two classes of the same size: the masks differ
+        y, x = int(rng.integers(0, 230 - 37)), int(rng.integers(0, 410 - 37))
+        templs.append((np.ascontiguousarray(img[y:y + 37, x:x + 37]), disc if i % 3 else other))
+    shape = (230 - 37 + 1, 410 - 37 + 1)
+    res = {}
+    for kernel, exact in (("naive", False), ("mfma", True), ("mfma", False)):
+        set_kernel(ctx, kernel)
+        set_exact(ctx, exact)
+        try:
+            ctx.set_image(img)
+            ctx.set_templates(templs, method)
+            res[(kernel, exact)] = [ctx.score_map(i, shape) for i in (0, 1, 7, 18)]
+            if kernel == "mfma":
+                hits = ctx.find_matches(0, 0.97 if method in (1, 3) else 1e9)
+                assert ctx.timing()["kernel_used"] == 3       # the integer path really ran
+        finally:
+            set_exact(ctx, False)
+            set_kernel(ctx, "auto")
+    for k, i in enumerate((0, 1, 7, 18)):
+        exp = O.match_template(img, templs[i][0], method, mask=templs[i][1])
+        map_close(res[("naive", False)][k], exp, tol=1e-6)
+        assert np.array_equal(res[("mfma", True)][k], res[("naive", False)][k]), (method, i)
+        ulp_close(res[("mfma", False)][k], res[("naive", False)][k], tol=2.4e-7)
+
+
+def test_masked_api_uses_integer_path(mtm, ctx, coins):
+    small, _ = coin_templates(coins)
+    mask = otsu_mask(small)
+    hits = mtm.matchTemplates([("testMask", small, mask)], coins, method=3, score_threshold=0.8, maxOverlap=0)
+    assert ctx.timing()["kernel_used"] == 3
+    assert_hits_equal(hits, G["notebook_G3"]["hits"], tol=1e-4)
