@@ -185,9 +185,13 @@ def _nms_raw(raw, scoreThreshold, sortAscending, N_object, maxOverlap):
 
 
 def _to_hit_list(raw, listTemplates, xOffset, yOffset):
+    """Structured hit array -> the reference's list of (label, (x, y, w, h), np.float32 score)
+    (MTM/__init__.py:241).  Column-wise tolist() keeps this cheap for thousands of hits."""
     labels = [t[0] for t in listTemplates]
-    return [(labels[int(r["templ_idx"])], (int(r["x"]) + xOffset, int(r["y"]) + yOffset, int(r["w"]), int(r["h"])),
-             np.float32(r["score"])) for r in raw]
+    return [(labels[t], (x, y, w, h), s)
+            for t, x, y, w, h, s in zip(raw["templ_idx"].tolist(), (raw["x"] + xOffset).tolist(),
+                                        (raw["y"] + yOffset).tolist(), raw["w"].tolist(), raw["h"].tolist(),
+                                        list(raw["score"]))]
 
 
 def findMatches(listTemplates: Sequence[TemplateTuple], image: np.ndarray, method: int = TM_CCOEFF_NORMED,

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
 STAMP = LIB + ".stamp"
 SOURCES = ["mtm_hip.hip", "mtm_host.cpp"]
-DEPS = SOURCES + ["mtm_device.hip.h", "mtm_mfma.hip.h", "mtm_kernels.h", "mtm_internal.h",
+DEPS = SOURCES + ["mtm_device.hip.h", "mtm_mfma.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
                   os.path.join("..", "..", "include", "mtm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default"]
@@ -29,6 +29,10 @@ def _hipcc():
     raise RuntimeError("hipcc not found (needed to build libmtm_hip.so for gfx950)")
 
 
+def _extra_flags():
+    return os.environ.get("MTM_EXTRA_FLAGS", "").split()     # experiments only (e.g. -DMTM_PROBE_NO_A)
+
+
 def _digest():
     h = hashlib.sha256()
     for f in DEPS:
@@ -36,7 +40,7 @@ def _digest():
         if os.path.exists(p):
             with open(p, "rb") as fh:
                 h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + _extra_flags()).encode())
     return h.hexdigest()
 
 
@@ -46,7 +50,7 @@ def build(force=False, verbose=False):
         with open(STAMP) as f:
             if f.read().strip() == dig:
                 return LIB
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
+    cmd = [_hipcc()] + FLAGS + _extra_flags() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

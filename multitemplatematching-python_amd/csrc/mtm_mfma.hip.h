@@ -188,6 +188,10 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
     }
 }
 
+#ifndef MTM_MFMA_NO_ASM
+#include "mtm_mfma_step_asm.inc"
+#endif
+
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
 template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false>
@@ -280,7 +284,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             {
                 const int nrow = ch + kMfRows - 1;
                 uint32_t* tile32 = reinterpret_cast<uint32_t*>(smem);
+#ifdef MTM_PROBE_NO_STAGE      /* timing experiment: skip the image-tile staging loads (wrong results) */
+                for (int idx = threadIdx.x; idx < 0; idx += 256) {
+#else
                 for (int idx = threadIdx.x; idx < nrow * tile_dw_per_row; idx += 256) {
+#endif
                     const int r = idx / tile_dw_per_row, d = idx - r * tile_dw_per_row;
                     const uint32_t v = *reinterpret_cast<const uint32_t*>(
                         plane + (size_t)(y0 + cy0 + r) * p.pitch + x0 + 4 * d);
@@ -315,16 +323,28 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
                 A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
+#ifdef MTM_PROBE_NO_A      /* timing experiment: no template-operand loads inside the K loop (wrong results) */
+#define MTM_MF_LOAD_LOOP(QA, QB, A)                                                     \
+            QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
+            QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);
+#elif defined(MTM_PROBE_NO_Q)   /* timing experiment: no LDS operand loads inside the K loop */
+#define MTM_MF_LOAD_LOOP(QA, QB, A)                                                     \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
+                A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
+#else
+#define MTM_MF_LOAD_LOOP(QA, QB, A) MTM_MF_LOAD(QA, QB, A)
+#endif
             MTM_MF_LOAD(qa0, qb0, a0)
+            MTM_MF_LOAD(qa1, qb1, a1)
             for (int ks = 0; ks < nsteps; ks += 2) {
                 MTM_MF_ADVANCE()
-                MTM_MF_LOAD(qa1, qb1, a1)
+                MTM_MF_LOAD_LOOP(qa1, qb1, a1)
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(p.dbg & 8)) mfma_step<MB>(acc, qa0, qb0, a0);
                 else acc[0][0] += qa0 + qb0 + a0[0] + a0[MB - 1];
                 __builtin_amdgcn_sched_barrier(0);
                 MTM_MF_ADVANCE()
-                MTM_MF_LOAD(qa0, qb0, a0)
+                MTM_MF_LOAD_LOOP(qa0, qb0, a0)
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < nsteps) {
                     if (!(p.dbg & 8)) mfma_step<MB>(acc, qa1, qb1, a1);
@@ -334,6 +354,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
 #undef MTM_MF_ADVANCE
 #undef MTM_MF_LOAD
+#undef MTM_MF_LOAD_LOOP
+            // the last MFMAs may have been issued from inline asm: give their results time to land
+            // before compiler-generated code reads the accumulators (hipcc does not see asm MFMAs)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         }
     }
 
