@@ -227,7 +227,7 @@ class Context:
 
     def allgather_hits(self, local):
         local = np.ascontiguousarray(local, dtype=HIT_DTYPE)
-        cap = max(1024, 4 * len(local) * self.n_ranks)
+        cap = max(4096, 4 * len(local) * self.n_ranks)
         while True:
             out = np.empty(cap, dtype=HIT_DTYPE)
             counts = np.zeros(self.n_ranks, dtype=np.int64)

@@ -1223,42 +1223,50 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
     }
     HIPC(hipSetDevice(c->device));
     const int R = c->n_ranks;
-    // 1) counts
-    MTMC(c->comm_send.ensure(sizeof(long long)));
-    MTMC(c->comm_recv.ensure(sizeof(long long) * R));
-    long long mine = n_local;
-    HIPC(hipMemcpyAsync(c->comm_send.p, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-    NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, 1, ncclInt64, c->comm, c->stream));
-    std::vector<long long> counts((size_t)R);
-    HIPC(hipMemcpyAsync(counts.data(), c->comm_recv.p, sizeof(long long) * R, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    long long total = 0, mx = 0;
+    // One all-gather of fixed-size slots: [count (16-byte header) | kSlotHits records].  Every rank
+    // sees every count; only if some rank produced more than kSlotHits hits is a second all-gather
+    // issued with slots of the (globally known) maximum count.  The usual case is ONE collective of
+    // ~49 KB per rank: latency-bound on xGMI, ring bandwidth irrelevant.
+    constexpr long long kSlotHits = 2048;
+    std::vector<long long> counts((size_t)R, 0);
+    std::vector<uint8_t> all;
+    long long slot_hits = kSlotHits;
+    for (int round = 0; round < 2; ++round) {
+        const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
+        MTMC(c->comm_send.ensure(slot));
+        MTMC(c->comm_recv.ensure(slot * R));
+        std::vector<uint8_t> mine(16 + sizeof(mtm_hit) * (size_t)std::min<long long>(n_local, slot_hits), 0);
+        const long long cnt = n_local;
+        std::memcpy(mine.data(), &cnt, sizeof(cnt));
+        if (n_local > 0)
+            std::memcpy(mine.data() + 16, local, sizeof(mtm_hit) * (size_t)std::min<long long>(n_local, slot_hits));
+        HIPC(hipMemcpyAsync(c->comm_send.p, mine.data(), mine.size(), hipMemcpyHostToDevice, c->stream));
+        NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream));
+        all.resize(slot * R);
+        HIPC(hipMemcpyAsync(all.data(), c->comm_recv.p, slot * R, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        long long mx = 0;
+        for (int r = 0; r < R; ++r) {
+            std::memcpy(&counts[r], all.data() + slot * r, sizeof(long long));
+            mx = std::max(mx, counts[r]);
+        }
+        if (mx <= slot_hits) break;
+        slot_hits = mx;                 // every rank computes the same maximum: the collective stays matched
+    }
+    long long total = 0;
     for (int r = 0; r < R; ++r) {
         counts_out[r] = counts[r];
         total += counts[r];
-        mx = std::max(mx, counts[r]);
     }
     *n_out = total;
     if (total > capacity) {
         set_error("mtm_comm_allgather_hits: output capacity too small");
         return MTM_E_OVERFLOW;   // every rank sees the same counts, so every rank returns here
     }
-    if (mx == 0) return MTM_OK;
-    // 2) fixed-size padded records (24 B each), one all-gather over xGMI
-    const size_t slot = sizeof(mtm_hit) * (size_t)mx;
-    MTMC(c->comm_send.ensure(slot));
-    MTMC(c->comm_recv.ensure(slot * R));
-    HIPC(hipMemsetAsync(c->comm_send.p, 0, slot, c->stream));
-    if (n_local)
-        HIPC(hipMemcpyAsync(c->comm_send.p, local, sizeof(mtm_hit) * (size_t)n_local, hipMemcpyHostToDevice,
-                            c->stream));
-    NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream));
-    std::vector<uint8_t> all(slot * R);
-    HIPC(hipMemcpyAsync(all.data(), c->comm_recv.p, slot * R, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
     int64_t o = 0;
     for (int r = 0; r < R; ++r) {
-        std::memcpy(out + o, all.data() + slot * r, sizeof(mtm_hit) * (size_t)counts[r]);
+        if (counts[r]) std::memcpy(out + o, all.data() + slot * r + 16, sizeof(mtm_hit) * (size_t)counts[r]);
         o += counts[r];
     }
     return MTM_OK;

@@ -455,6 +455,10 @@ def test_rccl_allgather_single_rank(mtm):
         assert list(counts) == [5] and np.array_equal(out, hits)
         out, counts = ctx.allgather_hits(hits[:0])
         assert list(counts) == [0] and len(out) == 0
+        big = np.zeros(5000, dtype=_lib.HIT_DTYPE)          # more than one fixed slot: second round
+        big["x"] = np.arange(5000)
+        out, counts = ctx.allgather_hits(big)
+        assert list(counts) == [5000] and np.array_equal(out, big)
     finally:
         ctx.close()
 
