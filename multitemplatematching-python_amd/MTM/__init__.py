@@ -21,7 +21,7 @@ from . import _lib
 from .NMS import NMS, Hit
 from .version import __version__
 
-__all__ = ["NMS", "Hit", "matchTemplates", "findMatches", "computeScoreMap", "drawBoxesOnRGB",
+__all__ = ["NMS", "Hit", "matchTemplates", "findMatches", "computeScoreMap", "TemplateMatcher", "drawBoxesOnRGB",
            "drawBoxesOnGray", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
            "TM_CCOEFF", "TM_CCOEFF_NORMED", "__version__"]
 
@@ -245,6 +245,68 @@ def matchTemplates(listTemplates: List[TemplateTuple], image: np.ndarray, method
     sortAscending = (method == 1)
     kept = _nms_raw(raw, score_threshold, sortAscending, N_object, maxOverlap)
     return _to_hit_list(kept, listTemplates, xOffset, yOffset)
+
+
+class TemplateMatcher:
+    """
+    The same templates over a stream of images (the "thousands of images" use of the reference,
+    tutorials/Tutorial3-SpeedingUp.ipynb): templates are validated, packed and uploaded ONCE and stay
+    resident on the GPU; every ``match(image)`` uploads one image and runs one batched search.
+    ``matcher.match(image)`` returns exactly what ``matchTemplates(listTemplates, image, ...)`` with
+    the constructor's arguments returns.
+
+    All images must have the dtype the templates were prepared for (uint8 templates with uint8
+    images, anything else float32) - mixing raises, use matchTemplates for one-off calls.
+    """
+
+    def __init__(self, listTemplates, method: int = TM_CCOEFF_NORMED, N_object=float("inf"),
+                 score_threshold: float = 0.5, maxOverlap: float = 0.25, context=None):
+        if maxOverlap < 0 or maxOverlap > 1:
+            raise ValueError("Maximal overlap between bounding box is in range [0-1]")
+        if N_object != float("inf") and not isinstance(N_object, int):
+            raise TypeError("N_object must be an integer")
+        self.listTemplates = list(listTemplates)
+        self.method, self.N_object = method, N_object
+        self.score_threshold, self.maxOverlap = score_threshold, maxOverlap
+        self._ctx = context or _lib.Context()
+        self._uploaded_for = None      # (dtype name, channel count) the resident templates were prepared for
+
+    def _upload(self, image):
+        units = []
+        for tempTuple in self.listTemplates:
+            mask = None
+            if len(tempTuple) >= 3:
+                if self.method in (0, 3):
+                    mask = tempTuple[2]
+                else:
+                    warnings.warn(_MSG_MASK_UNSUPPORTED)
+            t, im, m = _apply_pixel_policy(tempTuple[1], image, self.method, mask)
+            _check_opencv_preconditions(t, im)
+            units.append((t, m, im.dtype))
+        kinds = {str(u[2]) for u in units}
+        if len(kinds) > 1:
+            raise ValueError("TemplateMatcher needs templates of one pixel type (all uint8, or none)")
+        self._ctx.set_templates([(u[0], u[1]) for u in units], self.method)
+        self._uploaded_for = (kinds.pop() if kinds else str(image.dtype), 1 if image.ndim == 2 else image.shape[2])
+
+    def match(self, image: np.ndarray, searchBox: Optional[BBox] = None) -> List[Hit]:
+        image_s, xOffset, yOffset = _validate_search(self.listTemplates, image, self.N_object, searchBox)
+        with self._ctx.lock:
+            if self._uploaded_for is None:
+                self._upload(image_s)
+            want = "uint8" if (self._uploaded_for[0] == "uint8" and image_s.dtype == "uint8") else "float32"
+            if image_s.dtype == "float64":
+                raise ValueError("64-bit images not supported, max 32-bit")
+            if want != self._uploaded_for[0] or (1 if image_s.ndim == 2 else image_s.shape[2]) != self._uploaded_for[1]:
+                raise ValueError("TemplateMatcher: image pixel type / channel count differs from the resident templates")
+            im = image_s if want == "uint8" else np.float32(image_s)
+            self._ctx.set_image(im)
+            mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
+            raw = self._ctx.find_matches(mode, self.score_threshold).copy()
+        if self.method == 0:
+            raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
+        kept = _nms_raw(raw, self.score_threshold, self.method == 1, self.N_object, self.maxOverlap)
+        return _to_hit_list(kept, self.listTemplates, xOffset, yOffset)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -143,7 +143,10 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
     }
 }
 
-constexpr int kVsumBand = 32;
+#ifndef MTM_VSUM_BAND
+#define MTM_VSUM_BAND 32
+#endif
+constexpr int kVsumBand = MTM_VSUM_BAND;
 
 template <typename AccT, typename SumT>
 __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __restrict__ hs2,

@@ -144,7 +144,7 @@ struct mtm_ctx {
     bool cand_min = false;
     float cand_thr = 0.f;
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
-    int mfma_persistent = 1;
+    int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
     int mfma_stagger = -1;     // < 0: automatic
     int mfma_stagger_mode = 0;
     int mfma_per_cu = 2;

@@ -516,3 +516,13 @@ def test_masked_api_uses_integer_path(mtm, ctx, coins):
     hits = mtm.matchTemplates([("testMask", small, mask)], coins, method=3, score_threshold=0.8, maxOverlap=0)
     assert ctx.timing()["kernel_used"] == 3
     assert_hits_equal(hits, G["notebook_G3"]["hits"], tol=1e-4)
+
+
+def test_template_matcher_stream(mtm):
+    img, units, _ = synth.make_workload(seed=8, image_hw=(300, 520), n_base=5, templ=32)
+    matcher = mtm.TemplateMatcher(units, score_threshold=0.5)
+    for k in range(3):
+        im = np.ascontiguousarray(np.roll(img, 17 * k, axis=1))
+        assert matcher.match(im) == mtm.matchTemplates(units, im, score_threshold=0.5)
+    small = np.ascontiguousarray(img[:200, :400])                 # a different image size re-places the maps
+    assert matcher.match(small) == mtm.matchTemplates(units, small, score_threshold=0.5)

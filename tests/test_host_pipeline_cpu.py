@@ -96,3 +96,17 @@ def test_score_map_and_types(mtm):
     hits = mtm.matchTemplates([("small", small)], coins, maxOverlap=0)
     assert isinstance(hits, list) and isinstance(hits[0], tuple) and isinstance(hits[0][2], np.float32)
     assert all(type(v) is int for v in hits[0][1])
+
+
+def test_template_matcher_equals_match_templates(mtm):
+    """Resident-template API (stream of images) == one matchTemplates call per image."""
+    coins = load_coins()
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    matcher = mtm.TemplateMatcher(lt, score_threshold=0.3, maxOverlap=0.25, context=mtm._lib.default_context())
+    for img in (coins, np.ascontiguousarray(coins[::-1]), coins[20:280, 10:380]):
+        assert matcher.match(img) == mtm.matchTemplates(lt, img, score_threshold=0.3, maxOverlap=0.25)
+    assert matcher.match(coins, searchBox=(10, 20, 300, 200)) == \
+        mtm.matchTemplates(lt, coins, score_threshold=0.3, maxOverlap=0.25, searchBox=(10, 20, 300, 200))
+    with pytest.raises(ValueError, match="pixel type"):
+        matcher.match(coins.astype(np.float32))
