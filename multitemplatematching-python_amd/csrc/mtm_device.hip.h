@@ -80,6 +80,20 @@ __global__ void hsum_kernel(const float* __restrict__ img, int pitch, long long 
     }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP (no LDS, no ds_bpermute): the classic
+// row_shr 1/2/3, row_shr 4 (banks 1-3), row_shr 8 (banks 2-3), row_bcast 15 (rows 1,3), row_bcast 31
+// (rows 2,3) sequence.  Lanes without a source keep 0 (the `old` operand).
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t x) {
+    uint32_t s = x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);                // row_shr:2
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x113, 0xf, 0xf, false);                // row_shr:3
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, false);                // row_shr:4
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, false);                // row_shr:8
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, false);                // row_bcast:15
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);                // row_bcast:31
+    return s;
+}
+
 // Horizontal box sums of one uint8 image row per work-group, through inclusive prefix sums held in
 // LDS (uint32, exact): fully coalesced global reads and writes.  Element i of the row is owned by
 // thread i % 256 in round i / 256; each round is a 256-wide block scan (wave shuffles + one LDS
@@ -103,15 +117,7 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
     for (int base = 0; base < cols; base += 256) {
         const int i = base + threadIdx.x;
         const uint32_t v = i < cols ? row[i] : 0u;
-        uint32_t a = v, b = v * v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t ua = __shfl_up(a, off), ub = __shfl_up(b, off);
-            if (lane >= off) {
-                a += ua;
-                b += ub;
-            }
-        }
+        const uint32_t a = wave_inclusive_scan_u32(v), b = wave_inclusive_scan_u32(v * v);
         if (lane == 63) {
             wsum[0][wave] = a;
             wsum[1][wave] = b;
@@ -140,6 +146,130 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
     for (int x = threadIdx.x; x < ow; x += 256) {
         o1[x] = P1[x + w] - P1[x];
         o2[x] = P2[x + w] - P2[x];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused window statistics for single-channel uint8 images: one kernel, no intermediate planes.
+// A work-group owns 256 output columns x kStatBand output rows.  Column sums over the template
+// height (C1 = sum I, C2 = sum I^2 per image column) are kept in registers and slid down one row at a
+// time (two coalesced row reads per output row); the window sums are then differences of a prefix
+// scan of the column sums over the 256 + w - 1 columns of the strip, held in LDS (uint32, exact:
+// differences are taken modulo 2^32 and the true window sums fit).  Reads the image ~(h + 2 band) /
+// band times, writes only the statistics the epilogue needs.  The launcher uses it for w <= 768 and
+// w * h * 255^2 < 2^32; everything else takes hsum_* + vsum_stats_kernel.
+// ---------------------------------------------------------------------------------------------
+#ifndef MTM_STAT_BAND
+#define MTM_STAT_BAND 32
+#endif
+constexpr int kStatBand = MTM_STAT_BAND;
+constexpr int kStatMaxK = 4;        // image columns per thread: ceil((256 + w - 1) / 256) <= 4
+
+__global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict__ img, int pitch, int h, int w,
+                                                       int oh, int ow, double inv_area, int num_type, int want_sq,
+                                                       int want_t, int want_sum2, double* __restrict__ t0,
+                                                       double* __restrict__ sum2, double* __restrict__ sq,
+                                                       int st_pitch) {
+    __shared__ uint32_t P1[256 * kStatMaxK + 1], P2[256 * kStatMaxK + 1];
+    __shared__ uint32_t wsum[2][4];
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kStatBand;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int L = 256 + w - 1;                       // image columns of this strip
+    const int K = (L + 255) >> 8;                    // columns per thread (contiguous)
+    const uint8_t* base = img + (size_t)y0 * pitch + x0 + t * K;      // padded image: always readable
+    uint32_t c1[kStatMaxK] = {0, 0, 0, 0}, c2[kStatMaxK] = {0, 0, 0, 0};
+    // 8 rows per batch: the loads of a batch are all in flight before the first add needs one
+    for (int r0 = 0; r0 < h; r0 += 8) {
+        uint32_t v[8][kStatMaxK];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint8_t* row = base + (size_t)min(r0 + i, h - 1) * pitch;
+#pragma unroll
+            for (int k = 0; k < kStatMaxK; ++k) v[i][k] = (k < K) ? row[k] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (r0 + i < h) {
+#pragma unroll
+                for (int k = 0; k < kStatMaxK; ++k) {
+                    c1[k] += v[i][k];
+                    c2[k] += v[i][k] * v[i][k];
+                }
+            }
+    }
+    if (t == 0) {
+        P1[0] = 0;
+        P2[0] = 0;
+    }
+    const int y1 = min(y0 + kStatBand, oh);
+    for (int y = y0; y < y1; ++y) {
+        // request the two image rows of the slide at the end of this iteration now: their latency
+        // hides behind the scan and the float64 statistics
+        uint32_t vn[kStatMaxK] = {0, 0, 0, 0}, vo[kStatMaxK] = {0, 0, 0, 0};
+        if (y + 1 < y1) {
+            const uint8_t* rn = base + (size_t)(y - y0 + h) * pitch;
+            const uint8_t* ro = base + (size_t)(y - y0) * pitch;
+#pragma unroll
+            for (int k = 0; k < kStatMaxK; ++k)
+                if (k < K) {
+                    vn[k] = rn[k];
+                    vo[k] = ro[k];
+                }
+        }
+        // block-wide inclusive scan of the column sums (thread-local prefix, wave scan, cross-wave)
+        uint32_t a = 0, b = 0, la[kStatMaxK], lb[kStatMaxK];
+#pragma unroll
+        for (int k = 0; k < kStatMaxK; ++k) {
+            if (k < K) {
+                a += c1[k];
+                b += c2[k];
+            }
+            la[k] = a;
+            lb[k] = b;
+        }
+        const uint32_t sa = wave_inclusive_scan_u32(a), sb = wave_inclusive_scan_u32(b);
+        if (lane == 63) {
+            wsum[0][wave] = sa;
+            wsum[1][wave] = sb;
+        }
+        __syncthreads();                 // also: previous row's P reads are done
+        uint32_t oa = sa - a, ob = sb - b;          // exclusive offset of this thread inside its wave
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < wave) {
+                oa += wsum[0][k];
+                ob += wsum[1][k];
+            }
+#pragma unroll
+        for (int k = 0; k < kStatMaxK; ++k)
+            if (k < K) {
+                P1[t * K + k + 1] = oa + la[k];
+                P2[t * K + k + 1] = ob + lb[k];
+            }
+        __syncthreads();
+        const int x = x0 + t;
+        if (x < ow) {
+            const uint32_t s1 = P1[t + w] - P1[t], s2 = P2[t + w] - P2[t];
+            const double tt = (double)s1;
+            const double wnd_sum2 = (double)s2;
+            double wnd_mean2 = 0.0;
+            if (num_type == 1) wnd_mean2 = (tt * tt) * inv_area;
+            const size_t o = (size_t)y * st_pitch + x;
+            if (want_t) t0[o] = tt;
+            if (want_sum2) sum2[o] = wnd_sum2;
+            if (want_sq) {
+                const double diff2 = fmax(wnd_sum2 - wnd_mean2, 0.0);
+                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * wnd_sum2);
+                sq[o] = small ? 0.0 : sqrt(diff2);
+            }
+        }
+        // slide the column sums one row down (zeros on the last row: nothing changes)
+#pragma unroll
+        for (int k = 0; k < kStatMaxK; ++k)
+            if (k < K) {
+                c1[k] += vn[k] - vo[k];
+                c2[k] += vn[k] * vn[k] - vo[k] * vo[k];
+            }
     }
 }
 

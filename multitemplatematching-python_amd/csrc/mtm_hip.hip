@@ -136,6 +136,7 @@ struct mtm_ctx {
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
     int mfma_dbg = 0;
+    int fuse_stats = 1;        // MTM_FUSE_STATS: single-kernel window statistics (uint8, one channel)
     int n_cus = 0;
     std::map<std::pair<const void*, size_t>, int> occupancy_cache;
     int fuse_peaks = 1;        // MTM_FUSE_PEAKS: candidates from the MFMA epilogue + verify kernel
@@ -402,7 +403,15 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     const dim3 g2((ow + 255) / 256, (oh + kVsumBand - 1) / kVsumBand);
     const int want_t = (num_type == 1 || want_t_always) ? 1 : 0;
     const double inv_area = 1.0 / ((double)h * (double)w);
-    if (u8) {
+    // fused single-kernel statistics for the common case
+    const bool fused_stats = u8 && c->chans == 1 && w <= 768 && (double)w * h * 65025.0 < 4294967296.0 &&
+                             c->fuse_stats;
+    if (fused_stats) {
+        const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always) ? 1 : 0;
+        const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, inv_area,
+                           num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch);
+    } else if (u8) {
         if (c->cols <= 8191)
             hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
                                c->stream, img.u8, img.u8_pitch, img.u8_plane, c->cols, w, ow, c->hs1.as<uint32_t>(),
@@ -702,6 +711,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     }
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
+    if (const char* v = std::getenv("MTM_FUSE_STATS")) c->fuse_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
