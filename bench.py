@@ -141,6 +141,8 @@ def main():
                      % (args.gpus, args.gpus))
         args.gpus = world
 
+    if rank != 0:         # stdout is a protocol: exactly one JSON line, from rank 0
+        os.dup2(2, 1)
     import torch          # plumbing only: device sync + the distributed bootstrap/barrier
     import MTM
     from MTM import _lib
@@ -258,7 +260,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    # libraries (librccl prints a version banner at teardown) must not append to stdout after the JSON
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,6 +12,9 @@ Exchange backends
   "torch" : torch.distributed.all_gather on CPU tensors (gloo) - used by the CPU tests and as a
             fallback where RCCL is unavailable.
 """
+import contextlib
+import os
+import sys
 from typing import List, Sequence
 
 import numpy as np
@@ -40,6 +43,21 @@ def shard_units(costs: Sequence[float], world_size: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """librccl prints a version banner on stdout when it is first initialised; programs whose stdout
+    is a protocol (bench.py prints one JSON line) get it on stderr instead."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class HitExchange:
     """All-gather of structured hit arrays (dtype _lib.HIT_DTYPE) across ranks."""
 
@@ -51,9 +69,10 @@ class HitExchange:
         if backend == "rccl" and world_size > 1:
             import torch.distributed as dist
             self.ctx = context or _lib.default_context()
-            box = [_lib.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0, group=group)     # bootstrap only
-            self.ctx.comm_init(box[0], world_size, rank)
+            with _stdout_to_stderr():
+                box = [_lib.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, group=group)     # bootstrap only
+                self.ctx.comm_init(box[0], world_size, rank)
         elif backend not in ("rccl", "torch"):
             raise ValueError("backend must be 'rccl' or 'torch'")
 

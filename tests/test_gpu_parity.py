@@ -444,9 +444,11 @@ def test_cfg3_size_properties(mtm, ctx):
 # ------------------------------------------------------------------------------------------------
 def test_rccl_allgather_single_rank(mtm):
     from MTM import _lib
+    from MTM.distributed import _stdout_to_stderr
     ctx = _lib.Context(0)
     try:
-        ctx.comm_init(_lib.comm_unique_id(), 1, 0)
+        with _stdout_to_stderr():
+            ctx.comm_init(_lib.comm_unique_id(), 1, 0)
         hits = np.zeros(5, dtype=_lib.HIT_DTYPE)
         hits["templ_idx"] = np.arange(5)
         hits["x"] = 7
