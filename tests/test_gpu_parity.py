@@ -528,3 +528,35 @@ def test_template_matcher_stream(mtm):
         assert matcher.match(im) == mtm.matchTemplates(units, im, score_threshold=0.5)
     small = np.ascontiguousarray(img[:200, :400])                 # a different image size re-places the maps
     assert matcher.match(small) == mtm.matchTemplates(units, small, score_threshold=0.5)
+
+
+# ------------------------------------------------------------------------------------------------
+# assorted edge cases through the public API
+# ------------------------------------------------------------------------------------------------
+def test_edge_cases_api(mtm, coins):
+    small, big = coin_templates(coins)
+    assert mtm.matchTemplates([], coins) == []
+    assert mtm.findMatches([], coins) == []
+    # unnormalised methods (raw thresholds), maxima (2, 4)
+    for method, thr in ((2, 2.0e7), (4, 1.5e6)):
+        got = mtm.matchTemplates([("small", small)], coins, method=method, score_threshold=thr, maxOverlap=0.3)
+        exp = O.match_templates([("small", small)], coins, method=method, score_threshold=thr, maxOverlap=0.3)
+        assert len(got) > 0
+        assert_hits_equal(got, hits_json(exp), tol=1e-5)
+    # N_object == 1 with a mask, and with several templates (global extremum per template, then best)
+    mask = otsu_mask(small)
+    got = mtm.matchTemplates([("m", small, mask)], coins, method=3, N_object=1)
+    exp = O.match_templates([("m", small, mask)], coins, method=3, N_object=1)
+    assert_hits_equal(got, hits_json(exp), tol=1e-5)
+    got = mtm.matchTemplates([("small", small), ("big", big)], coins, method=1, N_object=1)
+    assert got[0][2] == 0.0 and got[0][0] in ("small", "big")
+    # float32 images through the resident-template API
+    imf = coins.astype(np.float32) / 255
+    tm = mtm.TemplateMatcher([("s", imf[37:75, 80:121])], method=5, score_threshold=0.5, maxOverlap=0)
+    assert tm.match(imf) == mtm.matchTemplates([("s", imf[37:75, 80:121])], imf, method=5, score_threshold=0.5, maxOverlap=0)
+    # non-contiguous inputs (column-strided view) are copied by the binding
+    view = coins[:, ::2]
+    t = np.ascontiguousarray(view[40:70, 30:60])
+    got = mtm.matchTemplates([("v", t)], view, score_threshold=0.6)
+    exp = O.match_templates([("v", t)], np.ascontiguousarray(view), score_threshold=0.6)
+    assert_hits_equal(got, hits_json(exp), tol=1e-5)
