@@ -544,7 +544,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
-        const size_t lds = lds_main + sizeof(MfTemplConst) * 32 + 16;
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+        const size_t lds = (size_t)p.st_off + (size_t)kMfRows * kMfStatBytesPerWave;
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;

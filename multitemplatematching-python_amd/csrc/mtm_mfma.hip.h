@@ -44,6 +44,9 @@ constexpr int kMfChunkH = 64;        // template rows per LDS tile
 constexpr int kMfEpiPitch = 260;
 constexpr int kMfEpiBytesPerWave = 8 * kMfEpiPitch * 4;
 __device__ __forceinline__ int mf_epi_rot(int j) { return 4 * ((j >> 1) & 3); }
+// Window statistics of a wave's 256 pixels, prefetched to LDS by LDS-DMA while the image tile is
+// staged: [3 planes: S1, S2, sqrt][2 halves][64 lanes][2 doubles]; lane L owns pixels 4L..4L+3.
+constexpr int kMfStatBytesPerWave = 3 * 2 * 1024;
 
 struct MfmaParams {
     const uint8_t* img;      // planar padded u8
@@ -61,6 +64,7 @@ struct MfmaParams {
     long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
     int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
+    int st_off;              // byte offset in LDS of the prefetched window statistics (4 waves)
     int persistent;          // 1: work items are pulled from *work_counter (grid = resident blocks)
     int stagger_sleeps;      // s_sleep(127) count of the second block on a CU before its first item
     int stagger_mode;        // how "second block on a CU" is guessed: 0 per-CU arrival counter (HW_ID),
@@ -144,6 +148,29 @@ __device__ __forceinline__ float finish_lean(int a32, double s1, double p1, doub
     const float satf = (num > 0.0) ? 1.0f : -1.0f;
     const float other = (METHOD == MTM_TM_SQDIFF_NORMED) ? 1.0f : 0.0f;
     return (an < tt) ? qf : ((an < tt * 1.125) ? satf : other);
+}
+
+// finish_lean with the quotient computed unconditionally (the empty asm keeps the compiler from
+// sinking it into a divergent branch): straight-line code, the four pixels of a lane interleave.
+// Same operations in the same order as finish_lean: bit-identical results.
+template <int METHOD, bool EXACT_DIV>
+__device__ __forceinline__ float finish_fast(int a32, double s1, double p1, double sum2, double sq, double rsq,
+                                             const MfTemplConst& T) {
+    constexpr bool normed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
+                            METHOD == MTM_TM_CCOEFF_NORMED;
+    const double corr = (double)a32 + (p1 + T.mfma_k);
+    double num = corr;
+    if (METHOD == MTM_TM_CCOEFF || METHOD == MTM_TM_CCOEFF_NORMED) num = corr - s1 * T.mean[0];
+    if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
+    if (!normed) return (float)num;
+    const double tt = sq * T.templ_norm;
+    float qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
+    asm volatile("" : "+v"(qf));
+    const double an = fabs(num);
+    const float satf = (num > 0.0) ? 1.0f : -1.0f;
+    const float other = (METHOD == MTM_TM_SQDIFF_NORMED) ? 1.0f : 0.0f;
+    const float r2 = (an < tt * 1.125) ? satf : other;
+    return (an < tt) ? qf : r2;
 }
 
 // Masked templates (OpenCV's matchTemplateMask, binary uint8 mask, reference MTM/__init__.py:78,:216):
@@ -272,6 +299,28 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
 
+    // window statistics of this wave's 256 pixels -> LDS (LDS-DMA, no registers; drained by the
+    // staging barriers below, read back in the epilogue).  Lane L fetches pixels 4L..4L+3.
+    constexpr bool kNeedSum2 = MASKED || METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED;
+    constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
+                                         METHOD == MTM_TM_CCOEFF_NORMED);
+    constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
+    if constexpr (C1) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
+        const size_t sidx = (size_t)yc * st.pitch + xc;
+        uint8_t* sbase = smem + p.st_off + wave * kMfStatBytesPerWave;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(st.t[0] + sidx + 2 * hh), (lptr_t)(sbase + (0 + hh) * 1024), 16, 0, 0);
+            if (kNeedSum2)
+                __builtin_amdgcn_global_load_lds((gptr_t)(st.sum2 + sidx + 2 * hh), (lptr_t)(sbase + (2 + hh) * 1024), 16, 0, 0);
+            if (kNormed)
+                __builtin_amdgcn_global_load_lds((gptr_t)(st.sq + sidx + 2 * hh), (lptr_t)(sbase + (4 + hh) * 1024), 16, 0, 0);
+        }
+    }
+
     const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
     const int tile_dw_per_row = p.lds_pitch >> 2;
 
@@ -368,6 +417,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // rolled (one copy of the float64 normalisation in the binary).  The buffer of a wave is
     // private to it: LDS executes a wave's instructions in order, so no work-group barrier is
     // needed between the stages.
+    {   // epilogue scope
+    // Lane coordinates are re-derived behind an opaque asm: everything the epilogue computes from
+    // them is then computed HERE instead of being hoisted above the K loop and spilled across it.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int wave = tid_e >> 6, lane = tid_e & 63;
+    const int j = lane & 15, q = lane >> 4;
     const int y = y0 + wave;
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
     if (p.dbg & 2) {            // probe: no epilogue (keep the accumulators observable)
@@ -379,74 +435,167 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if (sum == 0x7fffffff) maps[0] = 1.0f;
         continue;
     }
-    constexpr bool kNeedSum2 = MASKED || METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED;
-    constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
-                                         METHOD == MTM_TM_CCOEFF_NORMED);
-    constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
     const int xq = x0 + 4 * lane;                       // first of this lane's 4 pixels
-    double ps1[C1 ? 4 : 1], pp1[C1 ? 4 : 1], psum2[C1 ? 4 : 1], psq[C1 ? 4 : 1], prsq[C1 ? 4 : 1];
-    if (C1 && y < p.oh) {
+    const int rd_off = 16 * (lane >> 2) + ((4 * (lane & 3) + mf_epi_rot(lane >> 2)) & 15);
+    // registers e = 0..3 of phase c hold templates 4 (q & 1) + e of a stage, pixel 16 j + c
+    auto put = [&](const v4i (&blk)[16]) {
+        int* dst = &epi[(4 * (q & 1)) * kMfEpiPitch + 16 * j];
+        const int rot = mf_epi_rot(j);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int col = (c + rot) & 15;
+            dst[0 * kMfEpiPitch + col] = blk[c].x;
+            dst[1 * kMfEpiPitch + col] = blk[c].y;
+            dst[2 * kMfEpiPitch + col] = blk[c].z;
+            dst[3 * kMfEpiPitch + col] = blk[c].w;
+        }
+    };
+    // append the outputs above the threshold to the candidate list (rare)
+    auto emit = [&](const float (&out)[4], int li) {
+        unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int x = min(xq + i, p.ow - 1);
-            const size_t sidx = (size_t)y * st.pitch + x;
-            ps1[i] = st.t[0][sidx];
-            pp1[i] = 128.0 * ps1[i];
-            psum2[i] = kNeedSum2 ? st.sum2[sidx] : 0.0;
-            psq[i] = kNormed ? st.sq[sidx] : 0.0;
-            prsq[i] = (kNormed && !EXACT_DIV && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
-            if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
+            const float v = p.cand_min ? -out[i] : out[i];
+            if (xq + i < p.ow && v > p.cand_thr) m |= 1u << i;
         }
-    }
-    __syncthreads();              // every wave is done reading the image tile: the buffers alias it
-    const int rd_off = 16 * (lane >> 2) + ((4 * (lane & 3) + mf_epi_rot(lane >> 2)) & 15);
-#pragma unroll 1
-    for (int stage = 0; stage < 2 * MB; ++stage) {
-        const int mb = stage >> 1, round = stage & 1;
-        if ((q >> 1) == round) {
-            // registers e = 0..3 of phase c hold templates 4 (q & 1) + e of this stage, pixel 16 j + c
-            int* dst = &epi[(4 * (q & 1)) * kMfEpiPitch + 16 * j];
-            const int rot = mf_epi_rot(j);
-            auto put = [&](const v4i (&blk)[16]) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int col = (c + rot) & 15;
-                    dst[0 * kMfEpiPitch + col] = blk[c].x;
-                    dst[1 * kMfEpiPitch + col] = blk[c].y;
-                    dst[2 * kMfEpiPitch + col] = blk[c].z;
-                    dst[3 * kMfEpiPitch + col] = blk[c].w;
+        if (m) {
+            const int tglob = tlist[li];
+            for (int i = 0; i < 4; ++i)
+                if ((m >> i) & 1u) {
+                    const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+                    if (slot < p.cand_cap) {
+                        mtm_hit hrec;
+                        hrec.templ_idx = tglob;
+                        hrec.x = xq + i;
+                        hrec.y = y;
+                        hrec.w = p.w;
+                        hrec.h = p.h;
+                        hrec.score = out[i];
+                        p.cand_hits[slot] = hrec;
+                    }
                 }
-            };
-            if (mb == 0) put(acc[0]);
-            else put(acc[MB - 1]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS writes above, reads below
-        __builtin_amdgcn_wave_barrier();
-        if (y < p.oh && xq < p.ow) {
-#pragma unroll 1
-            for (int s8 = 0; s8 < 8; ++s8) {
-                // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
-                // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
-                const int lt = mb * 16 + 8 * round + s8;            // template inside this work item
-                const int li = tg * MB * 16 + lt;
-                if (li >= p.n_list) break;                          // wave-uniform
-                if (p.only_li >= 0 && li != p.only_li) continue;
-                const MfTemplConst T = tcl[lt];
-                const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
-                const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
-                float out[4];
+    };
+    auto store4 = [&](float* orow, const float (&out)[4]) {
+#ifdef MTM_PROBE_NO_STORE      /* timing experiment: no score-map stores (values kept alive) */
+        if (out[0] + out[1] + out[2] + out[3] == 12345.678f) orow[0] = 1.0f;
+        return;
+#endif
+        if (xq + 3 < p.ow) {
+            *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (p.dbg & 1) {
-                        out[i] = (float)a32[i];
-                    } else if (C1 && MASKED) {
-                        out[i] = finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[i], pp1[i], psum2[i],
-                                                                                         prsq[i], T);
-                    } else if (C1) {
-                        out[i] = T.all_ones ? 1.0f
-                                            : finish_lean<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(
-                                                  a32[i], ps1[i], pp1[i], psum2[i], psq[i], prsq[i], T);
-                    } else {
+            for (int i = 0; i < 4; ++i)
+                if (xq + i < p.ow) orow[i] = out[i];
+        }
+    };
+
+    if constexpr (C1) {
+        // ---- single channel, method fixed at compile time.  The statistics of the lane's pixels
+        // come from the LDS prefetch; the template loop is software pipelined (constants and
+        // accumulators of the next template are requested before the current one is normalised)
+        // and branch-free apart from wave-uniform tests.
+        double ps1[4], pp1[4], psum2[4], psq[4], prsq[4];
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint8_t* sl = smem + p.st_off + wave * kMfStatBytesPerWave + lane * 16;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const double2 a = *reinterpret_cast<const double2*>(sl + (0 + hh) * 1024);
+                ps1[2 * hh] = a.x;
+                ps1[2 * hh + 1] = a.y;
+                double2 b = make_double2(0.0, 0.0), d = make_double2(0.0, 0.0);
+                if (kNeedSum2) b = *reinterpret_cast<const double2*>(sl + (2 + hh) * 1024);
+                if (kNormed) d = *reinterpret_cast<const double2*>(sl + (4 + hh) * 1024);
+                psum2[2 * hh] = b.x;
+                psum2[2 * hh + 1] = b.y;
+                psq[2 * hh] = d.x;
+                psq[2 * hh + 1] = d.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pp1[i] = 128.0 * ps1[i];
+                prsq[i] = (kNormed && !EXACT_DIV && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+                if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
+            }
+        }
+        __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+        const bool lane_on = y < p.oh && xq < p.ow;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                if ((q >> 1) == round) put(acc[mb]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS writes above, reads below
+                __builtin_amdgcn_wave_barrier();
+                if (lane_on) {
+                    const int lt0 = mb * 16 + 8 * round;                  // template inside this work item
+                    MfTemplConst Tn = tcl[lt0];
+                    v4i an = *reinterpret_cast<const v4i*>(&epi[rd_off]);
+#pragma unroll 2
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
+                        // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
+                        const MfTemplConst T = Tn;
+                        const v4i a4 = an;
+                        if (s8 < 7) {
+                            Tn = tcl[lt0 + s8 + 1];
+                            an = *reinterpret_cast<const v4i*>(&epi[(s8 + 1) * kMfEpiPitch + rd_off]);
+                        }
+                        const int li = tg * MB * 16 + lt0 + s8;
+                        if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;   // wave-uniform
+                        const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+                        float out[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+#ifdef MTM_PROBE_CHEAP_EPI     /* timing experiment: no normalisation (wrong results) */
+                            out[i] = (float)a32[i];
+#else
+                            if (MASKED)
+                                out[i] = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
+                            else
+                                out[i] = finish_fast<METHOD, EXACT_DIV>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
+                                                                        prsq[i], T);
+#endif
+                        }
+                        if (!MASKED) {
+                            const bool ones = T.all_ones != 0;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
+                        }
+                        if (p.cand_on) emit(out, li);
+                        store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else {
+        // ---- generic path: any channel count, run-time method
+        __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+#pragma unroll 1
+        for (int stage = 0; stage < 2 * MB; ++stage) {
+            const int mb = stage >> 1, round = stage & 1;
+            if ((q >> 1) == round) {
+                if (mb == 0) put(acc[0]);
+                else put(acc[MB - 1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (y < p.oh && xq < p.ow) {
+#pragma unroll 1
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const int lt = mb * 16 + 8 * round + s8;
+                    const int li = tg * MB * 16 + lt;
+                    if (li >= p.n_list) break;                          // wave-uniform
+                    if (p.only_li >= 0 && li != p.only_li) continue;
+                    const MfTemplConst T = tcl[lt];
+                    const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
+                    const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+                    float out[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
                         const int x = min(xq + i, p.ow - 1);
                         const size_t sidx = (size_t)y * st.pitch + x;
                         double tv[kMaxChans] = {0.0, 0.0, 0.0, 0.0};
@@ -460,45 +609,15 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const double corr = ((double)a32[i] + 128.0 * s1) + T.mfma_k;
                         out[i] = finish_vals<-1>(p.method, corr, tv, st.sum2[sidx], st.sq[sidx], T, p.chans);
                     }
-                }
-                if (p.cand_on) {
-                    unsigned m = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = p.cand_min ? -out[i] : out[i];
-                        if (xq + i < p.ow && v > p.cand_thr) m |= 1u << i;
-                    }
-                    if (m) {                      // rare
-                        const int tglob = tlist[li];
-                        for (int i = 0; i < 4; ++i)
-                            if ((m >> i) & 1u) {
-                                const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
-                                if (slot < p.cand_cap) {
-                                    mtm_hit hrec;
-                                    hrec.templ_idx = tglob;
-                                    hrec.x = xq + i;
-                                    hrec.y = y;
-                                    hrec.w = p.w;
-                                    hrec.h = p.h;
-                                    hrec.score = out[i];
-                                    p.cand_hits[slot] = hrec;
-                                }
-                            }
-                    }
-                }
-                float* orow = maps + T.map_off + (size_t)y * T.map_pitch + xq;
-                if (xq + 3 < p.ow) {
-                    *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (xq + i < p.ow) orow[i] = out[i];
+                    if (p.cand_on) emit(out, li);
+                    store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below
-        __builtin_amdgcn_wave_barrier();
     }
+    }   // epilogue scope
     }   // work-item loop
 }
 
