@@ -19,9 +19,12 @@ namespace mtm {
 // ---------------------------------------------------------------------------------------------
 // image layout conversion: interleaved rows -> planar, padded, (u8 +) f32
 // ---------------------------------------------------------------------------------------------
+// u8b = the same planes with every byte ^ 0x80 (int8 view, value - 128): operand of the MFMA kernel,
+// which stages its tiles by LDS-DMA and therefore cannot convert on the way.
 __global__ void planarize_u8_kernel(const uint8_t* __restrict__ raw, int rows, int cols, int chans,
-                                    uint8_t* __restrict__ u8, int u8_pitch, long long u8_plane,
-                                    float* __restrict__ f32, int f32_pitch, long long f32_plane) {
+                                    uint8_t* __restrict__ u8, uint8_t* __restrict__ u8b, int u8_pitch,
+                                    long long u8_plane, float* __restrict__ f32, int f32_pitch,
+                                    long long f32_plane) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= cols || y >= rows) return;
@@ -29,6 +32,7 @@ __global__ void planarize_u8_kernel(const uint8_t* __restrict__ raw, int rows, i
     for (int c = 0; c < chans; ++c) {
         const uint8_t v = p[c];
         u8[c * u8_plane + (size_t)y * u8_pitch + x] = v;
+        u8b[c * u8_plane + (size_t)y * u8_pitch + x] = v ^ 0x80;
         f32[c * f32_plane + (size_t)y * f32_pitch + x] = (float)v;
     }
 }

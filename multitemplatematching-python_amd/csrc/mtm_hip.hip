@@ -115,7 +115,7 @@ struct mtm_ctx {
     bool have_image = false;
     int rows = 0, cols = 0, chans = 0, dtype = 0;
     int u8_pitch = 0, f32_pitch = 0, rows_alloc = 0;
-    DevBuf raw, u8, f32;
+    DevBuf raw, u8, u8b, f32;
 
     // templates
     bool have_templ = false;
@@ -511,7 +511,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int n_all = (int)sc.members.size();
         const int mb = n_all > 16 ? 2 : 1;
         MfmaParams p{};
-        p.img = img.u8;
+        p.img = c->u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
         p.pitch = img.u8_pitch;
         p.plane = img.u8_plane;
         p.chans = c->chans;
@@ -526,6 +526,9 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
         p.method = c->method;
         p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.cpr = p.lds_pitch / 16;
+        p.cpr_rstep = 256 / p.cpr;
+        p.cpr_dstep = 256 % p.cpr;
         p.group_bytes = sc.group_bytes;
         p.only_li = only_li;
         p.dbg = c->mfma_dbg;
@@ -731,7 +734,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     (void)hipSetDevice(c->device);
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->raw, &c->u8, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
+    for (DevBuf* b : {&c->raw, &c->u8, &c->u8b, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
                       &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->cands, &c->mask_td, &c->comm_send, &c->comm_recv})
         b->release();
     for (auto& p : c->ncc_ev) {
@@ -799,9 +802,12 @@ int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int
     if (dtype == MTM_U8) {
         const size_t u8_bytes = (size_t)c->u8_pitch * c->rows_alloc * chans;
         MTMC(c->u8.ensure(u8_bytes));
+        MTMC(c->u8b.ensure(u8_bytes));
         HIPC(hipMemsetAsync(c->u8.p, 0, u8_bytes, c->stream));
+        HIPC(hipMemsetAsync(c->u8b.p, 0x80, u8_bytes, c->stream));
         hipLaunchKernelGGL(planarize_u8_kernel, grd, dim3(256), 0, c->stream, c->raw.as<uint8_t>(), rows, cols,
-                           chans, c->u8.as<uint8_t>(), c->u8_pitch, (long long)c->u8_pitch * c->rows_alloc,
+                           chans, c->u8.as<uint8_t>(), c->u8b.as<uint8_t>(), c->u8_pitch,
+                           (long long)c->u8_pitch * c->rows_alloc,
                            c->f32.as<float>(), c->f32_pitch, (long long)c->f32_pitch * c->rows_alloc);
     } else {
         hipLaunchKernelGGL(planarize_f32_kernel, grd, dim3(256), 0, c->stream, c->raw.as<float>(), rows, cols,

@@ -49,7 +49,7 @@ __device__ __forceinline__ int mf_epi_rot(int j) { return 4 * ((j >> 1) & 3); }
 constexpr int kMfStatBytesPerWave = 3 * 2 * 1024;
 
 struct MfmaParams {
-    const uint8_t* img;      // planar padded u8
+    const uint8_t* img;      // planar padded image, bytes already biased to int8 (^ 0x80)
     int pitch;
     long long plane;
     int chans;
@@ -61,6 +61,7 @@ struct MfmaParams {
     int n_work;
     int method;
     int lds_pitch;           // bytes per LDS tile row: (16 + 4*nb + 1) * 16
+    int cpr, cpr_rstep, cpr_dstep;   // 16-byte chunks per tile row; 256 / cpr and 256 % cpr (tile DMA)
     long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
     int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
@@ -88,6 +89,7 @@ struct MfTemplConst {
     double mean[kMaxChans];
     double templ_norm, templ_sum2, mfma_k;
     double rtempl_norm;      // 1 / templ_norm (0 when templ_norm == 0)
+    double m128;             // 128 - mean[0]: CCOEFF numerator straight from the biased accumulator
     double tms, rsqrt_tms;   // masked templates: sum((T*M)^2) and its inverse square root
     long long map_off;
     int map_pitch, all_ones;
@@ -158,6 +160,21 @@ __device__ __forceinline__ float finish_fast(int a32, double s1, double p1, doub
                                              const MfTemplConst& T) {
     constexpr bool normed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                             METHOD == MTM_TM_CCOEFF_NORMED;
+    if constexpr (!EXACT_DIV && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
+        // Default (reciprocal) mode of the two north-star methods: 5-6 float64 operations per output.
+        //   num = a32 + K + 128 S1 [- mean S1]  as one fma on the biased accumulator,
+        //   q   = num * (1/sq) * (1/templ_norm)   (both reciprocals correctly rounded; 0 for a flat
+        //         window or a constant template, which yields the 0 OpenCV returns for t == 0),
+        //   |q| < 1 -> q,  |q| < 1.125 -> +-1,  else 0: the case analysis of common_matchTemplate
+        //   evaluated on the float32 quotient (it only differs from the float64 comparison when q is
+        //   within one float64 rounding of 1.125; at 1 both give +-1.0f).
+        const double base = (double)a32 + T.mfma_k;
+        const double num = fma(s1, METHOD == MTM_TM_CCOEFF_NORMED ? T.m128 : 128.0, base);
+        const float qf = (float)(num * (rsq * T.rtempl_norm));
+        const float aq = fabsf(qf);
+        const float sat = (aq < 1.125f) ? copysignf(1.0f, qf) : 0.0f;
+        return (aq < 1.0f) ? qf : sat;
+    }
     const double corr = (double)a32 + (p1 + T.mfma_k);
     double num = corr;
     if (METHOD == MTM_TM_CCOEFF || METHOD == MTM_TM_CCOEFF_NORMED) num = corr - s1 * T.mean[0];
@@ -290,6 +307,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.templ_sum2 = T.templ_sum2;
             k.mfma_k = T.mfma_k;
             k.rtempl_norm = T.templ_norm > 0.0 ? 1.0 / T.templ_norm : 0.0;
+            k.m128 = 128.0 - T.mean[0];
             k.tms = T.templ2_mask2_sum;
             k.rsqrt_tms = 1.0 / sqrt(T.templ2_mask2_sum);
             k.map_off = T.map_off;
@@ -322,27 +340,41 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     }
 
     const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
-    const int tile_dw_per_row = p.lds_pitch >> 2;
 
     for (int c = 0; c < p.chans; ++c) {
         const uint8_t* plane = p.img + c * p.plane;
         for (int cy0 = 0; cy0 < p.h; cy0 += kMfChunkH) {
             const int ch = min(kMfChunkH, p.h - cy0);
-            // ---- stage (ch + 3) image rows, biased to int8
+            // ---- stage (ch + 3) rows of the int8 image plane by LDS-DMA: the tile is one linear
+            // array of 16-byte chunks [row][cpr]; wave-instruction k of the work-group fills chunks
+            // 64 k .. 64 k + 63 (LDS destination = wave-uniform base + lane * 16), each lane
+            // supplying the global address of its chunk.  No registers, no VALU conversion.
             __syncthreads();
             {
-                const int nrow = ch + kMfRows - 1;
-                uint32_t* tile32 = reinterpret_cast<uint32_t*>(smem);
+                typedef const __attribute__((address_space(1))) void* gptr_t;
+                typedef __attribute__((address_space(3))) void* lptr_t;
+                const int nchunk = (ch + kMfRows - 1) * p.cpr;
+                int ci = threadIdx.x;
+                int r = ci / p.cpr, d = ci - r * p.cpr;
+                const uint8_t* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
+                uint8_t* lbase_w = smem + wave * 1024;
 #ifdef MTM_PROBE_NO_STAGE      /* timing experiment: skip the image-tile staging loads (wrong results) */
-                for (int idx = threadIdx.x; idx < 0; idx += 256) {
+                for (; ci < 0; ci += 256) {
 #else
-                for (int idx = threadIdx.x; idx < nrow * tile_dw_per_row; idx += 256) {
+                for (; ci - lane < nchunk; ci += 256) {
 #endif
-                    const int r = idx / tile_dw_per_row, d = idx - r * tile_dw_per_row;
-                    const uint32_t v = *reinterpret_cast<const uint32_t*>(
-                        plane + (size_t)(y0 + cy0 + r) * p.pitch + x0 + 4 * d);
-                    tile32[idx] = v ^ 0x80808080u;
+                    if (ci < nchunk)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(grow + (size_t)r * p.pitch + 16 * d), (lptr_t)lbase_w,
+                                                         16, 0, 0);
+                    lbase_w += 4096;
+                    r += p.cpr_rstep;
+                    d += p.cpr_dstep;
+                    if (d >= p.cpr) {
+                        d -= p.cpr;
+                        ++r;
+                    }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
             // ---- K loop: template rows of this chunk x 64-tap blocks, software pipelined with two
@@ -563,7 +595,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                             for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                         }
-                        if (p.cand_on) emit(out, li);
+                        if (p.cand_on) {
+                            // cheap any-of-4 test; emit() repeats the exact per-pixel test (rare)
+                            const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                            const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit(out, li);
+                        }
                         store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
                     }
                 }
