@@ -18,7 +18,7 @@ MTM_U8, MTM_F32 = 0, 1
 PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1
 BORDER_CONSTANT, BORDER_NEAREST = 0, 1
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
-OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV = 1, 2, 3, 4, 5
+OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY = 1, 2, 3, 4, 5, 6
 E_OVERFLOW = -5
 COMM_ID_BYTES = 128
 

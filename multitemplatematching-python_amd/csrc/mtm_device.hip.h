@@ -885,6 +885,81 @@ __global__ __launch_bounds__(256) void verify_peaks_kernel(const float* __restri
     }
 }
 
+// Hits-only mode (no score maps in memory): the same test on the candidate list alone.  Every pixel
+// above the threshold IS a candidate, so a neighbour that is not in the list is <= threshold < v and
+// cannot beat the candidate; neighbours that are in the list are found through an open-addressing
+// hash table keyed by (template, y, x) built by cand_hash_insert_kernel.
+__device__ __forceinline__ unsigned long long cand_key(int t, int y, int x) {
+    return ((unsigned long long)(t + 1) << 42) | ((unsigned long long)y << 21) | (unsigned long long)x;
+}
+__device__ __forceinline__ unsigned cand_slot(unsigned long long k, unsigned mask) {
+    return (unsigned)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+
+__global__ __launch_bounds__(256) void cand_hash_insert_kernel(const mtm_hit* __restrict__ cands,
+                                                               const unsigned long long* __restrict__ cand_count,
+                                                               unsigned long long cand_cap,
+                                                               unsigned long long* __restrict__ keys,
+                                                               int* __restrict__ vals, unsigned mask) {
+    const unsigned long long n = min(*cand_count, cand_cap);
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtm_hit c = cands[i];
+    const unsigned long long k = cand_key(c.templ_idx, c.y, c.x);
+    for (unsigned s = cand_slot(k, mask);; s = (s + 1) & mask) {
+        const unsigned long long prev = atomicCAS(&keys[s], 0ull, k);
+        if (prev == 0ull || prev == k) {
+            vals[s] = (int)i;
+            return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void verify_hash_kernel(const TemplDev* __restrict__ td, int mode_min, int border,
+                                                          const mtm_hit* __restrict__ cands,
+                                                          const unsigned long long* __restrict__ cand_count,
+                                                          unsigned long long cand_cap,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          const int* __restrict__ vals, unsigned mask,
+                                                          mtm_hit* __restrict__ hits, unsigned long long hit_cap,
+                                                          unsigned long long* __restrict__ hit_count,
+                                                          int* __restrict__ tcount) {
+    const unsigned long long n = min(*cand_count, cand_cap);
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtm_hit c = cands[i];
+    const TemplDev T = td[c.templ_idx];
+    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+    const float v = mode_min ? -c.score : c.score;
+    float mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dy == 0 && dx == 0) continue;
+            const int yy = c.y + dy, xx = c.x + dx;
+            if (yy < 0 || yy >= T.oh || xx < 0 || xx >= T.ow) {
+                mx = fmaxf(mx, padv);
+                continue;
+            }
+            const unsigned long long k = cand_key(c.templ_idx, yy, xx);
+            for (unsigned s = cand_slot(k, mask);; s = (s + 1) & mask) {
+                const unsigned long long have = keys[s];
+                if (have == 0ull) break;                  // not a candidate: <= threshold < v
+                if (have == k) {
+                    const float nv = cands[vals[s]].score;
+                    mx = fmaxf(mx, mode_min ? -nv : nv);
+                    break;
+                }
+            }
+        }
+    if (v == mx) {
+        const unsigned long long slot = atomicAdd(hit_count, 1ull);
+        if (slot < hit_cap) hits[slot] = c;
+        atomicAdd(&tcount[c.templ_idx], 1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // global extremum: cv2.minMaxLoc (reference MTM/__init__.py:226): first occurrence in row-major
 // order wins ties.  One packed 64-bit key per (template, min|max): high word = order-preserving

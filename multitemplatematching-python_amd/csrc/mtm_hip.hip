@@ -128,7 +128,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -144,6 +144,10 @@ struct mtm_ctx {
     bool cand_on = false;
     bool cand_min = false;
     float cand_thr = 0.f;
+    int hits_only = 1;         // MTM_OPT_HITS_ONLY: mtm_find_matches does not materialise the score maps when
+                               // every class runs the single-channel MFMA kernel (candidates + hash verify)
+    int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
+    bool hits_only_now = false;
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
     int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
     int mfma_stagger = -1;     // < 0: automatic
@@ -533,6 +537,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.only_li = only_li;
         p.dbg = c->mfma_dbg;
         p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        p.cand_thr_lo = (double)c->cand_thr - 1e-6 * std::max(1.0, std::fabs((double)c->cand_thr));
         p.cand_min = c->cand_min ? 1 : 0;
         p.cand_thr = c->cand_thr;
         p.cand_cap = (unsigned long long)c->hit_cap;
@@ -715,6 +721,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     }
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
+    if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_STATS")) c->fuse_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
@@ -764,6 +771,10 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
             return MTM_OK;
         case MTM_OPT_EXACT_DIV:
             c->exact_div = value ? 1 : 0;
+            return MTM_OK;
+        case MTM_OPT_HITS_ONLY:
+            c->hits_only = value ? 1 : 0;
+            c->hits_only_backoff = 0;
             return MTM_OK;
         case MTM_OPT_DOT4_VARIANT:
             if (value < 0 || value >= kNumDotVariants || kDotVariants[value].wide) break;
@@ -956,12 +967,30 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
     for (const SizeClass& sc : c->classes) fused = fused && resolved_kernel(c, sc) == MTM_KERNEL_MFMA;
     c->cand_on = false;
+    c->hits_only_now = false;
+    const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
     if (fused) {
         MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
         HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
         c->cand_on = true;
         c->cand_min = mode_min;
         c->cand_thr = mode_min ? -thr : thr;
+        // hits-only: single-channel MFMA classes, every map 2-D, no recent candidate overflow
+        bool honly = c->hits_only && c->chans == 1 && (int)c->list2d.size() == n;
+        if (honly && c->hits_only_backoff > 0) {
+            --c->hits_only_backoff;
+            honly = false;
+        }
+        c->hits_only_now = honly;
+    }
+    // hash table of the candidate positions (hits-only verification)
+    unsigned hash_mask = 0;
+    if (c->hits_only_now) {
+        size_t hsz = 1024;
+        while (hsz < 2 * (size_t)cand_cap) hsz <<= 1;
+        hash_mask = (unsigned)(hsz - 1);
+        MTMC(c->chash.ensure(hsz * (sizeof(unsigned long long) + sizeof(int))));
+        HIPC(hipMemsetAsync(c->chash.p, 0, hsz * sizeof(unsigned long long), c->stream));
     }
 
     HIPC(hipEventRecord(c->ev[0], c->stream));
@@ -1022,13 +1051,24 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
                 // counter[1] <- candidate count (for the overflow check on the host)
                 HIPC(hipMemcpyAsync(counter + 1, c->cands.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                                     c->stream));
-                const unsigned blocks = (unsigned)((c->hit_cap + 255) / 256);
-                hipLaunchKernelGGL(verify_peaks_kernel, dim3(std::min(blocks, 4096u)), dim3(256), 0, c->stream,
-                                   c->maps.as<float>(), c->td.as<TemplDev>(), mode_min ? 1 : 0, c->opt_border,
-                                   reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16),
-                                   c->cands.as<unsigned long long>(),
-                                   (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256), dhits,
-                                   (unsigned long long)c->hit_cap, counter, flags);
+                const unsigned blocks = std::min((unsigned)((c->hit_cap + 255) / 256), 4096u);
+                const mtm_hit* dcands = reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16);
+                if (c->hits_only_now) {
+                    unsigned long long* keys = c->chash.as<unsigned long long>();
+                    int* vals = reinterpret_cast<int*>(keys + (size_t)hash_mask + 1);
+                    hipLaunchKernelGGL(cand_hash_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, dcands,
+                                       c->cands.as<unsigned long long>(), (unsigned long long)cand_cap, keys, vals,
+                                       hash_mask);
+                    hipLaunchKernelGGL(verify_hash_kernel, dim3(blocks), dim3(256), 0, c->stream, c->td.as<TemplDev>(),
+                                       mode_min ? 1 : 0, c->opt_border, dcands, c->cands.as<unsigned long long>(),
+                                       (unsigned long long)cand_cap, keys, vals, hash_mask, dhits,
+                                       (unsigned long long)c->hit_cap, counter, flags);
+                } else {
+                    hipLaunchKernelGGL(verify_peaks_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                                       c->maps.as<float>(), c->td.as<TemplDev>(), mode_min ? 1 : 0, c->opt_border,
+                                       dcands, c->cands.as<unsigned long long>(), (unsigned long long)cand_cap, dhits,
+                                       (unsigned long long)c->hit_cap, counter, flags);
+                }
             } else {
                 int max_oh = 0, max_ow = 0;
                 for (int t : c->list2d) {
@@ -1050,8 +1090,17 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
             std::memcpy(&count, host_buf.data(), sizeof(count));
             std::memcpy(&ncand, host_buf.data() + sizeof(count), sizeof(ncand));
             std::memcpy(tflags.data(), host_buf.data() + 2 * sizeof(count), sizeof(int) * n);
-            if (use_fused && (int64_t)ncand > std::min<int64_t>(c->hit_cap, 4096LL * 256)) {
+            if (use_fused && (int64_t)ncand > cand_cap) {
                 use_fused = false;                  // dense maps: candidate list overflowed
+                if (c->hits_only_now) {
+                    // no maps in memory: compute them (this call pays twice; the next calls on this
+                    // context start in map mode)
+                    c->hits_only_now = false;
+                    c->hits_only_backoff = 16;
+                    c->timing.ncc_launches = 0;
+                    MTMC(run_score_all(c));
+                    HIPC(hipEventRecord(c->ev[1], c->stream));
+                }
                 continue;
             }
             if ((int64_t)count <= c->hit_cap) {

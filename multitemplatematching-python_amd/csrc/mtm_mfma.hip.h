@@ -79,6 +79,9 @@ struct MfmaParams {
     float cand_thr;
     int cand_min;
     int cand_on;
+    double cand_thr_lo;      // cand_thr minus 8 float32 ulps (hits-only pre-test in float64)
+    int hits_only;           // 1: candidates only, the score maps are not written (mtm_find_matches
+                             // without map consumers); needs cand_on
     int dbg;                 // profiling probes (MTM_MFMA_DBG): 1 cheap epilogue, 2 no epilogue, 4 frozen A
                              // pointer, 8 no MFMA; results are only valid with dbg == 0
 };
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 pp1[i] = 128.0 * ps1[i];
-                prsq[i] = (kNormed && !EXACT_DIV && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+                prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
         }
@@ -577,6 +580,25 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const int li = tg * MB * 16 + lt0 + s8;
                         if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;   // wave-uniform
                         const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+                        if (kNormed && p.hits_only) {
+                            // Nothing is stored in this mode, so only outputs that can reach the
+                            // threshold need the full normalisation: q is the float64 quotient of the
+                            // reciprocal path (within 2 ulp(double) of num / t), compared with a
+                            // threshold lowered by 8 float32 ulps.  |q| >= 1 (saturation cases) and
+                            // constant templates always take the exact path below.
+                            bool pass = T.all_ones != 0;
+                            const double rt = T.rtempl_norm;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const double base = (double)a32[i] + T.mfma_k;
+                                double num = fma(ps1[i], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128 : 128.0, base);
+                                if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[i] - 2.0 * num + T.templ_sum2, 0.0);
+                                const double qd = num * (prsq[i] * rt);
+                                const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
+                                pass = pass || quality > p.cand_thr_lo || fabs(qd) >= 0.999999999;
+                            }
+                            if (!pass) continue;
+                        }
                         float out[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -601,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                             if ((p.cand_min ? -lo : hi) > p.cand_thr) emit(out, li);
                         }
-                        store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
+                        if (!p.hits_only) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below

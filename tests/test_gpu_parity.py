@@ -560,3 +560,61 @@ def test_edge_cases_api(mtm, coins):
     got = mtm.matchTemplates([("v", t)], view, score_threshold=0.6)
     exp = O.match_templates([("v", t)], np.ascontiguousarray(view), score_threshold=0.6)
     assert_hits_equal(got, hits_json(exp), tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# hits-only mode (MTM_OPT_HITS_ONLY): no score maps in memory, peaks from the candidate list alone
+# ------------------------------------------------------------------------------------------------
+def test_hits_only_equals_map_mode(mtm, ctx, coins):
+    small, big = coin_templates(coins)
+    mask = otsu_mask(small)
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, (300, 500), dtype=np.uint8)
+    flat = noise.copy()
+    flat[100:220, 150:400] = 77                     # flat windows: guarded denominators
+    cases = [
+        ([("small", small), ("big", big)], coins, 5, 0.3),
+        ([("small", small), ("big", big)], coins, 5, -0.2),     # negative threshold, saturated scores
+        ([("small", small), ("big", big)], coins, 3, 0.7),
+        ([("small", small), ("big", big)], coins, 1, 0.4),      # minima
+        ([("small", small), ("big", big)], coins, 1, 1.5),      # every pixel below the threshold
+        ([("small", small), ("big", big)], coins, 2, 2.0e7),    # raw scores
+        ([("small", small), ("big", big)], coins, 4, 1.0e6),
+        ([("m", small, mask)], coins, 3, 0.8),                  # masked integer path
+        ([("n%d" % i, noise[10 * i:10 * i + 24, 7 * i:7 * i + 24].copy()) for i in range(20)], noise, 5, 0.4),
+        ([("f%d" % i, flat[90 + 9 * i:90 + 9 * i + 20, 140 + 5 * i:140 + 5 * i + 30].copy()) for i in range(6)], flat, 5, 0.2),
+        ([("f%d" % i, flat[90 + 9 * i:90 + 9 * i + 20, 140 + 5 * i:140 + 5 * i + 30].copy()) for i in range(6)], flat, 3, 0.9),
+        ([("f%d" % i, flat[90 + 9 * i:90 + 9 * i + 20, 140 + 5 * i:140 + 5 * i + 30].copy()) for i in range(6)], flat, 1, 0.1),
+        ([("c", np.full((12, 12), 50, np.uint8)), ("small", small)], coins, 5, 0.5),   # all-ones map + normal one
+    ]
+    set_kernel(ctx, "mfma")
+    try:
+        for exact in (0, 1):
+            set_exact(ctx, exact)
+            for border in (0, 1):
+                ctx.set_option(2, border)
+                for lt, img, method, thr in cases:
+                    res = []
+                    for honly in (0, 1):
+                        ctx.set_option(6, honly)
+                        res.append(mtm.findMatches(lt, img, method=method, score_threshold=thr))
+                    assert len(res[0]) == len(res[1]), (method, thr, exact, border, len(res[0]), len(res[1]))
+                    assert canon(res[0]) == canon(res[1]), (method, thr, exact, border)
+        # hits-only results against the oracle directly (dense: thousands of candidates)
+        ctx.set_option(6, 1)
+        set_exact(ctx, 0)
+        ctx.set_option(2, 0)
+        lt = [("small", small), ("big", big)]
+        for method, thr in ((5, 0.05), (3, 0.6), (1, 0.9)):
+            got = mtm.findMatches(lt, coins, method=method, score_threshold=thr)
+            exp = O.find_matches(lt, coins, method=method, score_threshold=thr)
+            assert len(got) == len(exp) and len(got) > 50
+            assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+        # the timing record says which mode ran
+        ctx.set_option(6, 1)
+        mtm.findMatches(lt, coins)
+    finally:
+        set_kernel(ctx, "auto")
+        set_exact(ctx, 0)
+        ctx.set_option(2, 0)
+        ctx.set_option(6, 1)

@@ -1,14 +1,17 @@
 #!/bin/bash
-# usage: tools/probe_variant.sh <variant.so>...   (GPU box; overwrites the in-tree library of the scratch copy)
-for so in "$@"; do
+# usage: tools/probe_variant.sh <variant.so>[:ENV=VAL[,ENV=VAL...]] ...
+# (GPU box; overwrites the in-tree library of the scratch copy)
+for spec in "$@"; do
+  so="${spec%%:*}"; envs=""
+  if [[ "$spec" == *:* ]]; then envs="${spec#*:}"; envs="${envs//,/ }"; fi
   cp "$so" multitemplatematching-python_amd/MTM/libmtm_hip.so
-  echo "== $so"
-  MTM_KERNEL=mfma python - <<'PY'
+  echo "== $spec"
+  env MTM_KERNEL=mfma $envs python - <<'PY'
 import sys, os, json
 sys.path.insert(0, os.path.join(os.getcwd(), "multitemplatematching-python_amd"))
 import synth
 from MTM import _lib
-img, units, plants = synth.make_config("cfg3_32")
+img, units, plants = synth.make_config(os.environ.get("PROBE_CFG", "cfg3_32"))
 ctx = _lib.Context(0)
 ctx.set_image(img); ctx.set_templates([(u[1], None) for u in units], 5)
 best = 1e9; tot = 1e9
