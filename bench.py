@@ -33,7 +33,11 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 DOT4_PEAK_TMACS = 314.6        # 256 CU x 4 SIMD x 32 lanes x 4 MAC x 2.4 GHz (v_dot4_u32_u8 full rate)
-I8_MFMA_PEAK_TMACS = 2200.0    # ~4.4 PTOPS dense measured (MI355X_MICROARCH.md) / 2
+# int8 MFMA, dense: MI355X_MICROARCH.md lists no spec figure for I8, "~2x the bf16 rate" (bf16 ~2.5 PF
+# dense) and a micro-benchmark ceiling of >= 3944 TOPS.  One v_mfma_i32_16x16x64_i8 is 16384 MAC in 16
+# cycles per SIMD: 1024 SIMDs x 2.4 GHz x 2048 op/cycle = 5.03 POPS.  `peak` below is that figure.
+I8_MFMA_PEAK_TOPS = 5000.0
+I8_MFMA_UBENCH_TOPS = 3944.0
 
 
 def parse():
@@ -75,6 +79,21 @@ def algorithmic_bytes(img, units):
     return b
 
 
+def algorithmic_bytes_hits_only(img, units):
+    """Hits-only mode (no map consumers): image + templates [+ masks] + the two float64 window-statistics
+    planes each size class reads (S1 and the guarded sqrt), nothing per (pixel, template) is written."""
+    H, W = img.shape[:2]
+    b = img.nbytes
+    classes = set()
+    for u in units:
+        t = u[1]
+        b += t.nbytes + (u[2].nbytes if len(u) >= 3 else 0)
+        classes.add(t.shape[:2])
+    for (h, w) in classes:
+        b += 2 * 8 * (H - h + 1) * (W - w + 1)
+    return b
+
+
 def algorithmic_macs(img, units):
     H, W = img.shape[:2]
     m = 0
@@ -85,13 +104,14 @@ def algorithmic_macs(img, units):
     return m
 
 
-def pmc_traffic(kernel_used, config, world):
+def pmc_traffic(kernel_used, config, world, hits_only=False):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
     profiles/ (FETCH_SIZE, WRITE_SIZE; collected separately, see tools/pmc_run.sh), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             table = json.load(f)
-        key = "%s/%s/n%d" % ({2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(kernel_used, "?"), config, world)
+        key = "%s/%s/n%d%s" % ({2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(kernel_used, "?"), config, world,
+                               "/hits_only" if hits_only else "")
         return table.get(key)
     except Exception:  # noqa: BLE001
         return None
@@ -211,7 +231,7 @@ def main():
         dt = float(tt.item())
 
     # PCIe-inclusive: one full MTM.matchTemplates call, numpy arrays in -> hit list out (never `value`)
-    e2e_ms = None
+    e2e_ms = stream_ms = None
     if world == 1:
         _lib._default_ctx = ctx
         ts = []
@@ -220,6 +240,14 @@ def main():
             MTM.matchTemplates(units, img, method=method, score_threshold=thr, maxOverlap=0.25)
             ts.append((time.perf_counter() - t1) * 1e3)
         e2e_ms = float(np.median(ts))
+        # image stream through resident templates (MTM.TemplateMatcher.match_stream): the upload of
+        # image i+1 overlaps the kernels of image i; numpy arrays in -> hit lists out, per image
+        matcher = MTM.TemplateMatcher(units, method=method, score_threshold=thr, maxOverlap=0.25, context=ctx)
+        frames = [np.ascontiguousarray(np.roll(img, 64 * k, axis=1)) for k in range(4)] * 4
+        list(matcher.match_stream(frames[:3]))
+        t1 = time.perf_counter()
+        n_out = sum(1 for _ in matcher.match_stream(frames))
+        stream_ms = (time.perf_counter() - t1) * 1e3 / max(n_out, 1)
 
     # sanity: the timed path found every planted template
     found = {(h[0], h[1]) for h in hits}
@@ -230,9 +258,29 @@ def main():
         value = px * len(units) * args.steps / dt / 1e6
         my_units = sub
         kms = float(np.mean(kernel_ms)) / max(launches, 1)          # avg duration of ONE ncc launch
-        bytes_launch = algorithmic_bytes(img, my_units) / max(launches, 1)
+        hits_only = bool(tinfo.get("hits_only", 0))
+        bytes_launch = (algorithmic_bytes_hits_only if hits_only else algorithmic_bytes)(img, my_units) / max(launches, 1)
         macs = algorithmic_macs(img, my_units)
         achieved = bytes_launch / (kms * 1e-3) / 1e9
+        kname = {1: "ncc_naive_kernel", 2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(tinfo["kernel_used"], "ncc_f64_kernel")
+        tmacs = macs / (float(np.mean(kernel_ms)) * 1e-3) / 1e12
+        traffic = pmc_traffic(tinfo["kernel_used"], args.config, world, hits_only)
+        hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch),
+               "maps_materialised": not hits_only}
+        if tinfo["kernel_used"] == 3:
+            # the dominant kernel runs on the int8 matrix cores: ~4096 MAC per output, ~1000 MAC per
+            # algorithmic byte even when the maps are written - MFMA is the roofline that bounds it
+            roof = {"bound": "mfma", "achieved": round(2.0 * tmacs, 1), "peak": I8_MFMA_PEAK_TOPS,
+                    "unit": "TOP/s (int8 ops, 2 per MAC; the TFLOP/s slot of an integer kernel)",
+                    "frac": round(2.0 * tmacs / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
+                    "ubench_ceiling": I8_MFMA_UBENCH_TOPS,
+                    "frac_of_ubench_ceiling": round(2.0 * tmacs / I8_MFMA_UBENCH_TOPS, 4), "hbm": hbm}
+        else:
+            roof = dict(hbm, bound="hbm", traffic=traffic, valu_dot4_peak_tmacs=DOT4_PEAK_TMACS,
+                        note="direct method, ~1000 MAC per algorithmic byte: VALU-bound by construction")
+        roof.update({"kernel": kname, "kernel_ms_per_launch": round(kms, 4), "launches_per_step": launches,
+                     "algorithmic_macs_per_launch": int(macs / max(launches, 1)), "achieved_tmacs": round(tmacs, 2)})
         out = {
             "metric": "Mpixel-correlations/s", "value": round(value, 1), "unit": "Mpx-corr/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -241,21 +289,17 @@ def main():
             "config": {"workload": desc, "image_hw": list(img.shape[:2]), "units": len(units),
                        "units_per_gpu": len(my_units), "method": method, "score_threshold": thr,
                        "max_overlap": 0.25, "parallelism": "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
-                       "timed_region": "score maps + peaks + D2H hits + all-gather + NMS; image/templates resident in HBM"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(tinfo["kernel_used"], args.config, world),
-                         "kernel": {1: "ncc_naive_kernel", 2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(tinfo["kernel_used"], "ncc_f64_kernel"),
-                         "kernel_ms_per_launch": round(kms, 4), "launches_per_step": launches,
-                         "algorithmic_bytes_per_launch": int(bytes_launch),
-                         "algorithmic_macs_per_launch": int(macs / max(launches, 1)),
-                         "achieved_tmacs": round(macs / (float(np.mean(kernel_ms)) * 1e-3) / 1e12, 2),
-                         "valu_dot4_peak_tmacs": DOT4_PEAK_TMACS,
-                         "note": "direct 64x64 method is ~1000 MAC per algorithmic byte: compute-bound by construction; "
-                                 "achieved_tmacs vs the dot4 / i8-MFMA peak is the meaningful utilisation"},
+                       "timed_region": "window statistics + correlation/normalisation kernel + peak extraction + D2H hits + "
+                                       "all-gather + NMS; image/templates resident in HBM",
+                       "score_maps": "not materialised (hits-only mode, MTM_OPT_HITS_ONLY=1: identical hit lists)" if hits_only
+                                     else "materialised in HBM"},
+            "roofline": roof,
             "gpu_ms": {"kernels_total": round(float(np.mean(total_ms)), 4), "ncc_kernel": round(float(np.mean(kernel_ms)), 4)},
             "hits": len(hits), "planted_found": bool(planted_ok),
             "e2e_call_ms": None if e2e_ms is None else round(e2e_ms, 3),
             "e2e_call_mpx_corr_s": None if e2e_ms is None else round(px * len(units) / e2e_ms / 1e3, 1),
+            "stream_ms_per_image": None if stream_ms is None else round(stream_ms, 3),
+            "stream_mpx_corr_s": None if stream_ms is None else round(px * len(units) / stream_ms / 1e3, 1),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 1
+#define MTM_ABI_VERSION 2
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -107,6 +107,8 @@ typedef struct mtm_timing {
     int32_t ncc_launches;
     int32_t kernel_used; /* MTM_KERNEL_* actually dispatched for the uint8 path           */
     int64_t n_hits;
+    int32_t hits_only;   /* 1: the last mtm_find_matches ran without materialising the score maps */
+    int32_t reserved_;
 } mtm_timing;
 
 /* ---- device / context ------------------------------------------------------------------- */
@@ -143,6 +145,17 @@ int mtm_score_map(mtm_ctx* ctx, int templ_idx, float* out, int64_t out_row_strid
  * float32 map exactly as numpy does.  On MTM_E_OVERFLOW *n_out is the capacity needed. */
 int mtm_find_matches(mtm_ctx* ctx, int mode, double score_threshold,
                      mtm_hit* out, int64_t capacity, int64_t* n_out);
+
+/* Stream form of mtm_find_matches ("thousands of images", reference
+ * tutorials/Tutorial3-SpeedingUp.ipynb:564: same templates, one image after the other): returns the
+ * hits of the CURRENT image exactly like mtm_find_matches and makes `next_px` the current image for
+ * the following call.  The next image is uploaded and converted on a second HIP stream while the
+ * kernels of the current image run, so its PCIe transfer costs no wall-clock.
+ * The caller's buffer is only read during the call.  On MTM_E_OVERFLOW the swap has happened too
+ * (fetch the hits with mtm_last_hits). */
+int mtm_find_matches_next(mtm_ctx* ctx, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                          int64_t* n_out, const void* next_px, int rows, int cols, int chans, int dtype,
+                          int64_t row_stride_bytes);
 
 /* The hit list of the last mtm_find_matches call again, without recomputing anything: the way to
  * collect the result after MTM_E_OVERFLOW told the caller the capacity it needs. */

@@ -289,24 +289,57 @@ class TemplateMatcher:
         self._ctx.set_templates([(u[0], u[1]) for u in units], self.method)
         self._uploaded_for = (kinds.pop() if kinds else str(image.dtype), 1 if image.ndim == 2 else image.shape[2])
 
-    def match(self, image: np.ndarray, searchBox: Optional[BBox] = None) -> List[Hit]:
+    def _prepare(self, image, searchBox):
+        """Validation + pixel policy of one image (same order as findMatches); returns the array to
+        upload and the searchBox offsets.  Caller holds the context lock."""
         image_s, xOffset, yOffset = _validate_search(self.listTemplates, image, self.N_object, searchBox)
-        with self._ctx.lock:
-            if self._uploaded_for is None:
-                self._upload(image_s)
-            want = "uint8" if (self._uploaded_for[0] == "uint8" and image_s.dtype == "uint8") else "float32"
-            if image_s.dtype == "float64":
-                raise ValueError("64-bit images not supported, max 32-bit")
-            if want != self._uploaded_for[0] or (1 if image_s.ndim == 2 else image_s.shape[2]) != self._uploaded_for[1]:
-                raise ValueError("TemplateMatcher: image pixel type / channel count differs from the resident templates")
-            im = image_s if want == "uint8" else np.float32(image_s)
-            self._ctx.set_image(im)
-            mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
-            raw = self._ctx.find_matches(mode, self.score_threshold).copy()
+        if self._uploaded_for is None:
+            self._upload(image_s)
+        want = "uint8" if (self._uploaded_for[0] == "uint8" and image_s.dtype == "uint8") else "float32"
+        if image_s.dtype == "float64":
+            raise ValueError("64-bit images not supported, max 32-bit")
+        if want != self._uploaded_for[0] or (1 if image_s.ndim == 2 else image_s.shape[2]) != self._uploaded_for[1]:
+            raise ValueError("TemplateMatcher: image pixel type / channel count differs from the resident templates")
+        return (image_s if want == "uint8" else np.float32(image_s)), xOffset, yOffset
+
+    def _finish(self, raw, xOffset, yOffset):
         if self.method == 0:
             raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
         kept = _nms_raw(raw, self.score_threshold, self.method == 1, self.N_object, self.maxOverlap)
         return _to_hit_list(kept, self.listTemplates, xOffset, yOffset)
+
+    def match(self, image: np.ndarray, searchBox: Optional[BBox] = None) -> List[Hit]:
+        with self._ctx.lock:
+            im, xOffset, yOffset = self._prepare(image, searchBox)
+            self._ctx.set_image(im)
+            mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
+            raw = self._ctx.find_matches(mode, self.score_threshold).copy()
+        return self._finish(raw, xOffset, yOffset)
+
+    def match_stream(self, images, searchBox: Optional[BBox] = None):
+        """
+        Generator over an iterable of images: yields ``match(image)`` for each, in order.  The upload
+        of image i+1 (PCIe transfer, plane conversion) is enqueued on a
+        second stream while the kernels of image i run (mtm_find_matches_next), so a stream costs
+        about the kernel time per image instead of upload + kernels.  The context stays locked while
+        the generator is being consumed.
+        """
+        mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
+        it = iter(images)
+        try:
+            first = next(it)
+        except StopIteration:
+            return
+        with self._ctx.lock:
+            cur = self._prepare(first, searchBox)
+            self._ctx.set_image(cur[0])
+            for nxt_image in it:
+                nxt = self._prepare(nxt_image, searchBox)
+                raw = self._ctx.find_matches(mode, self.score_threshold, next_image=nxt[0]).copy()
+                yield self._finish(raw, cur[1], cur[2])
+                cur = nxt
+            raw = self._ctx.find_matches(mode, self.score_threshold).copy()
+            yield self._finish(raw, cur[1], cur[2])
 
 
 # ---------------------------------------------------------------------------------------------

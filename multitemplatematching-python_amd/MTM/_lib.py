@@ -39,7 +39,7 @@ class MtmTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_float), ("score_ms", ctypes.c_float),
                 ("peaks_ms", ctypes.c_float), ("ncc_kernel_ms", ctypes.c_float),
                 ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
-                ("n_hits", ctypes.c_int64)]
+                ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),
@@ -61,6 +61,9 @@ SYMBOLS = {
     "mtm_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
     "mtm_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                         ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_find_matches_next": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                             ctypes.c_int64, _P(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "mtm_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_get_timing": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTiming)]),
     "mtm_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
@@ -97,7 +100,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.mtm_abi_version() != 1:
+        if lib.mtm_abi_version() != 2:
             raise MtmError("libmtm_hip.so ABI version mismatch")
         _lib = lib
         return lib
@@ -201,12 +204,21 @@ class Context:
         check(self._lib.mtm_score_map(self._h, int(idx), out.ctypes.data, out.strides[0]), "mtm_score_map")
         return out
 
-    def find_matches(self, mode, score_threshold):
+    def find_matches(self, mode, score_threshold, next_image=None):
+        """Hits of the current image.  With `next_image`, that image is uploaded while the kernels run
+        and is the current image when the call returns (mtm_find_matches_next)."""
         cap = 4096
         out = np.empty(cap, dtype=HIT_DTYPE)
         n = ctypes.c_int64(0)
-        rc = self._lib.mtm_find_matches(self._h, int(mode), float(score_threshold), out.ctypes.data, cap,
-                                        ctypes.byref(n))
+        if next_image is None:
+            rc = self._lib.mtm_find_matches(self._h, int(mode), float(score_threshold), out.ctypes.data, cap,
+                                            ctypes.byref(n))
+        else:
+            a, ptr, stride = _pixel_rows(next_image)
+            chans = 1 if a.ndim == 2 else a.shape[2]
+            rc = self._lib.mtm_find_matches_next(self._h, int(mode), float(score_threshold), out.ctypes.data, cap,
+                                                 ctypes.byref(n), ptr, a.shape[0], a.shape[1], chans,
+                                                 _dtype_code(a), stride)
         if rc == E_OVERFLOW:        # the result stays in the context: fetch it, do not recompute
             cap = int(n.value)
             out = np.empty(cap, dtype=HIT_DTYPE)

@@ -115,7 +115,16 @@ struct mtm_ctx {
     bool have_image = false;
     int rows = 0, cols = 0, chans = 0, dtype = 0;
     int u8_pitch = 0, f32_pitch = 0, rows_alloc = 0;
-    DevBuf raw, u8, u8b, f32;
+    // Device copies of an image: raw (as uploaded), planar padded u8 / int8-biased u8 / f32.  Two slots:
+    // `cur` is what the kernels read; the other one receives the next image of a stream
+    // (mtm_find_matches_next) on copy_stream while the kernels run.
+    struct ImageSlot {
+        DevBuf raw, u8, u8b, f32;
+        long long geom = -1;        // (rows, cols, chans, dtype) the padding was initialised for
+    } slot[2];
+    int cur = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t next_ready = nullptr;
 
     // templates
     bool have_templ = false;
@@ -169,8 +178,8 @@ namespace {
 
 ImageDev image_dev(const mtm_ctx* c) {
     ImageDev d;
-    d.u8 = c->u8.as<uint8_t>();
-    d.f32 = c->f32.as<float>();
+    d.u8 = c->slot[c->cur].u8.as<uint8_t>();
+    d.f32 = c->slot[c->cur].f32.as<float>();
     d.rows = c->rows;
     d.cols = c->cols;
     d.chans = c->chans;
@@ -515,7 +524,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int n_all = (int)sc.members.size();
         const int mb = n_all > 16 ? 2 : 1;
         MfmaParams p{};
-        p.img = c->u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
+        p.img = c->slot[c->cur].u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
         p.pitch = img.u8_pitch;
         p.plane = img.u8_plane;
         p.chans = c->chans;
@@ -741,9 +750,14 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     (void)hipSetDevice(c->device);
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->raw, &c->u8, &c->u8b, &c->f32, &c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1,
-                      &c->hs2, &c->stats, &c->hits, &c->counters, &c->sched, &c->cands, &c->mask_td, &c->comm_send, &c->comm_recv})
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& sl : c->slot)
+        for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
+    for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
+                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->comm_send, &c->comm_recv})
         b->release();
+    if (c->next_ready) (void)hipEventDestroy(c->next_ready);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& p : c->ncc_ev) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -786,52 +800,86 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
     return MTM_E_INVALID;
 }
 
-int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
-                  int64_t row_stride_bytes) {
-    if (!c || !px || rows <= 0 || cols <= 0 || chans < 1 || chans > kMaxChans ||
-        (dtype != MTM_U8 && dtype != MTM_F32)) {
-        set_error("mtm_set_image: bad arguments (1..4 channels, uint8 or float32)");
-        return MTM_E_INVALID;
-    }
-    HIPC(hipSetDevice(c->device));
+namespace {
+
+// Upload one image into `sl` and build its planar padded planes on `stream`.  `src` has tightly
+// packed rows when `src_stride` == cols * chans * elem size or any larger stride.
+int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int rows, int cols,
+                 int chans, int dtype, hipStream_t stream) {
     const size_t esz = dtype == MTM_U8 ? 1 : 4;
     const size_t tight = (size_t)cols * chans * esz;
-    if (row_stride_bytes < (int64_t)tight) {
-        set_error("mtm_set_image: row stride smaller than a row");
-        return MTM_E_INVALID;
-    }
-    MTMC(c->raw.ensure(tight * rows));
-    HIPC(hipMemcpy2DAsync(c->raw.p, tight, px, (size_t)row_stride_bytes, tight, rows, hipMemcpyHostToDevice,
-                          c->stream));
-    c->rows_alloc = rows + kPadRows;
-    c->u8_pitch = (int)round_up((size_t)cols + kPadCols, 64);
-    c->f32_pitch = (int)round_up((size_t)cols + kPadCols, 64);
-    const size_t f32_bytes = sizeof(float) * c->f32_pitch * c->rows_alloc * chans;
-    MTMC(c->f32.ensure(f32_bytes));
-    HIPC(hipMemsetAsync(c->f32.p, 0, f32_bytes, c->stream));
-    const dim3 grd((cols + 255) / 256, rows);
+    MTMC(sl.raw.ensure(tight * rows));
+    HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, rows, hipMemcpyHostToDevice, stream));
+    const int rows_alloc = rows + kPadRows;
+    const int pitch = (int)round_up((size_t)cols + kPadCols, 64);
+    const size_t f32_bytes = sizeof(float) * pitch * rows_alloc * chans;
+    const size_t u8_bytes = (size_t)pitch * rows_alloc * chans;
+    const long long geom = (((long long)rows * 65536 + cols) * 8 + chans) * 4 + dtype;
+    const size_t caps[3] = {sl.f32.cap, sl.u8.cap, sl.u8b.cap};
+    MTMC(sl.f32.ensure(f32_bytes));
     if (dtype == MTM_U8) {
-        const size_t u8_bytes = (size_t)c->u8_pitch * c->rows_alloc * chans;
-        MTMC(c->u8.ensure(u8_bytes));
-        MTMC(c->u8b.ensure(u8_bytes));
-        HIPC(hipMemsetAsync(c->u8.p, 0, u8_bytes, c->stream));
-        HIPC(hipMemsetAsync(c->u8b.p, 0x80, u8_bytes, c->stream));
-        hipLaunchKernelGGL(planarize_u8_kernel, grd, dim3(256), 0, c->stream, c->raw.as<uint8_t>(), rows, cols,
-                           chans, c->u8.as<uint8_t>(), c->u8b.as<uint8_t>(), c->u8_pitch,
-                           (long long)c->u8_pitch * c->rows_alloc,
-                           c->f32.as<float>(), c->f32_pitch, (long long)c->f32_pitch * c->rows_alloc);
-    } else {
-        hipLaunchKernelGGL(planarize_f32_kernel, grd, dim3(256), 0, c->stream, c->raw.as<float>(), rows, cols,
-                           chans, c->f32.as<float>(), c->f32_pitch, (long long)c->f32_pitch * c->rows_alloc);
+        MTMC(sl.u8.ensure(u8_bytes));
+        MTMC(sl.u8b.ensure(u8_bytes));
     }
+    // the padding (zeros; 0x80 in the int8 view) only needs writing when the planes are new
+    if (sl.geom != geom || caps[0] != sl.f32.cap || caps[1] != sl.u8.cap || caps[2] != sl.u8b.cap) {
+        HIPC(hipMemsetAsync(sl.f32.p, 0, f32_bytes, stream));
+        if (dtype == MTM_U8) {
+            HIPC(hipMemsetAsync(sl.u8.p, 0, u8_bytes, stream));
+            HIPC(hipMemsetAsync(sl.u8b.p, 0x80, u8_bytes, stream));
+        }
+        sl.geom = geom;
+    }
+    const dim3 grd((cols + 255) / 256, rows);
+    if (dtype == MTM_U8)
+        hipLaunchKernelGGL(planarize_u8_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint8_t>(), rows, cols, chans,
+                           sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch, (long long)pitch * rows_alloc,
+                           sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    else
+        hipLaunchKernelGGL(planarize_f32_kernel, grd, dim3(256), 0, stream, sl.raw.as<float>(), rows, cols, chans,
+                           sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(c->stream));
+    return MTM_OK;
+}
+
+void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype) {
     if (rows != c->rows || cols != c->cols || chans != c->chans || dtype != c->dtype) c->placed = false;
     c->rows = rows;
     c->cols = cols;
     c->chans = chans;
     c->dtype = dtype;
+    c->rows_alloc = rows + kPadRows;
+    c->u8_pitch = (int)round_up((size_t)cols + kPadCols, 64);
+    c->f32_pitch = c->u8_pitch;
     c->have_image = true;
+}
+
+int check_image_args(const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                     const char* who) {
+    if (!px || rows <= 0 || cols <= 0 || chans < 1 || chans > kMaxChans || (dtype != MTM_U8 && dtype != MTM_F32)) {
+        set_error(std::string(who) + ": bad arguments (1..4 channels, uint8 or float32)");
+        return MTM_E_INVALID;
+    }
+    if (row_stride_bytes < (int64_t)((size_t)cols * chans * (dtype == MTM_U8 ? 1 : 4))) {
+        set_error(std::string(who) + ": row stride smaller than a row");
+        return MTM_E_INVALID;
+    }
+    return MTM_OK;
+}
+
+}  // namespace
+
+int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
+                  int64_t row_stride_bytes) {
+    if (!c) {
+        set_error("mtm_set_image: null context");
+        return MTM_E_INVALID;
+    }
+    MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_set_image"));
+    HIPC(hipSetDevice(c->device));
+    MTMC(upload_image(c, c->slot[c->cur], px, row_stride_bytes, rows, cols, chans, dtype, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    adopt_image(c, rows, cols, chans, dtype);
     return MTM_OK;
 }
 
@@ -947,8 +995,72 @@ int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_
     return MTM_OK;
 }
 
+namespace {
+
+struct NextImage {
+    const void* px;
+    int rows, cols, chans, dtype;
+    int64_t stride;
+    bool staged;
+};
+
+// Enqueue the upload + plane conversion of the next image of a stream on the copy stream, into the
+// image slot the kernels are not reading.  Called by find_matches_impl after the kernels of the
+// current image are enqueued and before it waits for them: the PCIe transfer (and the host-side
+// staging the runtime does for pageable memory) runs under the kernels.
+int stage_next_image(mtm_ctx* c, NextImage* nx) {
+    if (!nx || nx->staged) return MTM_OK;
+    if (!c->copy_stream) HIPC(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->next_ready) HIPC(hipEventCreateWithFlags(&c->next_ready, hipEventDisableTiming));
+    // The runtime batches stream commands and only submits them when somebody asks about the stream:
+    // push the kernels of the current image out first, then (below) the copy, so that they overlap.
+    (void)hipStreamQuery(c->stream);
+    // straight from the caller's (pageable) rows: the runtime stages them through its own pinned
+    // buffers, which measured 5x faster than a host copy into hipHostMalloc memory on this platform
+    MTMC(upload_image(c, c->slot[1 - c->cur], nx->px, nx->stride, nx->rows, nx->cols, nx->chans, nx->dtype,
+                      c->copy_stream));
+    HIPC(hipEventRecord(c->next_ready, c->copy_stream));
+    (void)hipStreamQuery(c->copy_stream);
+    nx->staged = true;
+    return MTM_OK;
+}
+
+int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                      int64_t* n_out, NextImage* next);
+
+}  // namespace
+
 int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
                      int64_t* n_out) {
+    return find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr);
+}
+
+int mtm_find_matches_next(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                          int64_t* n_out, const void* next_px, int rows, int cols, int chans, int dtype,
+                          int64_t row_stride_bytes) {
+    if (!c) {
+        set_error("mtm_find_matches_next: null context");
+        return MTM_E_INVALID;
+    }
+    MTMC(check_image_args(next_px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_next"));
+    NextImage nx{next_px, rows, cols, chans, dtype, row_stride_bytes, false};
+    const int rc = find_matches_impl(c, mode, score_threshold, out, capacity, n_out, &nx);
+    if (rc != MTM_OK && rc != MTM_E_OVERFLOW) {
+        if (nx.staged) (void)hipStreamSynchronize(c->copy_stream);   // drop the staged image
+        return rc;
+    }
+    // the results of the current image are final: make the staged image current
+    if (!nx.staged) MTMC(stage_next_image(c, &nx));
+    HIPC(hipEventSynchronize(c->next_ready));
+    c->cur = 1 - c->cur;
+    adopt_image(c, rows, cols, chans, dtype);
+    return rc;
+}
+
+namespace {
+
+int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                      int64_t* n_out, NextImage* next) {
     if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) ||
         (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
         set_error("mtm_find_matches: bad arguments");
@@ -997,6 +1109,10 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
     MTMC(run_score_all(c));
     HIPC(hipEventRecord(c->ev[1], c->stream));
     c->cand_on = false;
+    // stream mode: the kernels of this image are on their way - start the upload of the next one now.
+    // (Not later: the device-to-host copy of the hit records below lands in pageable memory, which
+    // the runtime executes synchronously, i.e. after the kernels.)
+    MTMC(stage_next_image(c, next));
 
     if (mode == MTM_PEAKS_GLOBAL) {
         MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
@@ -1177,6 +1293,7 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
     HIPC(hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[2]));
     MTMC(collect_ncc_time(c));
     c->timing.n_hits = (int64_t)hits.size();
+    c->timing.hits_only = c->hits_only_now ? 1 : 0;
     *n_out = (int64_t)hits.size();
     c->last_hits.swap(hits);
     if ((int64_t)c->last_hits.size() > capacity) {
@@ -1186,6 +1303,8 @@ int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out,
     if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
     return MTM_OK;
 }
+
+}  // namespace
 
 int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
     if (!c || !n_out || capacity < 0 || (capacity > 0 && !out)) {

@@ -528,6 +528,17 @@ def test_template_matcher_stream(mtm):
         assert matcher.match(im) == mtm.matchTemplates(units, im, score_threshold=0.5)
     small = np.ascontiguousarray(img[:200, :400])                 # a different image size re-places the maps
     assert matcher.match(small) == mtm.matchTemplates(units, small, score_threshold=0.5)
+    # double-buffered stream (mtm_find_matches_next): sizes change mid-stream, strided views, N_object=1
+    stream = [np.ascontiguousarray(np.roll(img, 31 * k, axis=0)) for k in range(5)]
+    stream.insert(2, small)
+    stream.append(img[5:290, 3:500])                               # non-contiguous rows
+    assert list(matcher.match_stream(stream)) == [mtm.matchTemplates(units, im, score_threshold=0.5) for im in stream]
+    assert matcher.match(img) == mtm.matchTemplates(units, img, score_threshold=0.5)      # set_image after a stream
+    one = mtm.TemplateMatcher(units[:3], N_object=1)
+    assert list(one.match_stream(stream[:3])) == [mtm.matchTemplates(units[:3], im, N_object=1) for im in stream[:3]]
+    f32 = [im.astype(np.float32) for im in stream[:3]]
+    mf = mtm.TemplateMatcher([(n, t.astype(np.float32)) for n, t in units[:3]], score_threshold=0.5)
+    assert list(mf.match_stream(f32)) == [mtm.matchTemplates([(n, t.astype(np.float32)) for n, t in units[:3]], im, score_threshold=0.5) for im in f32]
 
 
 # ------------------------------------------------------------------------------------------------

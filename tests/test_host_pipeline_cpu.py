@@ -31,7 +31,14 @@ class OracleContext:
         assert out.shape == tuple(shape)
         return out
 
-    def find_matches(self, mode, thr):
+    def find_matches(self, mode, thr, next_image=None):
+        try:
+            return self._find(mode, thr)
+        finally:
+            if next_image is not None:      # mtm_find_matches_next: the next image becomes current
+                self.image = next_image
+
+    def _find(self, mode, thr):
         rows = []
         for i, (t, m) in enumerate(self.templates):
             cmap = O.match_template(self.image, t, self.method, mask=m)
@@ -110,3 +117,8 @@ def test_template_matcher_equals_match_templates(mtm):
         mtm.matchTemplates(lt, coins, score_threshold=0.3, maxOverlap=0.25, searchBox=(10, 20, 300, 200))
     with pytest.raises(ValueError, match="pixel type"):
         matcher.match(coins.astype(np.float32))
+    # stream form: same results, in order, any mix of sizes; empty iterable -> nothing
+    imgs = [coins, np.ascontiguousarray(coins[::-1]), coins[20:280, 10:380], coins]
+    assert list(matcher.match_stream(imgs)) == [matcher.match(i) for i in imgs]
+    assert list(matcher.match_stream(iter(imgs[:1]))) == [matcher.match(coins)]
+    assert list(matcher.match_stream([])) == []
