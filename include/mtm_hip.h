@@ -125,6 +125,14 @@ int         mtm_set_option(mtm_ctx* ctx, int option, int64_t value);
  * cv2.matchTemplate (MTM/__init__.py:92). */
 int mtm_set_image(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
                   int64_t row_stride_bytes);
+/* Same, but the image is area-downscaled by an integer factor on the device while it is laid out
+ * (the search image becomes rows/factor x cols/factor; remainder rows/columns are dropped).  Replaces
+ * the host-side cv2.resize(image, smallDim, interpolation=cv2.INTER_AREA) the reference's speed-up
+ * recipe runs before matching (tutorials/Tutorial3-SpeedingUp.ipynb:395).  uint8 rounding follows
+ * OpenCV's integer-factor INTER_AREA path: factor 2 -> (sum + 2) >> 2, else
+ * rint((float)sum * (1.f / factor^2)). */
+int mtm_set_image_downscaled(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
+                             int64_t row_stride_bytes, int factor);
 
 /* Upload all templates of one matchTemplates/findMatches call and fix the method.  Template
  * statistics (cv::meanStdDev) are computed here.  Replaces the per-template arguments of

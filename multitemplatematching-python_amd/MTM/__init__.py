@@ -385,3 +385,6 @@ def drawBoxesOnGray(image: np.ndarray, listHit: Sequence[Hit], boxThickness: int
     if showLabel:
         warnings.warn("drawBoxesOnGray: label text is not rendered by the MI355X drop-in (no cv2.putText).")
     return _draw_boxes(out, listHit, boxThickness, boxColor)
+
+
+from . import augment  # noqa: E402,F401  (template augmentation / downscaled matching helpers)

@@ -57,6 +57,8 @@ SYMBOLS = {
     "mtm_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "mtm_set_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "mtm_set_image_downscaled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     "mtm_set_templates": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTempl), ctypes.c_int, ctypes.c_int]),
     "mtm_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
     "mtm_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
@@ -170,11 +172,13 @@ class Context:
     def set_option(self, opt, value):
         check(self._lib.mtm_set_option(self._h, int(opt), int(value)), "mtm_set_option")
 
-    def set_image(self, image):
+    def set_image(self, image, downscale=1):
+        """Upload the search image; `downscale` > 1 area-averages it by that integer factor on the
+        device (mtm_set_image_downscaled)."""
         a, ptr, stride = _pixel_rows(image)
         chans = 1 if a.ndim == 2 else a.shape[2]
-        check(self._lib.mtm_set_image(self._h, ptr, a.shape[0], a.shape[1], chans, _dtype_code(a), stride),
-              "mtm_set_image")
+        check(self._lib.mtm_set_image_downscaled(self._h, ptr, a.shape[0], a.shape[1], chans, _dtype_code(a), stride,
+                                                 int(downscale)), "mtm_set_image")
 
     def set_templates(self, templates, method):
         """templates: list of (array, mask_or_None) with identical dtype policy already applied."""

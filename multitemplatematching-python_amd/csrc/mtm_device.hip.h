@@ -37,6 +37,50 @@ __global__ void planarize_u8_kernel(const uint8_t* __restrict__ raw, int rows, i
     }
 }
 
+// Integer-factor area downscale fused with the layout conversion (reference use:
+// cv2.resize(image, smallDim, interpolation=cv2.INTER_AREA) before matching,
+// tutorials/Tutorial3-SpeedingUp.ipynb:395).  Output pixel = mean of an f x f block; uint8 rounding as
+// OpenCV's integer-factor INTER_AREA path: f == 2 -> (sum + 2) >> 2, otherwise
+// rint((float)sum * (1.f / (f*f))) (float32 product, ties to even).
+__global__ void planarize_u8_down_kernel(const uint8_t* __restrict__ raw, int src_cols, int chans, int f,
+                                         int rows, int cols, uint8_t* __restrict__ u8,
+                                         uint8_t* __restrict__ u8b, int u8_pitch, long long u8_plane,
+                                         float* __restrict__ f32, int f32_pitch, long long f32_plane) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float scale = 1.0f / (float)(f * f);
+    for (int c = 0; c < chans; ++c) {
+        unsigned sum = 0;
+        for (int dy = 0; dy < f; ++dy) {
+            const uint8_t* p = raw + ((size_t)(y * f + dy) * src_cols + (size_t)x * f) * chans + c;
+            for (int dx = 0; dx < f; ++dx) sum += p[(size_t)dx * chans];
+        }
+        const unsigned r = (f == 2) ? ((sum + 2u) >> 2) : (unsigned)rintf((float)sum * scale);
+        const uint8_t v = (uint8_t)(r > 255u ? 255u : r);
+        u8[c * u8_plane + (size_t)y * u8_pitch + x] = v;
+        u8b[c * u8_plane + (size_t)y * u8_pitch + x] = v ^ 0x80;
+        f32[c * f32_plane + (size_t)y * f32_pitch + x] = (float)v;
+    }
+}
+
+// float32: block sum accumulated in float32 in row-major order, then * (1.f / (f*f)).
+__global__ void planarize_f32_down_kernel(const float* __restrict__ raw, int src_cols, int chans, int f, int rows,
+                                          int cols, float* __restrict__ f32, int f32_pitch, long long f32_plane) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float scale = 1.0f / (float)(f * f);
+    for (int c = 0; c < chans; ++c) {
+        float sum = 0.0f;
+        for (int dy = 0; dy < f; ++dy) {
+            const float* p = raw + ((size_t)(y * f + dy) * src_cols + (size_t)x * f) * chans + c;
+            for (int dx = 0; dx < f; ++dx) sum += p[(size_t)dx * chans];
+        }
+        f32[c * f32_plane + (size_t)y * f32_pitch + x] = sum * scale;
+    }
+}
+
 __global__ void planarize_f32_kernel(const float* __restrict__ raw, int rows, int cols, int chans,
                                      float* __restrict__ f32, int f32_pitch, long long f32_plane) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;

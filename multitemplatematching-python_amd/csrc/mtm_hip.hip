@@ -804,12 +804,13 @@ namespace {
 
 // Upload one image into `sl` and build its planar padded planes on `stream`.  `src` has tightly
 // packed rows when `src_stride` == cols * chans * elem size or any larger stride.
-int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int rows, int cols,
-                 int chans, int dtype, hipStream_t stream) {
+int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
+                 int chans, int dtype, hipStream_t stream, int factor = 1) {
     const size_t esz = dtype == MTM_U8 ? 1 : 4;
-    const size_t tight = (size_t)cols * chans * esz;
-    MTMC(sl.raw.ensure(tight * rows));
-    HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, rows, hipMemcpyHostToDevice, stream));
+    const size_t tight = (size_t)src_cols * chans * esz;
+    MTMC(sl.raw.ensure(tight * src_rows));
+    HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, src_rows, hipMemcpyHostToDevice, stream));
+    const int rows = src_rows / factor, cols = src_cols / factor;      // the planes hold the downscaled image
     const int rows_alloc = rows + kPadRows;
     const int pitch = (int)round_up((size_t)cols + kPadCols, 64);
     const size_t f32_bytes = sizeof(float) * pitch * rows_alloc * chans;
@@ -831,7 +832,14 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
         sl.geom = geom;
     }
     const dim3 grd((cols + 255) / 256, rows);
-    if (dtype == MTM_U8)
+    if (factor > 1 && dtype == MTM_U8)
+        hipLaunchKernelGGL(planarize_u8_down_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint8_t>(), src_cols, chans,
+                           factor, rows, cols, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
+                           (long long)pitch * rows_alloc, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    else if (factor > 1)
+        hipLaunchKernelGGL(planarize_f32_down_kernel, grd, dim3(256), 0, stream, sl.raw.as<float>(), src_cols, chans,
+                           factor, rows, cols, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    else if (dtype == MTM_U8)
         hipLaunchKernelGGL(planarize_u8_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint8_t>(), rows, cols, chans,
                            sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch, (long long)pitch * rows_alloc,
                            sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
@@ -869,18 +877,27 @@ int check_image_args(const void* px, int rows, int cols, int chans, int dtype, i
 
 }  // namespace
 
-int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
-                  int64_t row_stride_bytes) {
+int mtm_set_image_downscaled(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
+                             int64_t row_stride_bytes, int factor) {
     if (!c) {
         set_error("mtm_set_image: null context");
         return MTM_E_INVALID;
     }
     MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_set_image"));
+    if (factor < 1 || factor > 64 || rows / factor < 1 || cols / factor < 1) {
+        set_error("mtm_set_image_downscaled: factor must be in 1..64 and leave at least one pixel");
+        return MTM_E_INVALID;
+    }
     HIPC(hipSetDevice(c->device));
-    MTMC(upload_image(c, c->slot[c->cur], px, row_stride_bytes, rows, cols, chans, dtype, c->stream));
+    MTMC(upload_image(c, c->slot[c->cur], px, row_stride_bytes, rows, cols, chans, dtype, c->stream, factor));
     HIPC(hipStreamSynchronize(c->stream));
-    adopt_image(c, rows, cols, chans, dtype);
+    adopt_image(c, rows / factor, cols / factor, chans, dtype);
     return MTM_OK;
+}
+
+int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
+                  int64_t row_stride_bytes) {
+    return mtm_set_image_downscaled(c, px, rows, cols, chans, dtype, row_stride_bytes, 1);
 }
 
 int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int method) {

@@ -570,3 +570,40 @@ class FastPipeline:
         order = np.argsort(-v[rows, cols].astype(np.float64), kind="stable")
         th, tw = templ.shape
         return [(name, (int(cols[i]), int(rows[i]), tw, th), m[rows[i], cols[i]]) for i in order]
+
+
+# ---------------------------------------------------------------------------------------------
+# cv2.resize(image, smallDim, interpolation=cv2.INTER_AREA) with an integer factor - the downscale of
+# the reference's speed-up recipe (tutorials/Tutorial3-SpeedingUp.ipynb:395).  Restated from OpenCV's
+# imgproc/resize.cpp integer-factor path (ResizeAreaFast: uint8 factor 2 -> (sum + 2) >> 2; otherwise
+# saturate_cast<uchar>(sum * scale) with float scale = 1.f / area, i.e. round-half-even of a float32
+# product; float: float32 sum in offset-table (row-major) order, times scale).  PARITY UNPINNED: no
+# OpenCV in this image and no golden vector for it in the reference; checker of
+# MTM.augment.downscale / mtm_set_image_downscaled only.
+# ---------------------------------------------------------------------------------------------
+def downscale_area(image, factor):
+    factor = int(factor)
+    if factor == 1:
+        return image
+    rows, cols = image.shape[0] // factor, image.shape[1] // factor
+    chans = 1 if image.ndim == 2 else image.shape[2]
+    src = image.reshape(image.shape[0], image.shape[1], chans)
+    scale = np.float32(1.0) / np.float32(factor * factor)
+    if image.dtype == np.uint8:
+        out = np.zeros((rows, cols, chans), np.uint8)
+        total = np.zeros((rows, cols, chans), np.int64)
+        for dy in range(factor):
+            for dx in range(factor):
+                total += src[dy:rows * factor:factor, dx:cols * factor:factor].astype(np.int64)
+        if factor == 2:
+            out = ((total + 2) // 4).astype(np.uint8)
+        else:
+            prod = total.astype(np.float32) * scale                      # float32 product
+            out = np.clip(np.round(prod.astype(np.float64)), 0, 255).astype(np.uint8)   # np.round: half to even
+    else:
+        acc = np.zeros((rows, cols, chans), np.float32)
+        for dy in range(factor):
+            for dx in range(factor):
+                acc = (acc + src[dy:rows * factor:factor, dx:cols * factor:factor].astype(np.float32)).astype(np.float32)
+        out = (acc * scale).astype(np.float32)
+    return out.reshape((rows, cols) + image.shape[2:])

@@ -629,3 +629,37 @@ def test_hits_only_equals_map_mode(mtm, ctx, coins):
         set_exact(ctx, 0)
         ctx.set_option(2, 0)
         ctx.set_option(6, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# device-side area downscale (mtm_set_image_downscaled) and the augmentation helpers
+# ------------------------------------------------------------------------------------------------
+def test_device_downscale_and_augmentation(mtm, ctx, coins):
+    A = mtm.augment
+    rng = np.random.default_rng(21)
+    rgb = rng.integers(0, 256, (203, 317, 3), dtype=np.uint8)
+    cases = [(coins, np.uint8), (coins, np.float32), (rgb, np.uint8), (rgb, np.float32)]
+    with ctx.lock:
+        for img0, dt in cases:
+            img = img0.astype(dt)
+            for f in (2, 3, 4, 7):
+                small = O.downscale_area(img, f)
+                t = np.ascontiguousarray(small[3:3 + 20, 5:5 + 31])
+                ctx.set_image(img, downscale=f)
+                ctx.set_templates([(t, None)], 5)
+                got = ctx.score_map(0, (small.shape[0] - 19, small.shape[1] - 30))
+                map_close(got, O.match_template(small, t, 5), tol=1e-5)
+                # the exact copy scores 1 at its origin only if the device image equals the oracle's
+                assert abs(float(got[3, 5]) - 1.0) < 1e-6, (dt, f, float(got[3, 5]))
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    for f in (2, 3):
+        got = A.matchTemplatesDownscaled(lt, coins, f, score_threshold=0.4, maxOverlap=0.3)
+        exp = A.upscale_hits(O.match_templates([(n, O.downscale_area(t, f)) for n, t in lt], O.downscale_area(coins, f),
+                                               score_threshold=0.4, maxOverlap=0.3), f)
+        assert_hits_equal(got, hits_json(exp), tol=1e-5)
+    # rotations: every rotated copy of a planted template is found where np.rot90 puts it
+    img, units, plants = synth.make_workload(seed=12, image_hw=(400, 640), n_base=3, templ=32, rotations=4)
+    got = mtm.matchTemplates(units, img, score_threshold=0.5)
+    exp = O.match_templates(units, img, score_threshold=0.5)
+    assert_hits_equal(canon(got), canon(exp), tol=1e-5)

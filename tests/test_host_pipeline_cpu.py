@@ -19,8 +19,8 @@ class OracleContext:
         self.lock = threading.RLock()
         self.hit_dtype = hit_dtype
 
-    def set_image(self, image):
-        self.image = image
+    def set_image(self, image, downscale=1):
+        self.image = O.downscale_area(image, downscale)       # mtm_set_image_downscaled
 
     def set_templates(self, templates, method):
         self.templates, self.method = templates, method
@@ -122,3 +122,36 @@ def test_template_matcher_equals_match_templates(mtm):
     assert list(matcher.match_stream(imgs)) == [matcher.match(i) for i in imgs]
     assert list(matcher.match_stream(iter(imgs[:1]))) == [matcher.match(coins)]
     assert list(matcher.match_stream([])) == []
+
+
+def test_augment_helpers_and_downscaled_matching(mtm):
+    """MTM.augment: the tutorials' rot90 / flip augmentation, integer-factor INTER_AREA downscale (checked
+    against the oracle's restatement) and the downscale -> match -> upscale recipe in one call."""
+    A = mtm.augment
+    rng = np.random.default_rng(5)
+    for shape in [(37, 53), (64, 64, 3), (100, 41)]:
+        for dt in (np.uint8, np.float32):
+            img = (rng.random(shape) * 255).astype(dt)
+            for f in (1, 2, 3, 4, 5, 8):
+                assert np.array_equal(A.downscale(img, f), O.downscale_area(img, f)), (shape, dt, f)
+    with pytest.raises(ValueError, match="64-bit"):
+        A.downscale(np.zeros((8, 8)), 2)
+    t = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    rots = A.rotations([("t", t)], angles=(0, 90, 180))
+    assert [r[0] for r in rots] == ["t_0", "t_90", "t_180"]
+    assert np.array_equal(rots[1][1], np.rot90(t)) and rots[1][1].flags.c_contiguous
+    fl = A.flips([("t", t, t)])
+    assert [r[0] for r in fl] == ["t", "t_lr", "t_ud"] and np.array_equal(fl[1][2], np.fliplr(t))
+    assert [r[0] for r in A.scales([("t", np.zeros((8, 8), np.uint8))], (1, 2))] == ["t_d1", "t_d2"]
+    assert A.upscale_hits([("a", (1, 2, 3, 4), 0.5)], 4) == [("a", (4, 8, 12, 16), 0.5)]
+    # one call == downscale both on the host, match, upscale
+    coins = load_coins()
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    for f in (2, 3):
+        got = A.matchTemplatesDownscaled(lt, coins, f, score_threshold=0.4, maxOverlap=0.3)
+        exp = A.upscale_hits(mtm.matchTemplates([(n, A.downscale(t, f)) for n, t in lt], A.downscale(coins, f),
+                                                score_threshold=0.4, maxOverlap=0.3), f)
+        assert got == exp and len(got) > 3
+    with pytest.raises(ValueError, match="larger than image"):
+        A.matchTemplatesDownscaled([("all", coins)], coins[:200], 2)
