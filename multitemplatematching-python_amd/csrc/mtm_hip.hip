@@ -171,6 +171,7 @@ struct mtm_ctx {
     void* rccl_lib = nullptr;
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
+    long long comm_slot_hits = 512;
     DevBuf comm_send, comm_recv;
 };
 
@@ -249,6 +250,8 @@ void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
     }
 }
 
+int resolved_kernel(const mtm_ctx* c, const SizeClass& sc);
+
 int place_templates(mtm_ctx* c) {
     if (!c->have_image || !c->have_templ) {
         set_error("set the image and the templates first");
@@ -259,8 +262,18 @@ int place_templates(mtm_ctx* c) {
     c->td_host.assign(n, TemplDev{});
     size_t map_off = 0, w_off = 0, p_off = 0;
     const bool img_u8 = c->dtype == MTM_U8;
+    // Which kernel will run each class decides what has to be packed: int8 A-packs for the MFMA kernel,
+    // dot4 packs for the VALU kernel, float64 weights for the float64 / naive kernels.  (Changing
+    // MTM_OPT_KERNEL re-places.)
+    std::vector<int> class_kernel(c->classes.size(), MTM_KERNEL_AUTO);
+    for (size_t k = 0; k < c->classes.size(); ++k) {
+        c->classes[k].mfma_ok = mfma_class_ok(c, c->classes[k]);
+        class_kernel[k] = resolved_kernel(c, c->classes[k]);
+    }
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
+        const int kern = class_kernel[(size_t)t.cls];
+        const bool want_f64 = kern == MTM_KERNEL_AUTO || kern == MTM_KERNEL_NAIVE;
         if (t.chans != c->chans) {
             set_error("template " + std::to_string(i) + " has a different channel count than the image");
             return MTM_E_INVALID;
@@ -289,15 +302,16 @@ int place_templates(mtm_ctx* c) {
         d.map_off = (long long)map_off;
         map_off += (size_t)d.map_pitch * d.oh;
         const size_t plane = (size_t)t.chans * t.rows * t.cols;
-        d.k1_off = (long long)w_off;
-        w_off += plane;
-        if (t.masked) {
-            d.k2_off = (long long)w_off;
+        d.k1_off = d.k2_off = -1;
+        if (want_f64) {
+            d.k1_off = (long long)w_off;
             w_off += plane;
-        } else {
-            d.k2_off = -1;
+            if (t.masked) {
+                d.k2_off = (long long)w_off;
+                w_off += plane;
+            }
         }
-        if (img_u8 && t.dtype == MTM_U8 && !t.masked) {
+        if (kern == MTM_KERNEL_DOT4 && img_u8 && t.dtype == MTM_U8 && !t.masked) {
             d.pack_off = (long long)p_off;
             p_off += dot_pack_bytes(t.rows, t.cols, t.chans);
         } else {
@@ -306,8 +320,9 @@ int place_templates(mtm_ctx* c) {
     }
     c->maps_floats = map_off;
     // masked classes on the integer path: one dot4 pack of the (shared, binary) mask bytes per class
-    for (SizeClass& sc : c->classes) {
-        sc.masked_int = sc.masked && mfma_class_ok(c, sc);
+    for (size_t k = 0; k < c->classes.size(); ++k) {
+        SizeClass& sc = c->classes[k];
+        sc.masked_int = sc.masked && class_kernel[k] == MTM_KERNEL_MFMA;
         sc.mask_pack_off = -1;
         if (sc.masked_int) {
             sc.mask_pack_off = (long long)p_off;
@@ -321,13 +336,13 @@ int place_templates(mtm_ctx* c) {
         const HostTempl& t = c->templs[i];
         const TemplDev& d = c->td_host[i];
         const size_t plane = (size_t)t.chans * t.rows * t.cols;
-        if (t.masked) {
+        if (d.k1_off >= 0 && t.masked) {
             for (size_t k = 0; k < plane; ++k) {
                 const double m2 = t.mask[k] * t.mask[k];
                 wts[d.k1_off + k] = t.px[k] * m2;
                 wts[d.k2_off + k] = m2;
             }
-        } else {
+        } else if (d.k1_off >= 0) {
             std::copy(t.px.begin(), t.px.end(), wts.begin() + d.k1_off);
         }
         if (d.pack_off >= 0) pack_template_dot4(t, packs.data() + d.pack_off);
@@ -340,16 +355,16 @@ int place_templates(mtm_ctx* c) {
         }
     // int8 MFMA packs, per eligible class
     size_t a_off = 0;
-    for (SizeClass& sc : c->classes) {
-        sc.mfma_ok = mfma_class_ok(c, sc);
-        if (!sc.mfma_ok) continue;
+    for (size_t k = 0; k < c->classes.size(); ++k) {
+        SizeClass& sc = c->classes[k];
+        if (class_kernel[k] != MTM_KERNEL_MFMA) continue;
         sc.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
         sc.apack_off = (long long)a_off;
         a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
     }
     std::vector<uint8_t> apacks(a_off);
-    for (const SizeClass& sc : c->classes)
-        if (sc.mfma_ok) pack_class_mfma(c, sc, apacks.data() + sc.apack_off);
+    for (size_t k = 0; k < c->classes.size(); ++k)
+        if (class_kernel[k] == MTM_KERNEL_MFMA) pack_class_mfma(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
     // template lists: one per class, then the list of templates with a 2-D score map
     c->tlist_host.clear();
     for (SizeClass& sc : c->classes) {
@@ -497,11 +512,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     const int* tl = c->tlist.as<int>() + list_off;
     const TemplDev* td = c->td.as<TemplDev>();
     float* maps = c->maps.as<float>();
-    const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
-    int kernel = c->opt_kernel;
-    if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
-    if (kernel == MTM_KERNEL_MFMA && (!sc.mfma_ok || (sc.masked && c->method > 3))) kernel = MTM_KERNEL_DOT4;
-    if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;   // -> tiled float64
+    const int kernel = resolved_kernel(c, sc);      // the same decision place_templates packed for
 
     // timing events around the dominant kernel
     if ((int)c->ncc_ev.size() <= c->timing.ncc_launches) {
@@ -773,6 +784,7 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
     switch (option) {
         case MTM_OPT_KERNEL:
             if (value < MTM_KERNEL_AUTO || value > MTM_KERNEL_MFMA) break;
+            if (c->opt_kernel != (int)value) c->placed = false;     // the packs follow the kernel
             c->opt_kernel = (int)value;
             return MTM_OK;
         case MTM_OPT_PEAK_BORDER:
@@ -839,10 +851,21 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
     else if (factor > 1)
         hipLaunchKernelGGL(planarize_f32_down_kernel, grd, dim3(256), 0, stream, sl.raw.as<float>(), src_cols, chans,
                            factor, rows, cols, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
-    else if (dtype == MTM_U8)
-        hipLaunchKernelGGL(planarize_u8_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint8_t>(), rows, cols, chans,
-                           sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch, (long long)pitch * rows_alloc,
-                           sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    else if (dtype == MTM_U8) {
+        int x_begin = 0;
+        if (chans == 1 && cols >= 16) {        // 16 pixels per thread; the generic kernel takes the tail columns
+            const int cols16 = cols / 16;
+            hipLaunchKernelGGL(planarize_u8_c1_kernel, dim3((cols16 + 255) / 256, rows), dim3(256), 0, stream,
+                               sl.raw.as<uint8_t>(), rows, cols, cols16, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
+                               sl.f32.as<float>(), pitch);
+            x_begin = cols16 * 16;
+        }
+        if (x_begin < cols)
+            hipLaunchKernelGGL(planarize_u8_kernel, dim3((cols - x_begin + 255) / 256, rows), dim3(256), 0, stream,
+                               sl.raw.as<uint8_t>(), rows, cols, chans, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
+                               (long long)pitch * rows_alloc, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc,
+                               x_begin);
+    }
     else
         hipLaunchKernelGGL(planarize_f32_kernel, grd, dim3(256), 0, stream, sl.raw.as<float>(), rows, cols, chans,
                            sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
@@ -1412,6 +1435,7 @@ int mtm_comm_init(mtm_ctx* c, const void* id, int n_ranks, int rank) {
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
     NCCLC(g_rccl.CommInitRank(&c->comm, n_ranks, uid, rank));
+    c->comm_slot_hits = 512;
     c->n_ranks = n_ranks;
     c->rank = rank;
     return MTM_OK;
@@ -1425,14 +1449,15 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
     }
     HIPC(hipSetDevice(c->device));
     const int R = c->n_ranks;
-    // One all-gather of fixed-size slots: [count (16-byte header) | kSlotHits records].  Every rank
+    // One all-gather of fixed-size slots: [count (16-byte header) | slot_hits records].  Every rank
     // sees every count; only if some rank produced more than kSlotHits hits is a second all-gather
     // issued with slots of the (globally known) maximum count.  The usual case is ONE collective of
-    // ~49 KB per rank: latency-bound on xGMI, ring bandwidth irrelevant.
-    constexpr long long kSlotHits = 2048;
+    // ~12 KB per rank: latency-bound on xGMI, ring bandwidth irrelevant.
+    // The slot size adapts to the data: it starts at 512 records and follows twice the largest count
+    // of the previous exchange (a value every rank knows, so the ranks always agree on it).
     std::vector<long long> counts((size_t)R, 0);
     std::vector<uint8_t> all;
-    long long slot_hits = kSlotHits;
+    long long slot_hits = c->comm_slot_hits;
     for (int round = 0; round < 2; ++round) {
         const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
         MTMC(c->comm_send.ensure(slot));
@@ -1452,6 +1477,9 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
             std::memcpy(&counts[r], all.data() + slot * r, sizeof(long long));
             mx = std::max(mx, counts[r]);
         }
+        long long want = 512;
+        while (want < 2 * mx) want <<= 1;
+        c->comm_slot_hits = want;       // next exchange (identical on every rank)
         if (mx <= slot_hits) break;
         slot_hits = mx;                 // every rank computes the same maximum: the collective stays matched
     }
