@@ -663,3 +663,42 @@ def test_device_downscale_and_augmentation(mtm, ctx, coins):
     got = mtm.matchTemplates(units, img, score_threshold=0.5)
     exp = O.match_templates(units, img, score_threshold=0.5)
     assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded random configurations: shapes, template counts, methods, masks, thresholds
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configs_against_oracle(mtm, seed):
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(40, 260)), int(rng.integers(40, 420))
+    chans = int(rng.choice([1, 1, 1, 3]))
+    shape = (H, W) if chans == 1 else (H, W, chans)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    if seed % 4 == 0:                                   # smooth image: dense maps, plateaus after quantisation
+        base = rng.random((H // 8 + 2, W // 8 + 2) + shape[2:])
+        img = (np.kron(base, np.ones((8, 8) + (1,) * (len(shape) - 2)))[:H, :W] * 255).astype(np.uint8)
+    method = int(rng.choice([1, 3, 5, 5]))
+    n_t = int(rng.integers(1, 40))
+    lt = []
+    for i in range(n_t):
+        h, w = int(rng.integers(3, min(70, H))), int(rng.integers(3, min(90, W)))
+        if i % 3 == 0 and lt:                           # repeat a size: several templates in one class
+            h, w = lt[-1][1].shape[:2]
+        y, x = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+        t = img[y:y + h, x:x + w].copy()
+        if i % 2:
+            t = np.clip(t.astype(np.int32) + rng.integers(-30, 31, t.shape), 0, 255).astype(np.uint8)
+        tup = ("t%d" % i, t)
+        if method == 3 and chans == 1 and i % 4 == 1:
+            m = (rng.random(t.shape) > 0.3).astype(np.uint8) * 255
+            m[0, 0] = 255
+            tup = tup + (m,)
+        lt.append(tup)
+    thr = float(rng.choice([0.2, 0.5, 0.8])) if method != 1 else float(rng.choice([0.1, 0.3]))
+    got = mtm.findMatches(lt, img, method=method, score_threshold=thr)
+    exp = O.find_matches(lt, img, method=method, score_threshold=thr)
+    assert len(got) == len(exp), (len(got), len(exp))
+    assert_hits_equal(canon(got), canon(exp), tol=2e-5)
+    got = mtm.matchTemplates(lt, img, method=method, score_threshold=thr, maxOverlap=0.3, N_object=int(rng.choice([1, 3, 50])))
+    assert len(got) <= 50
