@@ -33,6 +33,10 @@ extern "C" {
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
 #define MTM_F32 1
+#define MTM_U16 2   /* the reference casts uint16 to float32 (exactly) before cv2; passing the uint16 pixels as they
+                       are gives the same results (every sum is an exact integer) and lets single-channel
+                       uint16 image + uint16 templates run on the int8 matrix cores (byte-plane decomposition)
+                       instead of the float64 kernel */
 
 /* OpenCV's TemplateMatchModes values, used as raw ints by the reference
  * (MTM/__init__.py:56,95,247 defaults; :78,:216,:227,:232 comparisons) */
@@ -55,7 +59,9 @@ extern "C" {
 #define MTM_KERNEL_AUTO  0
 #define MTM_KERNEL_NAIVE 1   /* one thread per output pixel, scalar loop: the in-library cross-check */
 #define MTM_KERNEL_DOT4  2   /* LDS-tiled sliding window on v_dot4_u32_u8 */
-#define MTM_KERNEL_MFMA  3   /* implicit-GEMM sliding window on v_mfma_i32_32x32x32_i8 */
+#define MTM_KERNEL_MFMA  3   /* implicit-GEMM sliding window on v_mfma_i32_16x16x64_i8 */
+#define MTM_KERNEL_MFMA16 4  /* reported in mtm_timing.kernel_used only: uint16 pixels as four byte-plane
+                                correlations on the MFMA kernel (selected by MTM_KERNEL_AUTO / _MFMA) */
 
 #define MTM_OPT_KERNEL      1
 #define MTM_OPT_PEAK_BORDER 2

@@ -46,7 +46,9 @@ def _apply_pixel_policy(template, image, method, mask):
         raise ValueError("64-bit images not supported, max 32-bit")
 
     # only 8-bit/8-bit stays 8-bit; every other combination is matched in float32
-    if not (template.dtype == "uint8" and image.dtype == "uint8"):
+    native16 = template.dtype == "uint16" and image.dtype == "uint16"
+    template16, image16 = template, image
+    if not (template.dtype == "uint8" and image.dtype == "uint8") and not (native16 and mask is None):
         template = np.float32(template)
         image = np.float32(image)
         if mask is not None:
@@ -59,6 +61,10 @@ def _apply_pixel_policy(template, image, method, mask):
         elif not (mask.shape == template.shape and mask.dtype == template.dtype):
             mask = None
             warnings.warn(_MSG_MASK_SHAPE)
+    # uint16 / uint16 without a mask: the float32 cast of the reference is exact, so the library takes
+    # the 16-bit pixels as they are (MTM_U16: exact integer matching on the int8 matrix cores)
+    if native16 and mask is None:
+        template, image = template16, image16
     return template, image, mask
 
 
@@ -149,7 +155,7 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
     parts = []
     with ctx.lock:
         # the pixel policy is per template: group the units by the dtype their match runs in
-        for code in ("uint8", "float32"):
+        for code in ("uint8", "uint16", "float32"):
             group = [u for u in units if u[2].dtype == code]
             if not group:
                 continue
@@ -285,7 +291,7 @@ class TemplateMatcher:
             units.append((t, m, im.dtype))
         kinds = {str(u[2]) for u in units}
         if len(kinds) > 1:
-            raise ValueError("TemplateMatcher needs templates of one pixel type (all uint8, or none)")
+            raise ValueError("TemplateMatcher needs templates of one pixel type (all uint8, all uint16, or neither)")
         self._ctx.set_templates([(u[0], u[1]) for u in units], self.method)
         self._uploaded_for = (kinds.pop() if kinds else str(image.dtype), 1 if image.ndim == 2 else image.shape[2])
 
@@ -295,12 +301,13 @@ class TemplateMatcher:
         image_s, xOffset, yOffset = _validate_search(self.listTemplates, image, self.N_object, searchBox)
         if self._uploaded_for is None:
             self._upload(image_s)
-        want = "uint8" if (self._uploaded_for[0] == "uint8" and image_s.dtype == "uint8") else "float32"
+        native = self._uploaded_for[0]          # "uint8" | "uint16" (pixels taken as they are) | "float32"
+        want = native if (native != "float32" and str(image_s.dtype) == native) else "float32"
         if image_s.dtype == "float64":
             raise ValueError("64-bit images not supported, max 32-bit")
-        if want != self._uploaded_for[0] or (1 if image_s.ndim == 2 else image_s.shape[2]) != self._uploaded_for[1]:
+        if want != native or (1 if image_s.ndim == 2 else image_s.shape[2]) != self._uploaded_for[1]:
             raise ValueError("TemplateMatcher: image pixel type / channel count differs from the resident templates")
-        return (image_s if want == "uint8" else np.float32(image_s)), xOffset, yOffset
+        return (image_s if want != "float32" else np.float32(image_s)), xOffset, yOffset
 
     def _finish(self, raw, xOffset, yOffset):
         if self.method == 0:

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmtm_hip.so")
 
-MTM_U8, MTM_F32 = 0, 1
+MTM_U8, MTM_F32, MTM_U16 = 0, 1, 2
 PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1
 BORDER_CONSTANT, BORDER_NEAREST = 0, 1
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
@@ -131,7 +131,9 @@ def _dtype_code(a):
         return MTM_U8
     if a.dtype == np.float32:
         return MTM_F32
-    raise MtmError("libmtm_hip takes uint8 or float32 pixels (got %s)" % a.dtype)
+    if a.dtype == np.uint16:
+        return MTM_U16
+    raise MtmError("libmtm_hip takes uint8, uint16 or float32 pixels (got %s)" % a.dtype)
 
 
 class Context:

@@ -9,7 +9,7 @@ The image is downscaled ON THE DEVICE while it is laid out (mtm_set_image_downsc
 resolution image crosses PCIe once and no host resize runs.  Templates are a few KB: they are
 augmented / resized on the host (a device kernel would buy nothing) with the same arithmetic.
 
-`downscale` follows OpenCV's integer-factor INTER_AREA path: uint8 -> factor 2: (sum + 2) >> 2,
+`downscale` follows OpenCV's integer-factor INTER_AREA path: uint8 / uint16 -> factor 2: (sum + 2) >> 2,
 otherwise rint(float32(sum) * float32(1 / factor**2)); float32 -> float32 row-major block sum times
 float32(1 / factor**2).  OpenCV is absent from this image, so this restatement is not pinned against
 cv2.resize itself.
@@ -66,11 +66,11 @@ def downscale(image: np.ndarray, factor: int) -> np.ndarray:
     a = image[:r * factor, :c * factor]
     blocks = a.reshape((r, factor, c, factor) + a.shape[2:])
     scale = np.float32(1.0) / np.float32(factor * factor)
-    if a.dtype == np.uint8:
+    if a.dtype == np.uint8 or a.dtype == np.uint16:
         s = blocks.sum(axis=(1, 3), dtype=np.uint32)
         if factor == 2:
-            return ((s + 2) >> 2).astype(np.uint8)
-        return np.minimum(np.rint(s.astype(np.float32) * scale), 255).astype(np.uint8)
+            return ((s + 2) >> 2).astype(a.dtype)
+        return np.minimum(np.rint(s.astype(np.float32) * scale), np.iinfo(a.dtype).max).astype(a.dtype)
     acc = np.zeros((r, c) + a.shape[2:], np.float32)
     src = blocks.astype(np.float32, copy=False)
     for dy in range(factor):                 # float32 accumulation in row-major order, like the kernel
@@ -122,7 +122,8 @@ def matchTemplatesDownscaled(listTemplates, image: np.ndarray, factor: int, meth
         kinds.add(str(im.dtype))
     if len(kinds) > 1:
         raise ValueError("matchTemplatesDownscaled needs templates of one pixel type (all uint8, or none)")
-    full = image if (kinds == {"uint8"} or not kinds) and image.dtype == np.uint8 else np.float32(image)
+    native = kinds.pop() if kinds else str(image.dtype)
+    full = image if (native in ("uint8", "uint16") and str(image.dtype) == native) else np.float32(image)
     ctx = context or _lib.default_context()
     mode = _lib.PEAKS_GLOBAL if N_object == 1 else _lib.PEAKS_LOCAL
     with ctx.lock:

@@ -39,6 +39,8 @@ namespace {
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+inline size_t elem_size(int dtype) { return dtype == MTM_U8 ? 1 : dtype == MTM_U16 ? 2 : 4; }
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -73,6 +75,10 @@ struct SizeClass {
     int h = 0, w = 0;
     bool masked = false;
     bool all_u8 = true;
+    bool all_u16 = true;
+    bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
+    int n_pad = 0;              // members rounded up to a multiple of 16 (uint16 packs)
+    long long tsum_off = -1;    // doubles: [sum(T_hi) per member][sum(T_lo) per member] in the tsum arena
     std::vector<int> members;
     int tlist_off = 0;          // offset into the device tlist array
     bool mfma_ok = false;       // packed for ncc_mfma_kernel
@@ -137,7 +143,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -231,6 +237,40 @@ bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
 long long mfma_group_bytes(int h, int w, int chans) { return (long long)chans * h * ((w + 63) / 64) * 1024; }
 int mfma_groups_alloc(int n) { return (((n + 15) / 16) + 1) & ~1; }     // multiple of MB = 2
 
+// uint16 image + uint16 templates, one channel, no mask: four uint8 byte-plane correlations on the int8
+// MFMA kernel (raw mode) + ncc16_combine_kernel.  Same int32 accumulator bound as the uint8 path.
+bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
+    return c->dtype == MTM_U16 && sc.all_u16 && c->chans == 1 && !sc.masked && sc.w <= kMfmaMaxW &&
+           (long long)sc.w * sc.h <= 131071;
+}
+
+// A packs of a uint16 class: 2 * n_pad pseudo-templates, [high bytes of member 0..n_pad-1][low bytes ...],
+// same lane order as pack_class_mfma.  Also the byte sums of every member (bias terms of the combine).
+void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, double* tsum) {
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, n_pad = sc.n_pad;
+    const long long gb = mfma_group_bytes(h, w, 1);
+    std::memset(out, 0, (size_t)gb * (2 * n_pad / 16));
+    for (int k = 0; k < 2 * n_pad; ++k) tsum[k] = 0.0;
+    for (size_t li = 0; li < sc.members.size(); ++li) {
+        const HostTempl& t = c->templs[sc.members[li]];
+        for (int part = 0; part < 2; ++part) {
+            const size_t pi = (size_t)part * n_pad + li;
+            uint8_t* g = out + (pi / 16) * gb;
+            const int i = (int)(pi % 16);
+            double sum = 0.0;
+            for (int dy = 0; dy < h; ++dy)
+                for (int dx = 0; dx < w; ++dx) {
+                    const unsigned v16 = (unsigned)t.px[(size_t)dy * w + dx];
+                    const uint8_t v = part == 0 ? (uint8_t)(v16 >> 8) : (uint8_t)(v16 & 255u);
+                    sum += v;
+                    const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
+                    g[(((size_t)dy * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                }
+            tsum[pi] = sum;
+        }
+    }
+}
+
 void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
     const int h = sc.h, w = sc.w, nb = (w + 63) / 64, chans = c->chans;
     const long long gb = mfma_group_bytes(h, w, chans);
@@ -268,6 +308,8 @@ int place_templates(mtm_ctx* c) {
     std::vector<int> class_kernel(c->classes.size(), MTM_KERNEL_AUTO);
     for (size_t k = 0; k < c->classes.size(); ++k) {
         c->classes[k].mfma_ok = mfma_class_ok(c, c->classes[k]);
+        c->classes[k].mfma16_ok = mfma16_class_ok(c, c->classes[k]);
+        c->classes[k].n_pad = (int)round_up(c->classes[k].members.size(), 16);
         class_kernel[k] = resolved_kernel(c, c->classes[k]);
     }
     for (int i = 0; i < n; ++i) {
@@ -362,9 +404,24 @@ int place_templates(mtm_ctx* c) {
         sc.apack_off = (long long)a_off;
         a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
     }
+    size_t ts_off = 0;
+    for (size_t k = 0; k < c->classes.size(); ++k) {
+        SizeClass& sc = c->classes[k];
+        sc.tsum_off = -1;
+        if (class_kernel[k] != MTM_KERNEL_MFMA16) continue;
+        sc.group_bytes = mfma_group_bytes(sc.h, sc.w, 1);
+        sc.apack_off = (long long)a_off;
+        a_off += (size_t)sc.group_bytes * (2 * sc.n_pad / 16);
+        sc.tsum_off = (long long)ts_off;
+        ts_off += 2 * (size_t)sc.n_pad;
+    }
     std::vector<uint8_t> apacks(a_off);
-    for (size_t k = 0; k < c->classes.size(); ++k)
+    std::vector<double> tsums(ts_off);
+    for (size_t k = 0; k < c->classes.size(); ++k) {
         if (class_kernel[k] == MTM_KERNEL_MFMA) pack_class_mfma(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
+        if (class_kernel[k] == MTM_KERNEL_MFMA16)
+            pack_class_mfma16(c, c->classes[k], apacks.data() + c->classes[k].apack_off, tsums.data() + c->classes[k].tsum_off);
+    }
     // template lists: one per class, then the list of templates with a 2-D score map
     c->tlist_host.clear();
     for (SizeClass& sc : c->classes) {
@@ -390,6 +447,8 @@ int place_templates(mtm_ctx* c) {
                             hipMemcpyHostToDevice, c->stream));
     if (w_off) HIPC(hipMemcpyAsync(c->weights.p, wts.data(), sizeof(double) * w_off, hipMemcpyHostToDevice, c->stream));
     if (p_off) HIPC(hipMemcpyAsync(c->packs.p, packs.data(), p_off, hipMemcpyHostToDevice, c->stream));
+    MTMC(c->tsum.ensure(sizeof(double) * std::max<size_t>(2, ts_off)));
+    if (ts_off) HIPC(hipMemcpyAsync(c->tsum.p, tsums.data(), sizeof(double) * ts_off, hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
     c->placed = true;
     return MTM_OK;
@@ -405,8 +464,9 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     StatPlanes st{};
     st.pitch = (int)round_up((size_t)ow, 4);
     *out = st;
-    const bool want_t_always = resolved_kernel(c, sc) == MTM_KERNEL_MFMA;
-    const bool masked_mfma = sc.masked && want_t_always;
+    const int rk = resolved_kernel(c, sc);
+    const bool want_t_always = rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16;
+    const bool masked_mfma = sc.masked && rk == MTM_KERNEL_MFMA;
     if ((sc.masked && !masked_mfma) || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // none needed
     const int num_type = masked_mfma ? 0
                        : (method == MTM_TM_CCORR_NORMED) ? 0
@@ -459,6 +519,13 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
         hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
                            inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
+    }
+    if (rk == MTM_KERNEL_MFMA16) {
+        // window sums of the high-byte plane (bias terms of the byte-plane correlations)
+        MTMC(c->stats_hi.ensure(sizeof(double) * plane));
+        const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, inv_area, 0, 0,
+                           1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr, st.pitch);
     }
     HIPC(hipGetLastError());
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
@@ -624,6 +691,67 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA;
+    } else if (kernel == MTM_KERNEL_MFMA16) {
+        // uint16: raw byte-plane correlations (2 launches: image high / low bytes x [T_hi..., T_lo...]),
+        // then the exact float64 combination + normalisation
+        const int n_all = (int)sc.members.size(), n_pad = sc.n_pad;
+        const int map_pitch = (int)round_up((size_t)ow, 4);
+        const long long raw_map = (long long)oh * map_pitch;
+        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(4LL * n_pad * raw_map)));
+        MfmaParams p{};
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = 1;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nb = (w + 63) / 64;
+        p.n_list = 2 * n_pad;
+        p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+        p.nyb = (oh + kMfRows - 1) / kMfRows;
+        p.ntg = n_pad / 16;
+        p.n_work = p.nseg * p.nyb * p.ntg;
+        p.method = c->method;
+        p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.cpr = p.lds_pitch / 16;
+        p.cpr_rstep = 256 / p.cpr;
+        p.cpr_dstep = 256 % p.cpr;
+        p.group_bytes = sc.group_bytes;
+        p.only_li = -1;
+        p.raw_map = raw_map;
+        p.raw_pitch = map_pitch;
+        const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
+                                                  (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
+        p.tc_off = (int)lds_main;
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+        const size_t lds = (size_t)p.st_off + (size_t)kMfRows * kMfStatBytesPerWave;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        const uint8_t* planes = c->slot[c->cur].u8b.as<uint8_t>();
+        for (int x = 0; x < 2; ++x) {
+            p.img = planes + (size_t)x * img.u8_plane;
+            p.raw_out = c->raw16.as<int>() + (size_t)x * 2 * n_pad * raw_map;
+            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td,
+                               c->tlist.as<int>() + sc.tlist_off, c->apacks.as<uint8_t>() + sc.apack_off, st, maps,
+                               c->sched.as<unsigned int>());
+        }
+        Ncc16Params q{};
+        q.raw = c->raw16.as<int>();
+        q.raw_plane = (long long)n_pad * raw_map;
+        q.raw_map = raw_map;
+        q.s1_hi = c->stats_hi.as<double>();
+        q.oh = oh;
+        q.ow = ow;
+        q.pitch = map_pitch;
+        q.n_list = n_all;
+        q.method = c->method;
+        q.area = (double)h * (double)w;
+        const double* ts = c->tsum.as<double>() + sc.tsum_off;
+        hipLaunchKernelGGL(ncc16_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
+                           c->tlist.as<int>() + sc.tlist_off, ts, ts + n_pad, st, maps, only_li);
+        c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
         const DotVariant& v = kDotVariants[wide ? kDotWideVariant : c->dot_variant];
@@ -668,6 +796,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
 int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
     const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
     int kernel = c->opt_kernel;
+    if (c->dtype == MTM_U16) {
+        if ((kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) && sc.mfma16_ok) return MTM_KERNEL_MFMA16;
+        return kernel == MTM_KERNEL_NAIVE ? MTM_KERNEL_NAIVE : MTM_KERNEL_AUTO;
+    }
     if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
     if (kernel == MTM_KERNEL_MFMA && (!sc.mfma_ok || (sc.masked && c->method > 3))) kernel = MTM_KERNEL_DOT4;
     if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;
@@ -765,7 +897,8 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
-                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->comm_send, &c->comm_recv})
+                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->comm_send,
+                      &c->comm_recv})
         b->release();
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -818,7 +951,7 @@ namespace {
 // packed rows when `src_stride` == cols * chans * elem size or any larger stride.
 int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
                  int chans, int dtype, hipStream_t stream, int factor = 1) {
-    const size_t esz = dtype == MTM_U8 ? 1 : 4;
+    const size_t esz = elem_size(dtype);
     const size_t tight = (size_t)src_cols * chans * esz;
     MTMC(sl.raw.ensure(tight * src_rows));
     HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, src_rows, hipMemcpyHostToDevice, stream));
@@ -830,21 +963,29 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
     const long long geom = (((long long)rows * 65536 + cols) * 8 + chans) * 4 + dtype;
     const size_t caps[3] = {sl.f32.cap, sl.u8.cap, sl.u8b.cap};
     MTMC(sl.f32.ensure(f32_bytes));
-    if (dtype == MTM_U8) {
+    // uint16, one channel: u8 = high-byte plane, u8b = [high ^ 0x80 plane][low ^ 0x80 plane]
+    const bool u16_planes = dtype == MTM_U16 && chans == 1;
+    const size_t u8b_bytes = u16_planes ? 2 * u8_bytes : u8_bytes;
+    if (dtype == MTM_U8 || u16_planes) {
         MTMC(sl.u8.ensure(u8_bytes));
-        MTMC(sl.u8b.ensure(u8_bytes));
+        MTMC(sl.u8b.ensure(u8b_bytes));
     }
     // the padding (zeros; 0x80 in the int8 view) only needs writing when the planes are new
     if (sl.geom != geom || caps[0] != sl.f32.cap || caps[1] != sl.u8.cap || caps[2] != sl.u8b.cap) {
         HIPC(hipMemsetAsync(sl.f32.p, 0, f32_bytes, stream));
-        if (dtype == MTM_U8) {
+        if (dtype == MTM_U8 || u16_planes) {
             HIPC(hipMemsetAsync(sl.u8.p, 0, u8_bytes, stream));
-            HIPC(hipMemsetAsync(sl.u8b.p, 0x80, u8_bytes, stream));
+            HIPC(hipMemsetAsync(sl.u8b.p, 0x80, u8b_bytes, stream));
         }
         sl.geom = geom;
     }
     const dim3 grd((cols + 255) / 256, rows);
-    if (factor > 1 && dtype == MTM_U8)
+    if (dtype == MTM_U16)
+        hipLaunchKernelGGL(planarize_u16_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint16_t>(), src_cols, chans, factor,
+                           rows, cols, u16_planes ? sl.u8.as<uint8_t>() : (uint8_t*)nullptr, sl.u8b.as<uint8_t>(),
+                           u16_planes ? sl.u8b.as<uint8_t>() + u8_bytes : (uint8_t*)nullptr, pitch, sl.f32.as<float>(),
+                           pitch, (long long)pitch * rows_alloc);
+    else if (factor > 1 && dtype == MTM_U8)
         hipLaunchKernelGGL(planarize_u8_down_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint8_t>(), src_cols, chans,
                            factor, rows, cols, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
                            (long long)pitch * rows_alloc, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
@@ -887,11 +1028,12 @@ void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype) {
 
 int check_image_args(const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
                      const char* who) {
-    if (!px || rows <= 0 || cols <= 0 || chans < 1 || chans > kMaxChans || (dtype != MTM_U8 && dtype != MTM_F32)) {
-        set_error(std::string(who) + ": bad arguments (1..4 channels, uint8 or float32)");
+    if (!px || rows <= 0 || cols <= 0 || chans < 1 || chans > kMaxChans ||
+        (dtype != MTM_U8 && dtype != MTM_F32 && dtype != MTM_U16)) {
+        set_error(std::string(who) + ": bad arguments (1..4 channels, uint8, uint16 or float32)");
         return MTM_E_INVALID;
     }
-    if (row_stride_bytes < (int64_t)((size_t)cols * chans * (dtype == MTM_U8 ? 1 : 4))) {
+    if (row_stride_bytes < (int64_t)((size_t)cols * chans * elem_size(dtype))) {
         set_error(std::string(who) + ": row stride smaller than a row");
         return MTM_E_INVALID;
     }
@@ -932,7 +1074,7 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
     for (int i = 0; i < n_templ; ++i) {
         const mtm_templ& s = templs[i];
         if (!s.px || s.rows <= 0 || s.cols <= 0 || s.chans < 1 || s.chans > kMaxChans ||
-            (s.dtype != MTM_U8 && s.dtype != MTM_F32)) {
+            (s.dtype != MTM_U8 && s.dtype != MTM_F32 && s.dtype != MTM_U16)) {
             set_error("mtm_set_templates: bad template " + std::to_string(i));
             return MTM_E_INVALID;
         }
@@ -956,6 +1098,11 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
                         t.px[dst] = (double)rp[src];
                         // CV_8U masks are binary masks (matchTemplateMask)
                         if (mp) t.mask[dst] = mp[src] > 0 ? 1.0 : 0.0;
+                    } else if (s.dtype == MTM_U16) {
+                        // the reference casts uint16 to float32 (exact) before cv2 (MTM/__init__.py:71-74):
+                        // a mask is then a float32 weight image, not a binary mask
+                        t.px[dst] = (double)((const uint16_t*)rp)[src];
+                        if (mp) t.mask[dst] = (double)((const uint16_t*)mp)[src];
                     } else {
                         t.px[dst] = (double)((const float*)rp)[src];
                         if (mp) t.mask[dst] = (double)((const float*)mp)[src];
@@ -963,7 +1110,7 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
                 }
         }
         t.st = compute_templ_stats(t.px.data(), t.masked ? t.mask.data() : nullptr, t.rows, t.cols, t.chans,
-                                   method, s.dtype == MTM_U8);
+                                   method, s.dtype == MTM_U8 || s.dtype == MTM_U16);
     }
     // size classes, in order of first appearance
     std::vector<SizeClass> classes;
@@ -993,6 +1140,7 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         SizeClass& sc = classes[it->second];
         sc.members.push_back(i);
         sc.all_u8 = sc.all_u8 && hts[i].dtype == MTM_U8;
+        sc.all_u16 = sc.all_u16 && hts[i].dtype == MTM_U16;
         hts[i].cls = it->second;
     }
     c->templs.swap(hts);

@@ -47,6 +47,9 @@ __device__ __forceinline__ int mf_epi_rot(int j) { return 4 * ((j >> 1) & 3); }
 // Window statistics of a wave's 256 pixels, prefetched to LDS by LDS-DMA while the image tile is
 // staged: [3 planes: S1, S2, sqrt][2 halves][64 lanes][2 doubles]; lane L owns pixels 4L..4L+3.
 constexpr int kMfStatBytesPerWave = 3 * 2 * 1024;
+// METHOD value of the raw mode: the biased int8 accumulators are stored as they are (uint16 images:
+// four byte-plane correlations combined by ncc16_combine_kernel).
+constexpr int kMfRaw = 6;
 
 struct MfmaParams {
     const uint8_t* img;      // planar padded image, bytes already biased to int8 (^ 0x80)
@@ -79,6 +82,9 @@ struct MfmaParams {
     float cand_thr;
     int cand_min;
     int cand_on;
+    int* raw_out;            // METHOD == kMfRaw: int32 accumulators of list position li at raw_out + li * raw_map
+    long long raw_map;       //   (+ y * raw_pitch + x); see ncc16_combine_kernel
+    int raw_pitch;
     double cand_thr_lo;      // cand_thr minus 8 float32 ulps (hits-only pre-test in float64)
     int hits_only;           // 1: candidates only, the score maps are not written (mtm_find_matches
                              // without map consumers); needs cand_on
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
     MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
-    if (threadIdx.x < 16 * MB) {
+    if (METHOD != kMfRaw && threadIdx.x < 16 * MB) {
         const int li = tg * MB * 16 + threadIdx.x;
         if (li < p.n_list) {
             const TemplDev& T = td[tlist[li]];
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                                          METHOD == MTM_TM_CCOEFF_NORMED);
     constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
-    if constexpr (C1) {
+    if constexpr (C1 && METHOD != kMfRaw) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
@@ -525,7 +531,39 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
 
-    if constexpr (C1) {
+    if constexpr (METHOD == kMfRaw) {
+        // ---- raw mode: transpose through LDS and store the int32 accumulators, 4 pixels per lane
+        __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+        const bool lane_on = y < p.oh && xq < p.ow;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                if ((q >> 1) == round) put(acc[mb]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lane_on) {
+#pragma unroll
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int li = tg * MB * 16 + mb * 16 + 8 * round + s8;
+                        if (li >= p.n_list) break;                          // wave-uniform
+                        const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
+                        int* orow = p.raw_out + (size_t)li * p.raw_map + (size_t)y * p.raw_pitch + xq;
+                        if (xq + 3 < p.ow) {
+                            *reinterpret_cast<v4i*>(orow) = a4;
+                        } else {
+                            const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (xq + i < p.ow) orow[i] = a32[i];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else if constexpr (C1) {
         // ---- single channel, method fixed at compile time.  The statistics of the lane's pixels
         // come from the LDS prefetch; the template loop is software pipelined (constants and
         // accumulators of the next template are requested before the current one is normalised)

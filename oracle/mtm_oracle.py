@@ -589,17 +589,17 @@ def downscale_area(image, factor):
     chans = 1 if image.ndim == 2 else image.shape[2]
     src = image.reshape(image.shape[0], image.shape[1], chans)
     scale = np.float32(1.0) / np.float32(factor * factor)
-    if image.dtype == np.uint8:
-        out = np.zeros((rows, cols, chans), np.uint8)
+    if image.dtype == np.uint8 or image.dtype == np.uint16:
+        top = int(np.iinfo(image.dtype).max)
         total = np.zeros((rows, cols, chans), np.int64)
         for dy in range(factor):
             for dx in range(factor):
                 total += src[dy:rows * factor:factor, dx:cols * factor:factor].astype(np.int64)
         if factor == 2:
-            out = ((total + 2) // 4).astype(np.uint8)
+            out = ((total + 2) // 4).astype(image.dtype)
         else:
             prod = total.astype(np.float32) * scale                      # float32 product
-            out = np.clip(np.round(prod.astype(np.float64)), 0, 255).astype(np.uint8)   # np.round: half to even
+            out = np.clip(np.round(prod.astype(np.float64)), 0, top).astype(image.dtype)   # np.round: half to even
     else:
         acc = np.zeros((rows, cols, chans), np.float32)
         for dy in range(factor):

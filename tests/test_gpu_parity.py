@@ -702,3 +702,75 @@ def test_random_configs_against_oracle(mtm, seed):
     assert_hits_equal(canon(got), canon(exp), tol=2e-5)
     got = mtm.matchTemplates(lt, img, method=method, score_threshold=thr, maxOverlap=0.3, N_object=int(rng.choice([1, 3, 50])))
     assert len(got) <= 50
+
+
+# ------------------------------------------------------------------------------------------------
+# uint16 pixels: exact integer matching through byte planes on the int8 MFMA kernel (MTM_U16)
+# ------------------------------------------------------------------------------------------------
+def _as_f32(lt):
+    return [(tup[0],) + tuple(a.astype(np.float32) for a in tup[1:]) for tup in lt]
+
+
+def test_uint16_exact_path(mtm, ctx, coins):
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 65536, (180, 300), dtype=np.uint16)
+    img[40:90, 100:220] = 31000                         # flat region: guarded denominators
+    img[:8, :8] = 65535                                 # saturated corner: largest byte products
+    lt = [("a", img[20:52, 30:70].copy()), ("b", img[60:92, 150:190].copy()), ("c", img[100:133, 200:251].copy()),
+          ("flat", np.full((9, 9), 500, np.uint16))]
+    noisy = np.clip(lt[0][1].astype(np.int64) + rng.integers(-3000, 3000, lt[0][1].shape), 0, 65535).astype(np.uint16)
+    lt.append(("noisy", noisy))
+    f32img = img.astype(np.float32)
+    # score maps, every method, against the oracle on the float32 cast (what the reference feeds cv2)
+    for method in range(6):
+        for name, t in lt[:3]:
+            got = mtm.computeScoreMap(t, img, method)
+            assert ctx.timing()["kernel_used"] == 4, "uint16 pair must take the byte-plane MFMA path"
+            exp = O.match_template(f32img, t.astype(np.float32), method)
+            if method in (0, 2, 4):
+                # raw sums of ~1e13: the oracle's float64 FFT carries ~1e-3 of absolute noise there (the
+                # integer path is the exact one), which only shows where SQDIFF cancels to ~0
+                assert np.abs(got.astype(np.float64) - exp).max() <= 1e-7 * np.abs(exp).max()
+            else:
+                map_close(got, exp, tol=1e-6)
+    # the constant template: all-ones map for method 5, guarded elsewhere
+    map_close(mtm.computeScoreMap(lt[3][1], img, 5), O.match_template(f32img, lt[3][1].astype(np.float32), 5), tol=1e-6)
+    # hit lists (several classes, several members per class after rot180)
+    lt2 = lt + [(n + "_r", np.ascontiguousarray(t[::-1, ::-1])) for n, t in lt[:3]]
+    for method, thr in ((5, 0.5), (3, 0.9), (1, 0.2)):
+        got = mtm.findMatches(lt2, img, method=method, score_threshold=thr)
+        exp = O.find_matches(_as_f32(lt2), f32img, method=method, score_threshold=thr)
+        assert len(got) == len(exp) and len(got) >= 3
+        # exact copies score exactly 0 (method 1) here and ~1e-15 in the oracle's FFT: compare order-free
+        assert_hits_equal(hits_json(got), hits_json(exp), tol=1e-6, ordered=False)
+    got = mtm.matchTemplates(lt2, img, N_object=1)
+    exp = O.match_templates(_as_f32(lt2), f32img, N_object=1)
+    assert_hits_equal(got, hits_json(exp), tol=1e-6)
+    # same numbers as the float32 route (the float64 kernel) - the policy change is invisible
+    a = mtm.computeScoreMap(lt[0][1], img, 5)
+    b = mtm.computeScoreMap(lt[0][1].astype(np.float32), f32img, 5)
+    assert ctx.timing()["kernel_used"] == 0
+    map_close(a, b, tol=1e-6)
+    # mixed dtypes and masks keep the reference's float32 policy
+    m8 = mtm.computeScoreMap(lt[0][1].astype(np.uint8), img, 5)
+    map_close(m8, O.match_template(f32img, lt[0][1].astype(np.uint8).astype(np.float32), 5), tol=1e-5)
+    mask = (rng.random(lt[0][1].shape) > 0.4).astype(np.uint16)
+    got = mtm.computeScoreMap(lt[0][1], img, 3, mask=mask)
+    exp = O.match_template(f32img, lt[0][1].astype(np.float32), 3, mask=mask.astype(np.float32))
+    map_close(got, exp, tol=1e-5)
+    # RGB uint16: float64 kernel from the uint16 upload
+    rgb = rng.integers(0, 65536, (90, 120, 3), dtype=np.uint16)
+    t3 = rgb[10:30, 20:50].copy()
+    map_close(mtm.computeScoreMap(t3, rgb, 5), O.match_template(rgb.astype(np.float32), t3.astype(np.float32), 5), tol=1e-5)
+    # big template (two 64-row chunks, three 64-tap blocks) and the resident-template stream
+    big = rng.integers(0, 65536, (300, 420), dtype=np.uint16)
+    tb = big[50:50 + 130, 60:60 + 150].copy()
+    map_close(mtm.computeScoreMap(tb, big, 5), O.match_template(big.astype(np.float32), tb.astype(np.float32), 5), tol=1e-6)
+    tm = mtm.TemplateMatcher(lt2, score_threshold=0.5)
+    frames = [img, np.ascontiguousarray(img[::-1]), img]
+    assert list(tm.match_stream(frames)) == [mtm.matchTemplates(lt2, f, score_threshold=0.5) for f in frames]
+    # downscaled matching in 16 bit
+    got = mtm.augment.matchTemplatesDownscaled(lt[:3], img, 2, score_threshold=0.5)
+    exp = mtm.augment.upscale_hits(O.match_templates(_as_f32([(n, O.downscale_area(t, 2)) for n, t in lt[:3]]),
+                                                     O.downscale_area(img, 2).astype(np.float32), score_threshold=0.5), 2)
+    assert_hits_equal(got, hits_json(exp), tol=1e-6)

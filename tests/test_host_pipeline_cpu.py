@@ -19,11 +19,17 @@ class OracleContext:
         self.lock = threading.RLock()
         self.hit_dtype = hit_dtype
 
+    @staticmethod
+    def _as_cv2_sees_it(a):
+        # MTM_U16: the library takes uint16 pixels as they are; the reference casts them to float32
+        # (exactly) before cv2.matchTemplate (MTM/__init__.py:71-74)
+        return a.astype(np.float32) if a is not None and a.dtype == np.uint16 else a
+
     def set_image(self, image, downscale=1):
-        self.image = O.downscale_area(image, downscale)       # mtm_set_image_downscaled
+        self.image = self._as_cv2_sees_it(O.downscale_area(image, downscale))       # mtm_set_image_downscaled
 
     def set_templates(self, templates, method):
-        self.templates, self.method = templates, method
+        self.templates, self.method = [(self._as_cv2_sees_it(t), self._as_cv2_sees_it(m)) for t, m in templates], method
 
     def score_map(self, idx, shape):
         t, m = self.templates[idx]
