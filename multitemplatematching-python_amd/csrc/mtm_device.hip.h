@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
                                                        int oh, int ow, double inv_area, int num_type, int want_sq,
                                                        int want_t, int want_sum2, double* __restrict__ t0,
                                                        double* __restrict__ sum2, double* __restrict__ sq,
-                                                       int st_pitch) {
+                                                       int st_pitch, double* __restrict__ rsq = nullptr) {
     __shared__ uint32_t P1[256 * kStatMaxK + 1], P2[256 * kStatMaxK + 1];
     __shared__ uint32_t wsum[2][4];
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kStatBand;
@@ -374,7 +374,9 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
             if (want_sq) {
                 const double diff2 = fmax(wnd_sum2 - wnd_mean2, 0.0);
                 const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * wnd_sum2);
-                sq[o] = small ? 0.0 : sqrt(diff2);
+                const double sqv = small ? 0.0 : sqrt(diff2);
+                sq[o] = sqv;
+                if (rsq != nullptr) rsq[o] = sqv > 0.0 ? 1.0 / sqv : 0.0;      // row-multiplexed MFMA classes
             }
         }
         // slide the column sums one row down (zeros on the last row: nothing changes)

@@ -77,6 +77,7 @@ struct SizeClass {
     bool all_u8 = true;
     bool all_u16 = true;
     bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
+    int rm_nt = 0, rm_R = 0;    // > 0: row-multiplexed MFMA mode (<= 16 templates: nt x R = 16 A rows)
     int n_pad = 0;              // members rounded up to a multiple of 16 (uint16 packs)
     long long tsum_off = -1;    // doubles: [sum(T_hi) per member][sum(T_lo) per member] in the tsum arena
     std::vector<int> members;
@@ -143,7 +144,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -159,6 +160,7 @@ struct mtm_ctx {
     bool cand_on = false;
     bool cand_min = false;
     float cand_thr = 0.f;
+    int row_mux = 1;           // MTM_ROW_MUX: row-multiplexed MFMA mode for classes of <= 16 templates
     int hits_only = 1;         // MTM_OPT_HITS_ONLY: mtm_find_matches does not materialise the score maps when
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
@@ -237,6 +239,27 @@ bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
 long long mfma_group_bytes(int h, int w, int chans) { return (long long)chans * h * ((w + 63) / 64) * 1024; }
 int mfma_groups_alloc(int n) { return (((n + 15) / 16) + 1) & ~1; }     // multiple of MB = 2
 
+// Row-multiplexed packs (<= 16 uint8 templates, one channel, no mask): steps sp' = 0 .. h + 3R - 2, A row
+// i = (template i % nt, row offset i / nt) holds template row sp' - R - i / nt (zero outside 0..h-1).
+// MFMA group 0 of step s reads pack step s + R, group 1 (the wave's next R output rows) pack step s.
+long long rm_pack_bytes(int h, int w, int R) { return (long long)(h + 3 * R - 1) * ((w + 63) / 64) * 1024; }
+
+void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, R = sc.rm_R, nt = sc.rm_nt;
+    std::memset(out, 0, (size_t)rm_pack_bytes(h, w, R));
+    for (int sp = 0; sp < h + 3 * R - 1; ++sp)
+        for (int i = 0; i < 16; ++i) {
+            const int t = i % nt, rho = i / nt, dy = sp - R - rho;
+            if (t >= (int)sc.members.size() || dy < 0 || dy >= h) continue;
+            const HostTempl& ht = c->templs[sc.members[(size_t)t]];
+            for (int dx = 0; dx < w; ++dx) {
+                const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
+                const uint8_t v = (uint8_t)ht.px[(size_t)dy * w + dx];
+                out[(((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+            }
+        }
+}
+
 // uint16 image + uint16 templates, one channel, no mask: four uint8 byte-plane correlations on the int8
 // MFMA kernel (raw mode) + ncc16_combine_kernel.  Same int32 accumulator bound as the uint8 path.
 bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
@@ -311,6 +334,18 @@ int place_templates(mtm_ctx* c) {
         c->classes[k].mfma16_ok = mfma16_class_ok(c, c->classes[k]);
         c->classes[k].n_pad = (int)round_up(c->classes[k].members.size(), 16);
         class_kernel[k] = resolved_kernel(c, c->classes[k]);
+        // row-multiplexed mode: unmasked uint8 class of <= 16 templates on one channel whose window
+        // statistics the fused kernel produces (it also writes the 1/sqrt plane this mode reads)
+        SizeClass& sc = c->classes[k];
+        sc.rm_nt = sc.rm_R = 0;
+        const size_t n_cls = sc.members.size();
+        if (c->row_mux && class_kernel[k] == MTM_KERNEL_MFMA && !sc.masked && c->chans == 1 && n_cls <= 16 &&
+            (double)sc.w * sc.h * 65025.0 < 4294967296.0 && c->fuse_stats) {
+            int nt = 1;
+            while (nt < (int)n_cls) nt <<= 1;
+            sc.rm_nt = nt;
+            sc.rm_R = 16 / nt;
+        }
     }
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
@@ -400,6 +435,12 @@ int place_templates(mtm_ctx* c) {
     for (size_t k = 0; k < c->classes.size(); ++k) {
         SizeClass& sc = c->classes[k];
         if (class_kernel[k] != MTM_KERNEL_MFMA) continue;
+        if (sc.rm_R > 0) {
+            sc.group_bytes = -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
+            sc.apack_off = (long long)a_off;
+            a_off += (size_t)rm_pack_bytes(sc.h, sc.w, sc.rm_R);
+            continue;
+        }
         sc.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
         sc.apack_off = (long long)a_off;
         a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
@@ -418,7 +459,10 @@ int place_templates(mtm_ctx* c) {
     std::vector<uint8_t> apacks(a_off);
     std::vector<double> tsums(ts_off);
     for (size_t k = 0; k < c->classes.size(); ++k) {
-        if (class_kernel[k] == MTM_KERNEL_MFMA) pack_class_mfma(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
+        if (class_kernel[k] == MTM_KERNEL_MFMA && c->classes[k].rm_R > 0)
+            pack_class_rm(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
+        else if (class_kernel[k] == MTM_KERNEL_MFMA)
+            pack_class_mfma(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
         if (class_kernel[k] == MTM_KERNEL_MFMA16)
             pack_class_mfma16(c, c->classes[k], apacks.data() + c->classes[k].apack_off, tsums.data() + c->classes[k].tsum_off);
     }
@@ -497,8 +541,13 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     if (fused_stats) {
         const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always) ? 1 : 0;
         const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+        double* rsq = nullptr;
+        if (sc.rm_R > 0 && normed) {
+            MTMC(c->stats_rsq.ensure(sizeof(double) * plane));
+            rsq = c->stats_rsq.as<double>();
+        }
         hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, inv_area,
-                           num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch);
+                           num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch, rsq);
     } else if (u8) {
         if (c->cols <= 8191)
             hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
@@ -600,7 +649,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         // the MFMA kernel works on whole 16-template groups of the class list; a single-template
         // request (mtm_score_map) computes its group and stores only that template
         const int n_all = (int)sc.members.size();
-        const int mb = n_all > 16 ? 2 : 1;
+        const bool rm = sc.rm_R > 0;
+        const int mb = (n_all > 16 || rm) ? 2 : 1;
         MfmaParams p{};
         p.img = c->slot[c->cur].u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
         p.pitch = img.u8_pitch;
@@ -632,19 +682,32 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         int tg0 = 0;
-        if (only_li >= 0) {          // one template: just its group
+        if (only_li >= 0 && !rm) {   // one template: just its group
             tg0 = only_li / (16 * mb);
             p.ntg = 1;
         }
+        int tile_rows = std::min(h, kMfChunkH) + kMfRows - 1;
+        if (rm) {
+            p.rm_R = sc.rm_R;
+            p.rm_nt = sc.rm_nt;
+            p.rm_log2nt = 0;
+            while ((1 << p.rm_log2nt) < sc.rm_nt) ++p.rm_log2nt;
+            p.rm_steps = h + 2 * sc.rm_R - 1;
+            p.rm_rsq = c->stats_rsq.as<double>();
+            p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
+            p.ntg = 1;
+            tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * sc.rm_R;
+        }
         p.n_work = p.nseg * p.nyb * p.ntg;
-        const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
+        const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch,
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
-        const size_t lds = (size_t)p.st_off + (size_t)kMfRows * kMfStatBytesPerWave;
+        const size_t lds = (size_t)p.st_off + (rm ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);   // RM loads its statistics directly
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
-        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off +
+                            (rm ? (long long)sc.rm_R * p.nb * 1024 : (long long)tg0 * mb * sc.group_bytes);
         // with a group offset the kernel's list positions must stay class-relative: shift the list
         // pointer and the counts instead (positions inside the kernel are relative to tg0)
         p.n_list = n_all - tg0 * 16 * mb;
@@ -659,7 +722,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             {{MTM_MF_ROW(1, false, true), MTM_MF_ROW(2, false, true)}, {MTM_MF_ROW(1, true, true), MTM_MF_ROW(2, true, true)}}};
 #undef MTM_MF_ROW
         // masked classes reach here only with methods 0..3 and one channel (mfma_class_ok)
-        const MfmaFn fn = kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
+#define MTM_MF_RM(X) {ncc_mfma_kernel<2, 0, X, false, true>, ncc_mfma_kernel<2, 1, X, false, true>,            \
+                     ncc_mfma_kernel<2, 2, X, false, true>, ncc_mfma_kernel<2, 3, X, false, true>,            \
+                     ncc_mfma_kernel<2, 4, X, false, true>, ncc_mfma_kernel<2, 5, X, false, true>}
+        static const MfmaFn kMfmaRmFns[2][6] = {MTM_MF_RM(false), MTM_MF_RM(true)};
+#undef MTM_MF_RM
+        const MfmaFn fn = rm ? kMfmaRmFns[c->exact_div ? 1 : 0][c->method]
+                             : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
         // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
@@ -874,6 +943,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
+    if (const char* v = std::getenv("MTM_ROW_MUX")) c->row_mux = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_STATS")) c->fuse_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
@@ -897,7 +967,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
-                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->comm_send,
+                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->comm_send,
                       &c->comm_recv})
         b->release();
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);

@@ -82,6 +82,13 @@ struct MfmaParams {
     float cand_thr;
     int cand_min;
     int cand_on;
+    // Row-multiplexed mode (template parameter RM; classes of <= 16 templates): the 16 A rows of an
+    // MFMA are rm_nt templates x rm_R consecutive output rows (A row i = template i % rm_nt, row
+    // i / rm_nt), a wave owns 2 * rm_R output rows (MFMA group 1 = the next rm_R rows, its A operand is
+    // the pack rm_R steps earlier: group_bytes = -rm_R * nb * 1024) and walks rm_steps = h + 2 rm_R - 1
+    // image rows.  rm_R = 16 / rm_nt.
+    int rm_R, rm_nt, rm_log2nt, rm_steps;
+    const double* rm_rsq;    // 1 / sqrt plane of the class (0 for flat windows), pitch = st.pitch
     int* raw_out;            // METHOD == kMfRaw: int32 accumulators of list position li at raw_out + li * raw_map
     long long raw_map;       //   (+ y * raw_pitch + x); see ncc16_combine_kernel
     int raw_pitch;
@@ -247,7 +254,7 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
-template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false>
+template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
@@ -295,7 +302,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
-    const int x0 = seg * kMfSeg, y0 = yb * kMfRows;
+    const int x0 = seg * kMfSeg, y0 = yb * (RM ? 8 * p.rm_R : kMfRows);
+    const int wave_rows = RM ? 2 * p.rm_R : 1;          // output rows per wave = tile-row stride between waves
 
     v4i acc[MB][16];
 #pragma unroll
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
     MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
-    if (METHOD != kMfRaw && threadIdx.x < 16 * MB) {
+    if (METHOD != kMfRaw && threadIdx.x < (RM ? p.rm_nt : 16 * MB)) {
         const int li = tg * MB * 16 + threadIdx.x;
         if (li < p.n_list) {
             const TemplDev& T = td[tlist[li]];
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                                          METHOD == MTM_TM_CCOEFF_NORMED);
     constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
-    if constexpr (C1 && METHOD != kMfRaw) {
+    if constexpr (C1 && METHOD != kMfRaw && !RM) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
@@ -352,8 +360,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     for (int c = 0; c < p.chans; ++c) {
         const uint8_t* plane = p.img + c * p.plane;
-        for (int cy0 = 0; cy0 < p.h; cy0 += kMfChunkH) {
-            const int ch = min(kMfChunkH, p.h - cy0);
+        const int krows = RM ? p.rm_steps : p.h;        // image rows a wave walks (K steps / nb)
+        for (int cy0 = 0; cy0 < krows; cy0 += kMfChunkH) {
+            const int ch = min(kMfChunkH, krows - cy0);
             // ---- stage (ch + 3) rows of the int8 image plane by LDS-DMA: the tile is one linear
             // array of 16-byte chunks [row][cpr]; wave-instruction k of the work-group fills chunks
             // 64 k .. 64 k + 63 (LDS destination = wave-uniform base + lane * 16), each lane
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             {
                 typedef const __attribute__((address_space(1))) void* gptr_t;
                 typedef __attribute__((address_space(3))) void* lptr_t;
-                const int nchunk = (ch + kMfRows - 1) * p.cpr;
+                const int nchunk = (ch + (kMfRows - 1) * wave_rows) * p.cpr;
                 int ci = threadIdx.x;
                 int r = ci / p.cpr, d = ci - r * p.cpr;
                 const uint8_t* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // are requested before the 16*MB MFMAs of the current step issue.  sched_barrier keeps
             // the compiler from sinking the requests below the MFMAs.
             const uint8_t* aptr = apack_g + ((size_t)(c * p.h + cy0) * p.nb) * 1024;   // + ks * 1024
-            const uint8_t* lbase = smem + wave * p.lds_pitch + (j + q) * 16;
+            const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
             const int nsteps = ch * p.nb;
             int nb_i = 0;                       // 64-tap block of the step last requested
             int loff = 0;                       // its LDS offset: dy * lds_pitch + b * 64
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
     // append the outputs above the threshold to the candidate list (rare)
-    auto emit = [&](const float (&out)[4], int li) {
+    auto emit_at = [&](const float (&out)[4], int li, int yrow) {
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         mtm_hit hrec;
                         hrec.templ_idx = tglob;
                         hrec.x = xq + i;
-                        hrec.y = y;
+                        hrec.y = yrow;
                         hrec.w = p.w;
                         hrec.h = p.h;
                         hrec.score = out[i];
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 }
         }
     };
+    auto emit = [&](const float (&out)[4], int li) { emit_at(out, li, y); };
     auto store4 = [&](float* orow, const float (&out)[4]) {
 #ifdef MTM_PROBE_NO_STORE      /* timing experiment: no score-map stores (values kept alive) */
         if (out[0] + out[1] + out[2] + out[3] == 12345.678f) orow[0] = 1.0f;
@@ -531,7 +541,95 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
 
-    if constexpr (METHOD == kMfRaw) {
+    if constexpr (RM) {
+        // ---- row-multiplexed mode: A row i of group mb is (template i % nt, output row mb R + i / nt) of
+        // this wave.  Statistics are per output row here, so they are loaded (S1 and 1/sqrt, both from
+        // the statistics pass) whenever the row changes; otherwise the same normalisation, hits-only
+        // pre-test, candidate emission and stores as the single-row path.
+        __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+        const int R = p.rm_R, ntm = p.rm_nt - 1, lg = p.rm_log2nt;
+        const bool col_on = xq < p.ow;
+        const int xs = min(xq, st.pitch - 4);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                if ((q >> 1) == round) put(acc[mb]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (col_on) {
+                    int cur_rho = -1;
+                    double ps1[4] = {0, 0, 0, 0}, pp1[4] = {0, 0, 0, 0}, psum2[4] = {0, 0, 0, 0}, psq[4] = {0, 0, 0, 0},
+                           prsq[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int i = 8 * round + s8;
+                        const int t = i & ntm, rho = i >> lg;
+                        const int yy = y0 + wave * wave_rows + mb * R + rho;
+                        if (t >= p.n_list || yy >= p.oh || (p.only_li >= 0 && t != p.only_li)) continue;   // wave-uniform
+                        if (rho != cur_rho) {
+                            cur_rho = rho;
+                            const size_t sidx = (size_t)yy * st.pitch + xs;
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
+                                ps1[2 * hh] = a.x;
+                                ps1[2 * hh + 1] = a.y;
+                                if (kNeedSum2) {
+                                    const double2 b = *reinterpret_cast<const double2*>(st.sum2 + sidx + 2 * hh);
+                                    psum2[2 * hh] = b.x;
+                                    psum2[2 * hh + 1] = b.y;
+                                }
+                                if (kNormed) {
+                                    const double2 d = *reinterpret_cast<const double2*>(st.sq + sidx + 2 * hh);
+                                    const double2 e = *reinterpret_cast<const double2*>(p.rm_rsq + sidx + 2 * hh);
+                                    psq[2 * hh] = d.x;
+                                    psq[2 * hh + 1] = d.y;
+                                    prsq[2 * hh] = e.x;
+                                    prsq[2 * hh + 1] = e.y;
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) pp1[k] = 128.0 * ps1[k];
+                        }
+                        const MfTemplConst T = tcl[t];
+                        const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
+                        const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+                        if (kNormed && p.hits_only) {
+                            bool pass = T.all_ones != 0;
+                            const double rt = T.rtempl_norm;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const double base = (double)a32[k] + T.mfma_k;
+                                double num = fma(ps1[k], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128 : 128.0, base);
+                                if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[k] - 2.0 * num + T.templ_sum2, 0.0);
+                                const double qd = num * (prsq[k] * rt);
+                                const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
+                                pass = pass || quality > p.cand_thr_lo || fabs(qd) >= 0.999999999;
+                            }
+                            if (!pass) continue;
+                        }
+                        float out[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            out[k] = finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], ps1[k], pp1[k], psum2[k], psq[k],
+                                                                                    prsq[k], T);
+                        const bool ones = T.all_ones != 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) out[k] = ones ? 1.0f : out[k];
+                        if (p.cand_on) {
+                            const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                            const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy);
+                        }
+                        if (!p.hits_only) store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, out);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else if constexpr (METHOD == kMfRaw) {
         // ---- raw mode: transpose through LDS and store the int32 accumulators, 4 pixels per lane
         __syncthreads();              // every wave is done reading the image tile: the buffers alias it
         const bool lane_on = y < p.oh && xq < p.ow;

@@ -774,3 +774,54 @@ def test_uint16_exact_path(mtm, ctx, coins):
     exp = mtm.augment.upscale_hits(O.match_templates(_as_f32([(n, O.downscale_area(t, 2)) for n, t in lt[:3]]),
                                                      O.downscale_area(img, 2).astype(np.float32), score_threshold=0.5), 2)
     assert_hits_equal(got, hits_json(exp), tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# row-multiplexed MFMA mode (classes of <= 16 templates: A rows = templates x output rows)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_templ", [1, 2, 3, 5, 8, 9, 16])
+def test_row_multiplexed_mode(mtm, n_templ):
+    rng = np.random.default_rng(300 + n_templ)
+    H, W = 157, 531                                        # not multiples of the 8R-row / 256-column work items
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[60:100, 200:330] = 93                              # flat windows
+    shapes = [(24, 24), (70, 33), (9, 130)]                # one chunk, two 64-row chunks, three 64-tap blocks
+    for (h, w) in shapes:
+        lt = []
+        for i in range(n_templ):
+            y, x = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+            t = img[y:y + h, x:x + w].copy()
+            if i % 2:
+                t = np.clip(t.astype(np.int32) + rng.integers(-40, 41, t.shape), 0, 255).astype(np.uint8)
+            lt.append(("t%d" % i, t))
+        ctx = mtm._lib.Context(0)
+        try:
+            ctx.set_option(1, 3)                           # MFMA
+            ctx.set_image(img)
+            for method in (1, 3, 5, 0, 2, 4):
+                ctx.set_templates([(t, None) for _, t in lt], method)
+                for exact in (1, 0):
+                    ctx.set_option(5, exact)
+                    for li in sorted({0, n_templ // 2, n_templ - 1}):
+                        got = ctx.score_map(li, (H - h + 1, W - w + 1))
+                        exp = O.match_template(img, lt[li][1], method)
+                        if exact and method in (1, 3, 5):
+                            assert np.array_equal(got, exp), (n_templ, (h, w), method, li, float(np.abs(got - exp).max()))
+                        elif method in (1, 3, 5):
+                            ulp_close(got, exp)
+                        else:
+                            assert np.array_equal(got, exp)
+                if method in (1, 3, 5):
+                    thr = 0.3 if method == 1 else 0.6
+                    res = []
+                    for honly in (0, 1):
+                        ctx.set_option(6, honly)
+                        res.append(ctx.find_matches(0, thr).copy())
+                        assert ctx.timing()["kernel_used"] == 3
+                    assert res[0].tobytes() == res[1].tobytes()
+                    exp = O.find_matches(lt, img, method=method, score_threshold=thr)
+                    assert len(res[1]) == len(exp)
+                    got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in res[1]]
+                    assert_hits_equal(canon(got), canon(exp), tol=1e-6)
+        finally:
+            del ctx
