@@ -254,7 +254,8 @@ void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
             const HostTempl& ht = c->templs[sc.members[(size_t)t]];
             for (int dx = 0; dx < w; ++dx) {
                 const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
-                const uint8_t v = (uint8_t)ht.px[(size_t)dy * w + dx];
+                const size_t k = (size_t)dy * w + dx;
+                const uint8_t v = (uint8_t)(ht.masked ? ht.px[k] * ht.mask[k] : ht.px[k]);   // masked: T*M, M in {0,1}
                 out[(((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
             }
         }
@@ -334,12 +335,12 @@ int place_templates(mtm_ctx* c) {
         c->classes[k].mfma16_ok = mfma16_class_ok(c, c->classes[k]);
         c->classes[k].n_pad = (int)round_up(c->classes[k].members.size(), 16);
         class_kernel[k] = resolved_kernel(c, c->classes[k]);
-        // row-multiplexed mode: unmasked uint8 class of <= 16 templates on one channel whose window
+        // row-multiplexed mode: uint8 class (masked or not) of <= 16 templates on one channel whose window
         // statistics the fused kernel produces (it also writes the 1/sqrt plane this mode reads)
         SizeClass& sc = c->classes[k];
         sc.rm_nt = sc.rm_R = 0;
         const size_t n_cls = sc.members.size();
-        if (c->row_mux && class_kernel[k] == MTM_KERNEL_MFMA && !sc.masked && c->chans == 1 && n_cls <= 16 &&
+        if (c->row_mux && class_kernel[k] == MTM_KERNEL_MFMA && c->chans == 1 && n_cls <= 16 &&
             (double)sc.w * sc.h * 65025.0 < 4294967296.0 && c->fuse_stats) {
             int nt = 1;
             while (nt < (int)n_cls) nt <<= 1;
@@ -722,12 +723,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             {{MTM_MF_ROW(1, false, true), MTM_MF_ROW(2, false, true)}, {MTM_MF_ROW(1, true, true), MTM_MF_ROW(2, true, true)}}};
 #undef MTM_MF_ROW
         // masked classes reach here only with methods 0..3 and one channel (mfma_class_ok)
-#define MTM_MF_RM(X) {ncc_mfma_kernel<2, 0, X, false, true>, ncc_mfma_kernel<2, 1, X, false, true>,            \
-                     ncc_mfma_kernel<2, 2, X, false, true>, ncc_mfma_kernel<2, 3, X, false, true>,            \
-                     ncc_mfma_kernel<2, 4, X, false, true>, ncc_mfma_kernel<2, 5, X, false, true>}
-        static const MfmaFn kMfmaRmFns[2][6] = {MTM_MF_RM(false), MTM_MF_RM(true)};
+#define MTM_MF_RM(X, M) {ncc_mfma_kernel<2, 0, X, M, true>, ncc_mfma_kernel<2, 1, X, M, true>,                      \
+                        ncc_mfma_kernel<2, 2, X, M, true>, ncc_mfma_kernel<2, 3, X, M, true>,                      \
+                        ncc_mfma_kernel<2, 4, X, false, true>, ncc_mfma_kernel<2, 5, X, false, true>}
+        static const MfmaFn kMfmaRmFns[2][2][6] = {{MTM_MF_RM(false, false), MTM_MF_RM(true, false)},
+                                                   {MTM_MF_RM(false, true), MTM_MF_RM(true, true)}};
 #undef MTM_MF_RM
-        const MfmaFn fn = rm ? kMfmaRmFns[c->exact_div ? 1 : 0][c->method]
+        const MfmaFn fn = rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
                              : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
         // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
         constexpr int kSchedWords = 1 + 4096;

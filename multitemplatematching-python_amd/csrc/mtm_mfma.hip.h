@@ -590,7 +590,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 }
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) pp1[k] = 128.0 * ps1[k];
+                            for (int k = 0; k < 4; ++k) {
+                                pp1[k] = 128.0 * ps1[k];
+                                if (kMaskedNormed && !EXACT_DIV) prsq[k] = 1.0 / sqrt(psum2[k]);
+                            }
                         }
                         const MfTemplConst T = tcl[t];
                         const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
@@ -612,9 +615,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         float out[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            out[k] = finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], ps1[k], pp1[k], psum2[k], psq[k],
-                                                                                    prsq[k], T);
-                        const bool ones = T.all_ones != 0;
+                            out[k] = MASKED ? finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], pp1[k], psum2[k],
+                                                                                                     prsq[k], T)
+                                            : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], ps1[k], pp1[k], psum2[k],
+                                                                                              psq[k], prsq[k], T);
+                        const bool ones = !MASKED && T.all_ones != 0;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) out[k] = ones ? 1.0f : out[k];
                         if (p.cand_on) {
