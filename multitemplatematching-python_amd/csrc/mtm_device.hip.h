@@ -500,6 +500,52 @@ __device__ __forceinline__ float finish_masked(int method, double c_i_tm2, doubl
 }
 
 // ---------------------------------------------------------------------------------------------
+// Masked templates: sum I^2 * M over every window on the matrix cores.  I^2 is a 16-bit number; its two
+// bytes are image planes of their own (square_planes_kernel), the binary mask is the "template" of a
+// row-multiplexed raw correlation (one template, 16 output rows per MFMA), and masksq_combine_kernel
+// puts the two byte-plane results together:  c2 = 256 (a_h + 128 S1_h + K) + (a_l + 128 S1_l + K),
+// K = 128 sum(M) - 16384 A, S1_h / S1_l the window sums of the byte planes (S1_l = S2 - 256 S1_h with
+// S2 the plain window sum of squares).  All integers < 2^53: exact.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void square_planes_kernel(const uint8_t* __restrict__ u8, size_t n16,
+                                                            uint8_t* __restrict__ sh, uint8_t* __restrict__ shb,
+                                                            uint8_t* __restrict__ slb) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n16) return;
+    const uint4 v = reinterpret_cast<const uint4*>(u8)[g];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        hi[k] = lo[k] = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t px = (w[k] >> (8 * b)) & 255u, sq = px * px;
+            hi[k] |= (sq >> 8) << (8 * b);
+            lo[k] |= (sq & 255u) << (8 * b);
+        }
+    }
+    reinterpret_cast<uint4*>(sh)[g] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    reinterpret_cast<uint4*>(shb)[g] = make_uint4(hi[0] ^ 0x80808080u, hi[1] ^ 0x80808080u, hi[2] ^ 0x80808080u,
+                                                  hi[3] ^ 0x80808080u);
+    reinterpret_cast<uint4*>(slb)[g] = make_uint4(lo[0] ^ 0x80808080u, lo[1] ^ 0x80808080u, lo[2] ^ 0x80808080u,
+                                                  lo[3] ^ 0x80808080u);
+}
+
+__global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restrict__ raw_h, const int* __restrict__ raw_l,
+                                                             int raw_pitch, const double* __restrict__ s1h,
+                                                             double* __restrict__ sum2, int st_pitch, double km,
+                                                             int oh, int ow) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= ow || y >= oh) return;
+    const size_t o = (size_t)y * st_pitch + x, r = (size_t)y * raw_pitch + x;
+    const double h1 = s1h[o], l1 = sum2[o] - 256.0 * h1;     // sum2 holds the plain window sum of squares here
+    const double ch = (double)raw_h[r] + 128.0 * h1 + km, cl = (double)raw_l[r] + 128.0 * l1 + km;
+    sum2[o] = 256.0 * ch + cl;
+}
+
+// ---------------------------------------------------------------------------------------------
 // uint16 images and templates on the int8 matrix cores, exactly.
 //   I = 256 Ih + Il, T = 256 Th + Tl  (bytes)  =>
 //   sum I*T = 65536 R_hh + 256 (R_hl + R_lh) + R_ll,   R_xy = sum I_x * T_y   (uint8 x uint8)

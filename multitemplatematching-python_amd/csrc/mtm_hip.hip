@@ -78,6 +78,8 @@ struct SizeClass {
     bool all_u16 = true;
     bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
     int rm_nt = 0, rm_R = 0;    // > 0: row-multiplexed MFMA mode (<= 16 templates: nt x R = 16 A rows)
+    long long mask_rm_off = -1; // masked class: row-multiplexed pack (1 "template" = the binary mask, R = 16) in apacks
+    double mask_ones = 0.0;     // number of set mask pixels
     int n_pad = 0;              // members rounded up to a multiple of 16 (uint16 packs)
     long long tsum_off = -1;    // doubles: [sum(T_hi) per member][sum(T_lo) per member] in the tsum arena
     std::vector<int> members;
@@ -130,6 +132,8 @@ struct mtm_ctx {
         long long geom = -1;        // (rows, cols, chans, dtype) the padding was initialised for
     } slot[2];
     int cur = 0;
+    DevBuf sq_planes;           // [high byte of I^2][the same ^ 0x80][low byte ^ 0x80] of the current uint8 image
+    bool sq_valid = false;
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_ready = nullptr;
 
@@ -243,6 +247,23 @@ int mfma_groups_alloc(int n) { return (((n + 15) / 16) + 1) & ~1; }     // multi
 // i = (template i % nt, row offset i / nt) holds template row sp' - R - i / nt (zero outside 0..h-1).
 // MFMA group 0 of step s reads pack step s + R, group 1 (the wave's next R output rows) pack step s.
 long long rm_pack_bytes(int h, int w, int R) { return (long long)(h + 3 * R - 1) * ((w + 63) / 64) * 1024; }
+
+// the binary mask of a masked class as the single "template" (nt = 1, R = 16) of the sum I^2 M pass
+void pack_mask_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, R = 16;
+    std::memset(out, 0, (size_t)rm_pack_bytes(h, w, R));
+    const HostTempl& ht = c->templs[sc.members[0]];
+    for (int sp = 0; sp < h + 3 * R - 1; ++sp)
+        for (int i = 0; i < 16; ++i) {
+            const int dy = sp - R - i;
+            if (dy < 0 || dy >= h) continue;
+            for (int dx = 0; dx < w; ++dx) {
+                const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
+                const uint8_t v = ht.mask[(size_t)dy * w + dx] > 0.0 ? 1 : 0;
+                out[(((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+            }
+        }
+}
 
 void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
     const int h = sc.h, w = sc.w, nb = (w + 63) / 64, R = sc.rm_R, nt = sc.rm_nt;
@@ -402,7 +423,7 @@ int place_templates(mtm_ctx* c) {
         SizeClass& sc = c->classes[k];
         sc.masked_int = sc.masked && class_kernel[k] == MTM_KERNEL_MFMA;
         sc.mask_pack_off = -1;
-        if (sc.masked_int) {
+        if (sc.masked_int && !(c->row_mux && c->fuse_stats)) {   // dot4 route of sum I^2 M (otherwise: matrix cores)
             sc.mask_pack_off = (long long)p_off;
             p_off += dot_pack_bytes(sc.h, sc.w, 1);
         }
@@ -426,7 +447,7 @@ int place_templates(mtm_ctx* c) {
         if (d.pack_off >= 0) pack_template_dot4(t, packs.data() + d.pack_off);
     }
     for (const SizeClass& sc : c->classes)
-        if (sc.masked_int) {
+        if (sc.masked_int && sc.mask_pack_off >= 0) {
             HostTempl mk = c->templs[sc.members[0]];
             for (size_t k = 0; k < mk.px.size(); ++k) mk.px[k] = mk.mask[k] > 0.0 ? 255.0 : 0.0;
             pack_template_dot4(mk, packs.data() + sc.mask_pack_off);
@@ -436,6 +457,13 @@ int place_templates(mtm_ctx* c) {
     for (size_t k = 0; k < c->classes.size(); ++k) {
         SizeClass& sc = c->classes[k];
         if (class_kernel[k] != MTM_KERNEL_MFMA) continue;
+        sc.mask_rm_off = -1;
+        if (sc.masked && c->row_mux && c->fuse_stats) {
+            sc.mask_rm_off = (long long)a_off;
+            a_off += (size_t)rm_pack_bytes(sc.h, sc.w, 16);
+            sc.mask_ones = 0.0;
+            for (double m : c->templs[sc.members[0]].mask) sc.mask_ones += m > 0.0 ? 1.0 : 0.0;
+        }
         if (sc.rm_R > 0) {
             sc.group_bytes = -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
             sc.apack_off = (long long)a_off;
@@ -460,6 +488,8 @@ int place_templates(mtm_ctx* c) {
     std::vector<uint8_t> apacks(a_off);
     std::vector<double> tsums(ts_off);
     for (size_t k = 0; k < c->classes.size(); ++k) {
+        if (class_kernel[k] == MTM_KERNEL_MFMA && c->classes[k].mask_rm_off >= 0)
+            pack_mask_rm(c, c->classes[k], apacks.data() + c->classes[k].mask_rm_off);
         if (class_kernel[k] == MTM_KERNEL_MFMA && c->classes[k].rm_R > 0)
             pack_class_rm(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
         else if (class_kernel[k] == MTM_KERNEL_MFMA)
@@ -540,7 +570,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     const bool fused_stats = u8 && c->chans == 1 && w <= 768 && (double)w * h * 65025.0 < 4294967296.0 &&
                              c->fuse_stats;
     if (fused_stats) {
-        const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always) ? 1 : 0;
+        const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always || masked_mfma) ? 1 : 0;
         const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
         double* rsq = nullptr;
         if (sc.rm_R > 0 && normed) {
@@ -581,9 +611,83 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
     st.sum2 = sum2;
     st.sq = sq;
-    if (masked_mfma) {
+    if (masked_mfma && sc.mask_rm_off >= 0 && fused_stats) {
+        // sum I^2 * M over every window on the matrix cores (see square_planes_kernel): two row-multiplexed
+        // raw correlations of the byte planes of I^2 with the mask, combined into the sum2 plane
+        const size_t plane_bytes = (size_t)img.u8_plane;
+        if (!c->sq_valid) {
+            MTMC(c->sq_planes.ensure(3 * plane_bytes));
+            const size_t n16 = plane_bytes / 16;
+            hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
+                               c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes,
+                               c->sq_planes.as<uint8_t>() + 2 * plane_bytes);
+            c->sq_valid = true;
+        }
+        MTMC(c->stats_hi.ensure(sizeof(double) * plane));
+        {
+            const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, c->sq_planes.as<uint8_t>(), img.u8_pitch, h, w, oh,
+                               ow, inv_area, 0, 0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr,
+                               st.pitch);
+        }
+        const int map_pitch = (int)round_up((size_t)ow, 4);
+        const long long raw_map = (long long)oh * map_pitch;
+        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(2 * raw_map)));
+        MfmaParams p{};
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = 1;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nb = (w + 63) / 64;
+        p.n_list = 1;
+        p.rm_R = 16;
+        p.rm_nt = 1;
+        p.rm_log2nt = 0;
+        p.rm_steps = h + 2 * 16 - 1;
+        p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+        p.nyb = (oh + 8 * 16 - 1) / (8 * 16);
+        p.ntg = 1;
+        p.n_work = p.nseg * p.nyb;
+        p.method = method;
+        p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.cpr = p.lds_pitch / 16;
+        p.cpr_rstep = 256 / p.cpr;
+        p.cpr_dstep = 256 % p.cpr;
+        p.group_bytes = -(long long)16 * p.nb * 1024;
+        p.only_li = -1;
+        p.raw_map = raw_map;
+        p.raw_pitch = map_pitch;
+        const int tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * 16;
+        const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
+                                ~(size_t)15;
+        p.tc_off = (int)lds_main;
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+        const size_t lds = (size_t)p.st_off;
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.mask_rm_off + (long long)16 * p.nb * 1024;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        for (int x = 0; x < 2; ++x) {
+            p.img = c->sq_planes.as<uint8_t>() + (size_t)(1 + x) * plane_bytes;
+            p.raw_out = c->raw16.as<int>() + (size_t)x * raw_map;
+            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false, true>), dim3(grid), dim3(256), lds, c->stream, p,
+                               c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>(),
+                               c->sched.as<unsigned int>());
+        }
+        const double km = 128.0 * sc.mask_ones - 16384.0 * (double)h * (double)w;
+        hipLaunchKernelGGL(masksq_combine_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, c->raw16.as<int>(),
+                           c->raw16.as<int>() + raw_map, map_pitch, c->stats_hi.as<double>(), sum2, st.pitch, km, oh, ow);
+        HIPC(hipGetLastError());
+    } else if (masked_mfma) {
         // sum I^2 * M over every window: dot4 kernel with the mask bytes as the "template", into the
         // sum2 plane (overwrites the unmasked window sum of squares, which the masked path never uses)
+        if (sc.mask_pack_off < 0) {
+            set_error("internal: masked class without a dot4 mask pack");
+            return MTM_E_STATE;
+        }
         const DotVariant v = {4, 4, 1, false, ncc_dot4_kernel<4, 4, 1, false, true>};
         DotParams p{};
         p.img = img.u8;
@@ -969,7 +1073,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
-                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->comm_send,
+                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})
         b->release();
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
@@ -1087,6 +1191,7 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
 }
 
 void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype) {
+    c->sq_valid = false;
     if (rows != c->rows || cols != c->cols || chans != c->chans || dtype != c->dtype) c->placed = false;
     c->rows = rows;
     c->cols = cols;

@@ -541,7 +541,43 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
 
-    if constexpr (RM) {
+    if constexpr (RM && METHOD == kMfRaw) {
+        // ---- row-multiplexed raw mode (sum I^2 M of masked classes): int32 accumulators of
+        // (template i % nt, output row mb R + i / nt) to raw_out + t * raw_map + row * raw_pitch
+        __syncthreads();
+        const int R = p.rm_R, ntm = p.rm_nt - 1, lg = p.rm_log2nt;
+        const bool col_on = xq < p.ow;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll 1
+            for (int round = 0; round < 2; ++round) {
+                if ((q >> 1) == round) put(acc[mb]);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (col_on) {
+#pragma unroll 1
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int i = 8 * round + s8;
+                        const int t = i & ntm, rho = i >> lg;
+                        const int yy = y0 + wave * wave_rows + mb * R + rho;
+                        if (t >= p.n_list || yy >= p.oh) continue;              // wave-uniform
+                        const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
+                        int* orow = p.raw_out + (size_t)t * p.raw_map + (size_t)yy * p.raw_pitch + xq;
+                        if (xq + 3 < p.ow) {
+                            *reinterpret_cast<v4i*>(orow) = a4;
+                        } else {
+                            const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (xq + k < p.ow) orow[k] = a32[k];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    } else if constexpr (RM) {
         // ---- row-multiplexed mode: A row i of group mb is (template i % nt, output row mb R + i / nt) of
         // this wave.  Statistics are per output row here, so they are loaded (S1 and 1/sqrt, both from
         // the statistics pass) whenever the row changes; otherwise the same normalisation, hits-only
