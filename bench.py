@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
                  templates as in MTM/__init__.py:172) timed on a bounded sample on this host.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -227,12 +228,17 @@ def main():
         step()
     kernel_ms.clear()
     total_ms.clear()
+    # like timeit: no cyclic garbage collection inside the timed region (with torch imported a full
+    # collection is a 30-40 ms pause that lands in one step at random)
+    gc.collect()
+    gc.disable()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         hits, tinfo = step()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
