@@ -178,6 +178,7 @@ struct mtm_ctx {
 
     mtm_timing timing{};
     std::vector<mtm_hit> last_hits;     // result of the last mtm_find_matches (for mtm_last_hits)
+    std::vector<uint8_t> templ_blob;    // bytes of the templates of the last mtm_set_templates (unchanged-input test)
 
     // RCCL
     void* rccl_lib = nullptr;
@@ -1247,7 +1248,6 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         set_error("mtm_set_templates: bad arguments");
         return MTM_E_INVALID;
     }
-    std::vector<HostTempl> hts((size_t)n_templ);
     for (int i = 0; i < n_templ; ++i) {
         const mtm_templ& s = templs[i];
         if (!s.px || s.rows <= 0 || s.cols <= 0 || s.chans < 1 || s.chans > kMaxChans ||
@@ -1255,6 +1255,31 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
             set_error("mtm_set_templates: bad template " + std::to_string(i));
             return MTM_E_INVALID;
         }
+    }
+    // The same templates again (a loop of matchTemplates calls over different images): keep everything that
+    // was derived from them - statistics, size classes, device packs.  The test is on the pixel bytes.
+    {
+        std::vector<uint8_t> blob;
+        auto put = [&](const void* p, size_t n) { blob.insert(blob.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
+        put(&n_templ, sizeof(n_templ));
+        put(&method, sizeof(method));
+        for (int i = 0; i < n_templ; ++i) {
+            const mtm_templ& s = templs[i];
+            const int hdr[5] = {s.rows, s.cols, s.chans, s.dtype, s.mask ? 1 : 0};
+            put(hdr, sizeof(hdr));
+            const size_t row = (size_t)s.cols * s.chans * elem_size(s.dtype);
+            for (int y = 0; y < s.rows; ++y) {
+                put((const uint8_t*)s.px + (size_t)y * s.row_stride, row);
+                if (s.mask) put((const uint8_t*)s.mask + (size_t)y * s.mask_row_stride, row);
+            }
+        }
+        if (c->have_templ && blob == c->templ_blob) return MTM_OK;
+        c->templ_blob.swap(blob);
+        c->have_templ = false;          // until the new set is complete
+    }
+    std::vector<HostTempl> hts((size_t)n_templ);
+    for (int i = 0; i < n_templ; ++i) {
+        const mtm_templ& s = templs[i];
         HostTempl& t = hts[i];
         t.rows = s.rows;
         t.cols = s.cols;
