@@ -337,16 +337,39 @@ class TemplateMatcher:
             first = next(it)
         except StopIteration:
             return
-        with self._ctx.lock:
+        # The native call of image i runs on a helper thread (ctypes releases the GIL) while this thread
+        # builds the hit list of image i-1 and the consumer works on it: neither the Python host layer nor
+        # the caller's own per-image code leaves the GPU idle.
+        from concurrent.futures import ThreadPoolExecutor
+        with self._ctx.lock, ThreadPoolExecutor(max_workers=1, thread_name_prefix="mtm-stream") as pool:
             cur = self._prepare(first, searchBox)
             self._ctx.set_image(cur[0])
-            for nxt_image in it:
-                nxt = self._prepare(nxt_image, searchBox)
-                raw = self._ctx.find_matches(mode, self.score_threshold, next_image=nxt[0]).copy()
-                yield self._finish(raw, cur[1], cur[2])
-                cur = nxt
-            raw = self._ctx.find_matches(mode, self.score_threshold).copy()
-            yield self._finish(raw, cur[1], cur[2])
+            pending = None          # (future of the raw hits, xOffset, yOffset) of the image in flight
+            try:
+                for nxt_image in it:
+                    nxt = self._prepare(nxt_image, searchBox)
+                    fut = pool.submit(self._ctx.find_matches, mode, self.score_threshold, nxt[0])
+                    if pending is not None:
+                        done, pending = pending, None
+                        pending = (fut, cur[1], cur[2])
+                        yield self._finish(done[0].result().copy(), done[1], done[2])
+                    else:
+                        pending = (fut, cur[1], cur[2])
+                    cur = nxt
+                fut = pool.submit(self._ctx.find_matches, mode, self.score_threshold)
+                if pending is not None:
+                    done, pending = pending, (fut, cur[1], cur[2])
+                    yield self._finish(done[0].result().copy(), done[1], done[2])
+                else:
+                    pending = (fut, cur[1], cur[2])
+                done, pending = pending, None
+                yield self._finish(done[0].result().copy(), done[1], done[2])
+            finally:
+                if pending is not None:      # consumer stopped early: let the call in flight finish
+                    try:
+                        pending[0].result()
+                    except Exception:        # noqa: BLE001 - nothing to report to: the generator is closing
+                        pass
 
 
 # ---------------------------------------------------------------------------------------------
