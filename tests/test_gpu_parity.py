@@ -825,3 +825,98 @@ def test_row_multiplexed_mode(mtm, n_templ):
                     assert_hits_equal(canon(got), canon(exp), tol=1e-6)
         finally:
             del ctx
+
+
+# ------------------------------------------------------------------------------------------------
+# state machine of a context: random sequences of uploads, template sets, options and queries
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(4))
+def test_context_state_sequences(mtm, seed):
+    """Everything a context caches (planes of two image slots, squares of the image, packs, the identical-
+    templates shortcut, hits-only back-off, the image staged by mtm_find_matches_next) must follow the
+    inputs: after any sequence of calls the answers are those of a fresh computation."""
+    rng = np.random.default_rng(4000 + seed)
+    ctx = mtm._lib.Context(0)
+    images, templs, method, staged = None, None, 5, None
+
+    def new_image(dtype):
+        H, W = int(rng.integers(60, 200)), int(rng.integers(80, 300))
+        top = 65536 if dtype == np.uint16 else 256
+        return rng.integers(0, top, (H, W)).astype(dtype)
+
+    def new_templates(img, masked):
+        out = []
+        for i in range(int(rng.integers(1, 7))):
+            h, w = int(rng.integers(4, 40)), int(rng.integers(4, 50))
+            if i and rng.random() < 0.5:
+                h, w = out[-1][0].shape
+            y, x = int(rng.integers(0, img.shape[0] - h + 1)), int(rng.integers(0, img.shape[1] - w + 1))
+            t = img[y:y + h, x:x + w].copy()
+            m = None
+            if masked and img.dtype == np.uint8:
+                m = (rng.random(t.shape) > 0.3).astype(np.uint8) * 255
+                m[0, 0] = 255
+            out.append((t, m))
+        return out
+
+    def as_cv2(a):
+        return a.astype(np.float32) if a is not None and a.dtype == np.uint16 else a
+
+    def check(cur_img):
+        thr = 0.6 if method != 1 else 0.25
+        lt = [("t%d" % i, as_cv2(t)) + ((as_cv2(m),) if m is not None else ()) for i, (t, m) in enumerate(templs)]
+        exp = O.find_matches(lt, as_cv2(cur_img), method=method, score_threshold=thr)
+        return thr, lt, exp
+
+    img = new_image(np.uint8)
+    ctx.set_image(img)
+    templs = new_templates(img, False)
+    ctx.set_templates(templs, method)
+    for step in range(30):
+        op = int(rng.integers(0, 8))
+        if op == 0:                                    # new image, maybe another size / dtype
+            dt = np.uint16 if rng.random() < 0.25 else np.uint8
+            if dt != img.dtype:                        # the pixel policy keeps image and templates alike
+                img = new_image(dt)
+                templs = new_templates(img, False)
+                ctx.set_image(img)
+                ctx.set_templates(templs, method)
+            else:
+                img = new_image(dt)
+                if any(t.shape[0] > img.shape[0] or t.shape[1] > img.shape[1] for t, _ in templs):
+                    templs = new_templates(img, False)
+                    ctx.set_templates(templs, method)
+                ctx.set_image(img)
+        elif op == 1:                                  # new templates (sometimes masked, sometimes identical)
+            if rng.random() < 0.3:
+                ctx.set_templates(templs, method)      # identical: the shortcut
+            else:
+                masked = rng.random() < 0.4
+                method = int(rng.choice([0, 3])) if masked else int(rng.choice([1, 3, 5]))
+                templs = new_templates(img, masked)
+                ctx.set_templates(templs, method)
+        elif op == 2:                                  # options
+            ctx.set_option(6, int(rng.integers(0, 2)))
+            ctx.set_option(5, int(rng.integers(0, 2)))
+        elif op == 3:                                  # tiny hit buffer: overflow / back-off paths
+            ctx.set_option(3, int(rng.choice([8, 1 << 18])))
+        elif op == 4 and method != 0:                  # stream step: current result + stage another image of the same kind
+            nxt = new_image(img.dtype)
+            if all(t.shape[0] <= nxt.shape[0] and t.shape[1] <= nxt.shape[1] for t, _ in templs):
+                thr, lt, exp = check(img)
+                got = ctx.find_matches(0, thr, next_image=nxt)
+                assert len(got) == len(exp), ("next", step, len(got), len(exp))
+                img = nxt
+        elif op == 5:                                  # one score map
+            li = int(rng.integers(0, len(templs)))
+            t, m = templs[li]
+            got = ctx.score_map(li, (img.shape[0] - t.shape[0] + 1, img.shape[1] - t.shape[1] + 1))
+            exp = O.match_template(as_cv2(img), as_cv2(t), method, mask=as_cv2(m))
+            ok = np.isfinite(exp)
+            assert np.abs(got[ok].astype(np.float64) - exp[ok]).max() <= 1e-5 * max(1.0, float(np.abs(exp[ok]).max())), ("map", step)
+        elif method != 0:                              # local or global search
+            thr, lt, exp = check(img)
+            got = ctx.find_matches(0, thr)
+            assert len(got) == len(exp), ("find", step, method, len(got), len(exp))
+            names = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in got]
+            assert_hits_equal(hits_json(names), hits_json(exp), tol=1e-5, ordered=False)
