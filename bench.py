@@ -110,7 +110,7 @@ def algorithmic_macs(img, units):
 
 def pmc_traffic(kernel_used, config, world, hits_only=False):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
-    profiles/ (FETCH_SIZE, WRITE_SIZE; collected separately, see tools/pmc_run.sh), or None."""
+    profiles/ (FETCH_SIZE, WRITE_SIZE; collected separately, see tools/profile_round.sh), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             table = json.load(f)
