@@ -165,8 +165,12 @@ def main():
                      % (args.gpus, args.gpus))
         args.gpus = world
 
-    if rank != 0:         # stdout is a protocol: exactly one JSON line, from rank 0
-        os.dup2(2, 1)
+    # stdout is a protocol: exactly one JSON line, from rank 0.  Libraries print there too (gloo's
+    # "[Gloo] Rank 0 is connected ..." at init, librccl's banner at teardown), so file descriptor 1 points
+    # to stderr for the whole run and rank 0 writes its line to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch          # plumbing only: device sync + the distributed bootstrap/barrier
     import MTM
     from MTM import _lib
@@ -176,12 +180,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only
+    # BENCH_FORCE_DEVICE: control-flow test of the N > 1 path on a single-GPU box (all ranks share one GPU;
+    # RCCL refuses that, so the exchange falls back to gloo) - never set by the driver
+    device = int(os.environ.get("BENCH_FORCE_DEVICE", local_rank))
     have_torch_gpu = torch.cuda.is_available()
     if have_torch_gpu:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
 
     img, units, plants, method, thr, desc = build_workload(args.config, world)
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(device)
     ctx.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
     exchange_kind = "rccl" if world > 1 else "none"
     try:
@@ -341,10 +348,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-    # libraries (librccl prints a version banner at teardown) must not append to stdout after the JSON
-    sys.stdout.flush()
-    os.dup2(2, 1)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
