@@ -809,7 +809,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
-        const size_t lds = (size_t)p.st_off + (rm ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);   // RM loads its statistics directly
+        // statistics prefetch region: (channels + 2) planes per wave (RM loads its statistics directly)
+        const size_t lds = (size_t)p.st_off + (rm ? 0 : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off +
@@ -834,7 +835,16 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         static const MfmaFn kMfmaRmFns[2][2][6] = {{MTM_MF_RM(false, false), MTM_MF_RM(true, false)},
                                                    {MTM_MF_RM(false, true), MTM_MF_RM(true, true)}};
 #undef MTM_MF_RM
-        const MfmaFn fn = rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
+        // 3-channel images: the same lean epilogue with per-channel window sums (methods fixed at compile time)
+#define MTM_MF_C3(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 3>, ncc_mfma_kernel<MB, 1, X, false, false, 3>,   \
+                         ncc_mfma_kernel<MB, 2, X, false, false, 3>, ncc_mfma_kernel<MB, 3, X, false, false, 3>,   \
+                         ncc_mfma_kernel<MB, 4, X, false, false, 3>, ncc_mfma_kernel<MB, 5, X, false, false, 3>}
+        static const MfmaFn kMfmaC3Fns[2][2][6] = {{MTM_MF_C3(1, false), MTM_MF_C3(2, false)},
+                                                   {MTM_MF_C3(1, true), MTM_MF_C3(2, true)}};
+#undef MTM_MF_C3
+        const bool c3 = c->chans == 3 && !sc.masked && !rm;
+        const MfmaFn fn = c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
+                        : rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
                              : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
         // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
         constexpr int kSchedWords = 1 + 4096;
@@ -1478,7 +1488,7 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         c->cand_min = mode_min;
         c->cand_thr = mode_min ? -thr : thr;
         // hits-only: single-channel MFMA classes, every map 2-D, no recent candidate overflow
-        bool honly = c->hits_only && c->chans == 1 && (int)c->list2d.size() == n;
+        bool honly = c->hits_only && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n;
         if (honly && c->hits_only_backoff > 0) {
             --c->hits_only_backoff;
             honly = false;

@@ -46,7 +46,9 @@ constexpr int kMfEpiBytesPerWave = 8 * kMfEpiPitch * 4;
 __device__ __forceinline__ int mf_epi_rot(int j) { return 4 * ((j >> 1) & 3); }
 // Window statistics of a wave's 256 pixels, prefetched to LDS by LDS-DMA while the image tile is
 // staged: [3 planes: S1, S2, sqrt][2 halves][64 lanes][2 doubles]; lane L owns pixels 4L..4L+3.
-constexpr int kMfStatBytesPerWave = 3 * 2 * 1024;
+constexpr int kMfStatPlaneBytes = 2 * 1024;                // one statistics plane of a wave's 256 pixels
+constexpr int kMfStatBytesPerWave = 3 * kMfStatPlaneBytes;   // single channel: S1, S2, sqrt
+__host__ __device__ constexpr int mf_stat_bytes_per_wave(int ch) { return (ch + 2) * kMfStatPlaneBytes; }
 // METHOD value of the raw mode: the biased int8 accumulators are stored as they are (uint16 images:
 // four byte-plane correlations combined by ncc16_combine_kernel).
 constexpr int kMfRaw = 6;
@@ -105,7 +107,7 @@ struct MfTemplConst {
     double mean[kMaxChans];
     double templ_norm, templ_sum2, mfma_k;
     double rtempl_norm;      // 1 / templ_norm (0 when templ_norm == 0)
-    double m128;             // 128 - mean[0]: CCOEFF numerator straight from the biased accumulator
+    double m128[kMaxChans];  // 128 - mean[c]: CCOEFF numerator straight from the biased accumulator
     double tms, rsqrt_tms;   // masked templates: sum((T*M)^2) and its inverse square root
     long long map_off;
     int map_pitch, all_ones;
@@ -171,9 +173,9 @@ __device__ __forceinline__ float finish_lean(int a32, double s1, double p1, doub
 // finish_lean with the quotient computed unconditionally (the empty asm keeps the compiler from
 // sinking it into a divergent branch): straight-line code, the four pixels of a lane interleave.
 // Same operations in the same order as finish_lean: bit-identical results.
-template <int METHOD, bool EXACT_DIV>
-__device__ __forceinline__ float finish_fast(int a32, double s1, double p1, double sum2, double sq, double rsq,
-                                             const MfTemplConst& T) {
+template <int METHOD, bool EXACT_DIV, int CH = 1>
+__device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], double p1, double sum2, double sq,
+                                             double rsq, const MfTemplConst& T) {
     constexpr bool normed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                             METHOD == MTM_TM_CCOEFF_NORMED;
     if constexpr (!EXACT_DIV && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
@@ -184,8 +186,9 @@ __device__ __forceinline__ float finish_fast(int a32, double s1, double p1, doub
         //   |q| < 1 -> q,  |q| < 1.125 -> +-1,  else 0: the case analysis of common_matchTemplate
         //   evaluated on the float32 quotient (it only differs from the float64 comparison when q is
         //   within one float64 rounding of 1.125; at 1 both give +-1.0f).
-        const double base = (double)a32 + T.mfma_k;
-        const double num = fma(s1, METHOD == MTM_TM_CCOEFF_NORMED ? T.m128 : 128.0, base);
+        double num = (double)a32 + T.mfma_k;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) num = fma(s1[cc], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[cc] : 128.0, num);
         const float qf = (float)(num * (rsq * T.rtempl_norm));
         const float aq = fabsf(qf);
         const float sat = (aq < 1.125f) ? copysignf(1.0f, qf) : 0.0f;
@@ -193,7 +196,10 @@ __device__ __forceinline__ float finish_fast(int a32, double s1, double p1, doub
     }
     const double corr = (double)a32 + (p1 + T.mfma_k);
     double num = corr;
-    if (METHOD == MTM_TM_CCOEFF || METHOD == MTM_TM_CCOEFF_NORMED) num = corr - s1 * T.mean[0];
+    if (METHOD == MTM_TM_CCOEFF || METHOD == MTM_TM_CCOEFF_NORMED) {
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) num -= s1[cc] * T.mean[cc];      // same order as finish_unmasked
+    }
     if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
     if (!normed) return (float)num;
     const double tt = sq * T.templ_norm;
@@ -254,13 +260,14 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
-template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false>
+template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false, int CH = 1>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
                                                           StatPlanes st, float* __restrict__ maps,
                                                           unsigned int* __restrict__ sched) {
-    constexpr bool C1 = METHOD >= 0;
+    constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
+    static_assert(CH == 1 || (!RM && !MASKED), "multi-channel: plain unmasked path only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -324,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.templ_sum2 = T.templ_sum2;
             k.mfma_k = T.mfma_k;
             k.rtempl_norm = T.templ_norm > 0.0 ? 1.0 / T.templ_norm : 0.0;
-            k.m128 = 128.0 - T.mean[0];
+#pragma unroll
+            for (int cc = 0; cc < kMaxChans; ++cc) k.m128[cc] = 128.0 - T.mean[cc];
             k.tms = T.templ2_mask2_sum;
             k.rsqrt_tms = 1.0 / sqrt(T.templ2_mask2_sum);
             k.map_off = T.map_off;
@@ -345,14 +353,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
         const size_t sidx = (size_t)yc * st.pitch + xc;
-        uint8_t* sbase = smem + p.st_off + wave * kMfStatBytesPerWave;
+        uint8_t* sbase = smem + p.st_off + wave * mf_stat_bytes_per_wave(CH);
+        // planes: S1 of channel 0..CH-1, then S2, then sqrt
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(st.t[0] + sidx + 2 * hh), (lptr_t)(sbase + (0 + hh) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int cc = 0; cc < CH; ++cc)
+                __builtin_amdgcn_global_load_lds((gptr_t)(st.t[cc] + sidx + 2 * hh), (lptr_t)(sbase + (2 * cc + hh) * 1024), 16, 0, 0);
             if (kNeedSum2)
-                __builtin_amdgcn_global_load_lds((gptr_t)(st.sum2 + sidx + 2 * hh), (lptr_t)(sbase + (2 + hh) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(st.sum2 + sidx + 2 * hh), (lptr_t)(sbase + (2 * CH + hh) * 1024), 16, 0, 0);
             if (kNormed)
-                __builtin_amdgcn_global_load_lds((gptr_t)(st.sq + sidx + 2 * hh), (lptr_t)(sbase + (4 + hh) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(st.sq + sidx + 2 * hh), (lptr_t)(sbase + (2 * CH + 2 + hh) * 1024), 16, 0, 0);
         }
     }
 
@@ -595,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 __builtin_amdgcn_wave_barrier();
                 if (col_on) {
                     int cur_rho = -1;
-                    double ps1[4] = {0, 0, 0, 0}, pp1[4] = {0, 0, 0, 0}, psum2[4] = {0, 0, 0, 0}, psq[4] = {0, 0, 0, 0},
+                    double ps1[4][1] = {{0}, {0}, {0}, {0}}, pp1[4] = {0, 0, 0, 0}, psum2[4] = {0, 0, 0, 0}, psq[4] = {0, 0, 0, 0},
                            prsq[4] = {0, 0, 0, 0};
 #pragma unroll 1
                     for (int s8 = 0; s8 < 8; ++s8) {
@@ -609,8 +620,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                             for (int hh = 0; hh < 2; ++hh) {
                                 const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
-                                ps1[2 * hh] = a.x;
-                                ps1[2 * hh + 1] = a.y;
+                                ps1[2 * hh][0] = a.x;
+                                ps1[2 * hh + 1][0] = a.y;
                                 if (kNeedSum2) {
                                     const double2 b = *reinterpret_cast<const double2*>(st.sum2 + sidx + 2 * hh);
                                     psum2[2 * hh] = b.x;
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             }
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                pp1[k] = 128.0 * ps1[k];
+                                pp1[k] = 128.0 * ps1[k][0];
                                 if (kMaskedNormed && !EXACT_DIV) prsq[k] = 1.0 / sqrt(psum2[k]);
                             }
                         }
@@ -640,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 const double base = (double)a32[k] + T.mfma_k;
-                                double num = fma(ps1[k], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128 : 128.0, base);
+                                double num = fma(ps1[k][0], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0, base);
                                 if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[k] - 2.0 * num + T.templ_sum2, 0.0);
                                 const double qd = num * (prsq[k] * rt);
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
@@ -707,18 +718,21 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // come from the LDS prefetch; the template loop is software pipelined (constants and
         // accumulators of the next template are requested before the current one is normalised)
         // and branch-free apart from wave-uniform tests.
-        double ps1[4], pp1[4], psum2[4], psq[4], prsq[4];
+        double ps1[4][CH], pp1[4], psum2[4], psq[4], prsq[4];
         {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint8_t* sl = smem + p.st_off + wave * kMfStatBytesPerWave + lane * 16;
+            const uint8_t* sl = smem + p.st_off + wave * mf_stat_bytes_per_wave(CH) + lane * 16;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const double2 a = *reinterpret_cast<const double2*>(sl + (0 + hh) * 1024);
-                ps1[2 * hh] = a.x;
-                ps1[2 * hh + 1] = a.y;
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    const double2 a = *reinterpret_cast<const double2*>(sl + (2 * cc + hh) * 1024);
+                    ps1[2 * hh][cc] = a.x;
+                    ps1[2 * hh + 1][cc] = a.y;
+                }
                 double2 b = make_double2(0.0, 0.0), d = make_double2(0.0, 0.0);
-                if (kNeedSum2) b = *reinterpret_cast<const double2*>(sl + (2 + hh) * 1024);
-                if (kNormed) d = *reinterpret_cast<const double2*>(sl + (4 + hh) * 1024);
+                if (kNeedSum2) b = *reinterpret_cast<const double2*>(sl + (2 * CH + hh) * 1024);
+                if (kNormed) d = *reinterpret_cast<const double2*>(sl + (2 * CH + 2 + hh) * 1024);
                 psum2[2 * hh] = b.x;
                 psum2[2 * hh + 1] = b.y;
                 psq[2 * hh] = d.x;
@@ -726,7 +740,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pp1[i] = 128.0 * ps1[i];
+                double s1all = ps1[i][0];           // bias term: 128 * sum over channels of S1 (exact integers)
+#pragma unroll
+                for (int cc = 1; cc < CH; ++cc) s1all += ps1[i][cc];
+                pp1[i] = 128.0 * s1all;
                 prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
@@ -767,8 +784,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             const double rt = T.rtempl_norm;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const double base = (double)a32[i] + T.mfma_k;
-                                double num = fma(ps1[i], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128 : 128.0, base);
+                                double num = (double)a32[i] + T.mfma_k;
+#pragma unroll
+                                for (int cc = 0; cc < CH; ++cc)
+                                    num = fma(ps1[i][cc], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[cc] : 128.0, num);
                                 if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[i] - 2.0 * num + T.templ_sum2, 0.0);
                                 const double qd = num * (prsq[i] * rt);
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
@@ -785,8 +804,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             if (MASKED)
                                 out[i] = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
                             else
-                                out[i] = finish_fast<METHOD, EXACT_DIV>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
-                                                                        prsq[i], T);
+                                out[i] = finish_fast<METHOD, EXACT_DIV, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
+                                                                            prsq[i], T);
 #endif
                         }
                         if (!MASKED) {

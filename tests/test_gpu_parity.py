@@ -920,3 +920,48 @@ def test_context_state_sequences(mtm, seed):
             assert len(got) == len(exp), ("find", step, method, len(got), len(exp))
             names = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in got]
             assert_hits_equal(hits_json(names), hits_json(exp), tol=1e-5, ordered=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# RGB uint8: the compile-time-method epilogue with per-channel window sums (CH = 3)
+# ------------------------------------------------------------------------------------------------
+def test_rgb_lean_path(mtm, ctx):
+    rng = np.random.default_rng(909)
+    img = rng.integers(0, 256, (170, 290, 3), dtype=np.uint8)
+    img[50:90, 100:180] = (40, 90, 200)                    # flat windows in every channel
+    lt = []
+    for i in range(20):                                     # 20 templates of one size: two MFMA groups
+        y, x = int(rng.integers(0, 170 - 28)), int(rng.integers(0, 290 - 36))
+        t = img[y:y + 28, x:x + 36].copy()
+        if i % 2:
+            t = np.clip(t.astype(np.int32) + rng.integers(-25, 26, t.shape), 0, 255).astype(np.uint8)
+        lt.append(("t%d" % i, t))
+    lt.append(("big", img[10:10 + 70, 20:20 + 130].copy()))  # chunked rows, three 64-tap blocks
+    set_kernel(ctx, "mfma")
+    try:
+        for method in range(6):
+            for exact in (1, 0):
+                set_exact(ctx, exact)
+                for name, t in (lt[0], lt[7], lt[-1]):
+                    got = mtm.computeScoreMap(t, img, method)
+                    assert ctx.timing()["kernel_used"] == 3
+                    exp = O.match_template(img, t, method)
+                    if exact or method in (0, 2, 4):
+                        assert np.array_equal(got, exp), (method, exact, name, float(np.abs(got - exp).max()))
+                    else:
+                        ulp_close(got, exp)
+        set_exact(ctx, 0)
+        for method, thr in ((5, 0.5), (3, 0.85), (1, 0.3)):
+            res = []
+            for honly in (0, 1):
+                ctx.set_option(6, honly)
+                res.append(mtm.findMatches(lt, img, method=method, score_threshold=thr))
+                assert ctx.timing()["hits_only"] == honly
+            assert canon(res[0]) == canon(res[1])
+            exp = O.find_matches(lt, img, method=method, score_threshold=thr)
+            assert len(res[1]) == len(exp) and len(exp) >= 10
+            assert_hits_equal(canon(res[1]), canon(exp), tol=1e-6)
+    finally:
+        set_kernel(ctx, "auto")
+        set_exact(ctx, 0)
+        ctx.set_option(6, 1)
