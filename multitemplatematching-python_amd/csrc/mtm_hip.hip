@@ -366,6 +366,10 @@ int place_templates(mtm_ctx* c) {
             (double)sc.w * sc.h * 65025.0 < 4294967296.0 && c->fuse_stats) {
             int nt = 1;
             while (nt < (int)n_cls) nt <<= 1;
+            // two work-groups per CU need <= ~76 KB of LDS each: wide templates take fewer rows per MFMA group
+            const size_t lds_pitch = (size_t)(16 + 4 * ((sc.w + 63) / 64) + 1) * 16;
+            auto tile_bytes = [&](int R) { return (size_t)(std::min(sc.h + 2 * R - 1, kMfChunkH) + 6 * R) * lds_pitch; };
+            while (nt < 16 && tile_bytes(16 / nt) > 72 * 1024) nt <<= 1;
             sc.rm_nt = nt;
             sc.rm_R = 16 / nt;
         }

@@ -785,7 +785,7 @@ def test_row_multiplexed_mode(mtm, n_templ):
     H, W = 157, 531                                        # not multiples of the 8R-row / 256-column work items
     img = rng.integers(0, 256, (H, W), dtype=np.uint8)
     img[60:100, 200:330] = 93                              # flat windows
-    shapes = [(24, 24), (70, 33), (9, 130)]                # one chunk, two 64-row chunks, three 64-tap blocks
+    shapes = [(24, 24), (70, 33), (9, 130), (12, 250)]     # one chunk, two 64-row chunks, 3 / 4 64-tap blocks (fewer rows per group)
     for (h, w) in shapes:
         lt = []
         for i in range(n_templ):
