@@ -714,6 +714,73 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
         }
     } else if constexpr (C1) {
+        // ---- hits-only screen, straight from the accumulator registers (no LDS transposition): in this
+        // mode nothing is stored, and almost no work item holds a candidate.  In the MFMA C/D layout lane
+        // (j, q) owns the 16 consecutive pixels 16 j + c and the templates 16 mb + 4 q + e.  Per template the
+        // lane keeps the running extremes of u = (acc + K + S1 (128 - mean)) / sqrt (reciprocal by
+        // v_rcp_f64, ~2^-26: this is a screen) and compares them ONCE with the threshold scaled by the
+        // template norm, lowered by 1e-6.  Only if some lane of the wave sees a possible candidate (or a
+        // saturated / constant-template output) does the wave run the full epilogue below, which
+        // repeats the exact test.  Results are therefore those of the full epilogue.
+        bool wave_has_work = true;
+        if constexpr (CH == 1 && !MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
+            if (p.hits_only) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint8_t* sw = smem + p.st_off + wave * mf_stat_bytes_per_wave(1);
+                const bool need_low = p.cand_thr_lo < 0.0;      // u <= -t can only matter for negative thresholds
+                const double hi = fmin(p.cand_thr_lo, 0.999999) - 1e-6;
+                bool pass = false;
+                // one MFMA group (4 templates of this lane) at a time: 4 x (K, 128 - mean, running extremes)
+                // stay in registers next to the 64 * MB accumulators
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    double kk[4], mm[4], umax[4], umin[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lt = 16 * mb + 4 * q + e;
+                        const bool live = tg * MB * 16 + lt < p.n_list;     // beyond the list: zero-padded A rows
+                        const MfTemplConst& T = tcl[lt];
+                        kk[e] = live ? T.mfma_k : 0.0;
+                        mm[e] = live ? (METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0) : 0.0;
+                        pass = pass || (live && T.all_ones != 0);
+                        umax[e] = -INFINITY;
+                        umin[e] = INFINITY;
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int L = 4 * j + g;
+                        const double2 sa = *reinterpret_cast<const double2*>(sw + 0 * 1024 + L * 16);
+                        const double2 sb = *reinterpret_cast<const double2*>(sw + 1 * 1024 + L * 16);
+                        const double2 qa = *reinterpret_cast<const double2*>(sw + 4 * 1024 + L * 16);
+                        const double2 qb = *reinterpret_cast<const double2*>(sw + 5 * 1024 + L * 16);
+                        const double s1g[4] = {sa.x, sa.y, sb.x, sb.y}, sqg[4] = {qa.x, qa.y, qb.x, qb.y};
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const double rq = sqg[c4] > 0.0 ? __builtin_amdgcn_rcp(sqg[c4]) : 0.0;
+                            const v4i a = acc[mb][4 * g + c4];
+                            const int av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const double u = fma(s1g[c4], mm[e], (double)av[e] + kk[e]) * rq;
+                                umax[e] = fmax(umax[e], u);
+                                if (need_low) umin[e] = fmin(umin[e], u);
+                            }
+                        }
+                    }
+                    // quotient q = u / templ_norm: candidate if q > threshold; q >= 1 saturates (above any
+                    // threshold < 1, tested anyway); q <= -1 saturates to -1 or 0: only matters below 0
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int lt = 16 * mb + 4 * q + e;
+                        const bool live = tg * MB * 16 + lt < p.n_list;
+                        const double tn = tcl[lt].templ_norm;
+                        pass = pass || (live && umax[e] > hi * tn);
+                        if (need_low) pass = pass || (live && umin[e] <= -0.999999 * tn);
+                    }
+                }
+                wave_has_work = __builtin_amdgcn_ballot_w64(pass) != 0ull;
+            }
+        }
         // ---- single channel, method fixed at compile time.  The statistics of the lane's pixels
         // come from the LDS prefetch; the template loop is software pipelined (constants and
         // accumulators of the next template are requested before the current one is normalised)
@@ -749,6 +816,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
         }
         __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+        if (!wave_has_work) continue;                       // wave-uniform; no work-group barrier below
         const bool lane_on = y < p.oh && xq < p.ow;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
