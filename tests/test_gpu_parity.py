@@ -956,7 +956,8 @@ def test_rgb_lean_path(mtm, ctx):
             for honly in (0, 1):
                 ctx.set_option(6, honly)
                 res.append(mtm.findMatches(lt, img, method=method, score_threshold=thr))
-                assert ctx.timing()["hits_only"] == honly
+                if os.environ.get("MTM_FUSE_PEAKS", "1") != "0":      # hits-only needs the fused candidates
+                    assert ctx.timing()["hits_only"] == honly
             assert canon(res[0]) == canon(res[1])
             exp = O.find_matches(lt, img, method=method, score_threshold=thr)
             assert len(res[1]) == len(exp) and len(exp) >= 10
