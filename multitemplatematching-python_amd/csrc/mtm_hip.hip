@@ -12,6 +12,7 @@
 #include <map>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "mtm_device.hip.h"
@@ -1499,14 +1500,14 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         }
         c->hits_only_now = honly;
     }
-    // hash table of the candidate positions (hits-only verification)
+    // hash table of the candidate positions (hits-only verification on the device: only when the
+    // candidates are too many to be checked on the host, see below)
     unsigned hash_mask = 0;
     if (c->hits_only_now) {
         size_t hsz = 1024;
         while (hsz < 2 * (size_t)cand_cap) hsz <<= 1;
         hash_mask = (unsigned)(hsz - 1);
         MTMC(c->chash.ensure(hsz * (sizeof(unsigned long long) + sizeof(int))));
-        HIPC(hipMemsetAsync(c->chash.p, 0, hsz * sizeof(unsigned long long), c->stream));
     }
 
     HIPC(hipEventRecord(c->ev[0], c->stream));
@@ -1560,7 +1561,55 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         std::vector<int> tflags((size_t)std::max(1, n), 0);
         std::vector<uint8_t> host_buf;
         bool use_fused = fused;
-        for (int attempt = 0; attempt < 3 && n2d > 0; ++attempt) {
+        // Few candidates (the usual case): they come back in one copy and the 3x3 test runs on the host.
+        // Every pixel above the threshold is in the list (in both modes), so a neighbour that is not
+        // is <= threshold < candidate: the list alone decides.  Saves two kernels, three fills and a copy.
+        bool verified_on_host = false;
+        if (use_fused && n2d > 0) {
+            const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
+            host_buf.resize(16 + sizeof(mtm_hit) * nfetch);
+            HIPC(hipMemcpyAsync(host_buf.data(), c->cands.p, host_buf.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipEventRecord(c->ev[2], c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            unsigned long long ncand = 0;
+            std::memcpy(&ncand, host_buf.data(), sizeof(ncand));
+            if (ncand <= nfetch) {
+                const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(host_buf.data() + 16);
+                std::unordered_map<unsigned long long, int> where;
+                where.reserve((size_t)ncand * 2 + 8);
+                auto key = [](int t, int y, int x) {
+                    return ((unsigned long long)(t + 1) << 42) | ((unsigned long long)y << 21) | (unsigned long long)x;
+                };
+                for (int i = 0; i < (int)ncand; ++i) where.emplace(key(cd[i].templ_idx, cd[i].y, cd[i].x), i);
+                const float padv = (c->opt_border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+                for (int i = 0; i < (int)ncand; ++i) {
+                    const mtm_hit& h = cd[i];
+                    const TemplDev& d = c->td_host[h.templ_idx];
+                    const float v = mode_min ? -h.score : h.score;
+                    float mx = v;
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (!dy && !dx) continue;
+                            const int yy = h.y + dy, xx = h.x + dx;
+                            if (yy < 0 || yy >= d.oh || xx < 0 || xx >= d.ow) {
+                                mx = fmaxf(mx, padv);
+                                continue;
+                            }
+                            const auto it = where.find(key(h.templ_idx, yy, xx));
+                            if (it != where.end()) mx = fmaxf(mx, mode_min ? -cd[it->second].score : cd[it->second].score);
+                        }
+                    if (v == mx) {
+                        hits.push_back(h);
+                        ++tflags[(size_t)h.templ_idx];
+                    }
+                }
+                count = hits.size();
+                verified_on_host = true;
+            }
+        }
+        if (!verified_on_host && c->hits_only_now)
+            HIPC(hipMemsetAsync(c->chash.p, 0, ((size_t)hash_mask + 1) * sizeof(unsigned long long), c->stream));
+        for (int attempt = 0; attempt < 3 && n2d > 0 && !verified_on_host; ++attempt) {
             MTMC(c->hits.ensure(hdr_bytes + sizeof(mtm_hit) * (size_t)c->hit_cap));
             uint8_t* dbase = c->hits.as<uint8_t>();
             HIPC(hipMemsetAsync(dbase, 0, hdr_bytes, c->stream));
