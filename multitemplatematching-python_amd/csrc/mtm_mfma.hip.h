@@ -724,17 +724,18 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // repeats the exact test.  Results are therefore those of the full epilogue.
         bool wave_has_work = true;
         if constexpr (CH == 1 && !MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
-            if (p.hits_only) {
+            // (quotients <= -1 saturate to -1 or 0, which can only be candidates below a negative threshold:
+            // such calls skip the screen instead of tracking the minima as well)
+            if (p.hits_only && p.cand_thr_lo >= 0.0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* sw = smem + p.st_off + wave * mf_stat_bytes_per_wave(1);
-                const bool need_low = p.cand_thr_lo < 0.0;      // u <= -t can only matter for negative thresholds
                 const double hi = fmin(p.cand_thr_lo, 0.999999) - 1e-6;
                 bool pass = false;
                 // one MFMA group (4 templates of this lane) at a time: 4 x (K, 128 - mean, running extremes)
                 // stay in registers next to the 64 * MB accumulators
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    double kk[4], mm[4], umax[4], umin[4];
+                    double kk[4], mm[4], umax[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int lt = 16 * mb + 4 * q + e;
@@ -744,7 +745,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         mm[e] = live ? (METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0) : 0.0;
                         pass = pass || (live && T.all_ones != 0);
                         umax[e] = -INFINITY;
-                        umin[e] = INFINITY;
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -763,19 +763,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             for (int e = 0; e < 4; ++e) {
                                 const double u = fma(s1g[c4], mm[e], (double)av[e] + kk[e]) * rq;
                                 umax[e] = fmax(umax[e], u);
-                                if (need_low) umin[e] = fmin(umin[e], u);
                             }
                         }
                     }
                     // quotient q = u / templ_norm: candidate if q > threshold; q >= 1 saturates (above any
-                    // threshold < 1, tested anyway); q <= -1 saturates to -1 or 0: only matters below 0
+                    // threshold < 1, tested anyway)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int lt = 16 * mb + 4 * q + e;
                         const bool live = tg * MB * 16 + lt < p.n_list;
                         const double tn = tcl[lt].templ_norm;
                         pass = pass || (live && umax[e] > hi * tn);
-                        if (need_low) pass = pass || (live && umin[e] <= -0.999999 * tn);
                     }
                 }
                 wave_has_work = __builtin_amdgcn_ballot_w64(pass) != 0ull;
