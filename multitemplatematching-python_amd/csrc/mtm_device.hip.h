@@ -556,6 +556,13 @@ __global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restri
 // raw layout: [image plane x (2)][template plane y (2)][template (n_pad)][oh][pitch] int32.
 // ---------------------------------------------------------------------------------------------
 struct Ncc16Params {
+    // fused peak candidates / hits-only, as in the MFMA epilogue (mtm_find_matches)
+    mtm_hit* cand_hits;
+    unsigned long long* cand_counter;
+    unsigned long long cand_cap;
+    float cand_thr;
+    int cand_min, cand_on, hits_only;
+    int w, h;
     const int* raw;
     long long raw_plane;       // ints per (x, y) pair block: n_pad * oh * pitch
     long long raw_map;         // ints per template map: oh * pitch
@@ -586,7 +593,21 @@ __global__ __launch_bounds__(256) void ncc16_combine_kernel(Ncc16Params p, const
     const double r_hh = a_hh + 128.0 * s1h + kh, r_hl = a_hl + 128.0 * s1h + kl;
     const double r_lh = a_lh + 128.0 * s1l + kh, r_ll = a_ll + 128.0 * s1l + kl;
     const double corr = 65536.0 * r_hh + 256.0 * (r_hl + r_lh) + r_ll;
-    maps[T.map_off + (size_t)y * T.map_pitch + x] = finish_unmasked(p.method, corr, st, sidx, T, 1);
+    const float out = finish_unmasked(p.method, corr, st, sidx, T, 1);
+    if (p.cand_on && (p.cand_min ? -out : out) > p.cand_thr) {
+        const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+        if (slot < p.cand_cap) {
+            mtm_hit hrec;
+            hrec.templ_idx = tlist[li];
+            hrec.x = x;
+            hrec.y = y;
+            hrec.w = p.w;
+            hrec.h = p.h;
+            hrec.score = out;
+            p.cand_hits[slot] = hrec;
+        }
+    }
+    if (!p.hits_only) maps[T.map_off + (size_t)y * T.map_pitch + x] = out;
 }
 
 // ---------------------------------------------------------------------------------------------

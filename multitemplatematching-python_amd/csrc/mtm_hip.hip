@@ -939,6 +939,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         q.n_list = n_all;
         q.method = c->method;
         q.area = (double)h * (double)w;
+        q.w = w;
+        q.h = h;
+        q.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        q.cand_min = c->cand_min ? 1 : 0;
+        q.cand_thr = c->cand_thr;
+        q.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        q.cand_counter = c->cands.as<unsigned long long>();
+        q.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        q.hits_only = (q.cand_on && c->hits_only_now) ? 1 : 0;
         const double* ts = c->tsum.as<double>() + sc.tsum_off;
         hipLaunchKernelGGL(ncc16_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
                            c->tlist.as<int>() + sc.tlist_off, ts, ts + n_pad, st, maps, only_li);
@@ -1482,7 +1491,10 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
 
     // fused peak candidates: only when every class runs the MFMA kernel
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
-    for (const SizeClass& sc : c->classes) fused = fused && resolved_kernel(c, sc) == MTM_KERNEL_MFMA;
+    for (const SizeClass& sc : c->classes) {
+        const int rk = resolved_kernel(c, sc);
+        fused = fused && (rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16);
+    }
     c->cand_on = false;
     c->hits_only_now = false;
     const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
