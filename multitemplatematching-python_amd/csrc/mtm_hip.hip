@@ -521,7 +521,8 @@ int place_templates(mtm_ctx* c) {
     MTMC(c->packs.ensure(std::max<size_t>(4, p_off)));
     MTMC(c->apacks.ensure(std::max<size_t>(16, a_off)));
     if (a_off) HIPC(hipMemcpyAsync(c->apacks.p, apacks.data(), a_off, hipMemcpyHostToDevice, c->stream));
-    MTMC(c->maps.ensure(sizeof(float) * std::max<size_t>(4, map_off)));
+    // the score-map arena (4 bytes per pixel and template) is only allocated when something writes maps:
+    // mtm_find_matches in hits-only mode never does (ensure_maps, called by the launch paths)
     HIPC(hipMemcpyAsync(c->td.p, c->td_host.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
     if (!c->tlist_host.empty())
         HIPC(hipMemcpyAsync(c->tlist.p, c->tlist_host.data(), sizeof(int) * c->tlist_host.size(),
@@ -1006,7 +1007,10 @@ int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
     return kernel;
 }
 
+int ensure_maps(mtm_ctx* c) { return c->maps.ensure(sizeof(float) * std::max<size_t>(4, c->maps_floats)); }
+
 int run_score_all(mtm_ctx* c) {
+    if (!c->hits_only_now) MTMC(ensure_maps(c));
     for (const SizeClass& sc : c->classes) {
         StatPlanes st;
         MTMC(launch_stats(c, sc, &st));
@@ -1399,6 +1403,7 @@ int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_
     while (sc.members[pos] != templ_idx) ++pos;
     c->timing = mtm_timing{};
     StatPlanes st;
+    MTMC(ensure_maps(c));
     MTMC(launch_stats(c, sc, &st));
     MTMC(launch_ncc(c, sc, sc.tlist_off + pos, 1, st, pos));
     HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off,
