@@ -106,7 +106,9 @@ def merge_and_nms(raw_all: np.ndarray, listTemplates, method, N_object, score_th
     """Global NMS over the gathered hits; identical on every rank.  The gathered list is first put
     in the single-process order (template index, then the per-template order each rank produced)."""
     from . import _nms_raw, _to_hit_list
-    raw_all = raw_all[np.argsort(raw_all["templ_idx"], kind="stable")]
+    idx = raw_all["templ_idx"]
+    if len(idx) > 1 and bool((idx[1:] < idx[:-1]).any()):       # one rank: already in template order
+        raw_all = raw_all[np.argsort(idx, kind="stable")]
     kept = _nms_raw(raw_all, score_threshold, method == 1, N_object, maxOverlap)
     return _to_hit_list(kept, listTemplates, xOffset, yOffset)
 
