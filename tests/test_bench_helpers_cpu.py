@@ -1,0 +1,37 @@
+"""bench.py's pure helpers (no GPU): workload sizes of the BASELINE configs, the algorithmic byte / MAC
+counts the roofline is computed from, defaults of the command line."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_defaults_and_constants(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert a.gpus == 1 and a.steps >= 20 and a.warmup >= 1 and a.config == "north_star"
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.I8_MFMA_PEAK_TOPS == 5000.0
+
+
+def test_north_star_workload_and_counts():
+    img, units, plants, method, thr, desc = bench.build_workload("north_star", 1)
+    assert img.shape == (2160, 3840) and img.dtype == np.uint8 and len(units) == 32
+    assert all(u[1].shape == (64, 64) for u in units) and method == 5 and thr == 0.5
+    out_px = (2160 - 63) * (3840 - 63)
+    assert bench.algorithmic_macs(img, units) == 32 * out_px * 4096 == 1038138605568
+    assert bench.algorithmic_bytes(img, units) == img.nbytes + 32 * (4096 + 4 * out_px) == 1022232704
+    assert bench.algorithmic_bytes_hits_only(img, units) == img.nbytes + 32 * 4096 + 2 * 8 * out_px
+    # weak scaling: 32 units per GPU
+    _, units8, _, _, _, _ = bench.build_workload("north_star", 8)
+    assert len(units8) == 256
+
+
+def test_pmc_traffic_table():
+    t = bench.pmc_traffic(3, "north_star", 1, hits_only=True)
+    m = bench.pmc_traffic(3, "north_star", 1, hits_only=False)
+    assert t and m and 1.0 <= t / 135151376 < 1.3 and 1.0 <= m / 1022232704 < 1.3   # no wasted re-reads
+    assert bench.pmc_traffic(3, "cfg5", 1) is None
