@@ -193,11 +193,11 @@ def _nms_raw(raw, scoreThreshold, sortAscending, N_object, maxOverlap):
 def _to_hit_list(raw, listTemplates, xOffset, yOffset):
     """Structured hit array -> the reference's list of (label, (x, y, w, h), np.float32 score)
     (MTM/__init__.py:241).  Column-wise tolist() keeps this cheap for thousands of hits."""
-    labels = [t[0] for t in listTemplates]
-    return [(labels[t], (x, y, w, h), s)
-            for t, x, y, w, h, s in zip(raw["templ_idx"].tolist(), (raw["x"] + xOffset).tolist(),
-                                        (raw["y"] + yOffset).tolist(), raw["w"].tolist(), raw["h"].tolist(),
-                                        list(raw["score"]))]
+    labels = np.empty(len(listTemplates), dtype=object)
+    for i, t in enumerate(listTemplates):          # element-wise: a label may be any object (even a tuple)
+        labels[i] = t[0]
+    boxes = zip((raw["x"] + xOffset).tolist(), (raw["y"] + yOffset).tolist(), raw["w"].tolist(), raw["h"].tolist())
+    return list(zip(labels[raw["templ_idx"]].tolist(), boxes, list(raw["score"])))
 
 
 def findMatches(listTemplates: Sequence[TemplateTuple], image: np.ndarray, method: int = TM_CCOEFF_NORMED,
