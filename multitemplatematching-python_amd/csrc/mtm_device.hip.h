@@ -389,6 +389,112 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
     }
 }
 
+// The same for CH interleaved-to-planar channels (RGB): per-channel window sums S1_c, the sum of squares
+// over all channels and the guarded sqrt of  sum_c S2_c - (sum_c S1_c^2) / A  (operation order of
+// vsum_stats_kernel, so both routes round alike).  One scan per channel and row.
+template <int CH>
+__global__ __launch_bounds__(256) void stats_u8_mc_kernel(const uint8_t* __restrict__ img, int pitch, long long plane,
+                                                          int h, int w, int oh, int ow, double inv_area, int num_type,
+                                                          int want_sq, int want_t, int want_sum2,
+                                                          double* __restrict__ t0, long long t_plane,
+                                                          double* __restrict__ sum2, double* __restrict__ sq,
+                                                          int st_pitch) {
+    __shared__ uint32_t P1[256 * kStatMaxK + 1], P2[256 * kStatMaxK + 1];
+    __shared__ uint32_t wsum[2][4];
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kStatBand;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int L = 256 + w - 1;
+    const int K = (L + 255) >> 8;
+    const uint8_t* base = img + (size_t)y0 * pitch + x0 + t * K;
+    uint32_t c1[CH][kStatMaxK], c2[CH][kStatMaxK];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int k = 0; k < kStatMaxK; ++k) c1[c][k] = c2[c][k] = 0u;
+        for (int r = 0; r < h; ++r) {
+            const uint8_t* row = base + c * plane + (size_t)r * pitch;
+#pragma unroll
+            for (int k = 0; k < kStatMaxK; ++k)
+                if (k < K) {
+                    const uint32_t v = row[k];
+                    c1[c][k] += v;
+                    c2[c][k] += v * v;
+                }
+        }
+    }
+    if (t == 0) {
+        P1[0] = 0;
+        P2[0] = 0;
+    }
+    const int y1 = min(y0 + kStatBand, oh);
+    for (int y = y0; y < y1; ++y) {
+        const int x = x0 + t;
+        const size_t o = (size_t)y * st_pitch + x;
+        double wnd_mean2 = 0.0, wnd_sum2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            uint32_t a = 0, b = 0, la[kStatMaxK], lb[kStatMaxK];
+#pragma unroll
+            for (int k = 0; k < kStatMaxK; ++k) {
+                if (k < K) {
+                    a += c1[c][k];
+                    b += c2[c][k];
+                }
+                la[k] = a;
+                lb[k] = b;
+            }
+            const uint32_t sa = wave_inclusive_scan_u32(a), sb = wave_inclusive_scan_u32(b);
+            __syncthreads();                 // the previous channel's / row's P reads are done
+            if (lane == 63) {
+                wsum[0][wave] = sa;
+                wsum[1][wave] = sb;
+            }
+            __syncthreads();
+            uint32_t oa = sa - a, ob = sb - b;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < wave) {
+                    oa += wsum[0][k];
+                    ob += wsum[1][k];
+                }
+#pragma unroll
+            for (int k = 0; k < kStatMaxK; ++k)
+                if (k < K) {
+                    P1[t * K + k + 1] = oa + la[k];
+                    P2[t * K + k + 1] = ob + lb[k];
+                }
+            __syncthreads();
+            if (x < ow) {
+                const double tt = (double)(P1[t + w] - P1[t]);
+                if (num_type == 1) wnd_mean2 += tt * tt;
+                if (want_t) t0[c * t_plane + o] = tt;
+                wnd_sum2 += (double)(P2[t + w] - P2[t]);
+            }
+            // slide this channel's column sums one row down
+            if (y + 1 < y1) {
+                const uint8_t* rn = base + c * plane + (size_t)(y - y0 + h) * pitch;
+                const uint8_t* ro = base + c * plane + (size_t)(y - y0) * pitch;
+#pragma unroll
+                for (int k = 0; k < kStatMaxK; ++k)
+                    if (k < K) {
+                        const uint32_t vn = rn[k], vo = ro[k];
+                        c1[c][k] += vn - vo;
+                        c2[c][k] += vn * vn - vo * vo;
+                    }
+            }
+        }
+        if (x < ow) {
+            wnd_mean2 *= inv_area;
+            if (want_sum2) sum2[o] = wnd_sum2;
+            if (want_sq) {
+                const double diff2 = fmax(wnd_sum2 - wnd_mean2, 0.0);
+                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * wnd_sum2);
+                sq[o] = small ? 0.0 : sqrt(diff2);
+            }
+        }
+    }
+}
+
 #ifndef MTM_VSUM_BAND
 #define MTM_VSUM_BAND 32
 #endif

@@ -586,6 +586,11 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
         }
         hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, inv_area,
                            num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch, rsq);
+    } else if (u8 && c->chans == 3 && w <= 768 && (double)w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
+        // RGB: the fused kernel with one scan per channel and row (sum2 always written: vsum_stats_kernel does)
+        const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+        hipLaunchKernelGGL(stats_u8_mc_kernel<3>, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, img.u8_plane, h, w, oh,
+                           ow, inv_area, num_type, normed ? 1 : 0, want_t, 1, tp[0], (long long)plane, sum2, sq, st.pitch);
     } else if (u8) {
         if (c->cols <= 8191)
             hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
