@@ -125,3 +125,24 @@ def test_oracle_peaks_definition(seed):
                 exp.add((y, x))
     all_local = all(a[y, x] == pad[y:y + 3, x:x + 3].max() for y in range(a.shape[0]) for x in range(a.shape[1]))
     assert got == (set() if all_local else exp)
+
+
+@settings(max_examples=120, **COMMON)
+@given(st.lists(st.tuples(st.integers(0, 5), boxes, scores), min_size=0, max_size=80), st.floats(0, 1), st.floats(0, 1),
+       st.booleans(), st.sampled_from([float("inf"), 0, 1, 3]))
+def test_raw_array_pipeline_equals_list_pipeline(MTM, items, thr, overlap, ascending, n_object):
+    """The host layer keeps hits in a structured array until the very end (_nms_raw + _to_hit_list); that must
+    be MTM.NMS applied to the equivalent list of tuples (the reference's data flow, MTM/__init__.py:296)."""
+    from MTM import _lib, _nms_raw, _to_hit_list
+    lt = [("label%d" % i, None) for i in range(6)]
+    raw = np.zeros(len(items), dtype=_lib.HIT_DTYPE)
+    for k, (t, (x, y, w, h), s) in enumerate(items):
+        raw[k] = (t, x, y, w, h, np.float32(s))
+    as_list = _to_hit_list(raw, lt, 0, 0)
+    assert [h[0] for h in as_list] == ["label%d" % t for t, _, _ in items]
+    got = _to_hit_list(_nms_raw(raw, thr, ascending, n_object, overlap), lt, 0, 0)
+    exp = MTM.NMS(as_list, thr, ascending, n_object, overlap)
+    assert got == exp
+    # offsets of a searchBox are added to x and y only
+    moved = _to_hit_list(raw, lt, 7, 11)
+    assert all(m[1] == (a[1][0] + 7, a[1][1] + 11, a[1][2], a[1][3]) for m, a in zip(moved, as_list))
