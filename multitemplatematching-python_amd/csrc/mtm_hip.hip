@@ -179,6 +179,8 @@ struct mtm_ctx {
 
     mtm_timing timing{};
     std::vector<mtm_hit> last_hits;     // result of the last mtm_find_matches (for mtm_last_hits)
+    void* pinned = nullptr;             // pinned host buffer the candidate records land in
+    size_t pinned_cap = 0;
     std::vector<uint8_t> templ_blob;    // bytes of the templates of the last mtm_set_templates (unchanged-input test)
 
     // RCCL
@@ -1110,6 +1112,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})
         b->release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& p : c->ncc_ev) {
@@ -1588,15 +1591,24 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         // is <= threshold < candidate: the list alone decides.  Saves two kernels, three fills and a copy.
         bool verified_on_host = false;
         if (use_fused && n2d > 0) {
+            // pinned landing buffer: the copy is a plain DMA instead of a staged one
             const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
-            host_buf.resize(16 + sizeof(mtm_hit) * nfetch);
-            HIPC(hipMemcpyAsync(host_buf.data(), c->cands.p, host_buf.size(), hipMemcpyDeviceToHost, c->stream));
+            const size_t fetch_bytes = 16 + sizeof(mtm_hit) * nfetch;
+            if (c->pinned_cap < fetch_bytes) {
+                if (c->pinned) (void)hipHostFree(c->pinned);
+                c->pinned = nullptr;
+                c->pinned_cap = 0;
+                HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
+                c->pinned_cap = fetch_bytes;
+            }
+            HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
             HIPC(hipEventRecord(c->ev[2], c->stream));
             HIPC(hipStreamSynchronize(c->stream));
+            const uint8_t* land = static_cast<const uint8_t*>(c->pinned);
             unsigned long long ncand = 0;
-            std::memcpy(&ncand, host_buf.data(), sizeof(ncand));
+            std::memcpy(&ncand, land, sizeof(ncand));
             if (ncand <= nfetch) {
-                const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(host_buf.data() + 16);
+                const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(land + 16);
                 std::unordered_map<unsigned long long, int> where;
                 where.reserve((size_t)ncand * 2 + 8);
                 auto key = [](int t, int y, int x) {
