@@ -66,6 +66,7 @@ class HitExchange:
         self.rank, self.world_size = rank, world_size
         self.group = group
         self.ctx = context
+        self._slot_hits = 512
         if backend == "rccl" and world_size > 1:
             import torch.distributed as dist
             self.ctx = context or _lib.default_context()
@@ -83,22 +84,33 @@ class HitExchange:
         if self.backend == "rccl":
             out, _ = self.ctx.allgather_hits(hits)
             return out
+        # same protocol as mtm_comm_allgather_hits: ONE all-gather of fixed slots [count | records]; a second
+        # one with larger slots only if some rank had more records than the slot holds.  The slot size follows
+        # twice the largest count of the previous exchange (every rank sees every count, so they agree).
         import torch
         import torch.distributed as dist
-        n = torch.tensor([len(hits)], dtype=torch.int64)
-        counts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world_size)]
-        dist.all_gather(counts, n, group=self.group)
-        counts = [int(c.item()) for c in counts]
-        mx = max(counts)
-        if mx == 0:
-            return hits[:0]
-        buf = np.zeros(mx * _lib.HIT_DTYPE.itemsize, dtype=np.uint8)
-        buf[:hits.nbytes] = hits.view(np.uint8).reshape(-1)
-        mine = torch.from_numpy(buf)
-        parts = [torch.zeros_like(mine) for _ in range(self.world_size)]
-        dist.all_gather(parts, mine, group=self.group)
-        out = [p.numpy()[:c * _lib.HIT_DTYPE.itemsize].view(_lib.HIT_DTYPE) for p, c in zip(parts, counts)]
-        return np.concatenate(out)
+        rec = _lib.HIT_DTYPE.itemsize
+        slot_hits = self._slot_hits
+        while True:
+            buf = np.zeros(16 + slot_hits * rec, dtype=np.uint8)
+            buf[:8] = np.frombuffer(np.int64(len(hits)).tobytes(), dtype=np.uint8)
+            k = min(len(hits), slot_hits)
+            buf[16:16 + k * rec] = hits[:k].view(np.uint8).reshape(-1)
+            mine = torch.from_numpy(buf)
+            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(parts, mine, group=self.group)
+            parts = [p.numpy() for p in parts]
+            counts = [int(np.frombuffer(p[:8].tobytes(), dtype=np.int64)[0]) for p in parts]
+            mx = max(counts)
+            want = 512
+            while want < 2 * mx:
+                want *= 2
+            self._slot_hits = want
+            if mx <= slot_hits:
+                break
+            slot_hits = mx
+        out = [p[16:16 + c * rec].view(_lib.HIT_DTYPE) for p, c in zip(parts, counts)]
+        return np.concatenate(out) if out else hits[:0]
 
 
 def merge_and_nms(raw_all: np.ndarray, listTemplates, method, N_object, score_threshold, maxOverlap,
