@@ -49,13 +49,16 @@ def _worker(rank, world, port, q):
         ok = True
         for n0, n1 in ((3, 0), (700, 5), (2, 1300), (0, 0), (4, 4)):
             n = n0 if rank == 0 else n1
-            mine = np.zeros(n, dtype=MTM._lib.HIT_DTYPE)
+            mine = np.zeros(n, dtype=_lib.HIT_DTYPE)
             mine["templ_idx"] = rank
             mine["x"] = np.arange(n)
             allh = ex.allgather(mine)
             ok = ok and len(allh) == n0 + n1 and list(allh["templ_idx"]) == [0] * n0 + [1] * n1
             ok = ok and list(allh["x"]) == list(range(n0)) + list(range(n1))
         q.put((rank, [(h[0], tuple(h[1]), float(h[2])) for h in got] if ok else "exchange failed"))
+    except Exception as e:  # noqa: BLE001 - report instead of leaving the parent waiting for the queue
+        q.put((rank, "worker failed: %r" % (e,)))
+        raise
     finally:
         dist.destroy_process_group()
 
