@@ -521,7 +521,7 @@ int place_templates(mtm_ctx* c) {
     MTMC(c->tlist.ensure(sizeof(int) * std::max<size_t>(1, c->tlist_host.size())));
     MTMC(c->weights.ensure(sizeof(double) * std::max<size_t>(1, w_off)));
     MTMC(c->packs.ensure(std::max<size_t>(4, p_off)));
-    MTMC(c->apacks.ensure(std::max<size_t>(16, a_off)));
+    MTMC(c->apacks.ensure(std::max<size_t>(16, a_off) + 16384));     // the K loop requests up to two steps past a pack
     if (a_off) HIPC(hipMemcpyAsync(c->apacks.p, apacks.data(), a_off, hipMemcpyHostToDevice, c->stream));
     // the score-map arena (4 bytes per pixel and template) is only allocated when something writes maps:
     // mtm_find_matches in hits-only mode never does (ensure_maps, called by the launch paths)

@@ -97,8 +97,8 @@ struct MfmaParams {
     double cand_thr_lo;      // cand_thr minus 8 float32 ulps (hits-only pre-test in float64)
     int hits_only;           // 1: candidates only, the score maps are not written (mtm_find_matches
                              // without map consumers); needs cand_on
-    int dbg;                 // profiling probes (MTM_MFMA_DBG): 1 cheap epilogue, 2 no epilogue, 4 frozen A
-                             // pointer, 8 no MFMA; results are only valid with dbg == 0
+    int dbg;                 // profiling probe (MTM_MFMA_DBG): 2 = no epilogue (results invalid); the other probes
+                             // are compile-time (-DMTM_PROBE_*)
 };
 
 // Per-template constants staged in LDS once per work-group (the epilogue reads them with LDS
@@ -415,19 +415,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             const int nsteps = ch * p.nb;
             int nb_i = 0;                       // 64-tap block of the step last requested
             int loff = 0;                       // its LDS offset: dy * lds_pitch + b * 64
-            int req = 0;                        // index of the step last requested
+            const int row_adv = p.lds_pitch - (p.nb - 1) * 64;
             v4i qa0, qb0, qa1, qb1, a0[MB], a1[MB];
+            // The loop body is branch-free: the bookkeeping of the next step is scalar selects, and the
+            // requests run up to two steps past the end of the chunk (the pack arena has slack, LDS reads
+            // past the tile stay inside the allocation; nothing of it is used).  Taken scalar branches
+            // cost more than the loads they would save.
 #define MTM_MF_ADVANCE()                                            \
-            if (req + 1 < nsteps) {                                 \
-                ++req;                                              \
-                if (!(p.dbg & 4)) aptr += 1024;                     \
-                if (++nb_i == p.nb) {                               \
-                    nb_i = 0;                                       \
-                    loff += p.lds_pitch - (p.nb - 1) * 64;          \
-                } else {                                            \
-                    loff += 64;                                     \
-                }                                                   \
+            {                                                       \
+                MTM_MF_APTR_STEP                                    \
+                const bool wrap_ = nb_i + 1 == p.nb;                \
+                loff += wrap_ ? row_adv : 64;                       \
+                nb_i = wrap_ ? 0 : nb_i + 1;                        \
             }
+#ifdef MTM_PROBE_FROZEN_A   /* timing experiment: the template operand pointer does not move (wrong results) */
+#define MTM_MF_APTR_STEP
+#else
+#define MTM_MF_APTR_STEP aptr += 1024;
+#endif
 #define MTM_MF_LOAD(QA, QB, A)                                                          \
             QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
             QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
@@ -444,27 +449,33 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #else
 #define MTM_MF_LOAD_LOOP(QA, QB, A) MTM_MF_LOAD(QA, QB, A)
 #endif
-            MTM_MF_LOAD(qa0, qb0, a0)
-            MTM_MF_LOAD(qa1, qb1, a1)
-            for (int ks = 0; ks < nsteps; ks += 2) {
+#ifdef MTM_PROBE_NO_MFMA   /* timing experiment: the loop skeleton without MFMAs and operand shifts */
+#define MTM_MF_STEP(QA, QB, A, K) acc[0][K] += QA + QB + A[0] + A[MB - 1];
+#else
+#define MTM_MF_STEP(QA, QB, A, K) mfma_step<MB>(acc, QA, QB, A);
+#endif
+            MTM_MF_LOAD(qa0, qb0, a0)            // step 0
+            int ks = 0;
+            for (; ks + 2 <= nsteps; ks += 2) {
                 MTM_MF_ADVANCE()
-                MTM_MF_LOAD_LOOP(qa1, qb1, a1)
+                MTM_MF_LOAD_LOOP(qa1, qb1, a1)    // step ks + 1
                 __builtin_amdgcn_sched_barrier(0);
-                if (!(p.dbg & 8)) mfma_step<MB>(acc, qa0, qb0, a0);
-                else acc[0][0] += qa0 + qb0 + a0[0] + a0[MB - 1];
+                MTM_MF_STEP(qa0, qb0, a0, 0)
                 __builtin_amdgcn_sched_barrier(0);
                 MTM_MF_ADVANCE()
-                MTM_MF_LOAD_LOOP(qa0, qb0, a0)
+                MTM_MF_LOAD_LOOP(qa0, qb0, a0)    // step ks + 2 (one past the end in the last iteration)
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks + 1 < nsteps) {
-                    if (!(p.dbg & 8)) mfma_step<MB>(acc, qa1, qb1, a1);
-                    else acc[0][1] += qa1 + qb1 + a1[0] + a1[MB - 1];
-                }
+                MTM_MF_STEP(qa1, qb1, a1, 1)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (ks < nsteps) {                    // odd number of steps: the last one is already in set 0
+                MTM_MF_STEP(qa0, qb0, a0, 0)
+            }
 #undef MTM_MF_ADVANCE
+#undef MTM_MF_APTR_STEP
 #undef MTM_MF_LOAD
 #undef MTM_MF_LOAD_LOOP
+#undef MTM_MF_STEP
             // the last MFMAs may have been issued from inline asm: give their results time to land
             // before compiler-generated code reads the accumulators (hipcc does not see asm MFMAs)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
