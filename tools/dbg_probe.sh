@@ -1,6 +1,7 @@
 #!/bin/bash
-# kernel time under the runtime probes of ncc_mfma_kernel (results invalid while probing)
-for envs in "X=0" "MTM_MFMA_DBG=2" "MTM_MFMA_DBG=10" "MTM_MFMA_DBG=6" "MTM_HITS_ONLY=0" "MTM_HITS_ONLY=0 MTM_MFMA_DBG=2"; do
+# kernel time with and without the epilogue (MTM_MFMA_DBG=2: results invalid), hits-only and map mode;
+# the other probes are compile-time: MTM_EXTRA_FLAGS=-DMTM_PROBE_{NO_A,NO_Q,NO_STAGE,NO_MFMA,FROZEN_A,NO_STORE,CHEAP_EPI}
+for envs in "X=0" "MTM_MFMA_DBG=2" "MTM_HITS_ONLY=0" "MTM_HITS_ONLY=0 MTM_MFMA_DBG=2"; do
   env $envs python - "$envs" <<'PY'
 import sys, os
 sys.path.insert(0, os.path.join(os.getcwd(), "multitemplatematching-python_amd"))
