@@ -175,6 +175,7 @@ struct mtm_ctx {
     int mfma_stagger = -1;     // < 0: automatic
     int mfma_stagger_mode = 0;
     int mfma_per_cu = 2;
+    int mfma_stagger_np = 0;   // > 0: stagger the first wave of blocks of a non-persistent launch by this many s_sleep(127)
     int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};
@@ -887,6 +888,17 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.stagger_sleeps = c->mfma_stagger >= 0 ? c->mfma_stagger : (int)(0.75 * main_cycles / 8128.0 + 0.5);
             HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
         }
+        if (!p.persistent && c->mfma_stagger_np > 0) {
+            if (c->n_cus == 0) {
+                hipDeviceProp_t prop;
+                HIPC(hipGetDeviceProperties(&prop, c->device));
+                c->n_cus = prop.multiProcessorCount;
+            }
+            p.stagger_first = c->mfma_per_cu * c->n_cus;
+            p.stagger_mode = c->mfma_stagger_mode;
+            p.stagger_sleeps = c->mfma_stagger_np;
+            HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
+        }
         hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA;
@@ -1092,6 +1104,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_STAGGER_MODE")) c->mfma_stagger_mode = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PER_CU")) c->mfma_per_cu = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_STAGGER_NP")) c->mfma_stagger_np = std::atoi(v);
     if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
         const int k = std::atoi(v);
         if (k >= 0 && k < kNumDotVariants && !kDotVariants[k].wide) c->dot_variant = k;

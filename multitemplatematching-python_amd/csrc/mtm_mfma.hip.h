@@ -73,6 +73,7 @@ struct MfmaParams {
     int st_off;              // byte offset in LDS of the prefetched window statistics (4 waves)
     int persistent;          // 1: work items are pulled from *work_counter (grid = resident blocks)
     int stagger_sleeps;      // s_sleep(127) count of the second block on a CU before its first item
+    int stagger_first;       // non-persistent launches: block indices below this take part in the staggering (0 = off)
     int stagger_mode;        // how "second block on a CU" is guessed: 0 per-CU arrival counter (HW_ID),
                              // 1 upper half of the grid, 2 bit 3 of the block index
     // fused peak candidates (mtm_find_matches, local-extrema mode): every output with
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // sched[1 + cu]) sleeps for about one main loop before its first item.  Placement only
     // affects speed, never results.
     int* s_item = reinterpret_cast<int*>(smem + p.tc_off + 32 * (int)sizeof(MfTemplConst));
-    if (p.persistent) {
+    if (p.persistent || (int)blockIdx.x < p.stagger_first) {
         if (threadIdx.x == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
             const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
@@ -438,7 +439,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
                 A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
-#ifdef MTM_PROBE_NO_A      /* timing experiment: no template-operand loads inside the K loop (wrong results) */
+#ifdef MTM_PROBE_NO_LOADS  /* timing experiment: no operand loads at all inside the K loop (wrong results) */
+#define MTM_MF_LOAD_LOOP(QA, QB, A)
+#elif defined(MTM_PROBE_NO_A)  /* timing experiment: no template-operand loads inside the K loop (wrong results) */
 #define MTM_MF_LOAD_LOOP(QA, QB, A)                                                     \
             QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
             QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);
