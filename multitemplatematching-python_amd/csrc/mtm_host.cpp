@@ -127,7 +127,8 @@ static inline float rect_overlap(const mtm_hit& a, const mtm_hit& b) {
     const int x1 = std::max(a.x, b.x), y1 = std::max(a.y, b.y);
     const int x2 = std::min(a.x + a.w, b.x + b.w), y2 = std::min(a.y + a.h, b.y + b.h);
     const int iw = x2 - x1, ih = y2 - y1;
-    const double aab = (iw > 0 && ih > 0) ? (double)((long long)iw * ih) : 0.0;
+    if (iw <= 0 || ih <= 0) return 0.0f;      // disjoint: 1.f - (float)(1.0 - 0.0 / u), without the division
+    const double aab = (double)((long long)iw * ih);
     const double dist = 1.0 - aab / ((double)aa + (double)ab - aab);
     return 1.0f - (float)dist;
 }
