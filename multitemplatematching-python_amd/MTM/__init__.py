@@ -180,11 +180,8 @@ def _nms_raw(raw, scoreThreshold, sortAscending, N_object, maxOverlap):
     if N_object == 1:       # python max()/min(): the first best hit wins ties
         i = int(np.argmin(raw["score"])) if sortAscending else int(np.argmax(raw["score"]))
         return raw[i:i + 1]
-    scores = raw["score"]
-    if sortAscending:
-        scores = np.float32(1) - scores          # np.float32 scores: 1 - score is a float32 subtraction
-        scoreThreshold = 1 - scoreThreshold
-    idx = _lib.nms_hits(raw, scores, scoreThreshold, maxOverlap)
+    # the 1 - score transform of sortAscending (float32 scores, python-float threshold) is done by mtm_nms
+    idx = _lib.nms_hits(raw, scoreThreshold, maxOverlap, ascending=sortAscending)
     if N_object != float("inf"):
         idx = idx[:N_object]
     return raw[idx]

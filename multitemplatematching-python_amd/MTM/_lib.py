@@ -280,16 +280,15 @@ def nms_indices(boxes, scores, score_threshold, max_overlap, ascending=False, n_
     return keep[:m.value]
 
 
-def nms_hits(hits, scores, score_threshold, max_overlap):
-    """Same as nms_indices, on a structured hit array (boxes are taken from it, scores given)."""
+def nms_hits(hits, score_threshold, max_overlap, ascending=False):
+    """Same as nms_indices, on a structured hit array (boxes and float32 scores are taken from it)."""
     n = len(hits)
-    work = np.ascontiguousarray(hits, dtype=HIT_DTYPE).copy()
-    if n:
-        work["score"] = np.asarray(scores, dtype=np.float32)
+    if hits.dtype != HIT_DTYPE or not hits.flags.c_contiguous:
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
     keep = np.empty(max(n, 1), dtype=np.int32)
     m = ctypes.c_int64(0)
-    check(load().mtm_nms(work.ctypes.data, n, float(score_threshold), 0, -1, float(max_overlap), keep.ctypes.data,
-                         ctypes.byref(m)), "mtm_nms")
+    check(load().mtm_nms(hits.ctypes.data, n, float(score_threshold), int(bool(ascending)), -1, float(max_overlap),
+                         keep.ctypes.data, ctypes.byref(m)), "mtm_nms")
     return keep[:m.value]
 
 
