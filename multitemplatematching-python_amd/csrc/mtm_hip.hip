@@ -170,6 +170,7 @@ struct mtm_ctx {
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
     bool hits_only_now = false;
+    bool ext_now = false;      // this call: global extrema come out of the MFMA epilogue (no maps, no extremum_kernel)
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
     int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
     int mfma_stagger = -1;     // < 0: automatic
@@ -824,7 +825,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
         // statistics prefetch region: (channels + 2) planes per wave (RM loads its statistics directly)
-        const size_t lds = (size_t)p.st_off + (rm ? 0 : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
+        size_t lds = (size_t)p.st_off + (rm ? 0 : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
+        const bool ext = c->ext_now && only_li < 0;      // find_matches_impl checked the class
+        if (ext) {
+            p.ext_off = (int)lds;                         // 4 waves x 32 keys
+            lds += (size_t)kMfRows * 32 * sizeof(unsigned long long);
+            p.ext_best = c->counters.as<unsigned long long>();
+            p.cand_on = 1;
+            p.hits_only = 1;
+        }
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off +
@@ -856,8 +865,16 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         static const MfmaFn kMfmaC3Fns[2][2][6] = {{MTM_MF_C3(1, false), MTM_MF_C3(2, false)},
                                                    {MTM_MF_C3(1, true), MTM_MF_C3(2, true)}};
 #undef MTM_MF_C3
+        // fused global extremum: same kernels with the per-template running best as the threshold
+#define MTM_MF_EXT(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 1, true>, ncc_mfma_kernel<MB, 1, X, false, false, 1, true>,   \
+                          ncc_mfma_kernel<MB, 2, X, false, false, 1, true>, ncc_mfma_kernel<MB, 3, X, false, false, 1, true>,   \
+                          ncc_mfma_kernel<MB, 4, X, false, false, 1, true>, ncc_mfma_kernel<MB, 5, X, false, false, 1, true>}
+        static const MfmaFn kMfmaExtFns[2][2][6] = {{MTM_MF_EXT(1, false), MTM_MF_EXT(2, false)},
+                                                    {MTM_MF_EXT(1, true), MTM_MF_EXT(2, true)}};
+#undef MTM_MF_EXT
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
-        const MfmaFn fn = c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
+        const MfmaFn fn = ext ? kMfmaExtFns[c->exact_div ? 1 : 0][mb - 1][c->method]
+                        : c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
                         : rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
                              : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
         // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
@@ -1523,6 +1540,23 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     }
     c->cand_on = false;
     c->hits_only_now = false;
+    c->ext_now = false;
+    // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the plain
+    // single-channel MFMA kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
+    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && c->chans == 1) {
+        bool ok = true;
+        for (const SizeClass& sc : c->classes)
+            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.rm_R == 0 && !sc.masked;
+        if (ok) {
+            MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
+            HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)n, c->stream));
+            c->ext_now = true;
+            c->cand_on = true;
+            c->hits_only_now = true;
+            c->cand_min = mode_min;
+            c->cand_thr = 0.0f;
+        }
+    }
     const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
     if (fused) {
         MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
@@ -1541,7 +1575,7 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     // hash table of the candidate positions (hits-only verification on the device: only when the
     // candidates are too many to be checked on the host, see below)
     unsigned hash_mask = 0;
-    if (c->hits_only_now) {
+    if (c->hits_only_now && !c->ext_now) {
         size_t hsz = 1024;
         while (hsz < 2 * (size_t)cand_cap) hsz <<= 1;
         hash_mask = (unsigned)(hsz - 1);
@@ -1558,9 +1592,11 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     MTMC(stage_next_image(c, next));
 
     if (mode == MTM_PEAKS_GLOBAL) {
-        MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
-        HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
-        if (n > 0) {
+        if (!c->ext_now) {
+            MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
+            HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
+        }
+        if (n > 0 && !c->ext_now) {
             const int nb = 256;
             hipLaunchKernelGGL(extremum_kernel, dim3(nb, n), dim3(256), 0, c->stream, c->maps.as<float>(),
                                c->td.as<TemplDev>(), nb, c->counters.as<unsigned long long>());

@@ -98,6 +98,12 @@ struct MfmaParams {
     double cand_thr_lo;      // cand_thr minus 8 float32 ulps (hits-only pre-test in float64)
     int hits_only;           // 1: candidates only, the score maps are not written (mtm_find_matches
                              // without map consumers); needs cand_on
+    // fused global extremum (template parameter EXT; mtm_find_matches, MTM_PEAKS_GLOBAL, plain single-channel classes): nothing is
+    // stored, every wave keeps the best (ordered score, ~index) key per template in LDS (ext_off: 4 waves x 32
+    // keys) and merges it into ext_best[2 * template + cand_min] with one atomicMax per improved template.  The
+    // best seen so far, re-read when a work item starts, is that template's threshold for the pre-tests.
+    int ext_off;
+    unsigned long long* ext_best;
     int dbg;                 // profiling probe (MTM_MFMA_DBG): 2 = no epilogue (results invalid); the other probes
                              // are compile-time (-DMTM_PROBE_*)
 };
@@ -112,7 +118,20 @@ struct MfTemplConst {
     double tms, rsqrt_tms;   // masked templates: sum((T*M)^2) and its inverse square root
     long long map_off;
     int map_pitch, all_ones;
+    double ext_thr_lo;       // ext_on: quality (score, or -score for minima) of the best output seen so far,
+    unsigned ext_hi;         //   lowered by 1e-6 relative; high word of its key (0: none yet)
+    int ext_pad_;
 };
+
+// order-preserving image of a float32 (the high word of the extremum keys, see extremum_kernel) and back
+__device__ __forceinline__ uint32_t mf_float_order(float v) {
+    if (v == 0.0f) v = 0.0f;     // -0 -> +0
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float mf_order_float(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
 
 // finish_unmasked on values already in registers (same arithmetic, same order).  METHOD >= 0 fixes
 // the matching method at compile time: the per-output code is then branch-free apart from the
@@ -261,7 +280,7 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
-template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false, int CH = 1>
+template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false, int CH = 1, bool EXT = false>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
@@ -269,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                           unsigned int* __restrict__ sched) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || (!RM && !MASKED), "multi-channel: plain unmasked path only");
+    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && !RM && !MASKED && CH == 1), "fused extremum: plain single-channel path");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -339,6 +359,20 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
+            k.ext_thr_lo = -INFINITY;
+            k.ext_hi = 0u;
+            k.ext_pad_ = 0;
+            if (EXT) {
+                const unsigned long long bk = __hip_atomic_load(&p.ext_best[2 * tlist[li] + p.cand_min], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                if (bk) {
+                    const uint32_t hiw = (uint32_t)(bk >> 32);
+                    const double sc = (double)mf_order_float(p.cand_min ? ~hiw : hiw);
+                    const double ql = p.cand_min ? -sc : sc;
+                    k.ext_hi = hiw;
+                    k.ext_thr_lo = ql - 1e-6 * fmax(1.0, fabs(ql));
+                }
+            }
             tcl[threadIdx.x] = k;
         }
     }
@@ -740,10 +774,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if constexpr (CH == 1 && !MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
             // (quotients <= -1 saturate to -1 or 0, which can only be candidates below a negative threshold:
             // such calls skip the screen instead of tracking the minima as well)
-            if (p.hits_only && p.cand_thr_lo >= 0.0) {
+            if (p.hits_only && (EXT || p.cand_thr_lo >= 0.0)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* sw = smem + p.st_off + wave * mf_stat_bytes_per_wave(1);
-                const double hi = fmin(p.cand_thr_lo, 0.999999) - 1e-6;
                 bool pass = false;
                 // one MFMA group (4 templates of this lane) at a time: 4 x (K, 128 - mean, running extremes)
                 // stay in registers next to the 64 * MB accumulators
@@ -787,7 +820,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const int lt = 16 * mb + 4 * q + e;
                         const bool live = tg * MB * 16 + lt < p.n_list;
                         const double tn = tcl[lt].templ_norm;
-                        pass = pass || (live && umax[e] > hi * tn);
+                        // extremum mode: the template's own running best is the threshold (negative or none
+                        // yet: no screen for this template)
+                        const double thr_lo_e = EXT ? tcl[lt].ext_thr_lo : p.cand_thr_lo;
+                        const double hi = fmin(thr_lo_e, 0.999999) - 1e-6;
+                        pass = pass || (live && (thr_lo_e < 0.0 || umax[e] > hi * tn));
                     }
                 }
                 wave_has_work = __builtin_amdgcn_ballot_w64(pass) != 0ull;
@@ -830,6 +867,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         __syncthreads();              // every wave is done reading the image tile: the buffers alias it
         if (!wave_has_work) continue;                       // wave-uniform; no work-group barrier below
         const bool lane_on = y < p.oh && xq < p.ow;
+        unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
+        if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll 1
@@ -871,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[i] - 2.0 * num + T.templ_sum2, 0.0);
                                 const double qd = num * (prsq[i] * rt);
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
-                                pass = pass || quality > p.cand_thr_lo || fabs(qd) >= 0.999999999;
+                                pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
                             }
                             if (!pass) continue;
                         }
@@ -893,7 +932,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                             for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                         }
-                        if (p.cand_on) {
+                        if constexpr (EXT) {
+                            // global extremum: the lane's best key not below the template's running best
+                            // goes to the wave's LDS slot (cv2.minMaxLoc: first index wins ties, NaN never)
+                            unsigned long long bestk = 0ull;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = out[i];
+                                const uint32_t o = mf_float_order(v);
+                                const uint32_t hiw = p.cand_min ? ~o : o;
+                                if (xq + i < p.ow && v == v && hiw >= T.ext_hi) {
+                                    const unsigned long long key =
+                                        ((unsigned long long)hiw << 32) |
+                                        (unsigned long long)(0xFFFFFFFFu - (uint32_t)(y * p.ow + xq + i));
+                                    bestk = key > bestk ? key : bestk;
+                                }
+                            }
+                            if (bestk) atomicMax(&ext_slot[lt0 + s8], bestk);
+                        } else if (p.cand_on) {
                             // cheap any-of-4 test; emit() repeats the exact per-pixel test (rare)
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
@@ -905,6 +961,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below
                 __builtin_amdgcn_wave_barrier();
             }
+        }
+        if (EXT && lane < 16 * MB) {       // one global atomic per template this wave improved
+            const unsigned long long key = ext_slot[lane];
+            const int li = tg * MB * 16 + lane;
+            if (key && li < p.n_list) atomicMax(&p.ext_best[2 * tlist[li] + p.cand_min], key);
         }
     } else {
         // ---- generic path: any channel count, run-time method

@@ -828,6 +828,70 @@ def test_row_multiplexed_mode(mtm, n_templ):
 
 
 # ------------------------------------------------------------------------------------------------
+# N_object == 1: cv2.minMaxLoc fused into the MFMA epilogue (no score maps, running best per template
+# as the threshold) == score maps + extremum_kernel == oracle, ties included
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_templ,row_mux", [(20, "1"), (37, "1"), (5, "0"), (16, "0")])
+def test_fused_global_extremum(mtm, n_templ, row_mux):
+    rng = np.random.default_rng(900 + n_templ)
+    H, W = 157, 531
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[60:100, 200:330] = 93                              # flat windows
+    tile = rng.integers(0, 256, (30, 40), dtype=np.uint8)  # exact copies: ties at score 1 / distance 0
+    for (y, x) in ((3, 470), (110, 12), (110, 300), (20, 100)):
+        img[y:y + 30, x:x + 40] = tile
+    old = os.environ.get("MTM_ROW_MUX")
+    os.environ["MTM_ROW_MUX"] = row_mux                    # "0": classes of <= 16 templates stay on the plain kernel
+    try:
+        ctx = mtm._lib.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("MTM_ROW_MUX", None)
+        else:
+            os.environ["MTM_ROW_MUX"] = old
+    try:
+        ctx.set_option(1, 3)                               # MFMA
+        ctx.set_image(img)
+        for (h, w) in [(24, 24), (70, 33), (9, 130)]:
+            lt = []
+            for i in range(n_templ):
+                if i % 5 == 0 and h <= 30 and w <= 40:
+                    t = tile[:h, :w].copy()                # several exact occurrences
+                else:
+                    y, x = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+                    t = img[y:y + h, x:x + w].copy()
+                    if i % 2:
+                        t = np.clip(t.astype(np.int32) + rng.integers(-40, 41, t.shape), 0, 255).astype(np.uint8)
+                if i == 3:
+                    t = np.full((h, w), 77, np.uint8)      # constant template
+                lt.append(("t%d" % i, t))
+            for method in (5, 3, 1, 0, 2, 4):
+                ctx.set_templates([(t, None) for _, t in lt], method)
+                for exact in (0, 1):
+                    ctx.set_option(5, exact)
+                    res = []
+                    for honly in (1, 0):
+                        ctx.set_option(6, honly)
+                        res.append(ctx.find_matches(1, 0.5).copy())
+                        tm = ctx.timing()
+                        assert tm["kernel_used"] == 3 and tm["hits_only"] == honly, tm
+                    assert res[0].tobytes() == res[1].tobytes(), (n_templ, (h, w), method, exact)
+                ctx.set_option(6, 1)
+                r = res[0]
+                assert len(r) == n_templ and list(r["templ_idx"]) == list(range(n_templ))
+                exp = O.find_matches(lt, img, method=method, N_object=1)
+                got = [(lt[int(q["templ_idx"])][0], (int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"])), q["score"]) for q in r]
+                if method in (1, 3, 5):
+                    assert_hits_equal(got, hits_json(exp), tol=1e-6)
+                else:                                      # unnormalised: exact integers in both
+                    assert [g[1] for g in got] == [tuple(e[1]) for e in exp]
+                    assert np.allclose([g[2] for g in got], [e[2] for e in exp], rtol=1e-6)
+    finally:
+        del ctx
+
+
+# ------------------------------------------------------------------------------------------------
 # state machine of a context: random sequences of uploads, template sets, options and queries
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", range(4))
