@@ -872,8 +872,14 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         static const MfmaFn kMfmaExtFns[2][2][6] = {{MTM_MF_EXT(1, false), MTM_MF_EXT(2, false)},
                                                     {MTM_MF_EXT(1, true), MTM_MF_EXT(2, true)}};
 #undef MTM_MF_EXT
+#define MTM_MF_RMEXT(X) {ncc_mfma_kernel<2, 0, X, false, true, 1, true>, ncc_mfma_kernel<2, 1, X, false, true, 1, true>,   \
+                        ncc_mfma_kernel<2, 2, X, false, true, 1, true>, ncc_mfma_kernel<2, 3, X, false, true, 1, true>,   \
+                        ncc_mfma_kernel<2, 4, X, false, true, 1, true>, ncc_mfma_kernel<2, 5, X, false, true, 1, true>}
+        static const MfmaFn kMfmaRmExtFns[2][6] = {MTM_MF_RMEXT(false), MTM_MF_RMEXT(true)};
+#undef MTM_MF_RMEXT
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
-        const MfmaFn fn = ext ? kMfmaExtFns[c->exact_div ? 1 : 0][mb - 1][c->method]
+        const MfmaFn fn = (ext && rm) ? kMfmaRmExtFns[c->exact_div ? 1 : 0][c->method]
+                        : ext ? kMfmaExtFns[c->exact_div ? 1 : 0][mb - 1][c->method]
                         : c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
                         : rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
                              : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
@@ -1541,12 +1547,12 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     c->cand_on = false;
     c->hits_only_now = false;
     c->ext_now = false;
-    // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the plain
-    // single-channel MFMA kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
+    // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the unmasked
+    // single-channel MFMA kernel (plain or row-multiplexed); same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
     if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && c->chans == 1) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
-            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.rm_R == 0 && !sc.masked;
+            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && !sc.masked;
         if (ok) {
             MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
             HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)n, c->stream));

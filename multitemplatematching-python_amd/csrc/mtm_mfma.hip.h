@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                           unsigned int* __restrict__ sched) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || (!RM && !MASKED), "multi-channel: plain unmasked path only");
-    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && !RM && !MASKED && CH == 1), "fused extremum: plain single-channel path");
+    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && !MASKED && CH == 1), "fused extremum: unmasked single-channel paths");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -586,6 +586,23 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
     auto emit = [&](const float (&out)[4], int li) { emit_at(out, li, y); };
+    // global extremum (EXT): the lane's best key not below the template's running best goes to the wave's
+    // LDS slot (cv2.minMaxLoc: the first index wins ties, NaN never wins)
+    auto ext_update = [&](const float (&out)[4], int yrow, uint32_t best_hi, unsigned long long* slot) {
+        unsigned long long bestk = 0ull;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = out[i];
+            const uint32_t o = mf_float_order(v);
+            const uint32_t hiw = p.cand_min ? ~o : o;
+            if (xq + i < p.ow && v == v && hiw >= best_hi) {
+                const unsigned long long key = ((unsigned long long)hiw << 32) |
+                                               (unsigned long long)(0xFFFFFFFFu - (uint32_t)(yrow * p.ow + xq + i));
+                bestk = key > bestk ? key : bestk;
+            }
+        }
+        if (bestk) atomicMax(slot, bestk);
+    };
     auto store4 = [&](float* orow, const float (&out)[4]) {
 #ifdef MTM_PROBE_NO_STORE      /* timing experiment: no score-map stores (values kept alive) */
         if (out[0] + out[1] + out[2] + out[3] == 12345.678f) orow[0] = 1.0f;
@@ -645,6 +662,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         const int R = p.rm_R, ntm = p.rm_nt - 1, lg = p.rm_log2nt;
         const bool col_on = xq < p.ow;
         const int xs = min(xq, st.pitch - 4);
+        unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
+        if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll 1
@@ -703,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[k] - 2.0 * num + T.templ_sum2, 0.0);
                                 const double qd = num * (prsq[k] * rt);
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
-                                pass = pass || quality > p.cand_thr_lo || fabs(qd) >= 0.999999999;
+                                pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
                             }
                             if (!pass) continue;
                         }
@@ -717,7 +736,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const bool ones = !MASKED && T.all_ones != 0;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) out[k] = ones ? 1.0f : out[k];
-                        if (p.cand_on) {
+                        if constexpr (EXT) {
+                            ext_update(out, yy, T.ext_hi, &ext_slot[t]);
+                        } else if (p.cand_on) {
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                             if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy);
@@ -728,6 +749,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+        }
+        if (EXT && lane < p.rm_nt) {            // one global atomic per template this wave improved
+            const unsigned long long key = ext_slot[lane];
+            if (key && lane < p.n_list) atomicMax(&p.ext_best[2 * tlist[lane] + p.cand_min], key);
         }
     } else if constexpr (METHOD == kMfRaw) {
         // ---- raw mode: transpose through LDS and store the int32 accumulators, 4 pixels per lane
@@ -933,22 +958,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                         }
                         if constexpr (EXT) {
-                            // global extremum: the lane's best key not below the template's running best
-                            // goes to the wave's LDS slot (cv2.minMaxLoc: first index wins ties, NaN never)
-                            unsigned long long bestk = 0ull;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v = out[i];
-                                const uint32_t o = mf_float_order(v);
-                                const uint32_t hiw = p.cand_min ? ~o : o;
-                                if (xq + i < p.ow && v == v && hiw >= T.ext_hi) {
-                                    const unsigned long long key =
-                                        ((unsigned long long)hiw << 32) |
-                                        (unsigned long long)(0xFFFFFFFFu - (uint32_t)(y * p.ow + xq + i));
-                                    bestk = key > bestk ? key : bestk;
-                                }
-                            }
-                            if (bestk) atomicMax(&ext_slot[lt0 + s8], bestk);
+                            ext_update(out, y, T.ext_hi, &ext_slot[lt0 + s8]);
                         } else if (p.cand_on) {
                             // cheap any-of-4 test; emit() repeats the exact per-pixel test (rare)
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));

@@ -832,7 +832,7 @@ def test_row_multiplexed_mode(mtm, n_templ):
 # as the threshold) == score maps + extremum_kernel == oracle, ties included
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_templ,row_mux", [(20, "1"), (37, "1"), (5, "0"), (16, "0")])
+@pytest.mark.parametrize("n_templ,row_mux", [(20, "1"), (37, "1"), (5, "0"), (16, "0"), (5, "1"), (12, "1"), (16, "1")])
 def test_fused_global_extremum(mtm, n_templ, row_mux):
     rng = np.random.default_rng(900 + n_templ)
     H, W = 157, 531
@@ -842,7 +842,7 @@ def test_fused_global_extremum(mtm, n_templ, row_mux):
     for (y, x) in ((3, 470), (110, 12), (110, 300), (20, 100)):
         img[y:y + 30, x:x + 40] = tile
     old = os.environ.get("MTM_ROW_MUX")
-    os.environ["MTM_ROW_MUX"] = row_mux                    # "0": classes of <= 16 templates stay on the plain kernel
+    os.environ["MTM_ROW_MUX"] = row_mux                    # "0": classes of <= 16 templates stay on the plain kernel, "1": row-multiplexed
     try:
         ctx = mtm._lib.Context(0)
     finally:
