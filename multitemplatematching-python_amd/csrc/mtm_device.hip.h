@@ -265,127 +265,149 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // Fused window statistics for single-channel uint8 images: one kernel, no intermediate planes.
-// A work-group owns 256 output columns x kStatBand output rows.  Column sums over the template
-// height (C1 = sum I, C2 = sum I^2 per image column) are kept in registers and slid down one row at a
-// time (two coalesced row reads per output row); the window sums are then differences of a prefix
-// scan of the column sums over the 256 + w - 1 columns of the strip, held in LDS (uint32, exact:
-// differences are taken modulo 2^32 and the true window sums fit).  Reads the image ~(h + 2 band) /
-// band times, writes only the statistics the epilogue needs.  The launcher uses it for w <= 768 and
-// w * h * 255^2 < 2^32; everything else takes hsum_* + vsum_stats_kernel.
+// A work-group owns a strip of `owg` output columns (owg + w - 1 <= 1024 image columns) x
+// kStatBand4 output rows; a thread owns FOUR adjacent image columns: one aligned dword load per
+// image row, four 8-byte statistics per plane and output row (two 16-byte stores).  Column sums over
+// the template height (C1 = sum I, C2 = sum I^2 per image column) are kept in registers and slid down
+// one row at a time (two dword loads per output row, requested one iteration ahead); the window
+// sums are differences of the exclusive prefix scan of the column sums over the strip, held in LDS
+// (uint32, exact: differences are taken modulo 2^32 and the true window sums fit).  One block scan
+// (thread-local prefix, DPP wave scan, one LDS exchange) and two barriers serve 4 x 256 columns.
+// The launcher uses it for w <= 768 and w * h * 255^2 < 2^32; everything else takes hsum_* +
+// vsum_stats_kernel.
 // ---------------------------------------------------------------------------------------------
 #ifndef MTM_STAT_BAND
 #define MTM_STAT_BAND 32
 #endif
-constexpr int kStatBand = MTM_STAT_BAND;
-constexpr int kStatMaxK = 4;        // image columns per thread: ceil((256 + w - 1) / 256) <= 4
+constexpr int kStatBand = MTM_STAT_BAND;      // stats_u8_mc_kernel (one column per thread)
+constexpr int kStatMaxK = 4;                   // image columns per thread there: ceil((256 + w - 1) / 256) <= 4
+#ifndef MTM_STAT_BAND4
+#define MTM_STAT_BAND4 8
+#endif
+constexpr int kStatBand4 = MTM_STAT_BAND4;    // stats_u8_kernel: output rows per work-group
+constexpr int kStatStrip = 1024;               // image columns per work-group (4 per thread)
+
+// output columns per work-group for a template width (multiple of 4: strips start dword-aligned)
+inline int stats_u8_owg(int w) { return (kStatStrip + 1 - w) & ~3; }
 
 __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict__ img, int pitch, int h, int w,
-                                                       int oh, int ow, double inv_area, int num_type, int want_sq,
-                                                       int want_t, int want_sum2, double* __restrict__ t0,
+                                                       int oh, int ow, int owg, double inv_area, int num_type,
+                                                       int want_sq, int want_t, int want_sum2, double* __restrict__ t0,
                                                        double* __restrict__ sum2, double* __restrict__ sq,
                                                        int st_pitch, double* __restrict__ rsq = nullptr) {
-    __shared__ uint32_t P1[256 * kStatMaxK + 1], P2[256 * kStatMaxK + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t E1[kStatStrip + 4], E2[kStatStrip + 4];   // exclusive prefixes
     __shared__ uint32_t wsum[2][4];
-    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kStatBand;
+    const int x0 = blockIdx.x * owg, y0 = blockIdx.y * kStatBand4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int L = 256 + w - 1;                       // image columns of this strip
-    const int K = (L + 255) >> 8;                    // columns per thread (contiguous)
-    const uint8_t* base = img + (size_t)y0 * pitch + x0 + t * K;      // padded image: always readable
-    uint32_t c1[kStatMaxK] = {0, 0, 0, 0}, c2[kStatMaxK] = {0, 0, 0, 0};
+    const int L = owg + w - 1;                       // image columns of this strip (<= kStatStrip)
+    // the image is padded by kPadCols columns only: quads further right (beyond every valid window) read 0
+    const bool ld = 4 * t < L && x0 + 4 * t + 3 < pitch;
+    const uint8_t* base = img + (size_t)y0 * pitch + x0 + 4 * t;
+    uint32_t c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+    auto unpack = [](uint32_t v, uint32_t (&b)[4]) {
+        b[0] = v & 255u;
+        b[1] = (v >> 8) & 255u;
+        b[2] = (v >> 16) & 255u;
+        b[3] = v >> 24;
+    };
     // 8 rows per batch: the loads of a batch are all in flight before the first add needs one
     for (int r0 = 0; r0 < h; r0 += 8) {
-        uint32_t v[8][kStatMaxK];
+        uint32_t v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint8_t* row = base + (size_t)min(r0 + i, h - 1) * pitch;
-#pragma unroll
-            for (int k = 0; k < kStatMaxK; ++k) v[i][k] = (k < K) ? row[k] : 0u;
-        }
+        for (int i = 0; i < 8; ++i)
+            v[i] = ld ? *reinterpret_cast<const uint32_t*>(base + (size_t)min(r0 + i, h - 1) * pitch) : 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (r0 + i < h) {
+                uint32_t b[4];
+                unpack(v[i], b);
 #pragma unroll
-                for (int k = 0; k < kStatMaxK; ++k) {
-                    c1[k] += v[i][k];
-                    c2[k] += v[i][k] * v[i][k];
+                for (int k = 0; k < 4; ++k) {
+                    c1[k] += b[k];
+                    c2[k] += b[k] * b[k];
                 }
             }
     }
-    if (t == 0) {
-        P1[0] = 0;
-        P2[0] = 0;
-    }
-    const int y1 = min(y0 + kStatBand, oh);
+    const int y1 = min(y0 + kStatBand4, oh);
+    const int xg = x0 + 4 * t;                       // first of this thread's four output columns
+    const bool out_on = 4 * t < owg && xg < st_pitch;   // st_pitch is a multiple of 4: xg + 3 < st_pitch too
     for (int y = y0; y < y1; ++y) {
         // request the two image rows of the slide at the end of this iteration now: their latency
         // hides behind the scan and the float64 statistics
-        uint32_t vn[kStatMaxK] = {0, 0, 0, 0}, vo[kStatMaxK] = {0, 0, 0, 0};
-        if (y + 1 < y1) {
-            const uint8_t* rn = base + (size_t)(y - y0 + h) * pitch;
-            const uint8_t* ro = base + (size_t)(y - y0) * pitch;
-#pragma unroll
-            for (int k = 0; k < kStatMaxK; ++k)
-                if (k < K) {
-                    vn[k] = rn[k];
-                    vo[k] = ro[k];
-                }
+        uint32_t vn = 0, vo = 0;
+        if (y + 1 < y1 && ld) {
+            vn = *reinterpret_cast<const uint32_t*>(base + (size_t)(y - y0 + h) * pitch);
+            vo = *reinterpret_cast<const uint32_t*>(base + (size_t)(y - y0) * pitch);
         }
-        // block-wide inclusive scan of the column sums (thread-local prefix, wave scan, cross-wave)
-        uint32_t a = 0, b = 0, la[kStatMaxK], lb[kStatMaxK];
-#pragma unroll
-        for (int k = 0; k < kStatMaxK; ++k) {
-            if (k < K) {
-                a += c1[k];
-                b += c2[k];
-            }
-            la[k] = a;
-            lb[k] = b;
-        }
+        // block-wide exclusive scan of the column sums (thread-local prefix, wave scan, cross-wave)
+        const uint32_t a = c1[0] + c1[1] + c1[2] + c1[3], b = c2[0] + c2[1] + c2[2] + c2[3];
         const uint32_t sa = wave_inclusive_scan_u32(a), sb = wave_inclusive_scan_u32(b);
         if (lane == 63) {
             wsum[0][wave] = sa;
             wsum[1][wave] = sb;
         }
-        __syncthreads();                 // also: previous row's P reads are done
-        uint32_t oa = sa - a, ob = sb - b;          // exclusive offset of this thread inside its wave
+        __syncthreads();                 // also: previous row's E reads are done
+        uint32_t oa = sa - a, ob = sb - b;          // exclusive offset of this thread's first column
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < wave) {
                 oa += wsum[0][k];
                 ob += wsum[1][k];
             }
-#pragma unroll
-        for (int k = 0; k < kStatMaxK; ++k)
-            if (k < K) {
-                P1[t * K + k + 1] = oa + la[k];
-                P2[t * K + k + 1] = ob + lb[k];
-            }
+        const uint32_t e1[4] = {oa, oa + c1[0], oa + c1[0] + c1[1], oa + c1[0] + c1[1] + c1[2]};
+        const uint32_t e2[4] = {ob, ob + c2[0], ob + c2[0] + c2[1], ob + c2[0] + c2[1] + c2[2]};
+        *reinterpret_cast<uint4*>(&E1[4 * t]) = make_uint4(e1[0], e1[1], e1[2], e1[3]);
+        *reinterpret_cast<uint4*>(&E2[4 * t]) = make_uint4(e2[0], e2[1], e2[2], e2[3]);
+        if (t == 255) {                  // E[kStatStrip]: read when the strip is full width
+            E1[kStatStrip] = oa + a;
+            E2[kStatStrip] = ob + b;
+        }
         __syncthreads();
-        const int x = x0 + t;
-        if (x < ow) {
-            const uint32_t s1 = P1[t + w] - P1[t], s2 = P2[t + w] - P2[t];
-            const double tt = (double)s1;
-            const double wnd_sum2 = (double)s2;
-            double wnd_mean2 = 0.0;
-            if (num_type == 1) wnd_mean2 = (tt * tt) * inv_area;
-            const size_t o = (size_t)y * st_pitch + x;
-            if (want_t) t0[o] = tt;
-            if (want_sum2) sum2[o] = wnd_sum2;
+        if (out_on) {
+            double tt[4], ws2[4], sqv[4], rs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t s1 = E1[4 * t + k + w] - e1[k], s2 = E2[4 * t + k + w] - e2[k];
+                tt[k] = (double)s1;
+                ws2[k] = (double)s2;
+                double wnd_mean2 = 0.0;
+                if (num_type == 1) wnd_mean2 = (tt[k] * tt[k]) * inv_area;
+                const double diff2 = fmax(ws2[k] - wnd_mean2, 0.0);
+                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * ws2[k]);
+#ifdef MTM_PROBE_STAT_NO_SQRT   /* timing experiment (wrong results) */
+                sqv[k] = small ? 0.0 : diff2;
+#else
+                sqv[k] = small ? 0.0 : sqrt(diff2);
+#endif
+                rs[k] = sqv[k] > 0.0 ? 1.0 / sqv[k] : 0.0;
+            }
+            const size_t o = (size_t)y * st_pitch + xg;
+            if (want_t) {
+                *reinterpret_cast<double2*>(t0 + o) = make_double2(tt[0], tt[1]);
+                *reinterpret_cast<double2*>(t0 + o + 2) = make_double2(tt[2], tt[3]);
+            }
+            if (want_sum2) {
+                *reinterpret_cast<double2*>(sum2 + o) = make_double2(ws2[0], ws2[1]);
+                *reinterpret_cast<double2*>(sum2 + o + 2) = make_double2(ws2[2], ws2[3]);
+            }
             if (want_sq) {
-                const double diff2 = fmax(wnd_sum2 - wnd_mean2, 0.0);
-                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * wnd_sum2);
-                const double sqv = small ? 0.0 : sqrt(diff2);
-                sq[o] = sqv;
-                if (rsq != nullptr) rsq[o] = sqv > 0.0 ? 1.0 / sqv : 0.0;      // row-multiplexed MFMA classes
+                *reinterpret_cast<double2*>(sq + o) = make_double2(sqv[0], sqv[1]);
+                *reinterpret_cast<double2*>(sq + o + 2) = make_double2(sqv[2], sqv[3]);
+                if (rsq != nullptr) {                // row-multiplexed MFMA classes
+                    *reinterpret_cast<double2*>(rsq + o) = make_double2(rs[0], rs[1]);
+                    *reinterpret_cast<double2*>(rsq + o + 2) = make_double2(rs[2], rs[3]);
+                }
             }
         }
         // slide the column sums one row down (zeros on the last row: nothing changes)
+        uint32_t bn[4], bo[4];
+        unpack(vn, bn);
+        unpack(vo, bo);
 #pragma unroll
-        for (int k = 0; k < kStatMaxK; ++k)
-            if (k < K) {
-                c1[k] += vn[k] - vo[k];
-                c2[k] += vn[k] * vn[k] - vo[k] * vo[k];
-            }
+        for (int k = 0; k < 4; ++k) {
+            c1[k] += bn[k] - bo[k];
+            c2[k] += bn[k] * bn[k] - bo[k] * bo[k];
+        }
     }
 }
 

@@ -582,13 +582,14 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
                              c->fuse_stats;
     if (fused_stats) {
         const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always || masked_mfma) ? 1 : 0;
-        const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+        const int owg = stats_u8_owg(w);
+        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
         double* rsq = nullptr;
         if (sc.rm_R > 0 && normed) {
             MTMC(c->stats_rsq.ensure(sizeof(double) * plane));
             rsq = c->stats_rsq.as<double>();
         }
-        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, inv_area,
+        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, owg, inv_area,
                            num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch, rsq);
     } else if (u8 && c->chans == 3 && w <= 768 && (double)w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
         // RGB: the fused kernel with one scan per channel and row (sum2 always written: vsum_stats_kernel does)
@@ -619,9 +620,10 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     if (rk == MTM_KERNEL_MFMA16) {
         // window sums of the high-byte plane (bias terms of the byte-plane correlations)
         MTMC(c->stats_hi.ensure(sizeof(double) * plane));
-        const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
-        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, inv_area, 0, 0,
-                           1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr, st.pitch);
+        const int owg = stats_u8_owg(w);
+        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
+        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, owg, inv_area, 0,
+                           0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr, st.pitch);
     }
     HIPC(hipGetLastError());
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
@@ -641,9 +643,10 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
         }
         MTMC(c->stats_hi.ensure(sizeof(double) * plane));
         {
-            const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+            const int owg = stats_u8_owg(w);
+            const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
             hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, c->sq_planes.as<uint8_t>(), img.u8_pitch, h, w, oh,
-                               ow, inv_area, 0, 0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr,
+                               ow, owg, inv_area, 0, 0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr,
                                st.pitch);
         }
         const int map_pitch = (int)round_up((size_t)ow, 4);
