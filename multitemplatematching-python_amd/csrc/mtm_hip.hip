@@ -170,6 +170,7 @@ struct mtm_ctx {
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
     bool hits_only_now = false;
+    const void* cands_zeroed = nullptr;   // candidate buffer whose counter was cleared after the previous call's fetch
     bool ext_now = false;      // this call: global extrema come out of the MFMA epilogue (no maps, no extremum_kernel)
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
     int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
@@ -1568,8 +1569,12 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     }
     const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
     if (fused) {
+        const size_t cands_cap = c->cands.cap;
         MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
-        HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        if (c->cands.cap != cands_cap) c->cands_zeroed = nullptr;      // reallocated (possibly at the same address)
+        // the counter is normally cleared right after the previous call fetched it (off the critical path)
+        if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        c->cands_zeroed = nullptr;
         c->cand_on = true;
         c->cand_min = mode_min;
         c->cand_thr = mode_min ? -thr : thr;
@@ -1666,6 +1671,8 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
             unsigned long long ncand = 0;
             std::memcpy(&ncand, land, sizeof(ncand));
             if (ncand <= nfetch) {
+                // everything needed is on the host: clear the counter for the next call while this one finishes
+                if (hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess) c->cands_zeroed = c->cands.p;
                 const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(land + 16);
                 std::unordered_map<unsigned long long, int> where;
                 where.reserve((size_t)ncand * 2 + 8);
