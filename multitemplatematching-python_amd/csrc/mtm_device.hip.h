@@ -276,11 +276,6 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
 // The launcher uses it for w <= 768 and w * h * 255^2 < 2^32; everything else takes hsum_* +
 // vsum_stats_kernel.
 // ---------------------------------------------------------------------------------------------
-#ifndef MTM_STAT_BAND
-#define MTM_STAT_BAND 32
-#endif
-constexpr int kStatBand = MTM_STAT_BAND;      // stats_u8_mc_kernel (one column per thread)
-constexpr int kStatMaxK = 4;                   // image columns per thread there: ceil((256 + w - 1) / 256) <= 4
 #ifndef MTM_STAT_BAND4
 #define MTM_STAT_BAND4 8
 #endif
@@ -413,105 +408,136 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
 
 // The same for CH interleaved-to-planar channels (RGB): per-channel window sums S1_c, the sum of squares
 // over all channels and the guarded sqrt of  sum_c S2_c - (sum_c S1_c^2) / A  (operation order of
-// vsum_stats_kernel, so both routes round alike).  One scan per channel and row.
+// vsum_stats_kernel, so both routes round alike; the squares of the channels are added as integers
+// before the scan, which is exact).  CH + 1 scans behind ONE pair of barriers per output row.  The
+// launcher requires CH * w * h * 255^2 < 2^32.
 template <int CH>
 __global__ __launch_bounds__(256) void stats_u8_mc_kernel(const uint8_t* __restrict__ img, int pitch, long long plane,
-                                                          int h, int w, int oh, int ow, double inv_area, int num_type,
-                                                          int want_sq, int want_t, int want_sum2,
+                                                          int h, int w, int oh, int ow, int owg, double inv_area,
+                                                          int num_type, int want_sq, int want_t, int want_sum2,
                                                           double* __restrict__ t0, long long t_plane,
                                                           double* __restrict__ sum2, double* __restrict__ sq,
                                                           int st_pitch) {
-    __shared__ uint32_t P1[256 * kStatMaxK + 1], P2[256 * kStatMaxK + 1];
-    __shared__ uint32_t wsum[2][4];
-    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kStatBand;
+    __shared__ __attribute__((aligned(16))) uint32_t E[CH + 1][kStatStrip + 4];     // exclusive prefixes: S1_c, S2
+    __shared__ uint32_t wsum[CH + 1][4];
+    const int x0 = blockIdx.x * owg, y0 = blockIdx.y * kStatBand4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int L = 256 + w - 1;
-    const int K = (L + 255) >> 8;
-    const uint8_t* base = img + (size_t)y0 * pitch + x0 + t * K;
-    uint32_t c1[CH][kStatMaxK], c2[CH][kStatMaxK];
+    const int L = owg + w - 1;
+    const bool ld = 4 * t < L && x0 + 4 * t + 3 < pitch;
+    const uint8_t* base = img + (size_t)y0 * pitch + x0 + 4 * t;
+    uint32_t cs[CH + 1][4];                          // column sums: S1 of each channel, S2 of all channels
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
+    for (int c = 0; c <= CH; ++c)
 #pragma unroll
-        for (int k = 0; k < kStatMaxK; ++k) c1[c][k] = c2[c][k] = 0u;
-        for (int r = 0; r < h; ++r) {
-            const uint8_t* row = base + c * plane + (size_t)r * pitch;
+        for (int k = 0; k < 4; ++k) cs[c][k] = 0u;
+    auto unpack = [](uint32_t v, uint32_t (&b)[4]) {
+        b[0] = v & 255u;
+        b[1] = (v >> 8) & 255u;
+        b[2] = (v >> 16) & 255u;
+        b[3] = v >> 24;
+    };
+    for (int r0 = 0; r0 < h; r0 += 4) {
+        uint32_t v[4][CH];
 #pragma unroll
-            for (int k = 0; k < kStatMaxK; ++k)
-                if (k < K) {
-                    const uint32_t v = row[k];
-                    c1[c][k] += v;
-                    c2[c][k] += v * v;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                v[i][c] = ld ? *reinterpret_cast<const uint32_t*>(base + c * plane + (size_t)min(r0 + i, h - 1) * pitch) : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + i < h) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    uint32_t b[4];
+                    unpack(v[i][c], b);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        cs[c][k] += b[k];
+                        cs[CH][k] += b[k] * b[k];
+                    }
                 }
-        }
+            }
     }
-    if (t == 0) {
-        P1[0] = 0;
-        P2[0] = 0;
-    }
-    const int y1 = min(y0 + kStatBand, oh);
+    const int y1 = min(y0 + kStatBand4, oh);
+    const int xg = x0 + 4 * t;
+    const bool out_on = 4 * t < owg && xg < st_pitch;
     for (int y = y0; y < y1; ++y) {
-        const int x = x0 + t;
-        const size_t o = (size_t)y * st_pitch + x;
-        double wnd_mean2 = 0.0, wnd_sum2 = 0.0;
+        uint32_t vn[CH], vo[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            uint32_t a = 0, b = 0, la[kStatMaxK], lb[kStatMaxK];
-#pragma unroll
-            for (int k = 0; k < kStatMaxK; ++k) {
-                if (k < K) {
-                    a += c1[c][k];
-                    b += c2[c][k];
-                }
-                la[k] = a;
-                lb[k] = b;
-            }
-            const uint32_t sa = wave_inclusive_scan_u32(a), sb = wave_inclusive_scan_u32(b);
-            __syncthreads();                 // the previous channel's / row's P reads are done
-            if (lane == 63) {
-                wsum[0][wave] = sa;
-                wsum[1][wave] = sb;
-            }
-            __syncthreads();
-            uint32_t oa = sa - a, ob = sb - b;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < wave) {
-                    oa += wsum[0][k];
-                    ob += wsum[1][k];
-                }
-#pragma unroll
-            for (int k = 0; k < kStatMaxK; ++k)
-                if (k < K) {
-                    P1[t * K + k + 1] = oa + la[k];
-                    P2[t * K + k + 1] = ob + lb[k];
-                }
-            __syncthreads();
-            if (x < ow) {
-                const double tt = (double)(P1[t + w] - P1[t]);
-                if (num_type == 1) wnd_mean2 += tt * tt;
-                if (want_t) t0[c * t_plane + o] = tt;
-                wnd_sum2 += (double)(P2[t + w] - P2[t]);
-            }
-            // slide this channel's column sums one row down
-            if (y + 1 < y1) {
-                const uint8_t* rn = base + c * plane + (size_t)(y - y0 + h) * pitch;
-                const uint8_t* ro = base + c * plane + (size_t)(y - y0) * pitch;
-#pragma unroll
-                for (int k = 0; k < kStatMaxK; ++k)
-                    if (k < K) {
-                        const uint32_t vn = rn[k], vo = ro[k];
-                        c1[c][k] += vn - vo;
-                        c2[c][k] += vn * vn - vo * vo;
-                    }
+            vn[c] = vo[c] = 0u;
+            if (y + 1 < y1 && ld) {
+                vn[c] = *reinterpret_cast<const uint32_t*>(base + c * plane + (size_t)(y - y0 + h) * pitch);
+                vo[c] = *reinterpret_cast<const uint32_t*>(base + c * plane + (size_t)(y - y0) * pitch);
             }
         }
-        if (x < ow) {
-            wnd_mean2 *= inv_area;
-            if (want_sum2) sum2[o] = wnd_sum2;
+        uint32_t tot[CH + 1], sc[CH + 1];
+#pragma unroll
+        for (int c = 0; c <= CH; ++c) {
+            tot[c] = cs[c][0] + cs[c][1] + cs[c][2] + cs[c][3];
+            sc[c] = wave_inclusive_scan_u32(tot[c]);
+            if (lane == 63) wsum[c][wave] = sc[c];
+        }
+        __syncthreads();                 // also: previous row's E reads are done
+        uint32_t e[CH + 1][4];
+#pragma unroll
+        for (int c = 0; c <= CH; ++c) {
+            uint32_t off = sc[c] - tot[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < wave) off += wsum[c][k];
+            e[c][0] = off;
+            e[c][1] = off + cs[c][0];
+            e[c][2] = e[c][1] + cs[c][1];
+            e[c][3] = e[c][2] + cs[c][2];
+            *reinterpret_cast<uint4*>(&E[c][4 * t]) = make_uint4(e[c][0], e[c][1], e[c][2], e[c][3]);
+            if (t == 255) E[c][kStatStrip] = off + tot[c];
+        }
+        __syncthreads();
+        if (out_on) {
+            const size_t o = (size_t)y * st_pitch + xg;
+            double mean2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                double tt[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tt[k] = (double)(E[c][4 * t + k + w] - e[c][k]);
+                    if (num_type == 1) mean2[k] += tt[k] * tt[k];
+                }
+                if (want_t) {
+                    *reinterpret_cast<double2*>(t0 + c * t_plane + o) = make_double2(tt[0], tt[1]);
+                    *reinterpret_cast<double2*>(t0 + c * t_plane + o + 2) = make_double2(tt[2], tt[3]);
+                }
+            }
+            double ws2[4], sqv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ws2[k] = (double)(E[CH][4 * t + k + w] - e[CH][k]);
+                const double wnd_mean2 = mean2[k] * inv_area;
+                const double diff2 = fmax(ws2[k] - wnd_mean2, 0.0);
+                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * ws2[k]);
+                sqv[k] = small ? 0.0 : sqrt(diff2);
+            }
+            if (want_sum2) {
+                *reinterpret_cast<double2*>(sum2 + o) = make_double2(ws2[0], ws2[1]);
+                *reinterpret_cast<double2*>(sum2 + o + 2) = make_double2(ws2[2], ws2[3]);
+            }
             if (want_sq) {
-                const double diff2 = fmax(wnd_sum2 - wnd_mean2, 0.0);
-                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * wnd_sum2);
-                sq[o] = small ? 0.0 : sqrt(diff2);
+                *reinterpret_cast<double2*>(sq + o) = make_double2(sqv[0], sqv[1]);
+                *reinterpret_cast<double2*>(sq + o + 2) = make_double2(sqv[2], sqv[3]);
+            }
+        }
+        // slide the column sums one row down (zeros on the last row: nothing changes)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            uint32_t bn[4], bo[4];
+            unpack(vn[c], bn);
+            unpack(vo[c], bo);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cs[c][k] += bn[k] - bo[k];
+                cs[CH][k] += bn[k] * bn[k] - bo[k] * bo[k];
             }
         }
     }

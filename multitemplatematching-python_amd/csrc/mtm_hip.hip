@@ -184,6 +184,8 @@ struct mtm_ctx {
     std::vector<mtm_hit> last_hits;     // result of the last mtm_find_matches (for mtm_last_hits)
     void* pinned = nullptr;             // pinned host buffer the candidate records land in
     size_t pinned_cap = 0;
+    void* comm_pin = nullptr;           // pinned staging of the hit exchange: [my slot | gathered slots]
+    size_t comm_pin_cap = 0;
     std::vector<uint8_t> templ_blob;    // bytes of the templates of the last mtm_set_templates (unchanged-input test)
 
     // RCCL
@@ -592,11 +594,14 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
         }
         hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, owg, inv_area,
                            num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch, rsq);
-    } else if (u8 && c->chans == 3 && w <= 768 && (double)w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
-        // RGB: the fused kernel with one scan per channel and row (sum2 always written: vsum_stats_kernel does)
-        const dim3 gs((ow + 255) / 256, (oh + kStatBand - 1) / kStatBand);
+    } else if (u8 && c->chans == 3 && w <= 768 && 3.0 * w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
+        // RGB: the fused kernel with one scan per channel + one for the squares (sum2 always written:
+        // vsum_stats_kernel does)
+        const int owg = stats_u8_owg(w);
+        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
         hipLaunchKernelGGL(stats_u8_mc_kernel<3>, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, img.u8_plane, h, w, oh,
-                           ow, inv_area, num_type, normed ? 1 : 0, want_t, 1, tp[0], (long long)plane, sum2, sq, st.pitch);
+                           ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, 1, tp[0], (long long)plane, sum2, sq,
+                           st.pitch);
     } else if (u8) {
         if (c->cols <= 8191)
             hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
@@ -1153,6 +1158,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
                       &c->comm_recv})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->comm_pin) (void)hipHostFree(c->comm_pin);
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& p : c->ncc_ev) {
@@ -1968,25 +1974,37 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
     // The slot size adapts to the data: it starts at 512 records and follows twice the largest count
     // of the previous exchange (a value every rank knows, so the ranks always agree on it).
     std::vector<long long> counts((size_t)R, 0);
-    std::vector<uint8_t> all;
+    const uint8_t* all = nullptr;      // the gathered slots of the last round (pinned staging)
     long long slot_hits = c->comm_slot_hits;
     for (int round = 0; round < 2; ++round) {
         const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
         MTMC(c->comm_send.ensure(slot));
         MTMC(c->comm_recv.ensure(slot * R));
-        std::vector<uint8_t> mine(16 + sizeof(mtm_hit) * (size_t)std::min<long long>(n_local, slot_hits), 0);
+        // pinned staging [my slot | R gathered slots]: both copies are plain DMAs queued behind each other
+        // on the stream, one synchronisation per exchange
+        const size_t pin_bytes = slot * (size_t)(R + 1);
+        if (c->comm_pin_cap < pin_bytes) {
+            if (c->comm_pin) (void)hipHostFree(c->comm_pin);
+            c->comm_pin = nullptr;
+            c->comm_pin_cap = 0;
+            HIPC(hipHostMalloc(&c->comm_pin, pin_bytes, hipHostMallocDefault));
+            c->comm_pin_cap = pin_bytes;
+        }
+        uint8_t* mine = static_cast<uint8_t*>(c->comm_pin);
+        uint8_t* gathered = mine + slot;
+        const size_t mine_bytes = 16 + sizeof(mtm_hit) * (size_t)std::min<long long>(n_local, slot_hits);
+        std::memset(mine, 0, 16);
         const long long cnt = n_local;
-        std::memcpy(mine.data(), &cnt, sizeof(cnt));
-        if (n_local > 0)
-            std::memcpy(mine.data() + 16, local, sizeof(mtm_hit) * (size_t)std::min<long long>(n_local, slot_hits));
-        HIPC(hipMemcpyAsync(c->comm_send.p, mine.data(), mine.size(), hipMemcpyHostToDevice, c->stream));
+        std::memcpy(mine, &cnt, sizeof(cnt));
+        if (n_local > 0) std::memcpy(mine + 16, local, mine_bytes - 16);
+        HIPC(hipMemcpyAsync(c->comm_send.p, mine, mine_bytes, hipMemcpyHostToDevice, c->stream));
         NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream));
-        all.resize(slot * R);
-        HIPC(hipMemcpyAsync(all.data(), c->comm_recv.p, slot * R, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipMemcpyAsync(gathered, c->comm_recv.p, slot * R, hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
+        all = gathered;
         long long mx = 0;
         for (int r = 0; r < R; ++r) {
-            std::memcpy(&counts[r], all.data() + slot * r, sizeof(long long));
+            std::memcpy(&counts[r], all + slot * r, sizeof(long long));
             mx = std::max(mx, counts[r]);
         }
         long long want = 512;
@@ -2008,7 +2026,7 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
     const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
     int64_t o = 0;
     for (int r = 0; r < R; ++r) {
-        if (counts[r]) std::memcpy(out + o, all.data() + slot * r + 16, sizeof(mtm_hit) * (size_t)counts[r]);
+        if (counts[r]) std::memcpy(out + o, all + slot * r + 16, sizeof(mtm_hit) * (size_t)counts[r]);
         o += counts[r];
     }
     return MTM_OK;
