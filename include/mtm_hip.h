@@ -69,10 +69,11 @@ extern "C" {
 #define MTM_OPT_DOT4_VARIANT 4  /* register-blocking variant of the dot4 kernel (tuning) */
 #define MTM_OPT_EXACT_DIV 5     /* 1: IEEE division in the MFMA epilogue (bit-identical to the other kernels);
                                    0 (default): reciprocal multiplies, <= 1 ulp(float32) on ~1e-8 of the pixels */
-#define MTM_OPT_HITS_ONLY 6     /* 1 (default): mtm_find_matches in local-extrema mode does not write the score
-                                   maps to memory when every template runs the single-channel int8 MFMA kernel
-                                   (peaks come from the in-kernel candidate list); 0: always materialise them.
-                                   Results are identical either way. */
+#define MTM_OPT_HITS_ONLY 6     /* 1 (default): mtm_find_matches does not write the score maps to memory when every
+                                   template runs the int8 MFMA kernel: in local-extrema mode the peaks come from
+                                   the in-kernel candidate list, in global-extremum mode (unmasked single-channel
+                                   templates) the per-template best is kept inside the score kernel;
+                                   0: always materialise the maps.  Results are identical either way. */
 
 /* error codes */
 #define MTM_OK            0
