@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--config", default="north_star", help="north_star | cfg2 | cfg3 | cfg5")
     ap.add_argument("--kernel", default=os.environ.get("MTM_KERNEL", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequential", action="store_true",
+                    help="N > 1 only: no software pipelining (the host part of a step finishes before the next step's "
+                         "GPU part starts)")
     ap.add_argument("--skip-extras", action="store_true",
                     help="only the timed steps (profiling runs): no map-mode / end-to-end / stream side measurements")
     ap.add_argument("--cpu-sample-templates", type=int, default=0)
@@ -215,7 +218,12 @@ def main():
 
     kernel_ms, total_ms, launches = [], [], 0
 
-    def step():
+    # A step = GPU part (window statistics, score kernel, peak extraction, D2H of the hits, all-gather of the
+    # hit records) + host part (merge in template order, global NMS, the reference's list of tuples).  The
+    # steps are software-pipelined like MTM.TemplateMatcher.match_stream: while this thread is inside the
+    # native calls of step i+1 (they release the GIL) a helper thread does the host part of step i.  Every
+    # step is complete - its hit list built - inside the timed region; `--sequential` turns it off.
+    def gpu_part():
         nonlocal launches
         raw = ctx.find_matches(_lib.PEAKS_LOCAL, thr).copy()
         t = ctx.timing()
@@ -223,16 +231,43 @@ def main():
         total_ms.append(t["total_ms"])
         launches = t["ncc_launches"]
         raw["templ_idx"] = gidx[raw["templ_idx"]]
-        allhits = exchange.allgather(raw)
-        return merge_and_nms(allhits, units, method, float("inf"), thr, 0.25), t
+        return exchange.allgather(raw), t
+
+    def host_part(allhits):
+        return merge_and_nms(allhits, units, method, float("inf"), thr, 0.25)
+
+    from concurrent.futures import ThreadPoolExecutor
+    # Worth it only where the host part is long: with N ranks every rank merges N times the hits (0.3-0.5 ms of
+    # Python per step at N = 8 against 0.05 ms at N = 1, where the hand-over to a thread costs as much as it
+    # hides: 0.87 ms pipelined against 0.83 ms sequential, measured).
+    pool = ThreadPoolExecutor(max_workers=1) if (world > 1 and not args.sequential) else None
+    if pool is not None:
+        sys.setswitchinterval(1e-4)      # a thread coming back from a native call gets the GIL within ~0.1 ms
+
+    def run_steps(k, pipelined=True):
+        """k steps; returns the hit list and the timing record of the last one."""
+        last = (None, None)
+        if pool is None or not pipelined:
+            for _ in range(k):
+                allhits, t = gpu_part()
+                last = (host_part(allhits), t)
+            return last
+        pending = None
+        for _ in range(k):
+            allhits, t = gpu_part()
+            if pending is not None:
+                pending.result()                 # host part of the previous step: finished during the GPU part
+            pending = pool.submit(host_part, allhits)
+            last = (None, t)
+        if pending is not None:
+            last = (pending.result(), last[1])
+        return last
 
     # The GPU leaves its idle clock only after ~50 ms of load (tools/ramp_probe.py: the first 40 calls run
     # 8 % slower than the steady state).  A fixed number of untimed steps - the same on every rank, the
     # step contains a collective - brings it to the sustained clock before the W warm-up steps.
-    for _ in range(PREWARM_STEPS):
-        step()
-    for _ in range(args.warmup):
-        step()
+    run_steps(PREWARM_STEPS)
+    run_steps(args.warmup)
     kernel_ms.clear()
     total_ms.clear()
     # like timeit: no cyclic garbage collection inside the timed region (with torch imported a full
@@ -241,8 +276,7 @@ def main():
     gc.disable()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hits, tinfo = step()
+    hits, tinfo = run_steps(args.steps)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -255,12 +289,11 @@ def main():
     maps_mode = None
     if world == 1 and tinfo.get("hits_only") and not args.skip_extras:
         ctx.set_option(_lib.OPT_HITS_ONLY, 0)
-        step()
+        run_steps(1)
         km0 = len(kernel_ms)
         sync()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            hits_m, _t = step()
+        hits_m, _t = run_steps(args.steps)
         sync()
         dtm = time.perf_counter() - t1
         maps_mode = {"value": round(img.shape[0] * img.shape[1] * len(units) * args.steps / dtm / 1e6, 1),
@@ -333,7 +366,10 @@ def main():
                        "units_per_gpu": len(my_units), "method": method, "score_threshold": thr,
                        "max_overlap": 0.25, "prewarm_steps": PREWARM_STEPS, "parallelism": "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
                        "timed_region": "window statistics + correlation/normalisation kernel + peak extraction + D2H hits + "
-                                       "all-gather + NMS; image/templates resident in HBM",
+                                       "all-gather + NMS + hit list; image/templates resident in HBM",
+                       "pipelining": "none (one rank, or --sequential)" if pool is None else
+                                     "host part of step i (merge, NMS, hit list; helper thread) overlaps the GPU part "
+                                     "of step i+1; all K hit lists are built inside the timed region",
                        "score_maps": "not materialised (hits-only mode, MTM_OPT_HITS_ONLY=1: identical hit lists)" if hits_only
                                      else "materialised in HBM"},
             "roofline": roof,
