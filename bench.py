@@ -51,8 +51,7 @@ def parse():
     ap.add_argument("--kernel", default=os.environ.get("MTM_KERNEL", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sequential", action="store_true",
-                    help="N > 1 only: no software pipelining (the host part of a step finishes before the next step's "
-                         "GPU part starts)")
+                    help="no software pipelining: the host part of a step finishes before the next step's GPU part starts")
     ap.add_argument("--skip-extras", action="store_true",
                     help="only the timed steps (profiling runs): no map-mode / end-to-end / stream side measurements")
     ap.add_argument("--cpu-sample-templates", type=int, default=0)
@@ -218,49 +217,40 @@ def main():
 
     kernel_ms, total_ms, launches = [], [], 0
 
-    # A step = GPU part (window statistics, score kernel, peak extraction, D2H of the hits, all-gather of the
-    # hit records) + host part (merge in template order, global NMS, the reference's list of tuples).  The
-    # steps are software-pipelined like MTM.TemplateMatcher.match_stream: while this thread is inside the
-    # native calls of step i+1 (they release the GIL) a helper thread does the host part of step i.  Every
-    # step is complete - its hit list built - inside the timed region; `--sequential` turns it off.
-    def gpu_part():
+    # A step = GPU part (window statistics, score kernel, peak extraction, D2H of the hits), the all-gather of
+    # the hit records, and the host part (merge in template order, global NMS, the reference's list of tuples).
+    # The steps are software-pipelined: the GPU part of step i+1 is started (mtm_find_matches_async: a worker
+    # thread of the library drives it) before this thread does the host part of step i, the way
+    # MTM.TemplateMatcher.match_stream overlaps the two for an image stream.  Every step is complete - its hit
+    # list built - inside the timed region; `--sequential` turns the overlap off.
+    def collect(raw):
         nonlocal launches
-        raw = ctx.find_matches(_lib.PEAKS_LOCAL, thr).copy()
+        raw = raw.copy()
         t = ctx.timing()
         kernel_ms.append(t["ncc_kernel_ms"])
         total_ms.append(t["total_ms"])
         launches = t["ncc_launches"]
         raw["templ_idx"] = gidx[raw["templ_idx"]]
-        return exchange.allgather(raw), t
+        return exchange.allgather(raw), t          # the context is idle here: the collective uses its stream
 
     def host_part(allhits):
         return merge_and_nms(allhits, units, method, float("inf"), thr, 0.25)
 
-    from concurrent.futures import ThreadPoolExecutor
-    # Worth it only where the host part is long: with N ranks every rank merges N times the hits (0.3-0.5 ms of
-    # Python per step at N = 8 against 0.05 ms at N = 1, where the hand-over to a thread costs as much as it
-    # hides: 0.87 ms pipelined against 0.83 ms sequential, measured).
-    pool = ThreadPoolExecutor(max_workers=1) if (world > 1 and not args.sequential) else None
-    if pool is not None:
-        sys.setswitchinterval(1e-4)      # a thread coming back from a native call gets the GIL within ~0.1 ms
-
     def run_steps(k, pipelined=True):
         """k steps; returns the hit list and the timing record of the last one."""
         last = (None, None)
-        if pool is None or not pipelined:
+        if args.sequential or not pipelined:
             for _ in range(k):
-                allhits, t = gpu_part()
+                allhits, t = collect(ctx.find_matches(_lib.PEAKS_LOCAL, thr))
                 last = (host_part(allhits), t)
             return last
-        pending = None
-        for _ in range(k):
-            allhits, t = gpu_part()
-            if pending is not None:
-                pending.result()                 # host part of the previous step: finished during the GPU part
-            pending = pool.submit(host_part, allhits)
-            last = (None, t)
-        if pending is not None:
-            last = (pending.result(), last[1])
+        if k > 0:
+            ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
+        for i in range(k):
+            allhits, t = collect(ctx.find_matches_wait())
+            if i + 1 < k:
+                ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
+            last = (host_part(allhits), t)
         return last
 
     # The GPU leaves its idle clock only after ~50 ms of load (tools/ramp_probe.py: the first 40 calls run
@@ -284,6 +274,20 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # the same K steps one after the other (host part of a step before the GPU part of the next): reported
+    # next to `value`
+    seq_ms = None
+    if world == 1 and not args.sequential and not args.skip_extras:
+        km0 = len(kernel_ms)
+        gc.disable()
+        sync()
+        t1 = time.perf_counter()
+        run_steps(args.steps, pipelined=False)
+        sync()
+        seq_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        gc.enable()
+        del kernel_ms[km0:], total_ms[km0:]
 
     # the same steps with the score maps written to HBM (MTM_OPT_HITS_ONLY = 0): reported next to `value`
     maps_mode = None
@@ -367,14 +371,15 @@ def main():
                        "max_overlap": 0.25, "prewarm_steps": PREWARM_STEPS, "parallelism": "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
                        "timed_region": "window statistics + correlation/normalisation kernel + peak extraction + D2H hits + "
                                        "all-gather + NMS + hit list; image/templates resident in HBM",
-                       "pipelining": "none (one rank, or --sequential)" if pool is None else
-                                     "host part of step i (merge, NMS, hit list; helper thread) overlaps the GPU part "
-                                     "of step i+1; all K hit lists are built inside the timed region",
+                       "pipelining": "none (--sequential)" if args.sequential else
+                                     "the GPU part of step i+1 (mtm_find_matches_async) runs under the host part of step i "
+                                     "(merge, NMS, hit list); all K hit lists are built inside the timed region",
                        "score_maps": "not materialised (hits-only mode, MTM_OPT_HITS_ONLY=1: identical hit lists)" if hits_only
                                      else "materialised in HBM"},
             "roofline": roof,
             "gpu_ms": {"kernels_total": round(float(np.mean(total_ms)), 4), "ncc_kernel": round(float(np.mean(kernel_ms)), 4)},
             "hits": len(hits), "planted_found": bool(planted_ok),
+            "sequential_ms_per_step": None if seq_ms is None else round(seq_ms, 4),
             "score_maps_materialised": maps_mode,
             "e2e_call_ms": None if e2e_ms is None else round(e2e_ms, 3),
             "e2e_call_mpx_corr_s": None if e2e_ms is None else round(px * len(units) / e2e_ms / 1e3, 1),

@@ -66,6 +66,8 @@ SYMBOLS = {
     "mtm_find_matches_next": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                              ctypes.c_int64, _P(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "mtm_find_matches_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]),
+    "mtm_find_matches_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "mtm_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_get_timing": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTiming)]),
     "mtm_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
@@ -230,6 +232,23 @@ class Context:
             out = np.empty(cap, dtype=HIT_DTYPE)
             rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
         check(rc, "mtm_find_matches")
+        return out[:n.value]
+
+    def find_matches_async(self, mode, score_threshold):
+        """Start mtm_find_matches on the context's worker thread and return at once; collect the hits with
+        find_matches_wait().  Nothing else may use the context in between."""
+        check(self._lib.mtm_find_matches_async(self._h, int(mode), float(score_threshold)), "mtm_find_matches_async")
+
+    def find_matches_wait(self):
+        cap = 4096
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_find_matches_wait(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        if rc == E_OVERFLOW:
+            cap = int(n.value)
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        check(rc, "mtm_find_matches_wait")
         return out[:n.value]
 
     def timing(self):

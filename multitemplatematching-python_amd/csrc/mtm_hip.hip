@@ -7,10 +7,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -115,6 +118,20 @@ constexpr int kNumDotVariants = sizeof(kDotVariants) / sizeof(kDotVariants[0]);
 
 }  // namespace
 
+// mtm_find_matches_async / _wait: one worker thread per context runs the (blocking) call, so that a
+// single-threaded host (the Python layer holds the GIL) can build the hit list of step i while the GPU
+// works on step i+1.
+struct AsyncWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int state = 0;             // 0 idle, 1 call posted / running, 2 result ready, 3 quit
+    int mode = 0;
+    double thr = 0.0;
+    int rc = 0;
+    std::string err;
+};
+
 struct mtm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -170,6 +187,7 @@ struct mtm_ctx {
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
     bool hits_only_now = false;
+    AsyncWorker* aw = nullptr;          // created by the first mtm_find_matches_async
     const void* cands_zeroed = nullptr;   // candidate buffer whose counter was cleared after the previous call's fetch
     bool ext_now = false;      // this call: global extrema come out of the MFMA epilogue (no maps, no extremum_kernel)
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
@@ -1147,6 +1165,17 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
 
 void mtm_ctx_destroy(mtm_ctx* c) {
     if (!c) return;
+    if (c->aw) {                         // let a call in flight finish, then stop the worker
+        {
+            std::unique_lock<std::mutex> lk(c->aw->mu);
+            c->aw->cv.wait(lk, [&] { return c->aw->state != 1; });
+            c->aw->state = 3;
+        }
+        c->aw->cv.notify_all();
+        c->aw->th.join();
+        delete c->aw;
+        c->aw = nullptr;
+    }
     (void)hipSetDevice(c->device);
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
@@ -1876,6 +1905,79 @@ int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
     }
     if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
     return MTM_OK;
+}
+
+int mtm_find_matches_async(mtm_ctx* c, int mode, double score_threshold) {
+    if (!c || (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
+        set_error("mtm_find_matches_async: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (!c->aw) {
+        c->aw = new AsyncWorker();
+        AsyncWorker* w = c->aw;
+        w->th = std::thread([c, w] {
+            for (;;) {
+                int mode;
+                double thr;
+                {
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    w->cv.wait(lk, [&] { return w->state == 1 || w->state == 3; });
+                    if (w->state == 3) return;
+                    mode = w->mode;
+                    thr = w->thr;
+                }
+                int64_t n = 0;
+                int rc = find_matches_impl(c, mode, thr, nullptr, 0, &n, nullptr);   // the hits stay in the context
+                std::string err;
+                if (rc == MTM_E_OVERFLOW) rc = MTM_OK;                               // capacity 0: expected
+                if (rc != MTM_OK) err = mtm_last_error();                            // this thread's message
+                {
+                    std::lock_guard<std::mutex> lk(w->mu);
+                    w->rc = rc;
+                    w->err.swap(err);
+                    w->state = 2;
+                }
+                w->cv.notify_all();
+            }
+        });
+    }
+    {
+        std::lock_guard<std::mutex> lk(c->aw->mu);
+        if (c->aw->state != 0) {
+            set_error("mtm_find_matches_async: a call is already in flight (collect it with mtm_find_matches_wait)");
+            return MTM_E_INVALID;
+        }
+        c->aw->mode = mode;
+        c->aw->thr = score_threshold;
+        c->aw->state = 1;
+    }
+    c->aw->cv.notify_all();
+    return MTM_OK;
+}
+
+int mtm_find_matches_wait(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        set_error("mtm_find_matches_wait: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (!c->aw) {
+        set_error("mtm_find_matches_wait: no call in flight");
+        return MTM_E_INVALID;
+    }
+    int rc;
+    {
+        std::unique_lock<std::mutex> lk(c->aw->mu);
+        if (c->aw->state == 0) {
+            set_error("mtm_find_matches_wait: no call in flight");
+            return MTM_E_INVALID;
+        }
+        c->aw->cv.wait(lk, [&] { return c->aw->state == 2; });
+        c->aw->state = 0;
+        rc = c->aw->rc;
+        if (rc != MTM_OK) set_error(c->aw->err);
+    }
+    if (rc != MTM_OK) return rc;
+    return mtm_last_hits(c, out, capacity, n_out);
 }
 
 int mtm_get_timing(mtm_ctx* c, mtm_timing* out) {

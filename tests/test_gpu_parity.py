@@ -893,6 +893,50 @@ def test_fused_global_extremum(mtm, n_templ, row_mux):
 
 
 # ------------------------------------------------------------------------------------------------
+# mtm_find_matches_async / _wait == mtm_find_matches (worker thread of the context)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_find_matches_async(mtm, coins):
+    lib = mtm._lib
+    small, big = coin_templates(coins)
+    ctx = lib.Context(0)
+    try:
+        ctx.set_image(coins)
+        with pytest.raises(lib.MtmError):
+            ctx.find_matches_wait()                        # nothing in flight (no worker yet)
+        for method, mode, thr in ((5, 0, 0.5), (1, 0, 0.3), (3, 1, 0.5), (5, 0, 0.99)):
+            ctx.set_templates([(small, None), (big, None)], method)
+            ref = ctx.find_matches(mode, thr).copy()
+            for _ in range(3):
+                ctx.find_matches_async(mode, thr)
+                got = ctx.find_matches_wait()
+                assert got.tobytes() == ref.tobytes()
+                assert ctx.timing()["n_hits"] == len(ref)
+        ctx.find_matches_async(0, 0.5)
+        with pytest.raises(lib.MtmError):
+            ctx.find_matches_async(0, 0.5)                 # one call in flight per context
+        ctx.find_matches_wait()
+        with pytest.raises(lib.MtmError):
+            ctx.find_matches_wait()                        # already collected
+        # an error inside the worker comes back from _wait with its message
+        empty = lib.Context(0)
+        empty.find_matches_async(0, 0.5)                   # no image, no templates
+        try:
+            r = empty.find_matches_wait()
+            assert len(r) == 0
+        except lib.MtmError as e:
+            assert str(e)
+        # low threshold: more hits than the first fetch holds (overflow inside the split call)
+        ctx.set_templates([(small, None)], 5)
+        ref = ctx.find_matches(0, -1.0).copy()
+        ctx.find_matches_async(0, -1.0)
+        assert ctx.find_matches_wait().tobytes() == ref.tobytes()
+        ctx.find_matches_async(0, 0.5)                     # destroyed with a call in flight: must not hang or crash
+    finally:
+        del ctx
+
+
+# ------------------------------------------------------------------------------------------------
 # state machine of a context: random sequences of uploads, template sets, options and queries
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", range(4))
