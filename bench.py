@@ -219,8 +219,8 @@ def main():
 
     # A step = GPU part (window statistics, score kernel, peak extraction, D2H of the hits), the all-gather of
     # the hit records, and the host part (merge in template order, global NMS, the reference's list of tuples).
-    # The steps are software-pipelined: the GPU part of step i+1 is started (mtm_find_matches_async: a worker
-    # thread of the library drives it) before this thread does the host part of step i, the way
+    # The steps are software-pipelined: the GPU part of step i+1 is queued (mtm_find_matches_async: no waiting
+    # for the GPU) before this thread does the host part of step i, the way
     # MTM.TemplateMatcher.match_stream overlaps the two for an image stream.  Every step is complete - its hit
     # list built - inside the timed region; `--sequential` turns the overlap off.
     def collect(raw):

@@ -172,12 +172,14 @@ int mtm_find_matches_next(mtm_ctx* ctx, int mode, double score_threshold, mtm_hi
                           int64_t* n_out, const void* next_px, int rows, int cols, int chans, int dtype,
                           int64_t row_stride_bytes);
 
-/* Split form of mtm_find_matches for hosts that want to work while the GPU does: _async starts the call
- * on a worker thread owned by the context and returns at once; _wait blocks until it is done and delivers
- * the hits exactly like mtm_find_matches (MTM_E_OVERFLOW: fetch them with mtm_last_hits).  Between the two
- * the context must not be used for anything else; one call in flight per context.  (The reference gets its
- * overlap from a thread pool per call, MTM/__init__.py:172-175; a Python host holds the GIL while it builds
- * the hit list of the previous image, so the overlap has to come from the native side.) */
+/* Split form of mtm_find_matches for hosts that want to work while the GPU does: _async queues everything
+ * the call needs on the context's stream (statistics, score kernels, the fetch of the candidate list) and
+ * returns without waiting for the GPU; _wait synchronises, extracts the peaks and delivers the hits exactly
+ * like mtm_find_matches (MTM_E_OVERFLOW: fetch them with mtm_last_hits).  mtm_find_matches is the two
+ * back to back.  Between the two the context must not be used for anything else; one call in flight per
+ * context.  (The reference gets its overlap from a thread pool per call, MTM/__init__.py:172-175; a Python
+ * host holds the GIL while it builds the hit list of the previous image, so the overlap has to come from
+ * the native side.) */
 int mtm_find_matches_async(mtm_ctx* ctx, int mode, double score_threshold);
 int mtm_find_matches_wait(mtm_ctx* ctx, mtm_hit* out, int64_t capacity, int64_t* n_out);
 

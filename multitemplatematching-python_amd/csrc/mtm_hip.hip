@@ -7,13 +7,10 @@
 
 #include <algorithm>
 #include <cmath>
-#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -118,18 +115,16 @@ constexpr int kNumDotVariants = sizeof(kDotVariants) / sizeof(kDotVariants[0]);
 
 }  // namespace
 
-// mtm_find_matches_async / _wait: one worker thread per context runs the (blocking) call, so that a
-// single-threaded host (the Python layer holds the GIL) can build the hit list of step i while the GPU
-// works on step i+1.
-struct AsyncWorker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv;
-    int state = 0;             // 0 idle, 1 call posted / running, 2 result ready, 3 quit
+// What mtm_find_matches knows after its asynchronous half (everything up to and including the kernels and the
+// first fetch are queued on the stream) and needs in its synchronising half.  mtm_find_matches_async /
+// mtm_find_matches_wait keep one of these in the context between the two calls.
+struct FmState {
     int mode = 0;
-    double thr = 0.0;
-    int rc = 0;
-    std::string err;
+    float thr = 0.0f;
+    bool mode_min = false, fused = false, prefetched = false;
+    int n = 0;
+    int64_t cand_cap = 0;
+    unsigned hash_mask = 0;
 };
 
 struct mtm_ctx {
@@ -187,7 +182,8 @@ struct mtm_ctx {
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
     bool hits_only_now = false;
-    AsyncWorker* aw = nullptr;          // created by the first mtm_find_matches_async
+    FmState fm;                         // mtm_find_matches_async -> mtm_find_matches_wait
+    bool fm_in_flight = false;
     const void* cands_zeroed = nullptr;   // candidate buffer whose counter was cleared after the previous call's fetch
     bool ext_now = false;      // this call: global extrema come out of the MFMA epilogue (no maps, no extremum_kernel)
     int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
@@ -1165,17 +1161,6 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
 
 void mtm_ctx_destroy(mtm_ctx* c) {
     if (!c) return;
-    if (c->aw) {                         // let a call in flight finish, then stop the worker
-        {
-            std::unique_lock<std::mutex> lk(c->aw->mu);
-            c->aw->cv.wait(lk, [&] { return c->aw->state != 1; });
-            c->aw->state = 3;
-        }
-        c->aw->cv.notify_all();
-        c->aw->th.join();
-        delete c->aw;
-        c->aw = nullptr;
-    }
     (void)hipSetDevice(c->device);
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);
@@ -1561,13 +1546,11 @@ int mtm_find_matches_next(mtm_ctx* c, int mode, double score_threshold, mtm_hit*
 
 namespace {
 
-int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
-                      int64_t* n_out, NextImage* next) {
-    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) ||
-        (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
-        set_error("mtm_find_matches: bad arguments");
-        return MTM_E_INVALID;
-    }
+constexpr size_t kHitPrefetch = 1024;       // candidate / hit records fetched together with the counters
+
+// Asynchronous half of mtm_find_matches: statistics, score kernels, the upload of the next image and (usual
+// case) the copy of the candidate list into pinned memory are queued; nothing waits for the GPU.
+int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmState& S) {
     HIPC(hipSetDevice(c->device));
     MTMC(place_templates(c));
     const int n = (int)c->templs.size();
@@ -1575,7 +1558,6 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     // numpy compares the float32 map with the python-float threshold in float32
     const float thr = (float)score_threshold;
     c->timing = mtm_timing{};
-    std::vector<mtm_hit> hits;
 
     // fused peak candidates: only when every class runs the MFMA kernel
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
@@ -1640,6 +1622,43 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     // the runtime executes synchronously, i.e. after the kernels.)
     MTMC(stage_next_image(c, next));
 
+    S.mode = mode;
+    S.thr = thr;
+    S.mode_min = mode_min;
+    S.fused = fused;
+    S.n = n;
+    S.cand_cap = cand_cap;
+    S.hash_mask = hash_mask;
+    S.prefetched = false;
+    if (mode == MTM_PEAKS_LOCAL && fused && !c->list2d.empty()) {
+        // Few candidates (the usual case): they come back in one copy and the 3x3 test runs on the host
+        // (fm_end).  Pinned landing buffer: the copy is a plain DMA instead of a staged one.
+        const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
+        const size_t fetch_bytes = 16 + sizeof(mtm_hit) * nfetch;
+        if (c->pinned_cap < fetch_bytes) {
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->pinned_cap = 0;
+            HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
+            c->pinned_cap = fetch_bytes;
+        }
+        HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipEventRecord(c->ev[2], c->stream));
+        S.prefetched = true;
+    }
+    return MTM_OK;
+}
+
+// Synchronising half: waits for the stream, verifies / extracts the peaks, delivers the hits.
+int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    HIPC(hipSetDevice(c->device));
+    const int mode = S.mode, n = S.n;
+    const float thr = S.thr;
+    const bool mode_min = S.mode_min, fused = S.fused;
+    const int64_t cand_cap = S.cand_cap;
+    const unsigned hash_mask = S.hash_mask;
+    std::vector<mtm_hit> hits;
+
     if (mode == MTM_PEAKS_GLOBAL) {
         if (!c->ext_now) {
             MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
@@ -1678,7 +1697,6 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         // candidate list; verify_peaks_kernel keeps the 3x3 local maxima.  If the candidate list
         // overflowed (dense maps), or on any non-MFMA class, the full peaks_kernel pass runs instead.
         const int n2d = (int)c->list2d.size();
-        constexpr size_t kHitPrefetch = 1024;
         const size_t hdr_bytes = round_up(2 * sizeof(unsigned long long) + sizeof(int) * (size_t)std::max(1, n), 16);
         unsigned long long count = 0;
         std::vector<int> tflags((size_t)std::max(1, n), 0);
@@ -1689,18 +1707,12 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         // is <= threshold < candidate: the list alone decides.  Saves two kernels, three fills and a copy.
         bool verified_on_host = false;
         if (use_fused && n2d > 0) {
-            // pinned landing buffer: the copy is a plain DMA instead of a staged one
+            // the candidate list is already on its way into the pinned landing buffer (fm_begin)
             const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
-            const size_t fetch_bytes = 16 + sizeof(mtm_hit) * nfetch;
-            if (c->pinned_cap < fetch_bytes) {
-                if (c->pinned) (void)hipHostFree(c->pinned);
-                c->pinned = nullptr;
-                c->pinned_cap = 0;
-                HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
-                c->pinned_cap = fetch_bytes;
+            if (!S.prefetched) {
+                set_error("mtm_find_matches: internal state (candidate fetch not queued)");
+                return MTM_E_INVALID;
             }
-            HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
-            HIPC(hipEventRecord(c->ev[2], c->stream));
             HIPC(hipStreamSynchronize(c->stream));
             const uint8_t* land = static_cast<const uint8_t*>(c->pinned);
             unsigned long long ncand = 0;
@@ -1891,6 +1903,22 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
     return MTM_OK;
 }
 
+int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                      int64_t* n_out, NextImage* next) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) ||
+        (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
+        set_error("mtm_find_matches: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (c->fm_in_flight) {
+        set_error("mtm_find_matches: a mtm_find_matches_async call is in flight (collect it with mtm_find_matches_wait)");
+        return MTM_E_INVALID;
+    }
+    FmState S;
+    MTMC(fm_begin(c, mode, score_threshold, next, S));
+    return fm_end(c, S, out, capacity, n_out);
+}
+
 }  // namespace
 
 int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
@@ -1912,46 +1940,12 @@ int mtm_find_matches_async(mtm_ctx* c, int mode, double score_threshold) {
         set_error("mtm_find_matches_async: bad arguments");
         return MTM_E_INVALID;
     }
-    if (!c->aw) {
-        c->aw = new AsyncWorker();
-        AsyncWorker* w = c->aw;
-        w->th = std::thread([c, w] {
-            for (;;) {
-                int mode;
-                double thr;
-                {
-                    std::unique_lock<std::mutex> lk(w->mu);
-                    w->cv.wait(lk, [&] { return w->state == 1 || w->state == 3; });
-                    if (w->state == 3) return;
-                    mode = w->mode;
-                    thr = w->thr;
-                }
-                int64_t n = 0;
-                int rc = find_matches_impl(c, mode, thr, nullptr, 0, &n, nullptr);   // the hits stay in the context
-                std::string err;
-                if (rc == MTM_E_OVERFLOW) rc = MTM_OK;                               // capacity 0: expected
-                if (rc != MTM_OK) err = mtm_last_error();                            // this thread's message
-                {
-                    std::lock_guard<std::mutex> lk(w->mu);
-                    w->rc = rc;
-                    w->err.swap(err);
-                    w->state = 2;
-                }
-                w->cv.notify_all();
-            }
-        });
+    if (c->fm_in_flight) {
+        set_error("mtm_find_matches_async: a call is already in flight (collect it with mtm_find_matches_wait)");
+        return MTM_E_INVALID;
     }
-    {
-        std::lock_guard<std::mutex> lk(c->aw->mu);
-        if (c->aw->state != 0) {
-            set_error("mtm_find_matches_async: a call is already in flight (collect it with mtm_find_matches_wait)");
-            return MTM_E_INVALID;
-        }
-        c->aw->mode = mode;
-        c->aw->thr = score_threshold;
-        c->aw->state = 1;
-    }
-    c->aw->cv.notify_all();
+    MTMC(fm_begin(c, mode, score_threshold, nullptr, c->fm));
+    c->fm_in_flight = true;
     return MTM_OK;
 }
 
@@ -1960,24 +1954,12 @@ int mtm_find_matches_wait(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n
         set_error("mtm_find_matches_wait: bad arguments");
         return MTM_E_INVALID;
     }
-    if (!c->aw) {
+    if (!c->fm_in_flight) {
         set_error("mtm_find_matches_wait: no call in flight");
         return MTM_E_INVALID;
     }
-    int rc;
-    {
-        std::unique_lock<std::mutex> lk(c->aw->mu);
-        if (c->aw->state == 0) {
-            set_error("mtm_find_matches_wait: no call in flight");
-            return MTM_E_INVALID;
-        }
-        c->aw->cv.wait(lk, [&] { return c->aw->state == 2; });
-        c->aw->state = 0;
-        rc = c->aw->rc;
-        if (rc != MTM_OK) set_error(c->aw->err);
-    }
-    if (rc != MTM_OK) return rc;
-    return mtm_last_hits(c, out, capacity, n_out);
+    c->fm_in_flight = false;
+    return fm_end(c, c->fm, out, capacity, n_out);
 }
 
 int mtm_get_timing(mtm_ctx* c, mtm_timing* out) {

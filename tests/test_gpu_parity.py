@@ -893,7 +893,7 @@ def test_fused_global_extremum(mtm, n_templ, row_mux):
 
 
 # ------------------------------------------------------------------------------------------------
-# mtm_find_matches_async / _wait == mtm_find_matches (worker thread of the context)
+# mtm_find_matches_async / _wait == mtm_find_matches (the same call split at its first synchronisation)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_find_matches_async(mtm, coins):
@@ -903,7 +903,7 @@ def test_find_matches_async(mtm, coins):
     try:
         ctx.set_image(coins)
         with pytest.raises(lib.MtmError):
-            ctx.find_matches_wait()                        # nothing in flight (no worker yet)
+            ctx.find_matches_wait()                        # nothing in flight
         for method, mode, thr in ((5, 0, 0.5), (1, 0, 0.3), (3, 1, 0.5), (5, 0, 0.99)):
             ctx.set_templates([(small, None), (big, None)], method)
             ref = ctx.find_matches(mode, thr).copy()
@@ -918,14 +918,15 @@ def test_find_matches_async(mtm, coins):
         ctx.find_matches_wait()
         with pytest.raises(lib.MtmError):
             ctx.find_matches_wait()                        # already collected
-        # an error inside the worker comes back from _wait with its message
+        # a context without image and templates
         empty = lib.Context(0)
-        empty.find_matches_async(0, 0.5)                   # no image, no templates
         try:
-            r = empty.find_matches_wait()
-            assert len(r) == 0
+            empty.find_matches_async(0, 0.5)               # no image, no templates: refused or empty
+            assert len(empty.find_matches_wait()) == 0
         except lib.MtmError as e:
             assert str(e)
+        with pytest.raises(lib.MtmError):
+            empty.find_matches_wait()                      # a refused call is not in flight
         # low threshold: more hits than the first fetch holds (overflow inside the split call)
         ctx.set_templates([(small, None)], 5)
         ref = ctx.find_matches(0, -1.0).copy()
