@@ -147,7 +147,14 @@ def cpu_baseline(img, units, method, thr, n_sample):
     O.NMS(hits, thr, method == 1, float("inf"), 0.25)
     dt = time.perf_counter() - t0
     mpx = img.shape[0] * img.shape[1] * n_sample / 1e6
-    return {"value": round(mpx / dt, 3), "unit": "Mpx-corr/s", "cores": workers, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
+    except OSError:
+        pass
+    return {"value": round(mpx / dt, 3), "unit": "Mpx-corr/s", "cores": workers, "kind": "port", "cpu_model": model,
+            "host_cores": cores,
             "sample": "%d of %d templates on the full %dx%d image, %s (oracle/mtm_oracle.py), "
                       "%d worker threads of %d host cores, %.1f s"
                       % (n_sample, len(units), img.shape[1], img.shape[0],
