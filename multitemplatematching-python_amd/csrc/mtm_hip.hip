@@ -290,19 +290,22 @@ void pack_mask_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
 
 void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
     const int h = sc.h, w = sc.w, nb = (w + 63) / 64, R = sc.rm_R, nt = sc.rm_nt;
-    std::memset(out, 0, (size_t)rm_pack_bytes(h, w, R));
-    for (int sp = 0; sp < h + 3 * R - 1; ++sp)
-        for (int i = 0; i < 16; ++i) {
-            const int t = i % nt, rho = i / nt, dy = sp - R - rho;
-            if (t >= (int)sc.members.size() || dy < 0 || dy >= h) continue;
-            const HostTempl& ht = c->templs[sc.members[(size_t)t]];
-            for (int dx = 0; dx < w; ++dx) {
-                const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
-                const size_t k = (size_t)dy * w + dx;
-                const uint8_t v = (uint8_t)(ht.masked ? ht.px[k] * ht.mask[k] : ht.px[k]);   // masked: T*M, M in {0,1}
-                out[(((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+    const int chans = sc.masked ? 1 : c->chans;                 // one pack per channel, rm_pack_bytes apart
+    const size_t cstride = (size_t)rm_pack_bytes(h, w, R);
+    std::memset(out, 0, cstride * chans);
+    for (int ch = 0; ch < chans; ++ch)
+        for (int sp = 0; sp < h + 3 * R - 1; ++sp)
+            for (int i = 0; i < 16; ++i) {
+                const int t = i % nt, rho = i / nt, dy = sp - R - rho;
+                if (t >= (int)sc.members.size() || dy < 0 || dy >= h) continue;
+                const HostTempl& ht = c->templs[sc.members[(size_t)t]];
+                for (int dx = 0; dx < w; ++dx) {
+                    const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
+                    const size_t k = ((size_t)ch * h + dy) * w + dx;
+                    const uint8_t v = (uint8_t)(ht.masked ? ht.px[k] * ht.mask[k] : ht.px[k]);   // masked: T*M, M in {0,1}
+                    out[ch * cstride + (((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                }
             }
-        }
 }
 
 // uint16 image + uint16 templates, one channel, no mask: four uint8 byte-plane correlations on the int8
@@ -379,13 +382,14 @@ int place_templates(mtm_ctx* c) {
         c->classes[k].mfma16_ok = mfma16_class_ok(c, c->classes[k]);
         c->classes[k].n_pad = (int)round_up(c->classes[k].members.size(), 16);
         class_kernel[k] = resolved_kernel(c, c->classes[k]);
-        // row-multiplexed mode: uint8 class (masked or not) of <= 16 templates on one channel whose window
-        // statistics the fused kernel produces (it also writes the 1/sqrt plane this mode reads)
+        // row-multiplexed mode: uint8 class of <= 16 templates (one channel, masked or not, or unmasked RGB) whose
+        // window statistics the fused kernels produce (the single-channel one also writes the 1/sqrt plane)
         SizeClass& sc = c->classes[k];
         sc.rm_nt = sc.rm_R = 0;
         const size_t n_cls = sc.members.size();
-        if (c->row_mux && class_kernel[k] == MTM_KERNEL_MFMA && c->chans == 1 && n_cls <= 16 &&
-            (double)sc.w * sc.h * 65025.0 < 4294967296.0 && c->fuse_stats) {
+        if (c->row_mux && class_kernel[k] == MTM_KERNEL_MFMA && n_cls <= 16 && c->fuse_stats &&
+            (c->chans == 1 || (c->chans == 3 && !sc.masked)) &&
+            (double)c->chans * sc.w * sc.h * 65025.0 < 4294967296.0) {
             int nt = 1;
             while (nt < (int)n_cls) nt <<= 1;
             // two work-groups per CU need <= ~76 KB of LDS each: wide templates take fewer rows per MFMA group
@@ -494,7 +498,7 @@ int place_templates(mtm_ctx* c) {
         if (sc.rm_R > 0) {
             sc.group_bytes = -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
             sc.apack_off = (long long)a_off;
-            a_off += (size_t)rm_pack_bytes(sc.h, sc.w, sc.rm_R);
+            a_off += (size_t)rm_pack_bytes(sc.h, sc.w, sc.rm_R) * (sc.masked ? 1 : c->chans);
             continue;
         }
         sc.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
@@ -837,6 +841,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.rm_log2nt = 0;
             while ((1 << p.rm_log2nt) < sc.rm_nt) ++p.rm_log2nt;
             p.rm_steps = h + 2 * sc.rm_R - 1;
+            p.rm_cstride = rm_pack_bytes(h, w, sc.rm_R);
             p.rm_rsq = c->stats_rsq.as<double>();
             p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
             p.ntg = 1;
@@ -881,6 +886,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         static const MfmaFn kMfmaRmFns[2][2][6] = {{MTM_MF_RM(false, false), MTM_MF_RM(true, false)},
                                                    {MTM_MF_RM(false, true), MTM_MF_RM(true, true)}};
 #undef MTM_MF_RM
+#define MTM_MF_RMC3(X) {ncc_mfma_kernel<2, 0, X, false, true, 3>, ncc_mfma_kernel<2, 1, X, false, true, 3>,   \
+                       ncc_mfma_kernel<2, 2, X, false, true, 3>, ncc_mfma_kernel<2, 3, X, false, true, 3>,   \
+                       ncc_mfma_kernel<2, 4, X, false, true, 3>, ncc_mfma_kernel<2, 5, X, false, true, 3>}
+        static const MfmaFn kMfmaRmC3Fns[2][6] = {MTM_MF_RMC3(false), MTM_MF_RMC3(true)};
+#undef MTM_MF_RMC3
         // 3-channel images: the same lean epilogue with per-channel window sums (methods fixed at compile time)
 #define MTM_MF_C3(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 3>, ncc_mfma_kernel<MB, 1, X, false, false, 3>,   \
                          ncc_mfma_kernel<MB, 2, X, false, false, 3>, ncc_mfma_kernel<MB, 3, X, false, false, 3>,   \
@@ -903,6 +913,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
         const MfmaFn fn = (ext && rm) ? kMfmaRmExtFns[c->exact_div ? 1 : 0][c->method]
                         : ext ? kMfmaExtFns[c->exact_div ? 1 : 0][mb - 1][c->method]
+                        : (rm && c->chans == 3) ? kMfmaRmC3Fns[c->exact_div ? 1 : 0][c->method]
                         : c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
                         : rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
                              : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];

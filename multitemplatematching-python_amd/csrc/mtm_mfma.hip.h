@@ -91,6 +91,7 @@ struct MfmaParams {
     // the pack rm_R steps earlier: group_bytes = -rm_R * nb * 1024) and walks rm_steps = h + 2 rm_R - 1
     // image rows.  rm_R = 16 / rm_nt.
     int rm_R, rm_nt, rm_log2nt, rm_steps;
+    long long rm_cstride;    // bytes between the packs of two channels (RM with 3 channels)
     const double* rm_rsq;    // 1 / sqrt plane of the class (0 for flat windows), pitch = st.pitch
     int* raw_out;            // METHOD == kMfRaw: int32 accumulators of list position li at raw_out + li * raw_map
     long long raw_map;       //   (+ y * raw_pitch + x); see ncc16_combine_kernel
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                           StatPlanes st, float* __restrict__ maps,
                                                           unsigned int* __restrict__ sched) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
-    static_assert(CH == 1 || (!RM && !MASKED), "multi-channel: plain unmasked path only");
+    static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
     static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && !MASKED && CH == 1), "fused extremum: unmasked single-channel paths");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -445,7 +446,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // register sets: the operands of the next step (2 LDS chunks + MB packed template rows)
             // are requested before the 16*MB MFMAs of the current step issue.  sched_barrier keeps
             // the compiler from sinking the requests below the MFMAs.
-            const uint8_t* aptr = apack_g + ((size_t)(c * p.h + cy0) * p.nb) * 1024;   // + ks * 1024
+            const uint8_t* aptr = apack_g + (RM ? (size_t)c * p.rm_cstride + (size_t)cy0 * p.nb * 1024     // + ks * 1024
+                                               : ((size_t)(c * p.h + cy0) * p.nb) * 1024);
             const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
             const int nsteps = ch * p.nb;
             int nb_i = 0;                       // 64-tap block of the step last requested
@@ -677,8 +679,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 __builtin_amdgcn_wave_barrier();
                 if (col_on) {
                     int cur_rho = -1;
-                    double ps1[4][1] = {{0}, {0}, {0}, {0}}, pp1[4] = {0, 0, 0, 0}, psum2[4] = {0, 0, 0, 0}, psq[4] = {0, 0, 0, 0},
+                    double ps1[4][CH], pp1[4] = {0, 0, 0, 0}, psum2[4] = {0, 0, 0, 0}, psq[4] = {0, 0, 0, 0},
                            prsq[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int cc = 0; cc < CH; ++cc) ps1[k][cc] = 0.0;
 #pragma unroll 1
                     for (int s8 = 0; s8 < 8; ++s8) {
                         const int i = 8 * round + s8;
@@ -690,9 +696,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             const size_t sidx = (size_t)yy * st.pitch + xs;
 #pragma unroll
                             for (int hh = 0; hh < 2; ++hh) {
-                                const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
-                                ps1[2 * hh][0] = a.x;
-                                ps1[2 * hh + 1][0] = a.y;
+#pragma unroll
+                                for (int cc = 0; cc < CH; ++cc) {
+                                    const double2 a = *reinterpret_cast<const double2*>(st.t[cc] + sidx + 2 * hh);
+                                    ps1[2 * hh][cc] = a.x;
+                                    ps1[2 * hh + 1][cc] = a.y;
+                                }
                                 if (kNeedSum2) {
                                     const double2 b = *reinterpret_cast<const double2*>(st.sum2 + sidx + 2 * hh);
                                     psum2[2 * hh] = b.x;
@@ -700,16 +709,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 }
                                 if (kNormed) {
                                     const double2 d = *reinterpret_cast<const double2*>(st.sq + sidx + 2 * hh);
-                                    const double2 e = *reinterpret_cast<const double2*>(p.rm_rsq + sidx + 2 * hh);
                                     psq[2 * hh] = d.x;
                                     psq[2 * hh + 1] = d.y;
-                                    prsq[2 * hh] = e.x;
-                                    prsq[2 * hh + 1] = e.y;
+                                    if constexpr (CH == 1) {     // the single-channel statistics pass writes 1/sqrt too
+                                        const double2 e = *reinterpret_cast<const double2*>(p.rm_rsq + sidx + 2 * hh);
+                                        prsq[2 * hh] = e.x;
+                                        prsq[2 * hh + 1] = e.y;
+                                    } else {
+                                        prsq[2 * hh] = d.x > 0.0 ? 1.0 / d.x : 0.0;
+                                        prsq[2 * hh + 1] = d.y > 0.0 ? 1.0 / d.y : 0.0;
+                                    }
                                 }
                             }
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                pp1[k] = 128.0 * ps1[k][0];
+                                double s1all = ps1[k][0];       // bias term: 128 * sum over channels of S1 (exact integers)
+#pragma unroll
+                                for (int cc = 1; cc < CH; ++cc) s1all += ps1[k][cc];
+                                pp1[k] = 128.0 * s1all;
                                 if (kMaskedNormed && !EXACT_DIV) prsq[k] = 1.0 / sqrt(psum2[k]);
                             }
                         }
@@ -721,8 +738,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             const double rt = T.rtempl_norm;
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const double base = (double)a32[k] + T.mfma_k;
-                                double num = fma(ps1[k][0], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0, base);
+                                double num = (double)a32[k] + T.mfma_k;
+#pragma unroll
+                                for (int cc = 0; cc < CH; ++cc)
+                                    num = fma(ps1[k][cc], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[cc] : 128.0, num);
                                 if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[k] - 2.0 * num + T.templ_sum2, 0.0);
                                 const double qd = num * (prsq[k] * rt);
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
@@ -735,8 +754,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         for (int k = 0; k < 4; ++k)
                             out[k] = MASKED ? finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], pp1[k], psum2[k],
                                                                                                      prsq[k], T)
-                                            : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], ps1[k], pp1[k], psum2[k],
-                                                                                              psq[k], prsq[k], T);
+                                            : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, CH>(a32[k], ps1[k], pp1[k], psum2[k],
+                                                                                                  psq[k], prsq[k], T);
                         const bool ones = !MASKED && T.all_ones != 0;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) out[k] = ones ? 1.0f : out[k];

@@ -828,6 +828,60 @@ def test_row_multiplexed_mode(mtm, n_templ):
 
 
 # ------------------------------------------------------------------------------------------------
+# RGB classes of <= 16 templates: the row-multiplexed kernel with three channel packs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_templ", [1, 3, 8, 16])
+def test_rgb_row_multiplexed(mtm, n_templ):
+    rng = np.random.default_rng(700 + n_templ)
+    H, W = 141, 397
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img[60:100, 200:330] = (93, 12, 240)                   # flat windows in every channel
+    ctx = mtm._lib.Context(0)
+    try:
+        ctx.set_option(1, 3)                               # MFMA
+        ctx.set_image(img)
+        for (h, w) in [(24, 24), (70, 33), (9, 130)]:      # one chunk, two 64-row chunks, three 64-tap blocks
+            lt = []
+            for i in range(n_templ):
+                y, x = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+                t = img[y:y + h, x:x + w].copy()
+                if i % 2:
+                    t = np.clip(t.astype(np.int32) + rng.integers(-40, 41, t.shape), 0, 255).astype(np.uint8)
+                lt.append(("t%d" % i, t))
+            for method in (5, 3, 1, 0, 2, 4):
+                ctx.set_templates([(t, None) for _, t in lt], method)
+                for exact in (1, 0):
+                    ctx.set_option(5, exact)
+                    for li in sorted({0, n_templ // 2, n_templ - 1}):
+                        got = ctx.score_map(li, (H - h + 1, W - w + 1))
+                        assert ctx.timing()["kernel_used"] == 3
+                        exp = O.match_template(img, lt[li][1], method)
+                        if exact or method in (0, 2, 4):
+                            assert np.array_equal(got, exp), (n_templ, (h, w), method, li, float(np.abs(got - exp).max()))
+                        else:
+                            ulp_close(got, exp)
+                if method in (1, 3, 5):
+                    thr = 0.3 if method == 1 else 0.6
+                    res = []
+                    for honly in (0, 1):
+                        ctx.set_option(6, honly)
+                        res.append(ctx.find_matches(0, thr).copy())
+                    ctx.set_option(6, 1)
+                    assert res[0].tobytes() == res[1].tobytes()
+                    exp = O.find_matches(lt, img, method=method, score_threshold=thr)
+                    assert len(res[1]) == len(exp)
+                    got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in res[1]]
+                    assert_hits_equal(canon(got), canon(exp), tol=1e-6)
+                    one = ctx.find_matches(1, 0.5)         # N_object == 1 (maps + extremum_kernel for RGB)
+                    exp1 = O.find_matches(lt, img, method=method, N_object=1)
+                    got1 = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in one]
+                    assert_hits_equal(got1, hits_json(exp1), tol=1e-6)
+    finally:
+        del ctx
+
+
+# ------------------------------------------------------------------------------------------------
 # N_object == 1: cv2.minMaxLoc fused into the MFMA epilogue (no score maps, running best per template
 # as the threshold) == score maps + extremum_kernel == oracle, ties included
 # ------------------------------------------------------------------------------------------------
