@@ -35,6 +35,15 @@ using namespace mtm;
         int r_ = (expr);                                                                    \
         if (r_ != MTM_OK) return r_;                                                        \
     } while (0)
+// between mtm_find_matches_async and mtm_find_matches_wait the context belongs to that call
+#define MTM_NOT_IN_FLIGHT(c, who)                                                                         \
+    do {                                                                                                  \
+        if ((c)->fm_in_flight) {                                                                          \
+            set_error(std::string(who) + ": a mtm_find_matches_async call is in flight (collect it with " \
+                      "mtm_find_matches_wait first)");                                                    \
+            return MTM_E_INVALID;                                                                         \
+        }                                                                                                 \
+    } while (0)
 
 namespace {
 
@@ -1198,6 +1207,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
 
 int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
     if (!c) return MTM_E_INVALID;
+    MTM_NOT_IN_FLIGHT(c, "mtm_set_option");
     switch (option) {
         case MTM_OPT_KERNEL:
             if (value < MTM_KERNEL_AUTO || value > MTM_KERNEL_MFMA) break;
@@ -1333,6 +1343,7 @@ int mtm_set_image_downscaled(mtm_ctx* c, const void* px, int rows, int cols, int
         set_error("mtm_set_image: null context");
         return MTM_E_INVALID;
     }
+    MTM_NOT_IN_FLIGHT(c, "mtm_set_image");
     MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_set_image"));
     if (factor < 1 || factor > 64 || rows / factor < 1 || cols / factor < 1) {
         set_error("mtm_set_image_downscaled: factor must be in 1..64 and leave at least one pixel");
@@ -1355,6 +1366,7 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         set_error("mtm_set_templates: bad arguments");
         return MTM_E_INVALID;
     }
+    MTM_NOT_IN_FLIGHT(c, "mtm_set_templates");
     for (int i = 0; i < n_templ; ++i) {
         const mtm_templ& s = templs[i];
         if (!s.px || s.rows <= 0 || s.cols <= 0 || s.chans < 1 || s.chans > kMaxChans ||
@@ -1465,6 +1477,7 @@ int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_
         set_error("mtm_score_map: bad arguments");
         return MTM_E_INVALID;
     }
+    MTM_NOT_IN_FLIGHT(c, "mtm_score_map");
     HIPC(hipSetDevice(c->device));
     MTMC(place_templates(c));
     if (templ_idx < 0 || templ_idx >= (int)c->templs.size()) {
@@ -2060,6 +2073,7 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
         set_error("mtm_comm_allgather_hits: bad arguments or communicator not initialised");
         return MTM_E_INVALID;
     }
+    MTM_NOT_IN_FLIGHT(c, "mtm_comm_allgather_hits");
     HIPC(hipSetDevice(c->device));
     const int R = c->n_ranks;
     // One all-gather of fixed-size slots: [count (16-byte header) | slot_hits records].  Every rank

@@ -969,6 +969,12 @@ def test_find_matches_async(mtm, coins):
         ctx.find_matches_async(0, 0.5)
         with pytest.raises(lib.MtmError):
             ctx.find_matches_async(0, 0.5)                 # one call in flight per context
+        with pytest.raises(lib.MtmError, match="in flight"):
+            ctx.set_option(6, 1)                           # ... and the context belongs to it
+        with pytest.raises(lib.MtmError, match="in flight"):
+            ctx.set_image(coins)
+        with pytest.raises(lib.MtmError, match="in flight"):
+            ctx.find_matches(0, 0.5)
         ctx.find_matches_wait()
         with pytest.raises(lib.MtmError):
             ctx.find_matches_wait()                        # already collected
