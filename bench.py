@@ -230,15 +230,13 @@ def main():
     # for the GPU) before this thread does the host part of step i, the way
     # MTM.TemplateMatcher.match_stream overlaps the two for an image stream.  Every step is complete - its hit
     # list built - inside the timed region; `--sequential` turns the overlap off.
-    def collect(raw):
+    def collect(raw, t):
         nonlocal launches
-        raw = raw.copy()
-        t = ctx.timing()
         kernel_ms.append(t["ncc_kernel_ms"])
         total_ms.append(t["total_ms"])
         launches = t["ncc_launches"]
-        raw["templ_idx"] = gidx[raw["templ_idx"]]
-        return exchange.allgather(raw), t          # the context is idle here: the collective uses its stream
+        raw["templ_idx"] = gidx[raw["templ_idx"]]      # (the arrays the context hands out are the caller's own)
+        return exchange.allgather(raw)
 
     def host_part(allhits):
         return merge_and_nms(allhits, units, method, float("inf"), thr, 0.25)
@@ -248,15 +246,23 @@ def main():
         last = (None, None)
         if args.sequential or not pipelined:
             for _ in range(k):
-                allhits, t = collect(ctx.find_matches(_lib.PEAKS_LOCAL, thr))
-                last = (host_part(allhits), t)
+                raw = ctx.find_matches(_lib.PEAKS_LOCAL, thr)
+                t = ctx.timing()
+                last = (host_part(collect(raw, t)), t)
             return last
         if k > 0:
             ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
         for i in range(k):
-            allhits, t = collect(ctx.find_matches_wait())
-            if i + 1 < k:
-                ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
+            raw = ctx.find_matches_wait()
+            t = ctx.timing()
+            if world == 1:                               # no collective: the context is free for the next step at once
+                if i + 1 < k:
+                    ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
+                allhits = collect(raw, t)
+            else:                                        # the all-gather uses the context's stream: before the next step
+                allhits = collect(raw, t)
+                if i + 1 < k:
+                    ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
             last = (host_part(allhits), t)
         return last
 
