@@ -71,8 +71,8 @@ extern "C" {
                                    0 (default): reciprocal multiplies, <= 1 ulp(float32) on ~1e-8 of the pixels */
 #define MTM_OPT_HITS_ONLY 6     /* 1 (default): mtm_find_matches does not write the score maps to memory when every
                                    template runs the int8 MFMA kernel: in local-extrema mode the peaks come from
-                                   the in-kernel candidate list, in global-extremum mode (unmasked single-channel
-                                   templates) the per-template best is kept inside the score kernel;
+                                   the in-kernel candidate list, in global-extremum mode (unmasked 1- or
+                                   3-channel templates) the per-template best is kept inside the score kernel;
                                    0: always materialise the maps.  Results are identical either way. */
 
 /* error codes */

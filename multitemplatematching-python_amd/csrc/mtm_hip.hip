@@ -919,9 +919,21 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                         ncc_mfma_kernel<2, 4, X, false, true, 1, true>, ncc_mfma_kernel<2, 5, X, false, true, 1, true>}
         static const MfmaFn kMfmaRmExtFns[2][6] = {MTM_MF_RMEXT(false), MTM_MF_RMEXT(true)};
 #undef MTM_MF_RMEXT
+#define MTM_MF_EXTC3(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 3, true>, ncc_mfma_kernel<MB, 1, X, false, false, 3, true>,   \
+                            ncc_mfma_kernel<MB, 2, X, false, false, 3, true>, ncc_mfma_kernel<MB, 3, X, false, false, 3, true>,   \
+                            ncc_mfma_kernel<MB, 4, X, false, false, 3, true>, ncc_mfma_kernel<MB, 5, X, false, false, 3, true>}
+        static const MfmaFn kMfmaExtC3Fns[2][2][6] = {{MTM_MF_EXTC3(1, false), MTM_MF_EXTC3(2, false)},
+                                                      {MTM_MF_EXTC3(1, true), MTM_MF_EXTC3(2, true)}};
+#undef MTM_MF_EXTC3
+#define MTM_MF_RMEXTC3(X) {ncc_mfma_kernel<2, 0, X, false, true, 3, true>, ncc_mfma_kernel<2, 1, X, false, true, 3, true>,   \
+                          ncc_mfma_kernel<2, 2, X, false, true, 3, true>, ncc_mfma_kernel<2, 3, X, false, true, 3, true>,   \
+                          ncc_mfma_kernel<2, 4, X, false, true, 3, true>, ncc_mfma_kernel<2, 5, X, false, true, 3, true>}
+        static const MfmaFn kMfmaRmExtC3Fns[2][6] = {MTM_MF_RMEXTC3(false), MTM_MF_RMEXTC3(true)};
+#undef MTM_MF_RMEXTC3
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
-        const MfmaFn fn = (ext && rm) ? kMfmaRmExtFns[c->exact_div ? 1 : 0][c->method]
-                        : ext ? kMfmaExtFns[c->exact_div ? 1 : 0][mb - 1][c->method]
+        const int xd = c->exact_div ? 1 : 0;
+        const MfmaFn fn = (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
+                        : ext ? (c->chans == 3 ? kMfmaExtC3Fns[xd][mb - 1][c->method] : kMfmaExtFns[xd][mb - 1][c->method])
                         : (rm && c->chans == 3) ? kMfmaRmC3Fns[c->exact_div ? 1 : 0][c->method]
                         : c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
                         : rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
@@ -1593,8 +1605,8 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     c->hits_only_now = false;
     c->ext_now = false;
     // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the unmasked
-    // single-channel MFMA kernel (plain or row-multiplexed); same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
-    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && c->chans == 1) {
+    // 1- or 3-channel MFMA kernel (plain or row-multiplexed); same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
+    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3)) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
             ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && !sc.masked;

@@ -1132,6 +1132,13 @@ def test_rgb_lean_path(mtm, ctx):
             exp = O.find_matches(lt, img, method=method, score_threshold=thr)
             assert len(res[1]) == len(exp) and len(exp) >= 10
             assert_hits_equal(canon(res[1]), canon(exp), tol=1e-6)
+            # N_object == 1: fused global extremum (21 RGB templates: plain and row-multiplexed classes) == maps
+            one = []
+            for honly in (0, 1):
+                ctx.set_option(6, honly)
+                one.append(mtm.findMatches(lt, img, method=method, N_object=1))
+            assert one[0] == one[1]
+            assert_hits_equal(one[1], hits_json(O.find_matches(lt, img, method=method, N_object=1)), tol=1e-6)
     finally:
         set_kernel(ctx, "auto")
         set_exact(ctx, 0)
