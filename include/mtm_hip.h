@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 2
+#define MTM_ABI_VERSION 3
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -51,9 +51,11 @@ extern "C" {
 #define MTM_PEAKS_LOCAL  0   /* MTM/__init__.py:231-235: local maxima (methods 2-5) / minima (0,1) */
 #define MTM_PEAKS_GLOBAL 1   /* MTM/__init__.py:225-230: N_object == 1, cv2.minMaxLoc              */
 
-/* 3x3 maximum-filter border rule of skimage.feature.peak_local_max */
-#define MTM_BORDER_CONSTANT 0  /* skimage <= 0.18: pad with 0 */
-#define MTM_BORDER_NEAREST  1  /* newer skimage: replicate the edge */
+/* 3x3 maximum-filter border rule of skimage.feature.peak_local_max (MTM/__init__.py:45; the reference leaves
+ * scikit-image unpinned, setup.py:24).  The two rules differ only where the filtered map is negative at its
+ * border: local MINIMA (methods 0/1, the map is negated, MTM/__init__.py:53) and negative thresholds. */
+#define MTM_BORDER_CONSTANT 0  /* skimage <= 0.18: pad with 0 (border minima are never peaks) */
+#define MTM_BORDER_NEAREST  1  /* skimage >= 0.19: replicate the edge - the default */
 
 /* kernel selection for the uint8 score-map path (mtm_set_option MTM_OPT_KERNEL) */
 #define MTM_KERNEL_AUTO  0
@@ -187,6 +189,12 @@ int mtm_find_matches_wait(mtm_ctx* ctx, mtm_hit* out, int64_t capacity, int64_t*
  * collect the result after MTM_E_OVERFLOW told the caller the capacity it needs. */
 int mtm_last_hits(mtm_ctx* ctx, mtm_hit* out, int64_t capacity, int64_t* n_out);
 
+/* The score map of template `templ_idx` exactly as the last mtm_find_matches call computed it inside its
+ * batched launch (cv2.matchTemplate, MTM/__init__.py:92) - nothing is recomputed.  Only valid when that call
+ * materialised the maps (MTM_OPT_HITS_ONLY = 0, or any class that is not on the MFMA kernel); MTM_E_STATE
+ * otherwise.  Parity tests use it to check the production launch at full size against the oracle. */
+int mtm_last_score_map(mtm_ctx* ctx, int templ_idx, float* out, int64_t out_row_stride_bytes);
+
 int mtm_get_timing(mtm_ctx* ctx, mtm_timing* out);
 
 /* cv2.dnn.NMSBoxes as MTM.NMS uses it (MTM/NMS.py:73-82): keep hits with score > threshold
@@ -207,6 +215,10 @@ int mtm_comm_init(mtm_ctx* ctx, const void* id, int n_ranks, int rank);
  * counts_out[n_ranks] receives the per-rank counts.  Collective call. */
 int mtm_comm_allgather_hits(mtm_ctx* ctx, const mtm_hit* local, int64_t n_local,
                             mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out);
+/* The result of the last mtm_comm_allgather_hits again (no communication): the way to collect it after
+ * MTM_E_OVERFLOW told the caller the capacity it needs.  The collective itself is never repeated - a rank whose
+ * buffer was large enough has already left it. */
+int mtm_comm_last_gather(mtm_ctx* ctx, mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out);
 int mtm_comm_destroy(mtm_ctx* ctx);
 
 #ifdef __cplusplus

@@ -1,13 +1,29 @@
 """
-Non-Maxima Suppression for template matching: same public function, arguments, defaults and
-results as the reference's MTM/NMS.py:20-84, with cv2.dnn.NMSBoxes (reference MTM/NMS.py:78)
-replaced by the float32-faithful C++ restatement behind ``mtm_nms`` in libmtm_hip.so.
+Non-Maxima Suppression for template matching (public ``MTM.NMS.NMS`` of the reference, MTM/NMS.py:20-84).
+
+The suppression itself - cv2.dnn.NMSBoxes at reference MTM/NMS.py:78 - is ``mtm_nms`` in libmtm_hip.so
+(float32-faithful C++ restatement, grid-accelerated).  This module only converts between the reference's
+list of ``(label, (x, y, w, h), score)`` tuples and the structured hit records the library works on; the
+package's own matchTemplates never builds the tuples before the suppression (``MTM._nms_raw``).
 """
 from typing import List, Sequence, Tuple
+
+import numpy as np
 
 from . import _lib
 
 Hit = Tuple[str, Tuple[int, int, int, int], float]
+
+
+def _records(hits, quality):
+    """Hit tuples -> structured records; ``quality`` (higher = better) goes into the float32 score field,
+    which is the narrowing the cv2 binding applies to the reference's score list."""
+    rec = np.zeros(len(hits), dtype=_lib.HIT_DTYPE)
+    box = np.asarray([h[1] for h in hits], dtype=np.int64).reshape(len(hits), 4)
+    rec["templ_idx"] = np.arange(len(hits), dtype=np.int32)
+    rec["x"], rec["y"], rec["w"], rec["h"] = box[:, 0], box[:, 1], box[:, 2], box[:, 3]
+    rec["score"] = np.asarray(quality, dtype=np.float32)
+    return rec
 
 
 def NMS(listHit: Sequence[Hit], scoreThreshold: float = 0.5, sortAscending: bool = False,
@@ -20,29 +36,23 @@ def NMS(listHit: Sequence[Hit], scoreThreshold: float = 0.5, sortAscending: bool
     - N_object      : keep at most this many hits (``float("inf")`` = all that pass)
     - maxOverlap    : largest allowed Intersection-over-Union between two kept boxes
 
-    A list of at most one hit is returned as a copy without thresholding, and ``N_object == 1``
-    returns the single best hit, exactly as the reference does.
+    Reference behaviours kept: a list of at most one hit comes back as a copy, unthresholded
+    (MTM/NMS.py:53-55); ``N_object == 1`` returns the single best hit whatever its score, the first one
+    winning ties (:61-69); difference scores are suppressed on ``1 - score`` against ``1 - scoreThreshold``
+    computed on the caller's scalar types (:73-75).
     """
-    nHits = len(listHit)
-    if nHits <= 1:
-        return listHit[:]
-
-    listLabel, listBoxes, listScores = zip(*listHit)
-
+    hits = list(listHit)
+    if len(hits) <= 1:
+        return hits
+    scores = [h[2] for h in hits]
     if N_object == 1:
-        if sortAscending:
-            bestHit = min(listHit, key=lambda hit: hit[2])
-        else:
-            bestHit = max(listHit, key=lambda hit: hit[2])
-        return [bestHit]
-
-    if sortAscending:   # same arithmetic, on the same scalar types, as the reference
-        listScores = [1 - score for score in listScores]
-        scoreThreshold = 1 - scoreThreshold
-
-    indexes = _lib.nms_indices(listBoxes, listScores, scoreThreshold, maxOverlap)
-
+        s = np.asarray(scores, dtype=np.float64)        # exact for float32 and python floats alike
+        return [hits[int(np.argmin(s) if sortAscending else np.argmax(s))]]
+    if sortAscending:
+        quality, threshold = [1 - s for s in scores], 1 - scoreThreshold
+    else:
+        quality, threshold = scores, scoreThreshold
+    keep = _lib.nms_hits(_records(hits, quality), threshold, maxOverlap)
     if N_object != float("inf"):
-        indexes = indexes[:N_object]
-
-    return [listHit[x] for x in indexes]
+        keep = keep[:N_object]
+    return [hits[int(i)] for i in keep]

@@ -21,6 +21,7 @@ KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
 OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY = 1, 2, 3, 4, 5, 6
 E_OVERFLOW = -5
 COMM_ID_BYTES = 128
+ABI_VERSION = 3
 
 
 class MtmTempl(ctypes.Structure):
@@ -69,6 +70,7 @@ SYMBOLS = {
     "mtm_find_matches_async": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double]),
     "mtm_find_matches_wait": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     "mtm_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_last_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
     "mtm_get_timing": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTiming)]),
     "mtm_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
                                ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, _P(ctypes.c_int64)]),
@@ -77,6 +79,8 @@ SYMBOLS = {
     "mtm_comm_allgather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                _P(ctypes.c_int64)]),
+    "mtm_comm_last_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                            _P(ctypes.c_int64)]),
     "mtm_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
@@ -104,7 +108,7 @@ def load():
             fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.mtm_abi_version() != 2:
+        if lib.mtm_abi_version() != ABI_VERSION:
             raise MtmError("libmtm_hip.so ABI version mismatch")
         _lib = lib
         return lib
@@ -251,6 +255,12 @@ class Context:
         check(rc, "mtm_find_matches_wait")
         return out[:n.value]
 
+    def last_score_map(self, idx, shape):
+        """Score map of template `idx` as the last find_matches computed it (map mode only)."""
+        out = np.empty(shape, dtype=np.float32)
+        check(self._lib.mtm_last_score_map(self._h, int(idx), out.ctypes.data, out.strides[0]), "mtm_last_score_map")
+        return out
+
     def timing(self):
         t = MtmTiming()
         check(self._lib.mtm_get_timing(self._h, ctypes.byref(t)), "mtm_get_timing")
@@ -263,19 +273,22 @@ class Context:
         self.n_ranks = n_ranks
 
     def allgather_hits(self, local):
+        """RCCL all-gather of hit records.  Collective: exactly ONE exchange per call on every rank - when the
+        output buffer turns out too small (a local matter: the buffers are sized per rank) the gathered
+        records are fetched from the context with mtm_comm_last_gather, the collective is not repeated."""
         local = np.ascontiguousarray(local, dtype=HIT_DTYPE)
-        cap = max(4096, 4 * len(local) * self.n_ranks)
-        while True:
+        cap = 4096
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        counts = np.zeros(self.n_ranks, dtype=np.int64)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_comm_allgather_hits(self._h, local.ctypes.data, len(local), out.ctypes.data, cap,
+                                               counts.ctypes.data, ctypes.byref(n))
+        if rc == E_OVERFLOW:
+            cap = int(n.value)
             out = np.empty(cap, dtype=HIT_DTYPE)
-            counts = np.zeros(self.n_ranks, dtype=np.int64)
-            n = ctypes.c_int64(0)
-            rc = self._lib.mtm_comm_allgather_hits(self._h, local.ctypes.data, len(local), out.ctypes.data, cap,
-                                                   counts.ctypes.data, ctypes.byref(n))
-            if rc == E_OVERFLOW:
-                cap = int(n.value) + 16
-                continue
-            check(rc, "mtm_comm_allgather_hits")
-            return out[:n.value], counts
+            rc = self._lib.mtm_comm_last_gather(self._h, out.ctypes.data, cap, counts.ctypes.data, ctypes.byref(n))
+        check(rc, "mtm_comm_allgather_hits")
+        return out[:n.value], counts
 
 
 def comm_unique_id():

@@ -54,13 +54,15 @@ inline size_t elem_size(int dtype) { return dtype == MTM_U8 ? 1 : dtype == MTM_U
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    // Grows to at least `bytes` (contents are NOT preserved).  The new block is allocated before the old one
+    // is released: a failed allocation leaves the buffer as it was.
     int ensure(size_t bytes) {
         if (bytes <= cap) return MTM_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
         const size_t want = round_up(bytes + bytes / 8, 256);
-        HIPC(hipMalloc(&p, want));
+        void* fresh = nullptr;
+        HIPC(hipMalloc(&fresh, want));
+        if (p) (void)hipFree(p);
+        p = fresh;
         cap = want;
         return MTM_OK;
     }
@@ -174,7 +176,7 @@ struct mtm_ctx {
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
-    int opt_border = MTM_BORDER_CONSTANT;
+    int opt_border = MTM_BORDER_NEAREST;   // scikit-image >= 0.19 (maximum_filter mode='nearest'); MTM_PEAK_BORDER=constant: <= 0.18
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
     int mfma_dbg = 0;
@@ -191,6 +193,7 @@ struct mtm_ctx {
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
     bool hits_only_now = false;
+    bool maps_valid = false;   // the map arena holds every score map of the last mtm_find_matches (mtm_last_score_map)
     FmState fm;                         // mtm_find_matches_async -> mtm_find_matches_wait
     bool fm_in_flight = false;
     const void* cands_zeroed = nullptr;   // candidate buffer whose counter was cleared after the previous call's fetch
@@ -217,6 +220,8 @@ struct mtm_ctx {
     int n_ranks = 1, rank = 0;
     long long comm_slot_hits = 512;
     DevBuf comm_send, comm_recv;
+    std::vector<long long> comm_last_counts;   // per-rank counts of the last exchange (mtm_comm_last_gather)
+    size_t comm_last_slot = 0;                 //   and its slot size in bytes; the slots are still in comm_pin
 };
 
 namespace {
@@ -379,21 +384,25 @@ int place_templates(mtm_ctx* c) {
     }
     if (c->placed) return MTM_OK;
     const int n = (int)c->templs.size();
-    c->td_host.assign(n, TemplDev{});
+    // Everything is derived into locals and committed at the end: a failure half-way (an allocation, a copy)
+    // leaves the context exactly as it was - templates set, not placed.
+    std::vector<SizeClass> classes = c->classes;
+    std::vector<TemplDev> td_host((size_t)n, TemplDev{});
+    std::vector<int> tlist_host, list2d;
     size_t map_off = 0, w_off = 0, p_off = 0;
     const bool img_u8 = c->dtype == MTM_U8;
     // Which kernel will run each class decides what has to be packed: int8 A-packs for the MFMA kernel,
     // dot4 packs for the VALU kernel, float64 weights for the float64 / naive kernels.  (Changing
     // MTM_OPT_KERNEL re-places.)
-    std::vector<int> class_kernel(c->classes.size(), MTM_KERNEL_AUTO);
-    for (size_t k = 0; k < c->classes.size(); ++k) {
-        c->classes[k].mfma_ok = mfma_class_ok(c, c->classes[k]);
-        c->classes[k].mfma16_ok = mfma16_class_ok(c, c->classes[k]);
-        c->classes[k].n_pad = (int)round_up(c->classes[k].members.size(), 16);
-        class_kernel[k] = resolved_kernel(c, c->classes[k]);
+    std::vector<int> class_kernel(classes.size(), MTM_KERNEL_AUTO);
+    for (size_t k = 0; k < classes.size(); ++k) {
+        classes[k].mfma_ok = mfma_class_ok(c, classes[k]);
+        classes[k].mfma16_ok = mfma16_class_ok(c, classes[k]);
+        classes[k].n_pad = (int)round_up(classes[k].members.size(), 16);
+        class_kernel[k] = resolved_kernel(c, classes[k]);
         // row-multiplexed mode: uint8 class of <= 16 templates (one channel, masked or not, or unmasked RGB) whose
         // window statistics the fused kernels produce (the single-channel one also writes the 1/sqrt plane)
-        SizeClass& sc = c->classes[k];
+        SizeClass& sc = classes[k];
         sc.rm_nt = sc.rm_R = 0;
         const size_t n_cls = sc.members.size();
         if (c->row_mux && class_kernel[k] == MTM_KERNEL_MFMA && n_cls <= 16 && c->fuse_stats &&
@@ -421,7 +430,7 @@ int place_templates(mtm_ctx* c) {
             set_error("template " + std::to_string(i) + " is larger than the image");
             return MTM_E_INVALID;
         }
-        TemplDev& d = c->td_host[i];
+        TemplDev& d = td_host[i];
         for (int k = 0; k < kMaxChans; ++k) d.mean[k] = t.st.mean[k];
         d.templ_norm = t.st.templ_norm;
         d.templ_sum2 = t.st.templ_sum2;
@@ -457,10 +466,9 @@ int place_templates(mtm_ctx* c) {
             d.pack_off = -1;
         }
     }
-    c->maps_floats = map_off;
     // masked classes on the integer path: one dot4 pack of the (shared, binary) mask bytes per class
-    for (size_t k = 0; k < c->classes.size(); ++k) {
-        SizeClass& sc = c->classes[k];
+    for (size_t k = 0; k < classes.size(); ++k) {
+        SizeClass& sc = classes[k];
         sc.masked_int = sc.masked && class_kernel[k] == MTM_KERNEL_MFMA;
         sc.mask_pack_off = -1;
         if (sc.masked_int && !(c->row_mux && c->fuse_stats)) {   // dot4 route of sum I^2 M (otherwise: matrix cores)
@@ -473,7 +481,7 @@ int place_templates(mtm_ctx* c) {
     std::vector<uint8_t> packs(p_off);
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
-        const TemplDev& d = c->td_host[i];
+        const TemplDev& d = td_host[i];
         const size_t plane = (size_t)t.chans * t.rows * t.cols;
         if (d.k1_off >= 0 && t.masked) {
             for (size_t k = 0; k < plane; ++k) {
@@ -486,7 +494,7 @@ int place_templates(mtm_ctx* c) {
         }
         if (d.pack_off >= 0) pack_template_dot4(t, packs.data() + d.pack_off);
     }
-    for (const SizeClass& sc : c->classes)
+    for (const SizeClass& sc : classes)
         if (sc.masked_int && sc.mask_pack_off >= 0) {
             HostTempl mk = c->templs[sc.members[0]];
             for (size_t k = 0; k < mk.px.size(); ++k) mk.px[k] = mk.mask[k] > 0.0 ? 255.0 : 0.0;
@@ -494,8 +502,8 @@ int place_templates(mtm_ctx* c) {
         }
     // int8 MFMA packs, per eligible class
     size_t a_off = 0;
-    for (size_t k = 0; k < c->classes.size(); ++k) {
-        SizeClass& sc = c->classes[k];
+    for (size_t k = 0; k < classes.size(); ++k) {
+        SizeClass& sc = classes[k];
         if (class_kernel[k] != MTM_KERNEL_MFMA) continue;
         sc.mask_rm_off = -1;
         if (sc.masked && c->row_mux && c->fuse_stats) {
@@ -515,8 +523,8 @@ int place_templates(mtm_ctx* c) {
         a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
     }
     size_t ts_off = 0;
-    for (size_t k = 0; k < c->classes.size(); ++k) {
-        SizeClass& sc = c->classes[k];
+    for (size_t k = 0; k < classes.size(); ++k) {
+        SizeClass& sc = classes[k];
         sc.tsum_off = -1;
         if (class_kernel[k] != MTM_KERNEL_MFMA16) continue;
         sc.group_bytes = mfma_group_bytes(sc.h, sc.w, 1);
@@ -527,45 +535,49 @@ int place_templates(mtm_ctx* c) {
     }
     std::vector<uint8_t> apacks(a_off);
     std::vector<double> tsums(ts_off);
-    for (size_t k = 0; k < c->classes.size(); ++k) {
-        if (class_kernel[k] == MTM_KERNEL_MFMA && c->classes[k].mask_rm_off >= 0)
-            pack_mask_rm(c, c->classes[k], apacks.data() + c->classes[k].mask_rm_off);
-        if (class_kernel[k] == MTM_KERNEL_MFMA && c->classes[k].rm_R > 0)
-            pack_class_rm(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
+    for (size_t k = 0; k < classes.size(); ++k) {
+        if (class_kernel[k] == MTM_KERNEL_MFMA && classes[k].mask_rm_off >= 0)
+            pack_mask_rm(c, classes[k], apacks.data() + classes[k].mask_rm_off);
+        if (class_kernel[k] == MTM_KERNEL_MFMA && classes[k].rm_R > 0)
+            pack_class_rm(c, classes[k], apacks.data() + classes[k].apack_off);
         else if (class_kernel[k] == MTM_KERNEL_MFMA)
-            pack_class_mfma(c, c->classes[k], apacks.data() + c->classes[k].apack_off);
+            pack_class_mfma(c, classes[k], apacks.data() + classes[k].apack_off);
         if (class_kernel[k] == MTM_KERNEL_MFMA16)
-            pack_class_mfma16(c, c->classes[k], apacks.data() + c->classes[k].apack_off, tsums.data() + c->classes[k].tsum_off);
+            pack_class_mfma16(c, classes[k], apacks.data() + classes[k].apack_off, tsums.data() + classes[k].tsum_off);
     }
     // template lists: one per class, then the list of templates with a 2-D score map
-    c->tlist_host.clear();
-    for (SizeClass& sc : c->classes) {
-        sc.tlist_off = (int)c->tlist_host.size();
-        c->tlist_host.insert(c->tlist_host.end(), sc.members.begin(), sc.members.end());
+    for (SizeClass& sc : classes) {
+        sc.tlist_off = (int)tlist_host.size();
+        tlist_host.insert(tlist_host.end(), sc.members.begin(), sc.members.end());
     }
-    c->list2d.clear();
     for (int i = 0; i < n; ++i)
-        if (c->td_host[i].oh > 1 && c->td_host[i].ow > 1) c->list2d.push_back(i);
-    c->list2d_off = (int)c->tlist_host.size();
-    c->tlist_host.insert(c->tlist_host.end(), c->list2d.begin(), c->list2d.end());
+        if (td_host[i].oh > 1 && td_host[i].ow > 1) list2d.push_back(i);
+    const int list2d_off = (int)tlist_host.size();
+    tlist_host.insert(tlist_host.end(), list2d.begin(), list2d.end());
 
     MTMC(c->td.ensure(sizeof(TemplDev) * n));
-    MTMC(c->tlist.ensure(sizeof(int) * std::max<size_t>(1, c->tlist_host.size())));
+    MTMC(c->tlist.ensure(sizeof(int) * std::max<size_t>(1, tlist_host.size())));
     MTMC(c->weights.ensure(sizeof(double) * std::max<size_t>(1, w_off)));
     MTMC(c->packs.ensure(std::max<size_t>(4, p_off)));
     MTMC(c->apacks.ensure(std::max<size_t>(16, a_off) + 16384));     // the K loop requests up to two steps past a pack
     if (a_off) HIPC(hipMemcpyAsync(c->apacks.p, apacks.data(), a_off, hipMemcpyHostToDevice, c->stream));
     // the score-map arena (4 bytes per pixel and template) is only allocated when something writes maps:
     // mtm_find_matches in hits-only mode never does (ensure_maps, called by the launch paths)
-    HIPC(hipMemcpyAsync(c->td.p, c->td_host.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
-    if (!c->tlist_host.empty())
-        HIPC(hipMemcpyAsync(c->tlist.p, c->tlist_host.data(), sizeof(int) * c->tlist_host.size(),
+    HIPC(hipMemcpyAsync(c->td.p, td_host.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
+    if (!tlist_host.empty())
+        HIPC(hipMemcpyAsync(c->tlist.p, tlist_host.data(), sizeof(int) * tlist_host.size(),
                             hipMemcpyHostToDevice, c->stream));
     if (w_off) HIPC(hipMemcpyAsync(c->weights.p, wts.data(), sizeof(double) * w_off, hipMemcpyHostToDevice, c->stream));
     if (p_off) HIPC(hipMemcpyAsync(c->packs.p, packs.data(), p_off, hipMemcpyHostToDevice, c->stream));
     MTMC(c->tsum.ensure(sizeof(double) * std::max<size_t>(2, ts_off)));
     if (ts_off) HIPC(hipMemcpyAsync(c->tsum.p, tsums.data(), sizeof(double) * ts_off, hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
+    c->classes.swap(classes);
+    c->td_host.swap(td_host);
+    c->tlist_host.swap(tlist_host);
+    c->list2d.swap(list2d);
+    c->list2d_off = list2d_off;
+    c->maps_floats = map_off;
     c->placed = true;
     return MTM_OK;
 }
@@ -1594,6 +1606,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // numpy compares the float32 map with the python-float threshold in float32
     const float thr = (float)score_threshold;
     c->timing = mtm_timing{};
+    c->maps_valid = false;
 
     // fused peak candidates: only when every class runs the MFMA kernel
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
@@ -1929,6 +1942,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     MTMC(collect_ncc_time(c));
     c->timing.n_hits = (int64_t)hits.size();
     c->timing.hits_only = c->hits_only_now ? 1 : 0;
+    c->maps_valid = !c->hits_only_now && !c->ext_now;
     *n_out = (int64_t)hits.size();
     c->last_hits.swap(hits);
     if ((int64_t)c->last_hits.size() > capacity) {
@@ -1968,6 +1982,33 @@ int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
         return MTM_E_OVERFLOW;
     }
     if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
+    return MTM_OK;
+}
+
+int mtm_last_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_bytes) {
+    if (!c || !out) {
+        set_error("mtm_last_score_map: bad arguments");
+        return MTM_E_INVALID;
+    }
+    MTM_NOT_IN_FLIGHT(c, "mtm_last_score_map");
+    if (!c->placed || !c->maps_valid) {
+        set_error("mtm_last_score_map: the last mtm_find_matches did not materialise the score maps "
+                  "(MTM_OPT_HITS_ONLY = 0 makes it), or the inputs changed since");
+        return MTM_E_STATE;
+    }
+    if (templ_idx < 0 || templ_idx >= (int)c->templs.size()) {
+        set_error("mtm_last_score_map: template index out of range");
+        return MTM_E_INVALID;
+    }
+    const TemplDev& d = c->td_host[templ_idx];
+    if (out_row_stride_bytes < (int64_t)(sizeof(float) * d.ow)) {
+        set_error("mtm_last_score_map: output row stride too small");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off, sizeof(float) * d.map_pitch,
+                          sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
     return MTM_OK;
 }
 
@@ -2134,21 +2175,42 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
         if (mx <= slot_hits) break;
         slot_hits = mx;                 // every rank computes the same maximum: the collective stays matched
     }
+    c->comm_last_counts = counts;
+    c->comm_last_slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
+    (void)all;
+    // The collective is over.  A too-small output buffer is a purely local matter: the gathered slots stay in
+    // the pinned staging area and mtm_comm_last_gather() delivers them - the exchange is NEVER repeated (the
+    // other ranks, whose buffers were large enough, have already moved on).
+    return mtm_comm_last_gather(c, out, capacity, counts_out, n_out);
+}
+
+int mtm_comm_last_gather(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out) {
+    if (!c || !counts_out || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        set_error("mtm_comm_last_gather: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (c->comm_last_counts.empty() || !c->comm_pin) {
+        set_error("mtm_comm_last_gather: no exchange has run on this context");
+        return MTM_E_STATE;
+    }
+    const int R = (int)c->comm_last_counts.size();
     long long total = 0;
     for (int r = 0; r < R; ++r) {
-        counts_out[r] = counts[r];
-        total += counts[r];
+        counts_out[r] = c->comm_last_counts[(size_t)r];
+        total += c->comm_last_counts[(size_t)r];
     }
     *n_out = total;
     if (total > capacity) {
-        set_error("mtm_comm_allgather_hits: output capacity too small");
-        return MTM_E_OVERFLOW;   // every rank sees the same counts, so every rank returns here
+        set_error("mtm_comm_allgather_hits: output capacity too small (fetch the result with mtm_comm_last_gather)");
+        return MTM_E_OVERFLOW;
     }
-    const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
+    const size_t slot = c->comm_last_slot;
+    const uint8_t* all = static_cast<const uint8_t*>(c->comm_pin) + slot;      // [my slot | R gathered slots]
     int64_t o = 0;
     for (int r = 0; r < R; ++r) {
-        if (counts[r]) std::memcpy(out + o, all + slot * r + 16, sizeof(mtm_hit) * (size_t)counts[r]);
-        o += counts[r];
+        const long long cnt = c->comm_last_counts[(size_t)r];
+        if (cnt) std::memcpy(out + o, all + slot * r + 16, sizeof(mtm_hit) * (size_t)cnt);
+        o += cnt;
     }
     return MTM_OK;
 }

@@ -43,11 +43,14 @@ TM_SQDIFF, TM_SQDIFF_NORMED, TM_CCORR, TM_CCORR_NORMED, TM_CCOEFF, TM_CCOEFF_NOR
 FLT_EPSILON = float(np.finfo(np.float32).eps)
 DBL_EPSILON = float(np.finfo(np.float64).eps)
 
-# peak_local_max border handling.  skimage <= 0.18 (the only version importable here) pads the
-# 3x3 maximum filter with the constant 0 ('constant'); newer releases are believed to use
-# 'nearest'.  The two agree whenever the threshold is >= 0 (methods 2..5); they differ only for
-# _findLocalMin_ (negated map) on the map border.
-DEFAULT_PEAK_BORDER = "constant"
+# peak_local_max border handling.  skimage <= 0.18 (the only version importable here) pads the 3x3 maximum
+# filter with the constant 0 ('constant'); releases >= 0.19 replicate the edge ('nearest').  The two agree
+# whenever the filtered map is >= 0 at its border (methods 2..5 with a threshold >= 0); they differ for
+# _findLocalMin_ (negated map: with zero padding a border minimum is never a peak) and for negative thresholds.
+# Default = current scikit-image (the reference leaves it unpinned, setup.py:24); both rules are pinned by
+# fixtures: "<call>@constant" from the real 0.18.3, "<call>@nearest" from the same code with mode='nearest'
+# (tests/golden/make_golden.py).
+DEFAULT_PEAK_BORDER = "nearest"
 
 
 # --------------------------------------------------------------------------------------------
@@ -72,12 +75,19 @@ def _next_fast(n):
     return best
 
 
-def corr_fft(img2d, ker2d):
-    """Valid-mode cross-correlation sum_{dy,dx} img[y+dy,x+dx]*ker[dy,dx] in float64 via FFT."""
+def corr_fft(img2d, ker2d, cache=None, cache_key=None):
+    """Valid-mode cross-correlation sum_{dy,dx} img[y+dy,x+dx]*ker[dy,dx] in float64 via FFT.
+    ``cache`` (a dict owned by the caller) keeps the image spectrum under ``cache_key`` so that many
+    templates over one image (full-size parity tests) transform the image once."""
     H, W = img2d.shape
     h, w = ker2d.shape
     fh, fw = _next_fast(H), _next_fast(W)
-    F = np.fft.rfft2(img2d.astype(np.float64), s=(fh, fw))
+    if cache is not None and cache_key in cache:
+        F = cache[cache_key]
+    else:
+        F = np.fft.rfft2(img2d.astype(np.float64), s=(fh, fw))
+        if cache is not None:
+            cache[cache_key] = F
     G = np.fft.rfft2(ker2d.astype(np.float64)[::-1, ::-1], s=(fh, fw))
     full = np.fft.irfft2(F * G, s=(fh, fw))
     return full[h - 1:H, w - 1:W]
@@ -99,7 +109,7 @@ def corr_direct(img2d, ker2d, acc_dtype):
     return out
 
 
-def sliding_corr(img2d, ker2d, exact_int=False, force=None):
+def sliding_corr(img2d, ker2d, exact_int=False, force=None, cache=None, cache_key=None):
     """Cross-correlation of one channel.  exact_int: both operands hold integers whose products
     fit in int64 -> result is the exact integer (as float64).  FFT in float64 + rint is exact for
     the sizes used here (|error| << 0.5); small problems use the direct sum."""
@@ -111,7 +121,7 @@ def sliding_corr(img2d, ker2d, exact_int=False, force=None):
         if exact_int:
             return corr_direct(img2d, ker2d, np.int64).astype(np.float64)
         return corr_direct(img2d, ker2d, np.float64)
-    out = corr_fft(img2d, ker2d)
+    out = corr_fft(img2d, ker2d, cache, cache_key)
     if exact_int:
         out = np.rint(out)
     return out
@@ -150,12 +160,13 @@ def _templ_mean_sdv(t3, integer):
     return means, sdvs
 
 
-def match_template(image, templ, method, mask=None, corr="auto"):
+def match_template(image, templ, method, mask=None, corr="auto", cache=None):
     """cv2.matchTemplate(image, templ, method, mask=mask) -> float32 (H-h+1, W-w+1).
 
     Reference call site: MTM/__init__.py:92.  image/templ: uint8 or float32, (rows, cols) or
     (rows, cols, C) with equal C.  ``corr``: "auto" | "direct" | "fft" (how the exact sliding dot
-    product is evaluated; results agree)."""
+    product is evaluated; results agree).  ``cache``: a dict the caller reuses across calls on the SAME image
+    (image spectra are kept in it; pure speed-up)."""
     img3 = _as3d(image)
     t3 = _as3d(templ)
     if img3.dtype != t3.dtype or img3.shape[2] != t3.shape[2]:
@@ -169,12 +180,12 @@ def match_template(image, templ, method, mask=None, corr="auto"):
     force = None if corr == "auto" else corr
     integer = img3.dtype == np.uint8
     if mask is not None:
-        return _match_template_mask(img3, t3, method, mask, force)
+        return _match_template_mask(img3, t3, method, mask, force, cache)
 
     # exact sliding dot product, summed over channels
     corr_map = np.zeros((H - h + 1, W - w + 1), dtype=np.float64)
     for c in range(C):
-        corr_map += sliding_corr(img3[:, :, c], t3[:, :, c], exact_int=integer, force=force)
+        corr_map += sliding_corr(img3[:, :, c], t3[:, :, c], exact_int=integer, force=force, cache=cache, cache_key=("I", c))
     if method == TM_CCORR:
         return corr_map.astype(np.float32)
 
@@ -226,7 +237,7 @@ def match_template(image, templ, method, mask=None, corr="auto"):
     return num.astype(np.float32)
 
 
-def _match_template_mask(img3, t3, method, mask, force):
+def _match_template_mask(img3, t3, method, mask, force, cache=None):
     """cv::matchTemplateMask (OpenCV >= 4.5.4), methods TM_SQDIFF and TM_CCORR_NORMED are the only
     ones MTM lets through (MTM/__init__.py:78, :216)."""
     m3 = _as3d(mask)
@@ -252,8 +263,8 @@ def _match_template_mask(img3, t3, method, mask, force):
     c_i_tm2 = np.zeros((H - h + 1, W - w + 1))
     c_i2_m2 = np.zeros_like(c_i_tm2)
     for c in range(C):
-        c_i_tm2 += sliding_corr(img[:, :, c], tm2[:, :, c], exact_int=integer, force=force)
-        c_i2_m2 += sliding_corr(img[:, :, c] ** 2, m2[:, :, c], exact_int=integer, force=force)
+        c_i_tm2 += sliding_corr(img[:, :, c], tm2[:, :, c], exact_int=integer, force=force, cache=cache, cache_key=("I", c))
+        c_i2_m2 += sliding_corr(img[:, :, c] ** 2, m2[:, :, c], exact_int=integer, force=force, cache=cache, cache_key=("I2", c))
     with np.errstate(divide="ignore", invalid="ignore"):
         if method == TM_SQDIFF:
             res = -2.0 * c_i_tm2 + c_i2_m2 + templ2_mask2_sum

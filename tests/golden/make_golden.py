@@ -24,7 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(HERE, "cv2_standin"))
 sys.path.insert(0, "/root/reference")
-sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
+sys.path.append(os.path.join(ROOT, "multitemplatematching-python_amd"))     # synth only: `MTM` must be the reference's
 sys.dont_write_bytecode = True
 warnings.simplefilter("ignore")
 
@@ -112,6 +112,52 @@ ref["testpy"] = hits_json(MTM.matchTemplates([("small", small), ("big", big)], i
 ref["tut1_two"] = hits_json(MTM.matchTemplates([("small", small), ("large", big)], image, score_threshold=0.4, method=5, maxOverlap=0))
 # method 1 (difference score, minima)
 ref["sqdiff_normed"] = hits_json(MTM.matchTemplates([("small", small), ("big", big)], image, method=1, score_threshold=0.2, maxOverlap=0))
+# ---- border rule of peak_local_max.  scikit-image 0.18.3 (the only release importable here) runs its 3x3
+# maximum filter with mode='constant'; releases >= 0.19 pass mode='nearest' - with zero padding a local MINIMUM
+# on the map border (methods 0/1: the map is negated, MTM/__init__.py:53) can never be a peak.  The
+# "<name>@nearest" fixtures are the same calls through the same 0.18.3 code with that one argument replaced.
+import contextlib  # noqa: E402
+import skimage.feature.peak as _pk  # noqa: E402
+
+
+class _NdiNearest:
+    """scipy.ndimage with maximum_filter(..., mode='nearest'), every other attribute untouched."""
+
+    def __init__(self, ndi):
+        self._ndi = ndi
+
+    def __getattr__(self, name):
+        return getattr(self._ndi, name)
+
+    def maximum_filter(self, *a, **kw):
+        kw["mode"] = "nearest"
+        return self._ndi.maximum_filter(*a, **kw)
+
+
+@contextlib.contextmanager
+def nearest_border():
+    saved = _pk.ndi
+    _pk.ndi = _NdiNearest(saved)
+    try:
+        yield
+    finally:
+        _pk.ndi = saved
+
+
+corner = image[0:38, 0:41]          # an object touching the image corner: its best match is map pixel (0, 0)
+edge = image[120:158, 343:384]      # ... and one touching the right edge
+border_calls = {
+    "sqdiff_normed": dict(lt=[("small", small), ("big", big)], kw=dict(method=1, score_threshold=0.2, maxOverlap=0)),
+    "corner_m1": dict(lt=[("corner", corner), ("edge", edge)], kw=dict(method=1, score_threshold=0.25, maxOverlap=0.1)),
+    "corner_m5_negthr": dict(lt=[("corner", corner)], kw=dict(method=5, score_threshold=-0.2, maxOverlap=0.0)),
+}
+for name, cdef in border_calls.items():
+    ref[name + "@constant"] = hits_json(MTM.matchTemplates(cdef["lt"], image, **cdef["kw"]))
+    with nearest_border():
+        ref[name + "@nearest"] = hits_json(MTM.matchTemplates(cdef["lt"], image, **cdef["kw"]))
+ref["corner_m1_pre@constant"] = canon(MTM.findMatches([("corner", corner), ("edge", edge)], image, method=1, score_threshold=0.25))
+with nearest_border():
+    ref["corner_m1_pre@nearest"] = canon(MTM.findMatches([("corner", corner), ("edge", edge)], image, method=1, score_threshold=0.25))
 # maxOverlap > 0, finite N_object
 ref["overlap025"] = hits_json(MTM.matchTemplates([("small", small), ("big", big)], image, score_threshold=0.3, method=5, maxOverlap=0.25))
 ref["nobj3"] = hits_json(MTM.matchTemplates([("small", small), ("big", big)], image, score_threshold=0.3, method=5, maxOverlap=0.25, N_object=3))
@@ -191,6 +237,7 @@ np.savez_compressed(os.path.join(HERE, "coins_maps_sub3.npz"), mask=mask, **sub)
 synth_cases = {
     "cfg2_small": dict(seed=2, image_hw=(360, 640), n_base=4, templ=32),
     "cfg3_small": dict(seed=3, image_hw=(400, 640), n_base=3, templ=32, rotations=4),
+    "cfg4_small": dict(seed=4, image_hw=(480, 800), n_base=40, templ=32, noisy_per_unit=1),
     "cfg5_small": dict(seed=5, image_hw=(480, 800), n_base=2, templ=32, scales=(16, 28, 40, 52, 64), masked=True),
     "rgb_small": dict(seed=6, image_hw=(300, 420), n_base=3, templ=24, channels=3),
 }

@@ -358,7 +358,7 @@ def test_peaks_vs_oracle_low_threshold(mtm, ctx, coins):
                 assert len(got) == len(exp) and (len(got) > 64 or thr == 0.05)
                 assert_hits_equal(canon(got), canon(exp), tol=1e-5)
         finally:
-            ctx.set_option(2, 0)
+            ctx.set_option(2, 1)          # back to the default (edge replication)
             ctx.set_option(3, 1 << 18)
 
 
@@ -437,6 +437,147 @@ def test_cfg3_size_properties(mtm, ctx):
             set_kernel(ctx, "auto")
     assert res["mfma"] == hits
     hits_close(sorted(res["dot4"], key=lambda h: (h[0], h[1])), sorted(hits, key=lambda h: (h[0], h[1])))
+
+
+def _batched_maps(mtm, ctx, units, img, method, thr, picks):
+    """One production-style batched search in map mode (MTM_OPT_HITS_ONLY = 0): returns its hit records and
+    the complete score maps of the templates in `picks`, copied out of the map arena as the batched launch
+    wrote them (mtm_last_score_map) - not recomputed one template at a time."""
+    from MTM import _lib
+    with ctx.lock:
+        ctx.set_option(_lib.OPT_HITS_ONLY, 0)
+        try:
+            ctx.set_image(img)
+            ctx.set_templates([(u[1], u[2] if len(u) >= 3 else None) for u in units], method)
+            raw = ctx.find_matches(_lib.PEAKS_LOCAL, thr).copy()
+            assert ctx.timing()["hits_only"] == 0
+            maps = {}
+            for i in picks:
+                t = units[i][1]
+                maps[i] = ctx.last_score_map(i, (img.shape[0] - t.shape[0] + 1, img.shape[1] - t.shape[1] + 1))
+        finally:
+            ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+    return raw, maps
+
+
+def test_cfg3_full_size_maps_against_oracle(mtm, ctx):
+    """BASELINE configs[2] at full size (3840x2160 x 128 units): complete score maps out of the batched
+    128-unit launch against the oracle, pixel by pixel."""
+    img, units, plants = synth.make_config("cfg3")
+    picks = [5, 77, 126]                               # a 0-degree, a 90-degree and a 180-degree unit
+    raw, maps = _batched_maps(mtm, ctx, units, img, 5, 0.5, picks)
+    cache = {}
+    for i in picks:
+        exp = O.match_template(img, units[i][1], 5, cache=cache)
+        map_close(maps[i], exp, tol=1e-6)
+        assert np.array_equal(maps[i], mtm.computeScoreMap(units[i][1], img, 5))      # single-template launch: same bits
+    # the map-mode hit records are those of the default (hits-only) call
+    hits = mtm.findMatches(units, img, score_threshold=0.5)
+    assert len(raw) == len(hits) == len(plants)
+    assert sorted((units[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), float(r["score"])) for r in raw) == \
+        sorted((h[0], h[1], float(h[2])) for h in hits)
+
+
+def test_cfg5_full_size_maps_against_oracle(mtm, ctx):
+    """BASELINE configs[4] at full size (7680x4320, 80 masked units at 5 scales, TM_CCORR_NORMED): two complete
+    score maps per size class - 32, 56, 80, 104 and 128 pixels, disc masks - out of the batched launch against
+    the oracle's matchTemplateMask, plus the hit list properties."""
+    img, units, plants = synth.make_config("cfg5")
+    sides = sorted({u[1].shape[0] for u in units})
+    assert sides == [32, 56, 80, 104, 128]
+    picks = []
+    for sd in sides:
+        idx = [i for i, u in enumerate(units) if u[1].shape[0] == sd]
+        picks += [idx[0], idx[-1]]
+    raw, maps = _batched_maps(mtm, ctx, units, img, 3, 0.9, picks)
+    assert ctx.timing()["kernel_used"] == 3            # every class on the int8 matrix cores (sum I^2 M included)
+    cache = {}
+    for i in picks:
+        exp = O.match_template(img, units[i][1], 3, mask=units[i][2], cache=cache)
+        assert np.isfinite(exp).all()
+        map_close(maps[i], exp, tol=1e-6)
+    hits = mtm.matchTemplates(units, img, method=3, score_threshold=0.9, maxOverlap=0.25)
+    found = {(h[0], h[1]): float(h[2]) for h in hits}
+    planted = {(p[0], p[1]): p[2] for p in plants}
+    assert set(planted) <= set(found)                   # every plant; masked CCORR_NORMED also fires near plants
+    for k, amp in planted.items():
+        if amp == 0:
+            assert abs(found[k] - 1.0) <= 1e-6          # exact copies under the mask
+    pre = mtm.findMatches(units, img, method=3, score_threshold=0.9)
+    assert len(pre) == len(raw)
+
+
+def test_cfg4_full_list_and_eight_way_shards(mtm):
+    """BASELINE configs[3]: 3840x2160 x 256 units.  The whole list on one GPU, the 32-unit shard rank 0 of an
+    8-GPU job holds (LPT partition), and the sharded pipeline end to end - every rank's search done by the HIP
+    path, the exchange replaced by an in-process gather - against the unsharded call."""
+    from MTM import _lib, _raw_matches
+    from MTM.distributed import matchTemplates_sharded, shard_units, unit_cost
+    img, units, plants = synth.make_config("cfg4")
+    assert len(units) == 256
+    full = mtm.matchTemplates(units, img, score_threshold=0.5)
+    found = {(h[0], h[1]): float(h[2]) for h in full}
+    assert set(found) == {(p[0], p[1]) for p in plants}          # every plant, nothing else
+    for p in plants:
+        assert (found[(p[0], p[1])] == 1.0) if p[2] == 0 else (0.6 < found[(p[0], p[1])] < 0.99)
+    world = 8
+    shards = shard_units([unit_cost(u[1], img.shape) for u in units], world)
+    assert sorted(i for s in shards for i in s) == list(range(256)) and all(len(s) == 32 for s in shards)
+    # one GPU's share of the job
+    sub = [units[i] for i in shards[0]]
+    part = mtm.matchTemplates(sub, img, score_threshold=0.5)
+    labels = {u[0] for u in sub}
+    assert part == [h for h in full if h[0] in labels]           # plants never overlap: the global NMS drops nothing
+    # all eight ranks, one after the other on this GPU
+    raws = []
+    for r in range(world):
+        raw = _raw_matches([units[i] for i in shards[r]], img, 5, float("inf"), 0.5).copy()
+        raw["templ_idx"] = np.asarray(shards[r], dtype=np.int32)[raw["templ_idx"]]
+        raws.append(raw)
+    gathered = np.concatenate(raws)
+
+    class Gather:                                                  # the exchange: every rank receives every rank's hits
+        world_size = world
+
+        def __init__(self, rank):
+            self.rank = rank
+
+        def allgather(self, hits):
+            assert np.array_equal(hits, raws[self.rank])
+            return gathered
+
+    for r in (0, 3, 7):
+        def local(sub_list, image, r=r):
+            assert [u[0] for u in sub_list] == [units[i][0] for i in shards[r]]
+            return _raw_matches(sub_list, image, 5, float("inf"), 0.5)
+        assert matchTemplates_sharded(units, img, Gather(r), score_threshold=0.5, find_local=local) == full
+
+
+BORDER_CALLS = {
+    "sqdiff_normed": lambda im: ([("small", im[37:75, 80:121]), ("big", im[14:73, 302:367])],
+                                 dict(method=1, score_threshold=0.2, maxOverlap=0)),
+    "corner_m1": lambda im: ([("corner", im[0:38, 0:41]), ("edge", im[120:158, 343:384])],
+                             dict(method=1, score_threshold=0.25, maxOverlap=0.1)),
+    "corner_m5_negthr": lambda im: ([("corner", im[0:38, 0:41])], dict(method=5, score_threshold=-0.2, maxOverlap=0.0)),
+}
+
+
+@pytest.mark.parametrize("border", ["constant", "nearest"])
+@pytest.mark.parametrize("name", sorted(BORDER_CALLS))
+def test_border_rules_reference_runs(mtm, ctx, coins, name, border):
+    """Objects touching the image border under a difference score: scikit-image <= 0.18 (zero padding, real 0.18.3
+    fixtures) never reports them, >= 0.19 (edge replication, the default here) does."""
+    templates, kw = BORDER_CALLS[name](coins)
+    ctx.set_option(2, {"constant": 0, "nearest": 1}[border])
+    try:
+        hits = mtm.matchTemplates(templates, coins, **kw)
+        pre = mtm.findMatches(templates, coins, method=kw["method"], score_threshold=kw["score_threshold"])
+    finally:
+        ctx.set_option(2, 1)
+    assert_hits_equal(canon(hits), canon([(h[0], tuple(h[1]), h[2]) for h in REF["%s@%s" % (name, border)]]), tol=1e-5)
+    if name == "corner_m1":
+        assert_hits_equal(canon(pre), REF["corner_m1_pre@" + border], tol=1e-5)
+        assert (("corner", (0, 0, 41, 38)) in {(h[0], h[1]) for h in hits}) == (border == "nearest")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -614,7 +755,7 @@ def test_hits_only_equals_map_mode(mtm, ctx, coins):
         # hits-only results against the oracle directly (dense: thousands of candidates)
         ctx.set_option(6, 1)
         set_exact(ctx, 0)
-        ctx.set_option(2, 0)
+        ctx.set_option(2, 1)
         lt = [("small", small), ("big", big)]
         for method, thr in ((5, 0.05), (3, 0.6), (1, 0.9)):
             got = mtm.findMatches(lt, coins, method=method, score_threshold=thr)
@@ -627,7 +768,7 @@ def test_hits_only_equals_map_mode(mtm, ctx, coins):
     finally:
         set_kernel(ctx, "auto")
         set_exact(ctx, 0)
-        ctx.set_option(2, 0)
+        ctx.set_option(2, 1)
         ctx.set_option(6, 1)
 
 

@@ -77,6 +77,32 @@ def test_reference_run_match_templates(coins, name):
         assert_hits_equal(hits, REF[name], tol=1e-6)
 
 
+BORDER_CALLS = {
+    "sqdiff_normed": lambda im: ([("small", im[37:75, 80:121]), ("big", im[14:73, 302:367])],
+                                 dict(method=1, score_threshold=0.2, maxOverlap=0)),
+    "corner_m1": lambda im: ([("corner", im[0:38, 0:41]), ("edge", im[120:158, 343:384])],
+                             dict(method=1, score_threshold=0.25, maxOverlap=0.1)),
+    "corner_m5_negthr": lambda im: ([("corner", im[0:38, 0:41])], dict(method=5, score_threshold=-0.2, maxOverlap=0.0)),
+}
+
+
+@pytest.mark.parametrize("border", ["constant", "nearest"])
+@pytest.mark.parametrize("name", sorted(BORDER_CALLS))
+def test_reference_run_border_rules(coins, name, border):
+    """peak_local_max of scikit-image <= 0.18 ('constant': real 0.18.3) and >= 0.19 ('nearest': the same code with
+    maximum_filter(mode='nearest')): objects touching the image border under a difference score."""
+    templates, kw = BORDER_CALLS[name](coins)
+    hits = O.match_templates(templates, coins, border=border, **kw)
+    assert_hits_equal(canon(hits), canon([(h[0], tuple(h[1]), h[2]) for h in REF["%s@%s" % (name, border)]]), tol=1e-6)
+    if name == "corner_m1":
+        pre = O.find_matches(templates, coins, method=1, score_threshold=0.25, border=border)
+        assert_hits_equal(canon(pre), REF["corner_m1_pre@" + border], tol=1e-6)
+        found = {(h[0], tuple(h[1])) for h in hits}
+        # the object in the image corner is only found with the edge-replicating filter
+        assert (("corner", (0, 0, 41, 38)) in found) == (border == "nearest")
+    assert O.DEFAULT_PEAK_BORDER == "nearest"
+
+
 def test_reference_run_1d_maps(coins):
     tall = coins[:, 100:141]
     wide = coins[50:90, :]
