@@ -4,24 +4,31 @@ bench.py - throughput of the MTM hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
 
-A "step" is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
-per-template score maps (window statistics + sliding-window NCC kernel), peak extraction, D2H of
-the hit list, RCCL all-gather of hits (N > 1) and the global NMS - i.e. one MTM.matchTemplates call
-minus the H2D upload of image and templates.
+A "step" is ONE ``MTM.matchTemplates`` call as a user of the reference makes it: numpy
+arrays in, list of hits out - argument validation, template hand-over (unchanged templates stay resident on the
+GPU, as a loop over images leaves them), H2D of the image, window statistics, the sliding-window score kernel,
+peak extraction, D2H of the hits, (N > 1: RCCL all-gather of the hit records) and the NMS.  ``value`` is
+image pixels x templates x K / the wall-clock of the K timed calls; the per-call median is reported too.
+The rate with the inputs already resident in HBM (software-pipelined and call by call), the rate with fresh
+template bytes in every call, the image-stream rate and the rate with materialised score maps are extra keys
+of the same line.
 
-Default workload (weak scaling family of BASELINE.json's north_star target line):
+Default workload (weak-scaling family of BASELINE.json's north_star target line):
     3840x2160 uint8 image x 32*N templates of 64x64, TM_CCOEFF_NORMED, score_threshold 0.5,
-    maxOverlap 0.25; units sharded 32 per GPU (N=8 is BASELINE configs[3]).
-Other configs (--config cfg2|cfg3|cfg5) are the parity-test cases of BASELINE.json.
+    maxOverlap 0.25; units sharded 32 per GPU (N = 8 is BASELINE configs[3]).
+Other configs (--config cfg2|cfg3|cfg4|cfg5) are the parity-test cases of BASELINE.json on ONE GPU.
 
 Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
-  roofline     - achieved algorithmic GB/s of the dominant (score-map) kernel against the 8 TB/s
-                 HBM peak, kernel time measured with HIP events on the library's own stream;
+  roofline     - the dominant (score-map) kernel against the dense int8 MFMA peak: 2 x algorithmic MACs of a step /
+                 the kernel's time in that step, measured with HIP events on the library's own streams inside
+                 the timed region; the shader clock the kernel actually ran at, measured inside the kernel;
+                 the HBM view (algorithmic bytes against 8 TB/s) and the PMC-measured HBM traffic;
   cpu_baseline - the CPU oracle (FFT-based restatement of the reference pipeline, thread pool over
                  templates as in MTM/__init__.py:172) timed on a bounded sample on this host.
 """
 import argparse
 import gc
+import glob
 import json
 import os
 import sys
@@ -39,7 +46,9 @@ DOT4_PEAK_TMACS = 314.6        # 256 CU x 4 SIMD x 32 lanes x 4 MAC x 2.4 GHz (v
 # cycles per SIMD: 1024 SIMDs x 2.4 GHz x 2048 op/cycle = 5.03 POPS.  `peak` below is that figure.
 I8_MFMA_PEAK_TOPS = 5000.0
 I8_MFMA_UBENCH_TOPS = 3944.0
-PREWARM_STEPS = int(os.environ.get("BENCH_PREWARM", "120"))   # untimed, before the W warm-up steps: clock ramp (see main)
+I8_OPS_PER_CLK = 1024 * 2048   # whole chip, per shader cycle
+PREWARM_SECONDS = float(os.environ.get("BENCH_PREWARM_S", "0.6"))   # untimed load before the W warm-up calls (clock ramp)
+CONFIGS = ("north_star", "cfg2", "cfg3", "cfg4", "cfg5")
 
 
 def parse():
@@ -47,13 +56,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="north_star", help="north_star | cfg2 | cfg3 | cfg5")
+    ap.add_argument("--config", default="north_star", choices=CONFIGS)
     ap.add_argument("--kernel", default=os.environ.get("MTM_KERNEL", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sequential", action="store_true",
-                    help="no software pipelining: the host part of a step finishes before the next step's GPU part starts")
     ap.add_argument("--skip-extras", action="store_true",
-                    help="only the timed steps (profiling runs): no map-mode / end-to-end / stream side measurements")
+                    help="only the timed calls (profiling runs): no resident / fresh-template / map-mode / stream side measurements")
     ap.add_argument("--cpu-sample-templates", type=int, default=0)
     return ap.parse_args()
 
@@ -100,19 +107,36 @@ def algorithmic_bytes_hits_only(img, units):
     return b
 
 
-def algorithmic_macs(img, units):
+def score_kernel_macs(img, units):
+    """Multiply-accumulates of the launches the library's kernel timer brackets (mtm_timing.ncc_kernel_ms): the
+    template correlations sum I*T (or I*(T*M)), out_px * w * h * C per unit.  The second correlation of a masked
+    unit, sum I^2*M, is computed ONCE per distinct mask by separate launches of the statistics phase, outside that
+    timer: it is counted in `masked_stat_macs`, never in the roofline of the timed kernel."""
     H, W = img.shape[:2]
     m = 0
     for u in units:
         t = u[1]
         c = 1 if t.ndim == 2 else t.shape[2]
-        m += (H - t.shape[0] + 1) * (W - t.shape[1] + 1) * t.shape[0] * t.shape[1] * c * (2 if len(u) >= 3 else 1)
+        m += (H - t.shape[0] + 1) * (W - t.shape[1] + 1) * t.shape[0] * t.shape[1] * c
+    return m
+
+
+def masked_stat_macs(img, units):
+    H, W = img.shape[:2]
+    seen, m = set(), 0
+    for u in units:
+        if len(u) >= 3:
+            key = (u[1].shape[:2], u[2].tobytes())
+            if key not in seen:
+                seen.add(key)
+                m += 2 * (H - u[1].shape[0] + 1) * (W - u[1].shape[1] + 1) * u[1].shape[0] * u[1].shape[1]   # two byte planes of I^2
     return m
 
 
 def pmc_traffic(kernel_used, config, world, hits_only=False):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under
-    profiles/ (FETCH_SIZE, WRITE_SIZE; collected separately, see tools/profile_round.sh), or None."""
+    """HBM bytes per FULL-IMAGE launch of the dominant kernel from the rocprofv3 PMC passes committed under
+    profiles/ (FETCH_SIZE, WRITE_SIZE; collected separately, see tools/profile_round.sh), or None.  A table
+    look-up, not a measurement of this run."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             table = json.load(f)
@@ -121,6 +145,25 @@ def pmc_traffic(kernel_used, config, world, hits_only=False):
         return table.get(key)
     except Exception:  # noqa: BLE001
         return None
+
+
+def gpu_sensors():
+    """Engine clock (MHz) and power (W) the driver reports right now (sysfs hwmon of the first amdgpu card), or {}."""
+    out = {}
+    for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        try:
+            with open(os.path.join(hw, "freq1_input")) as f:
+                out["sclk_mhz_sysfs"] = round(int(f.read()) / 1e6, 1)
+            for name in ("power1_average", "power1_input"):
+                pth = os.path.join(hw, name)
+                if os.path.exists(pth):
+                    with open(pth) as f:
+                        out["power_w"] = round(int(f.read()) / 1e6, 1)
+                    break
+            break
+        except (OSError, ValueError):
+            continue
+    return out
 
 
 def cpu_baseline(img, units, method, thr, n_sample):
@@ -180,7 +223,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    import torch          # plumbing only: device sync + the distributed bootstrap/barrier
+    import torch          # the driver's contract: device synchronisation + torch.distributed barrier / max-over-ranks
     import MTM
     from MTM import _lib
     from MTM.distributed import HitExchange, merge_and_nms, shard_units, unit_cost
@@ -190,7 +233,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only
     # BENCH_FORCE_DEVICE: control-flow test of the N > 1 path on a single-GPU box (all ranks share one GPU;
-    # RCCL refuses that, so the exchange falls back to gloo) - never set by the driver
+    # RCCL refuses that, so the exchange falls back to the control plane) - never set by the driver
     device = int(os.environ.get("BENCH_FORCE_DEVICE", local_rank))
     have_torch_gpu = torch.cuda.is_available()
     if have_torch_gpu:
@@ -199,22 +242,25 @@ def main():
     img, units, plants, method, thr, desc = build_workload(args.config, world)
     ctx = _lib.Context(device)
     ctx.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
+    _lib._default_ctx = ctx                  # MTM.matchTemplates below runs on this context
     exchange_kind = "rccl" if world > 1 else "none"
     try:
-        exchange = HitExchange("rccl" if world > 1 else "torch", rank, world, context=ctx)
+        exchange = HitExchange("rccl", rank, world, context=ctx)       # unique id through the package's TCP store
     except Exception as e:  # noqa: BLE001 - keep the job alive: same records over gloo instead of RCCL
         sys.stderr.write("[bench] RCCL hit exchange unavailable (%s); falling back to gloo\n" % e)
-        exchange = HitExchange("torch", rank, world)
+
+        def gloo_allgather(payload):
+            parts = [None] * world
+            dist.all_gather_object(parts, payload)
+            return parts
+        exchange = HitExchange("custom", rank, world, allgather_bytes=gloo_allgather)
         exchange_kind = "gloo-fallback"
 
     costs = [unit_cost(u[1], img.shape, len(u) >= 3) for u in units]
     mine = shard_units(costs, world)[rank]
     sub = [units[i] for i in mine]
     gidx = np.asarray(mine, dtype=np.int32)
-
-    # inputs resident in HBM before the timed region
-    ctx.set_image(img)
-    ctx.set_templates([(u[1], u[2] if len(u) >= 3 else None) for u in sub], method)
+    inf = float("inf")
 
     def sync():
         if have_torch_gpu:
@@ -222,158 +268,231 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    kernel_ms, total_ms, launches = [], [], 0
+    kernel_ms, total_ms, clocks, launches = [], [], [], 0
 
-    # A step = GPU part (window statistics, score kernel, peak extraction, D2H of the hits), the all-gather of
-    # the hit records, and the host part (merge in template order, global NMS, the reference's list of tuples).
-    # The steps are software-pipelined: the GPU part of step i+1 is queued (mtm_find_matches_async: no waiting
-    # for the GPU) before this thread does the host part of step i, the way
-    # MTM.TemplateMatcher.match_stream overlaps the two for an image stream.  Every step is complete - its hit
-    # list built - inside the timed region; `--sequential` turns the overlap off.
-    def collect(raw, t):
+    def note_timing():
         nonlocal launches
+        t = ctx.timing()
         kernel_ms.append(t["ncc_kernel_ms"])
         total_ms.append(t["total_ms"])
+        if t["sclk_mhz"] > 0:
+            clocks.append(t["sclk_mhz"])
         launches = t["ncc_launches"]
-        raw["templ_idx"] = gidx[raw["templ_idx"]]      # (the arrays the context hands out are the caller's own)
+        return t
+
+    # ---- the timed step: one matchTemplates call, numpy arrays in -> hit list out
+    if world == 1:
+        def call(lt=units):
+            return MTM.matchTemplates(lt, img, method=method, score_threshold=thr, maxOverlap=0.25)
+    else:
+        def call(lt=None):
+            # the same call with the units sharded over the ranks: this rank's templates + the image go to its GPU,
+            # hit records are exchanged (RCCL all-gather), every rank runs the global NMS
+            raw = MTM._raw_matches(sub, img, method, inf, thr, context=ctx).copy()
+            raw["templ_idx"] = gidx[raw["templ_idx"]]
+            return merge_and_nms(exchange.allgather(raw), units, method, inf, thr, 0.25)
+
+    def run_calls(k, lt_of=None, stamps=None):
+        hits = None
+        for i in range(k):
+            t1 = time.perf_counter()
+            hits = call(lt_of(i)) if lt_of else call()
+            if stamps is not None:
+                stamps.append(time.perf_counter() - t1)
+            note_timing()
+        return hits
+
+    # ---- resident-input steps (image and templates in HBM before the clock starts), software-pipelined: the GPU
+    # part of step i+1 is queued (mtm_find_matches_async) before this thread does the host part of step i
+    def collect(raw):
+        raw["templ_idx"] = gidx[raw["templ_idx"]]
         return exchange.allgather(raw)
 
     def host_part(allhits):
-        return merge_and_nms(allhits, units, method, float("inf"), thr, 0.25)
+        return merge_and_nms(allhits, units, method, inf, thr, 0.25)
 
-    def run_steps(k, pipelined=True):
-        """k steps; returns the hit list and the timing record of the last one."""
-        last = (None, None)
-        if args.sequential or not pipelined:
+    def run_resident(k, pipelined=True):
+        last = None
+        if not pipelined:
             for _ in range(k):
                 raw = ctx.find_matches(_lib.PEAKS_LOCAL, thr)
-                t = ctx.timing()
-                last = (host_part(collect(raw, t)), t)
+                note_timing()
+                last = host_part(collect(raw))
             return last
         if k > 0:
             ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
         for i in range(k):
             raw = ctx.find_matches_wait()
-            t = ctx.timing()
+            note_timing()
             if world == 1:                               # no collective: the context is free for the next step at once
                 if i + 1 < k:
                     ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
-                allhits = collect(raw, t)
+                allhits = collect(raw)
             else:                                        # the all-gather uses the context's stream: before the next step
-                allhits = collect(raw, t)
+                allhits = collect(raw)
                 if i + 1 < k:
                     ctx.find_matches_async(_lib.PEAKS_LOCAL, thr)
-            last = (host_part(allhits), t)
+            last = host_part(allhits)
         return last
 
-    # The GPU leaves its idle clock only after ~50 ms of load (tools/ramp_probe.py: the first 40 calls run
-    # 8 % slower than the steady state).  A fixed number of untimed steps - the same on every rank, the
-    # step contains a collective - brings it to the sustained clock before the W warm-up steps.
-    run_steps(PREWARM_STEPS)
-    run_steps(args.warmup)
-    kernel_ms.clear()
-    total_ms.clear()
+    # The GPU leaves its idle clock only after tens of ms of load and then settles to its power budget.  Untimed
+    # calls for a fixed TIME (the same on every rank: the step contains a collective, so the count is agreed on
+    # rank 0's clock) bring it to the sustained state before the W warm-up calls.
+    call()
+    t0 = time.perf_counter()
+    n_pre = 0
+    while True:
+        run_calls(8)
+        n_pre += 8
+        go_on = (time.perf_counter() - t0) < PREWARM_SECONDS
+        if dist is not None:
+            flag = torch.tensor([1 if go_on else 0])
+            dist.broadcast(flag, src=0)
+            go_on = bool(flag.item())
+        if not go_on:
+            break
+    run_calls(args.warmup)
+    kernel_ms.clear(), total_ms.clear(), clocks.clear()
+    sensors_before = gpu_sensors()
     # like timeit: no cyclic garbage collection inside the timed region (with torch imported a full
     # collection is a 30-40 ms pause that lands in one step at random)
     gc.collect()
     gc.disable()
+    per_call = []
     sync()
     t0 = time.perf_counter()
-    hits, tinfo = run_steps(args.steps)
+    hits = run_calls(args.steps, stamps=per_call)
     sync()
     dt = time.perf_counter() - t0
     gc.enable()
+    sensors_after = gpu_sensors()
+    tinfo = ctx.timing()
+    k_ms, t_ms, clk = list(kernel_ms), list(total_ms), list(clocks)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # the same K steps one after the other (host part of a step before the GPU part of the next): reported
-    # next to `value`
-    seq_ms = None
-    if world == 1 and not args.sequential and not args.skip_extras:
-        km0 = len(kernel_ms)
-        gc.disable()
-        sync()
-        t1 = time.perf_counter()
-        run_steps(args.steps, pipelined=False)
-        sync()
-        seq_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        gc.enable()
-        del kernel_ms[km0:], total_ms[km0:]
-
-    # the same steps with the score maps written to HBM (MTM_OPT_HITS_ONLY = 0): reported next to `value`
-    maps_mode = None
-    if world == 1 and tinfo.get("hits_only") and not args.skip_extras:
-        ctx.set_option(_lib.OPT_HITS_ONLY, 0)
-        run_steps(1)
-        km0 = len(kernel_ms)
-        sync()
-        t1 = time.perf_counter()
-        hits_m, _t = run_steps(args.steps)
-        sync()
-        dtm = time.perf_counter() - t1
-        maps_mode = {"value": round(img.shape[0] * img.shape[1] * len(units) * args.steps / dtm / 1e6, 1),
-                     "ms_per_step": round(dtm / args.steps * 1e3, 4),
-                     "ncc_kernel_ms": round(float(np.mean(kernel_ms[km0:])), 4), "identical_hits": hits_m == hits,
-                     "hits_only": int(_t["hits_only"])}
-        del kernel_ms[km0 - 1:], total_ms[km0 - 1:]
-        ctx.set_option(_lib.OPT_HITS_ONLY, 1)
-
-    # PCIe-inclusive: one full MTM.matchTemplates call, numpy arrays in -> hit list out (never `value`)
-    e2e_ms = stream_ms = None
+    px = img.shape[0] * img.shape[1]
+    rate = lambda ms: round(px * len(units) / ms / 1e3, 1)        # noqa: E731  ms per call -> Mpx-corr/s
+    extras = {}
     if world == 1 and not args.skip_extras:
-        _lib._default_ctx = ctx
-        ts = []
-        for _ in range(5):
+        gc.disable()
+        # (a) fresh template bytes in every call: nothing derived from the previous call's templates is reused
+        variants = []
+        for i in range(4):
+            lt = []
+            for (name, t, *rest) in units:
+                t2 = t.copy()
+                t2[0, 0] ^= (i + 1)                      # one different byte: a different template set for the library
+                lt.append((name, t2) + tuple(rest))
+            variants.append(lt)
+        run_calls(2, lt_of=lambda i: variants[i % 4])
+        st = []
+        run_calls(max(10, min(args.steps, 40)), lt_of=lambda i: variants[i % 4], stamps=st)
+        extras["fresh_templates"] = {"median_ms_per_call": round(float(np.median(st)) * 1e3, 4),
+                                     "value": rate(float(np.median(st)) * 1e3),
+                                     "note": "every call gets template bytes the library has not seen in the previous call: "
+                                             "statistics, packing and upload of the templates are inside the call"}
+        call()
+        # (b) inputs resident in HBM: round 1's headline (pipelined) and the same call by call
+        ctx.set_image(img)
+        ctx.set_templates([(u[1], u[2] if len(u) >= 3 else None) for u in sub], method)
+        run_resident(3)
+        km0 = len(kernel_ms)
+        sync()
+        t1 = time.perf_counter()
+        hits_r = run_resident(args.steps)
+        sync()
+        d_pipe = (time.perf_counter() - t1) / args.steps * 1e3
+        res_kernel = float(np.mean(kernel_ms[km0:])) / max(launches, 1)
+        res_total = float(np.mean(total_ms[km0:]))
+        res_clk = [c for c in clocks[-args.steps:]]
+        sync()
+        t1 = time.perf_counter()
+        run_resident(args.steps, pipelined=False)
+        sync()
+        d_seq = (time.perf_counter() - t1) / args.steps * 1e3
+        extras["resident_inputs"] = {"pipelined_ms_per_step": round(d_pipe, 4), "pipelined_value": rate(d_pipe),
+                                     "sequential_ms_per_step": round(d_seq, 4), "sequential_value": rate(d_seq),
+                                     "kernel_ms_per_launch": round(res_kernel, 4), "launches_per_step": launches,
+                                     "gpu_ms_kernels_total": round(res_total, 4), "identical_hits": hits_r == hits,
+                                     "sclk_mhz_in_kernel": round(float(np.median(res_clk)), 1) if res_clk else None,
+                                     "note": "image and templates in HBM before the clock starts (round 1's `value`): "
+                                             "statistics + score kernel + peaks + D2H hits + NMS + hit list"}
+        # (c) the same with the score maps written to HBM (MTM_OPT_HITS_ONLY = 0)
+        if tinfo.get("hits_only"):
+            ctx.set_option(_lib.OPT_HITS_ONLY, 0)
+            run_resident(2)
+            km0 = len(kernel_ms)
+            sync()
             t1 = time.perf_counter()
-            MTM.matchTemplates(units, img, method=method, score_threshold=thr, maxOverlap=0.25)
-            ts.append((time.perf_counter() - t1) * 1e3)
-        e2e_ms = float(np.median(ts))
-        # image stream through resident templates (MTM.TemplateMatcher.match_stream): the upload of
-        # image i+1 overlaps the kernels of image i; numpy arrays in -> hit lists out, per image
+            hits_m = run_resident(args.steps)
+            sync()
+            dtm = (time.perf_counter() - t1) / args.steps * 1e3
+            extras["score_maps_materialised"] = {"ms_per_step": round(dtm, 4), "value": rate(dtm),
+                                                 "ncc_kernel_ms": round(float(np.mean(kernel_ms[km0:])), 4),
+                                                 "identical_hits": hits_m == hits, "inputs": "resident, pipelined"}
+            ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+        # (d) image stream through resident templates (MTM.TemplateMatcher.match_stream): the upload of image i+1
+        # overlaps the kernels of image i; numpy arrays in -> hit lists out, per image
         matcher = MTM.TemplateMatcher(units, method=method, score_threshold=thr, maxOverlap=0.25, context=ctx)
         frames = [np.ascontiguousarray(np.roll(img, 64 * k, axis=1)) for k in range(4)] * 4
         list(matcher.match_stream(frames[:3]))        # warm-up: both image slots allocated
         stamps = [time.perf_counter()]
         for _ in matcher.match_stream(frames):
             stamps.append(time.perf_counter())
-        # median of the per-image intervals: a Python garbage-collection pause (tens of ms once torch is
-        # imported) lands in one interval and says nothing about the pipeline
-        stream_ms = float(np.median(np.diff(stamps))) * 1e3
+        sm = float(np.median(np.diff(stamps))) * 1e3
+        extras["image_stream"] = {"median_ms_per_image": round(sm, 4), "value": rate(sm)}
+        gc.enable()
 
     # sanity: the timed path found every planted template
     found = {(h[0], h[1]) for h in hits}
     planted_ok = all((p[0], p[1]) in found for p in plants) if method == 5 else True
 
     if rank == 0:
-        px = img.shape[0] * img.shape[1]
         value = px * len(units) * args.steps / dt / 1e6
         my_units = sub
-        kms = float(np.mean(kernel_ms)) / max(launches, 1)          # avg duration of ONE ncc launch
+        k_step = float(np.mean(k_ms))                               # score-kernel time of one step (all its launches)
+        kms = k_step / max(launches, 1)                             # avg duration of ONE launch (what rocprofv3 averages)
         hits_only = bool(tinfo.get("hits_only", 0))
-        bytes_launch = (algorithmic_bytes_hits_only if hits_only else algorithmic_bytes)(img, my_units) / max(launches, 1)
-        macs = algorithmic_macs(img, my_units)
-        achieved = bytes_launch / (kms * 1e-3) / 1e9
+        bytes_step = (algorithmic_bytes_hits_only if hits_only else algorithmic_bytes)(img, my_units)
+        macs = score_kernel_macs(img, my_units)
+        achieved = bytes_step / (k_step * 1e-3) / 1e9
         kname = {1: "ncc_naive_kernel", 2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(tinfo["kernel_used"], "ncc_f64_kernel")
-        tmacs = macs / (float(np.mean(kernel_ms)) * 1e-3) / 1e12
+        tmacs = macs / (k_step * 1e-3) / 1e12
         traffic = pmc_traffic(tinfo["kernel_used"], args.config, world, hits_only)
         hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(bytes_launch),
+               "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(bytes_step),
                "maps_materialised": not hits_only}
+        sclk = float(np.median(clk)) if clk else None
         if tinfo["kernel_used"] == 3:
             # the dominant kernel runs on the int8 matrix cores: ~4096 MAC per output, ~1000 MAC per
             # algorithmic byte even when the maps are written - MFMA is the roofline that bounds it
             roof = {"bound": "mfma", "achieved": round(2.0 * tmacs, 1), "peak": I8_MFMA_PEAK_TOPS,
                     "unit": "TOP/s (int8 ops, 2 per MAC; the TFLOP/s slot of an integer kernel)",
                     "frac": round(2.0 * tmacs / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes of one full-image launch from the committed PMC passes (profiles/), not of this run",
                     "ubench_ceiling": I8_MFMA_UBENCH_TOPS,
                     "frac_of_ubench_ceiling": round(2.0 * tmacs / I8_MFMA_UBENCH_TOPS, 4), "hbm": hbm}
+            if sclk:
+                peak_at_clk = I8_OPS_PER_CLK * sclk * 1e6 / 1e12
+                roof.update({"sclk_mhz_in_kernel": round(sclk, 1),
+                             "peak_at_measured_clock": round(peak_at_clk, 1),
+                             "frac_at_measured_clock": round(2.0 * tmacs / peak_at_clk, 4)})
         else:
             roof = dict(hbm, bound="hbm", traffic=traffic, valu_dot4_peak_tmacs=DOT4_PEAK_TMACS,
                         note="direct method, ~1000 MAC per algorithmic byte: VALU-bound by construction")
         roof.update({"kernel": kname, "kernel_ms_per_launch": round(kms, 4), "launches_per_step": launches,
-                     "algorithmic_macs_per_launch": int(macs / max(launches, 1)), "achieved_tmacs": round(tmacs, 2)})
+                     "kernel_ms_per_step": round(k_step, 4),
+                     "algorithmic_macs_per_step": int(macs), "algorithmic_macs_per_launch": int(macs / max(launches, 1)),
+                     "achieved_tmacs": round(tmacs, 2),
+                     "launch_note": "the image arrives in row bands: one launch per band over that band's rows" if launches > 1
+                                    and len({u[1].shape[:2] for u in my_units}) == 1 else "one launch per size class"})
+        msm = masked_stat_macs(img, my_units)
+        if msm:
+            roof["masked_stat_macs_per_step"] = int(msm)      # sum I^2*M launches: outside the kernel timer, not in `achieved`
+        med = float(np.median(per_call)) * 1e3
         out = {
             "metric": "Mpixel-correlations/s", "value": round(value, 1), "unit": "Mpx-corr/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -381,24 +500,21 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": desc, "image_hw": list(img.shape[:2]), "units": len(units),
                        "units_per_gpu": len(my_units), "method": method, "score_threshold": thr,
-                       "max_overlap": 0.25, "prewarm_steps": PREWARM_STEPS, "parallelism": "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
-                       "timed_region": "window statistics + correlation/normalisation kernel + peak extraction + D2H hits + "
-                                       "all-gather + NMS + hit list; image/templates resident in HBM",
-                       "pipelining": "none (--sequential)" if args.sequential else
-                                     "the GPU part of step i+1 (mtm_find_matches_async) runs under the host part of step i "
-                                     "(merge, NMS, hit list); all K hit lists are built inside the timed region",
+                       "max_overlap": 0.25, "prewarm_seconds": PREWARM_SECONDS, "prewarm_calls": n_pre + 1,
+                       "parallelism": "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
+                       "timed_region": "K x one MTM.matchTemplates call, numpy arrays in -> hit list out (SURVEY 8d): validation, "
+                                       "template hand-over (unchanged templates stay resident), image H2D, window statistics, "
+                                       "score kernel, peak extraction, D2H hits, all-gather (N > 1), NMS, hit list",
                        "score_maps": "not materialised (hits-only mode, MTM_OPT_HITS_ONLY=1: identical hit lists)" if hits_only
                                      else "materialised in HBM"},
+            "median_ms_per_call": round(med, 4), "median_value": rate(med),
             "roofline": roof,
-            "gpu_ms": {"kernels_total": round(float(np.mean(total_ms)), 4), "ncc_kernel": round(float(np.mean(kernel_ms)), 4)},
+            "gpu_ms": {"kernels_total": round(float(np.mean(t_ms)), 4), "ncc_kernel": round(k_step, 4)},
+            "clock": {"sclk_mhz_in_kernel": None if sclk is None else round(sclk, 1),
+                      "before": sensors_before, "after": sensors_after},
             "hits": len(hits), "planted_found": bool(planted_ok),
-            "sequential_ms_per_step": None if seq_ms is None else round(seq_ms, 4),
-            "score_maps_materialised": maps_mode,
-            "e2e_call_ms": None if e2e_ms is None else round(e2e_ms, 3),
-            "e2e_call_mpx_corr_s": None if e2e_ms is None else round(px * len(units) / e2e_ms / 1e3, 1),
-            "stream_ms_per_image": None if stream_ms is None else round(stream_ms, 3),
-            "stream_mpx_corr_s": None if stream_ms is None else round(px * len(units) / stream_ms / 1e3, 1),
         }
+        out.update(extras)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

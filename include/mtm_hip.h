@@ -117,7 +117,8 @@ typedef struct mtm_timing {
     int32_t kernel_used; /* MTM_KERNEL_* actually dispatched for the uint8 path           */
     int64_t n_hits;
     int32_t hits_only;   /* 1: the last mtm_find_matches ran without materialising the score maps */
-    int32_t reserved_;
+    float   sclk_mhz;    /* shader clock the score kernel ran at, measured inside it (s_memtime ticks per
+                            s_memrealtime tick x 100 MHz) by one mid-grid work-group; 0 when not measured */
 } mtm_timing;
 
 /* ---- device / context ------------------------------------------------------------------- */
@@ -163,6 +164,17 @@ int mtm_score_map(mtm_ctx* ctx, int templ_idx, float* out, int64_t out_row_strid
 int mtm_find_matches(mtm_ctx* ctx, int mode, double score_threshold,
                      mtm_hit* out, int64_t capacity, int64_t* n_out);
 
+/* One call for "this image, these templates": mtm_set_image + mtm_find_matches without the round trip to the
+ * host in between - what one MTM.matchTemplates / findMatches call does with the image it is given
+ * (MTM/__init__.py:95-177; the templates come from mtm_set_templates).  The image becomes the context's
+ * current image.  Where the layout allows (one unmasked single-channel uint8 size class on the matrix-core
+ * kernel) the image crosses PCIe in row bands, and the score kernel of the rows already there runs under the
+ * transfer of the next band: the upload costs little more than its first band.  Results are those of the two
+ * separate calls. */
+int mtm_find_matches_image(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
+                           int64_t row_stride_bytes, int mode, double score_threshold,
+                           mtm_hit* out, int64_t capacity, int64_t* n_out);
+
 /* Stream form of mtm_find_matches ("thousands of images", reference
  * tutorials/Tutorial3-SpeedingUp.ipynb:564: same templates, one image after the other): returns the
  * hits of the CURRENT image exactly like mtm_find_matches and makes `next_px` the current image for
@@ -204,6 +216,31 @@ int mtm_get_timing(mtm_ctx* ctx, mtm_timing* out);
  * keep[] receives indices into hits[]; capacity of keep must be >= n. */
 int mtm_nms(const mtm_hit* hits, int64_t n, double score_threshold, int ascending,
             int64_t n_object, double max_overlap, int32_t* keep, int64_t* n_keep);
+
+/* ---- multi-GPU, one process: a group of per-device contexts -------------------------------- */
+/* The units (templates / rotations / scales) of a search are independent given the image - the reference runs
+ * one thread-pool task per template (MTM/__init__.py:172-175).  A group holds one context and one worker thread
+ * per listed device (a device may be listed more than once: several contexts on one GPU).  A search shards the
+ * units over the devices by longest-processing-time-first on their multiply-accumulate cost
+ * out_px * w * h * C (* 2 with a mask), every device uploads the image and searches its shard concurrently
+ * (mtm_set_templates + mtm_find_matches_image; unchanged templates stay resident per device), and the hit lists
+ * are merged on the host in template order: the result equals the single-device call.  No collective: in one
+ * process every list is in host memory when its worker returns (the one-process-per-GPU form with the RCCL
+ * all-gather follows below). */
+typedef struct mtm_group mtm_group;
+int      mtm_group_create(mtm_group** out, const int* device_ids, int n_devices);
+void     mtm_group_destroy(mtm_group* g);
+int      mtm_group_size(const mtm_group* g);
+mtm_ctx* mtm_group_ctx(mtm_group* g, int i);                       /* per-device context (options, timing) */
+int      mtm_group_set_option(mtm_group* g, int option, int64_t value);   /* on every context */
+/* the partition a search would use: device_of_unit[i] = index (0 .. size-1) of the device unit i goes to */
+int      mtm_group_shards(const mtm_group* g, const mtm_templ* templs, int n_templ, int method, int rows, int cols,
+                          int32_t* device_of_unit);
+/* mtm_set_templates + mtm_find_matches_image over all devices; hits ordered as mtm_find_matches orders them */
+int      mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, int method,
+                                const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                                int mode, double score_threshold, mtm_hit* out, int64_t capacity, int64_t* n_out);
+int      mtm_group_last_hits(mtm_group* g, mtm_hit* out, int64_t capacity, int64_t* n_out);
 
 /* ---- multi-GPU: one process per GPU, templates sharded across ranks (north_star) ------------ */
 /* RCCL all-gather of per-rank hit lists over xGMI.  The 128-byte unique id is created on rank 0

@@ -118,25 +118,57 @@ def _validate_search(listTemplates, image, N_object, searchBox):
     else:
         xOffset = yOffset = 0
 
+    ishape = image.shape
     for index, tempTuple in enumerate(listTemplates):
         if not isinstance(tempTuple, tuple) or len(tempTuple) < 2:
             raise ValueError("listTemplates should be a list of tuples as ('name','array') or ('name', 'array', 'mask')")
-        tempName, tempImage = tempTuple[0], tempTuple[1]
-        if tempImage.shape[0] == 0:
-            raise ValueError(f"Template '{tempName}' has a height of 0.")
-        if tempImage.shape[1] == 0:
-            raise ValueError(f"Template '{tempName}' has a width of 0.")
-        fits = all(t <= i for t, i in zip(tempImage.shape, image.shape))
-        if not fits:
+        tshape = tempTuple[1].shape
+        if tshape[0] == 0:
+            raise ValueError(f"Template '{tempTuple[0]}' has a height of 0.")
+        if tshape[1] == 0:
+            raise ValueError(f"Template '{tempTuple[0]}' has a width of 0.")
+        # the reference compares the shapes dimension by dimension as far as both have one (channels included)
+        if tshape[0] > ishape[0] or tshape[1] > ishape[1] or (len(tshape) > 2 and len(ishape) > 2 and tshape[2] > ishape[2]):
             where = "searchBox" if (searchBox is not None) else "image"
-            raise ValueError("Template '{}' at index {} in the list of templates is larger than {}.".format(tempName, index, where))
+            raise ValueError("Template '{}' at index {} in the list of templates is larger than {}.".format(
+                tempTuple[0], index, where))
     return image, xOffset, yOffset
 
 
-def _raw_matches(listTemplates, image, method, N_object, score_threshold, context=None):
+_U8 = np.dtype(np.uint8)
+
+
+def _raw_matches(listTemplates, image, method, N_object, score_threshold, context=None, devices=None):
     """Batched equivalent of one _multi_compute per template (MTM/__init__.py:179-244).
     Returns a structured array of hits (template index, box relative to `image`, score) ordered by
     template index, then descending quality, then row-major position."""
+    mode = _lib.PEAKS_GLOBAL if N_object == 1 else _lib.PEAKS_LOCAL
+    ichans = image.shape[2] if image.ndim == 3 else 1
+    # the usual call - 8-bit image, 8-bit templates - needs no pixel policy at all: one pass over the list
+    units = None
+    if image.dtype == _U8 and image.ndim in (2, 3) and ichans <= 4:
+        units = []
+        for tempTuple in listTemplates:
+            t = tempTuple[1]
+            mask = None
+            if len(tempTuple) >= 3:
+                if method in (0, 3):
+                    mask = tempTuple[2]
+                    if not (mask.shape == t.shape and mask.dtype == _U8):
+                        units = None
+                        break
+                else:
+                    warnings.warn(_MSG_MASK_UNSUPPORTED)
+            if t.dtype != _U8 or t.ndim != image.ndim or (t.ndim == 3 and t.shape[2] != ichans):
+                units = None
+                break
+            units.append((t, mask))
+    if units is not None:
+        engine = context or _lib.engine_for(devices)
+        with engine.lock:
+            return engine.search(units, image, method, mode, score_threshold)
+
+    # general case: the pixel policy is per template (MTM/__init__.py:67-88)
     units = []       # (index, template, image-as-matched, mask)
     for index, tempTuple in enumerate(listTemplates):
         template = tempTuple[1]
@@ -149,20 +181,18 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
         t, im, m = _apply_pixel_policy(template, image, method, mask)
         _check_opencv_preconditions(t, im)
         units.append((index, t, im, m))
-
-    ctx = context or _lib.default_context()
-    mode = _lib.PEAKS_GLOBAL if N_object == 1 else _lib.PEAKS_LOCAL
     parts = []
-    with ctx.lock:
-        # the pixel policy is per template: group the units by the dtype their match runs in
+    engine = context or _lib.engine_for(devices)      # only now: argument errors come before "no GPU"
+    with engine.lock:
+        # group the units by the dtype their match runs in
         for code in ("uint8", "uint16", "float32"):
             group = [u for u in units if u[2].dtype == code]
             if not group:
                 continue
-            ctx.set_image(group[0][2])
-            ctx.set_templates([(u[1], u[3]) for u in group], method)
-            hits = ctx.find_matches(mode, score_threshold).copy()
-            hits["templ_idx"] = np.asarray([u[0] for u in group], dtype=np.int32)[hits["templ_idx"]]
+            hits = engine.search([(u[1], u[3]) for u in group], group[0][2], method, mode, score_threshold)
+            if len(group) != len(units):
+                hits = hits.copy()
+                hits["templ_idx"] = np.asarray([u[0] for u in group], dtype=np.int32)[hits["templ_idx"]]
             parts.append(hits)
     if not parts:
         return np.zeros(0, dtype=_lib.HIT_DTYPE)
@@ -198,7 +228,8 @@ def _to_hit_list(raw, listTemplates, xOffset, yOffset):
 
 
 def findMatches(listTemplates: Sequence[TemplateTuple], image: np.ndarray, method: int = TM_CCOEFF_NORMED,
-                N_object=float("inf"), score_threshold: float = 0.5, searchBox: Optional[BBox] = None) -> List[Hit]:
+                N_object=float("inf"), score_threshold: float = 0.5, searchBox: Optional[BBox] = None,
+                *, devices=None) -> List[Hit]:
     """
     All template locations satisfying the score threshold, before Non-Maxima Suppression
     (reference MTM/__init__.py:95-177).
@@ -210,26 +241,30 @@ def findMatches(listTemplates: Sequence[TemplateTuple], image: np.ndarray, metho
     - N_object       : int or float("inf"); 1 returns the global extremum of every template
     - score_threshold: local maxima above it (minima below it for methods 0/1) are returned
     - searchBox      : optional (x, y, width, height) region of the image to search
+    - devices        : (not in the reference) GPUs to search on: None = the default GPU, ``"all"``, a list of
+                       device ids or ``"0,1,2"``; also the MTM_DEVICES environment variable.  With several
+                       devices the templates are sharded over them (the reference's thread pool over templates,
+                       MTM/__init__.py:172-175, with GPUs as workers); the result does not depend on it.
 
     Returns a list of hits ``(label, (x, y, width, height), score)``.  Hits come grouped by
     template in list order, each group by descending quality (the reference's cross-template
     order is the completion order of its worker threads).
     """
     image, xOffset, yOffset = _validate_search(listTemplates, image, N_object, searchBox)
-    raw = _raw_matches(listTemplates, image, method, N_object, score_threshold)
+    raw = _raw_matches(listTemplates, image, method, N_object, score_threshold, devices=devices)
     return _to_hit_list(raw, listTemplates, xOffset, yOffset)
 
 
 def matchTemplates(listTemplates: List[TemplateTuple], image: np.ndarray, method: int = TM_CCOEFF_NORMED,
                    N_object=float("inf"), score_threshold: float = 0.5, maxOverlap: float = 0.25,
-                   searchBox: Optional[BBox] = None) -> List[Hit]:
+                   searchBox: Optional[BBox] = None, *, devices=None) -> List[Hit]:
     """
     Search each template in the image and return the best N_object locations that do not overlap
     more than maxOverlap (reference MTM/__init__.py:247-296).
 
     - method     : 1..5 (0/TM_SQDIFF is rejected: no NMS for an unbounded difference score)
     - maxOverlap : float in [0, 1], maximal Intersection-over-Union between two returned boxes
-    Other arguments as in findMatches.
+    Other arguments as in findMatches (``devices``: which GPUs; the result does not depend on it).
 
     Returns a list of hits ``(label, (x, y, width, height), score)``:
         N_object == 1   -> the best match, whatever its score
@@ -240,7 +275,7 @@ def matchTemplates(listTemplates: List[TemplateTuple], image: np.ndarray, method
         raise ValueError("Maximal overlap between bounding box is in range [0-1]")
 
     image_s, xOffset, yOffset = _validate_search(listTemplates, image, N_object, searchBox)
-    raw = _raw_matches(listTemplates, image_s, method, N_object, score_threshold)
+    raw = _raw_matches(listTemplates, image_s, method, N_object, score_threshold, devices=devices)
 
     if method == 0:     # as in the reference, only after the search ran (MTM/__init__.py:291)
         raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
@@ -315,9 +350,8 @@ class TemplateMatcher:
     def match(self, image: np.ndarray, searchBox: Optional[BBox] = None) -> List[Hit]:
         with self._ctx.lock:
             im, xOffset, yOffset = self._prepare(image, searchBox)
-            self._ctx.set_image(im)
             mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
-            raw = self._ctx.find_matches(mode, self.score_threshold).copy()
+            raw = self._ctx.find_matches_image(im, mode, self.score_threshold)
         return self._finish(raw, xOffset, yOffset)
 
     def match_stream(self, images, searchBox: Optional[BBox] = None):

@@ -40,12 +40,16 @@ class MtmTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_float), ("score_ms", ctypes.c_float),
                 ("peaks_ms", ctypes.c_float), ("ncc_kernel_ms", ctypes.c_float),
                 ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
-                ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+                ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("sclk_mhz", ctypes.c_float)]
 
 
 HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),
                       ("score", "<f4")])
 assert HIT_DTYPE.itemsize == ctypes.sizeof(MtmHit) == 24
+# mtm_templ as a numpy record: a whole template list is filled column-wise instead of field by field
+TEMPL_DTYPE = np.dtype([("px", "<u8"), ("mask", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("chans", "<i4"),
+                        ("dtype", "<i4"), ("row_stride", "<i8"), ("mask_row_stride", "<i8")])
+assert TEMPL_DTYPE.itemsize == ctypes.sizeof(MtmTempl) == 48
 
 # every symbol include/mtm_hip.h declares: (restype, argtypes)
 _P = ctypes.POINTER
@@ -60,10 +64,13 @@ SYMBOLS = {
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "mtm_set_image_downscaled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
-    "mtm_set_templates": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTempl), ctypes.c_int, ctypes.c_int]),
+    "mtm_set_templates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mtm_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
     "mtm_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                         ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_find_matches_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                              ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_find_matches_next": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                              ctypes.c_int64, _P(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
@@ -74,6 +81,18 @@ SYMBOLS = {
     "mtm_get_timing": (ctypes.c_int, [ctypes.c_void_p, _P(MtmTiming)]),
     "mtm_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int,
                                ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, _P(ctypes.c_int64)]),
+    "mtm_group_create": (ctypes.c_int, [_P(ctypes.c_void_p), _P(ctypes.c_int), ctypes.c_int]),
+    "mtm_group_destroy": (None, [ctypes.c_void_p]),
+    "mtm_group_size": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtm_group_ctx": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int]),
+    "mtm_group_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "mtm_group_shards": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_void_p]),
+    "mtm_group_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                              ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
+                                              _P(ctypes.c_int64)]),
+    "mtm_group_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "mtm_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mtm_comm_allgather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
@@ -123,6 +142,10 @@ def check(rc, what=""):
 def _pixel_rows(a):
     """Return (array_kept_alive, pointer, row_stride_bytes) for a (rows, cols[, C]) array whose
     rows have contiguous pixels; anything else (e.g. a transposed view) is copied."""
+    ai = a.__array_interface__
+    if ai["strides"] is None:           # C-contiguous (the usual case): one dictionary look-up, no checks needed
+        shp = ai["shape"]
+        return a, ai["data"][0], (shp[1] * shp[2] if len(shp) == 3 else shp[1]) * a.itemsize
     item = a.itemsize
     ok = a.strides[-1] == item and (a.ndim == 2 or a.strides[1] == a.shape[2] * item)
     if a.ndim == 3 and a.shape[2] == 1:
@@ -140,6 +163,41 @@ def _dtype_code(a):
     if a.dtype == np.uint16:
         return MTM_U16
     raise MtmError("libmtm_hip takes uint8, uint16 or float32 pixels (got %s)" % a.dtype)
+
+
+_DT_CODES = {np.dtype(np.uint8): MTM_U8, np.dtype(np.float32): MTM_F32, np.dtype(np.uint16): MTM_U16}
+
+
+def templ_records(templates):
+    """[(template, mask or None), ...] (pixel policy already applied) -> (mtm_templ records, arrays kept alive)."""
+    n = len(templates)
+    rec = np.zeros(max(n, 1), dtype=TEMPL_DTYPE)
+    keep, px, mk, rows, cols, ch, dt, rs, ms = [], [], [], [], [], [], [], [], []
+    for t, m in templates:
+        t, tp, ts = _pixel_rows(t)
+        keep.append(t)
+        shp = t.shape
+        px.append(tp)
+        rows.append(shp[0])
+        cols.append(shp[1])
+        ch.append(shp[2] if len(shp) == 3 else 1)
+        code = _DT_CODES.get(t.dtype)
+        if code is None:
+            raise MtmError("libmtm_hip takes uint8, uint16 or float32 pixels (got %s)" % t.dtype)
+        dt.append(code)
+        rs.append(ts)
+        if m is not None:
+            m, mp, mst = _pixel_rows(m)
+            keep.append(m)
+            mk.append(mp)
+            ms.append(mst)
+        else:
+            mk.append(0)
+            ms.append(0)
+    if n:
+        rec["px"], rec["mask"], rec["rows"], rec["cols"] = px, mk, rows, cols
+        rec["chans"], rec["dtype"], rec["row_stride"], rec["mask_row_stride"] = ch, dt, rs, ms
+    return rec, keep
 
 
 class Context:
@@ -190,26 +248,13 @@ class Context:
 
     def set_templates(self, templates, method):
         """templates: list of (array, mask_or_None) with identical dtype policy already applied."""
-        n = len(templates)
-        arr = (MtmTempl * max(n, 1))()
-        keep = []
-        for i, (t, m) in enumerate(templates):
-            t, tp, ts = _pixel_rows(t)
-            keep.append(t)
-            arr[i].px = tp
-            arr[i].rows, arr[i].cols = t.shape[0], t.shape[1]
-            arr[i].chans = 1 if t.ndim == 2 else t.shape[2]
-            arr[i].dtype = _dtype_code(t)
-            arr[i].row_stride = ts
-            if m is not None:
-                m, mp, ms = _pixel_rows(m)
-                keep.append(m)
-                arr[i].mask = mp
-                arr[i].mask_row_stride = ms
-            else:
-                arr[i].mask = None
-                arr[i].mask_row_stride = 0
-        check(self._lib.mtm_set_templates(self._h, arr, n, int(method)), "mtm_set_templates")
+        rec, keep = templ_records(templates)
+        check(self._lib.mtm_set_templates(self._h, rec.ctypes.data, len(templates), int(method)), "mtm_set_templates")
+
+    def search(self, templates, image, method, mode, score_threshold):
+        """One search = templates + image in, hit records out (the engine interface shared with Group)."""
+        self.set_templates(templates, method)
+        return self.find_matches_image(image, mode, score_threshold)
 
     def score_map(self, idx, shape):
         out = np.empty(shape, dtype=np.float32)
@@ -236,6 +281,23 @@ class Context:
             out = np.empty(cap, dtype=HIT_DTYPE)
             rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
         check(rc, "mtm_find_matches")
+        return out[:n.value]
+
+    def find_matches_image(self, image, mode, score_threshold):
+        """set_image + find_matches in one native call (mtm_find_matches_image): no round trip in between, the
+        image crosses PCIe in row bands under the score kernel where the layout allows."""
+        a, ptr, stride = _pixel_rows(image)
+        chans = 1 if a.ndim == 2 else a.shape[2]
+        cap = 4096
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_find_matches_image(self._h, ptr, a.shape[0], a.shape[1], chans, _dtype_code(a), stride,
+                                              int(mode), float(score_threshold), out.ctypes.data, cap, ctypes.byref(n))
+        if rc == E_OVERFLOW:
+            cap = int(n.value)
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        check(rc, "mtm_find_matches_image")
         return out[:n.value]
 
     def find_matches_async(self, mode, score_threshold):
@@ -289,6 +351,117 @@ class Context:
             rc = self._lib.mtm_comm_last_gather(self._h, out.ctypes.data, cap, counts.ctypes.data, ctypes.byref(n))
         check(rc, "mtm_comm_allgather_hits")
         return out[:n.value], counts
+
+
+class Group:
+    """Several GPUs in one process (mtm_group): units sharded over the devices (LPT on their MAC cost), the image
+    uploaded and searched on every device concurrently by native worker threads, hit lists merged on the host in
+    template order.  Same ``search`` interface and results as a single Context."""
+
+    def __init__(self, devices):
+        lib = load()
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise MtmError("Group needs at least one device")
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        check(lib.mtm_group_create(ctypes.byref(h), arr, len(devices)), "mtm_group_create")
+        self._lib, self._h, self.devices = lib, h, devices
+        self.lock = threading.RLock()
+        for env, opt, table in (("MTM_KERNEL", OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}),
+                                ("MTM_PEAK_BORDER", OPT_PEAK_BORDER, {"constant": 0, "nearest": 1})):
+            v = os.environ.get(env)
+            if v:
+                self.set_option(opt, table[v.lower()])
+
+    def close(self):
+        if self._h:
+            self._lib.mtm_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def __len__(self):
+        return len(self.devices)
+
+    def set_option(self, opt, value):
+        check(self._lib.mtm_group_set_option(self._h, int(opt), int(value)), "mtm_group_set_option")
+
+    def shards(self, templates, image_shape, method):
+        """device index of every unit, as a search over an image of this shape would assign them"""
+        rec, keep = templ_records(templates)
+        dev = np.zeros(max(len(templates), 1), dtype=np.int32)
+        check(self._lib.mtm_group_shards(self._h, rec.ctypes.data, len(templates), int(method), int(image_shape[0]),
+                                         int(image_shape[1]), dev.ctypes.data), "mtm_group_shards")
+        return dev[:len(templates)]
+
+    def timing(self, i):
+        t = MtmTiming()
+        check(self._lib.mtm_get_timing(self._lib.mtm_group_ctx(self._h, int(i)), ctypes.byref(t)), "mtm_get_timing")
+        return {f: getattr(t, f) for f, _ in MtmTiming._fields_}
+
+    def search(self, templates, image, method, mode, score_threshold):
+        rec, keep = templ_records(templates)
+        a, ptr, stride = _pixel_rows(image)
+        chans = 1 if a.ndim == 2 else a.shape[2]
+        cap = 4096
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_group_find_matches(self._h, rec.ctypes.data, len(templates), int(method), ptr, a.shape[0],
+                                              a.shape[1], chans, _dtype_code(a), stride, int(mode), float(score_threshold),
+                                              out.ctypes.data, cap, ctypes.byref(n))
+        if rc == E_OVERFLOW:
+            cap = int(n.value)
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            rc = self._lib.mtm_group_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        check(rc, "mtm_group_find_matches")
+        return out[:n.value]
+
+
+def parse_devices(spec):
+    """"all" | "0,1,2" | iterable of ints | int -> list of device ids (validated against the visible devices)."""
+    n = load().mtm_device_count()
+    if isinstance(spec, str):
+        spec = spec.strip().lower()
+        ids = list(range(n)) if spec == "all" else [int(x) for x in spec.split(",") if x.strip() != ""]
+    elif isinstance(spec, int):
+        ids = [spec]
+    else:
+        ids = [int(x) for x in spec]
+    if not ids:
+        raise MtmError("no HIP device visible (libmtm_hip has no CPU fallback)")
+    for d in ids:
+        if d < 0 or d >= n:
+            raise MtmError("device %d is not visible (%d device(s))" % (d, n))
+    return ids
+
+
+_engines = {}
+
+
+def engine_for(devices=None):
+    """The search engine of a matchTemplates / findMatches call: the default single-GPU context, or a device
+    group when several devices are asked for (argument, or the MTM_DEVICES environment variable: "all" or a
+    comma-separated list).  Engines are created once per device list and reused."""
+    if devices is None:
+        devices = os.environ.get("MTM_DEVICES")
+    if devices is None or devices == "":
+        return default_context()
+    ids = tuple(parse_devices(devices))
+    if len(ids) == 1 and "MTM_DEVICES_FORCE_GROUP" not in os.environ:
+        key = ("ctx", ids[0])
+        with _default_lock:
+            if key not in _engines:
+                _engines[key] = Context(ids[0])
+            return _engines[key]
+    with _default_lock:
+        if ids not in _engines:
+            _engines[ids] = Group(ids)
+        return _engines[ids]
 
 
 def comm_unique_id():

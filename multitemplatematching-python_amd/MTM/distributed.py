@@ -1,26 +1,33 @@
 """
-Multi-GPU template sharding: one process per GPU, every rank holds the whole image and a subset
-of the units (templates / rotations / scales); the only exchange step is an all-gather of the
-per-rank hit lists (24-byte records), after which every rank runs the same global NMS.
+Multi-GPU template sharding, one process per GPU: every rank holds the whole image and a subset of the units
+(templates / rotations / scales); the only exchange step is an all-gather of the per-rank hit lists (24-byte
+records), after which every rank runs the same global NMS.  (Several GPUs in ONE process need none of this:
+``MTM.matchTemplates(..., devices="all")`` / ``_lib.Group``.)
 
-The reference has no distributed code at all: its only parallelism is one thread-pool task per
-template (MTM/__init__.py:172-175), which is the same independence this module exploits.
+The reference has no distributed code at all: its only parallelism is one thread-pool task per template
+(MTM/__init__.py:172-175), which is the same independence this module exploits.
 
-Exchange backends
-  "rccl"  : ncclAllGather inside libmtm_hip.so (mtm_comm_*; RCCL over xGMI).  The 128-byte unique
-            id travels through the caller's bootstrap (here: torch.distributed's store).
-  "torch" : torch.distributed.all_gather on CPU tensors (gloo) - used by the CPU tests and as a
-            fallback where RCCL is unavailable.
+Exchange backends of :class:`HitExchange`
+  "rccl"   : ncclAllGather inside libmtm_hip.so (mtm_comm_*; RCCL over xGMI).  The 128-byte unique id travels
+             through a :class:`TcpStore` (rank 0 listens on MASTER_ADDR : MTM_STORE_PORT, default MASTER_PORT + 1).
+  "tcp"    : the same fixed-slot protocol over the store's sockets - no GPU, no third-party package; control-plane
+             fallback and CPU tests.
+  "custom" : the caller supplies ``allgather_bytes(payload: bytes) -> list[bytes]`` (one entry per rank, rank
+             order) built on whatever collective library it already runs (gloo, MPI ...).
+
+Nothing here imports torch: the package's only dependencies are numpy and libmtm_hip.so.
 """
 import contextlib
 import os
+import socket
+import struct
 import sys
+import time
 from typing import List, Sequence
 
 import numpy as np
 
 from . import _lib
-from .NMS import NMS
 
 
 def unit_cost(template, image_shape, masked=False) -> float:
@@ -32,7 +39,8 @@ def unit_cost(template, image_shape, masked=False) -> float:
 
 
 def shard_units(costs: Sequence[float], world_size: int) -> List[List[int]]:
-    """Longest-processing-time-first partition of unit indices over ranks (deterministic)."""
+    """Longest-processing-time-first partition of unit indices over ranks (deterministic; the same rule as
+    mtm_group_shards)."""
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
     loads = [0.0] * world_size
     shards = [[] for _ in range(world_size)]
@@ -58,24 +66,123 @@ def _stdout_to_stderr():
         os.close(saved)
 
 
+def _send(sock, payload: bytes):
+    sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+
+def _recv(sock) -> bytes:
+    def exactly(n):
+        buf = bytearray()
+        while len(buf) < n:
+            part = sock.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("MTM TcpStore: peer closed the connection")
+            buf += part
+        return bytes(buf)
+    (n,) = struct.unpack("<q", exactly(8))
+    return exactly(n)
+
+
+class TcpStore:
+    """Star-shaped rendezvous over plain sockets: rank 0 listens, every other rank keeps one connection to it.
+    Carries the RCCL unique id (``broadcast``) and, for the "tcp" backend, the hit records (``allgather``).
+    Address and port default to MASTER_ADDR / MTM_STORE_PORT (else MASTER_PORT + 1), the variables every
+    launcher (torch.distributed.run, mpirun wrappers, srun) already exports."""
+
+    def __init__(self, rank, world_size, addr=None, port=None, timeout=120.0):
+        self.rank, self.world_size = int(rank), int(world_size)
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        if port is None:
+            port = int(os.environ.get("MTM_STORE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+        self.peers = {}
+        self.sock = None
+        if self.world_size == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", int(port)))
+            srv.listen(self.world_size)
+            srv.settimeout(timeout)
+            try:
+                while len(self.peers) < self.world_size - 1:
+                    conn, _ = srv.accept()
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    conn.settimeout(timeout)
+                    (r,) = struct.unpack("<i", _recv(conn))
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, int(port)), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            _send(s, struct.pack("<i", self.rank))
+            self.sock = s
+
+    def broadcast(self, payload=None) -> bytes:
+        """rank 0's payload on every rank"""
+        if self.world_size == 1:
+            return payload
+        if self.rank == 0:
+            for r in sorted(self.peers):
+                _send(self.peers[r], payload)
+            return payload
+        return _recv(self.sock)
+
+    def allgather(self, payload: bytes) -> List[bytes]:
+        if self.world_size == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv(self.peers[r]) for r in range(1, self.world_size)]
+            blob = struct.pack("<%dq" % len(parts), *[len(p) for p in parts]) + b"".join(parts)
+            for r in sorted(self.peers):
+                _send(self.peers[r], blob)
+            return parts
+        _send(self.sock, payload)
+        blob = _recv(self.sock)
+        lens = struct.unpack_from("<%dq" % self.world_size, blob)
+        out, off = [], 8 * self.world_size
+        for n in lens:
+            out.append(blob[off:off + n])
+            off += n
+        return out
+
+    def close(self):
+        for c in self.peers.values():
+            c.close()
+        if self.sock is not None:
+            self.sock.close()
+        self.peers, self.sock = {}, None
+
+
 class HitExchange:
     """All-gather of structured hit arrays (dtype _lib.HIT_DTYPE) across ranks."""
 
-    def __init__(self, backend="torch", rank=0, world_size=1, context=None, group=None):
+    def __init__(self, backend="tcp", rank=0, world_size=1, context=None, store=None, allgather_bytes=None):
+        if backend not in ("rccl", "tcp", "custom"):
+            raise ValueError("backend must be 'rccl', 'tcp' or 'custom'")
         self.backend = backend
         self.rank, self.world_size = rank, world_size
-        self.group = group
         self.ctx = context
-        self._slot_hits = 512
+        self.store = store
+        self._allgather_bytes = allgather_bytes
+        if backend == "custom" and world_size > 1 and allgather_bytes is None:
+            raise ValueError("backend 'custom' needs allgather_bytes(payload) -> [bytes per rank]")
+        if world_size > 1 and backend in ("rccl", "tcp") and store is None:
+            self.store = TcpStore(rank, world_size)
         if backend == "rccl" and world_size > 1:
-            import torch.distributed as dist
             self.ctx = context or _lib.default_context()
             with _stdout_to_stderr():
-                box = [_lib.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0, group=group)     # bootstrap only
-                self.ctx.comm_init(box[0], world_size, rank)
-        elif backend not in ("rccl", "torch"):
-            raise ValueError("backend must be 'rccl' or 'torch'")
+                uid = self.store.broadcast(_lib.comm_unique_id() if rank == 0 else None)     # bootstrap only
+                self.ctx.comm_init(uid, world_size, rank)
 
     def allgather(self, hits: np.ndarray) -> np.ndarray:
         hits = np.ascontiguousarray(hits, dtype=_lib.HIT_DTYPE)
@@ -84,33 +191,12 @@ class HitExchange:
         if self.backend == "rccl":
             out, _ = self.ctx.allgather_hits(hits)
             return out
-        # same protocol as mtm_comm_allgather_hits: ONE all-gather of fixed slots [count | records]; a second
-        # one with larger slots only if some rank had more records than the slot holds.  The slot size follows
-        # twice the largest count of the previous exchange (every rank sees every count, so they agree).
-        import torch
-        import torch.distributed as dist
-        rec = _lib.HIT_DTYPE.itemsize
-        slot_hits = self._slot_hits
-        while True:
-            buf = np.zeros(16 + slot_hits * rec, dtype=np.uint8)
-            buf[:8] = np.frombuffer(np.int64(len(hits)).tobytes(), dtype=np.uint8)
-            k = min(len(hits), slot_hits)
-            buf[16:16 + k * rec] = hits[:k].view(np.uint8).reshape(-1)
-            mine = torch.from_numpy(buf)
-            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
-            dist.all_gather(parts, mine, group=self.group)
-            parts = [p.numpy() for p in parts]
-            counts = [int(np.frombuffer(p[:8].tobytes(), dtype=np.int64)[0]) for p in parts]
-            mx = max(counts)
-            want = 512
-            while want < 2 * mx:
-                want *= 2
-            self._slot_hits = want
-            if mx <= slot_hits:
-                break
-            slot_hits = mx
-        out = [p[16:16 + c * rec].view(_lib.HIT_DTYPE) for p, c in zip(parts, counts)]
-        return np.concatenate(out) if out else hits[:0]
+        # host backends: one exchange of the raw records (variable length), concatenated in rank order
+        fn = self._allgather_bytes if self.backend == "custom" else self.store.allgather
+        parts = fn(hits.tobytes())
+        if len(parts) != self.world_size:
+            raise _lib.MtmError("hit exchange returned %d parts for %d ranks" % (len(parts), self.world_size))
+        return np.frombuffer(b"".join(parts), dtype=_lib.HIT_DTYPE).copy()
 
 
 def merge_and_nms(raw_all: np.ndarray, listTemplates, method, N_object, score_threshold, maxOverlap,

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["mtm_hip.hip", "mtm_host.cpp"]
+SOURCES = ["mtm_hip.hip", "mtm_host.cpp", "mtm_group.cpp"]
 DEPS = SOURCES + ["mtm_device.hip.h", "mtm_mfma.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
                   os.path.join("..", "..", "include", "mtm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
         with open(STAMP) as f:
             if f.read().strip() == dig:
                 return LIB
-    cmd = [_hipcc()] + FLAGS + _extra_flags() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl"]
+    cmd = [_hipcc()] + FLAGS + _extra_flags() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl", "-pthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -289,10 +289,11 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
                                                        int oh, int ow, int owg, double inv_area, int num_type,
                                                        int want_sq, int want_t, int want_sum2, double* __restrict__ t0,
                                                        double* __restrict__ sum2, double* __restrict__ sq,
-                                                       int st_pitch, double* __restrict__ rsq = nullptr) {
+                                                       int st_pitch, double* __restrict__ rsq = nullptr,
+                                                       int yb_off = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t E1[kStatStrip + 4], E2[kStatStrip + 4];   // exclusive prefixes
     __shared__ uint32_t wsum[2][4];
-    const int x0 = blockIdx.x * owg, y0 = blockIdx.y * kStatBand4;
+    const int x0 = blockIdx.x * owg, y0 = ((int)blockIdx.y + yb_off) * kStatBand4;   // yb_off: banded launches
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int L = owg + w - 1;                       // image columns of this strip (<= kStatStrip)
     // the image is padded by kPadCols columns only: quads further right (beyond every valid window) read 0

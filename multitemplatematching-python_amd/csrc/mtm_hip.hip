@@ -160,6 +160,11 @@ struct mtm_ctx {
     bool sq_valid = false;
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_ready = nullptr;
+    // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
+    // statistics of the rows that became computable); the score kernel of a band waits for its event
+    hipStream_t stats_stream = nullptr;     // non-null while a banded call queues its statistics launches
+    std::vector<hipEvent_t> band_ev;
+    std::vector<double> upload_bands{0.16, 0.44, 0.72, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
 
     // templates
     bool have_templ = false;
@@ -585,7 +590,9 @@ int place_templates(mtm_ctx* c) {
 int resolved_kernel(const mtm_ctx* c, const SizeClass& sc);
 
 // Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
-int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
+// `sb0`, `sb1`: range of kStatBand4-row output blocks to compute (banded image upload; fused single-channel
+// kernel only), sb1 < 0 = all.
+int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, int sb1 = -1) {
     const int h = sc.h, w = sc.w;
     const int oh = c->rows - h + 1, ow = c->cols - w + 1;
     const int method = c->method;
@@ -625,14 +632,19 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
     if (fused_stats) {
         const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always || masked_mfma) ? 1 : 0;
         const int owg = stats_u8_owg(w);
-        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
+        const int nsb = (oh + kStatBand4 - 1) / kStatBand4;
+        const int b1 = sb1 < 0 ? nsb : std::min(sb1, nsb);
         double* rsq = nullptr;
         if (sc.rm_R > 0 && normed) {
             MTMC(c->stats_rsq.ensure(sizeof(double) * plane));
             rsq = c->stats_rsq.as<double>();
         }
-        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, owg, inv_area,
-                           num_type, normed ? 1 : 0, want_t, want_sum2, tp[0], sum2, sq, st.pitch, rsq);
+        if (b1 > sb0) {
+            const dim3 gs((ow + owg - 1) / owg, b1 - sb0);
+            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, img.u8,
+                               img.u8_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, want_sum2, tp[0],
+                               sum2, sq, st.pitch, rsq, sb0);
+        }
     } else if (u8 && c->chans == 3 && w <= 768 && 3.0 * w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
         // RGB: the fused kernel with one scan per channel + one for the squares (sum2 always written:
         // vsum_stats_kernel does)
@@ -790,7 +802,9 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out) {
 }
 
 // Score maps of `n_list` templates of class `sc` (device list at tlist + list_off).
-int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const StatPlanes& st, int only_li = -1) {
+// `yb0`, `yb1`: range of output row blocks (MFMA kernel only; banded image upload), yb1 < 0 = all.
+int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const StatPlanes& st, int only_li = -1,
+               int yb0 = 0, int yb1 = -1) {
     const int h = sc.h, w = sc.w;
     const int oh = c->rows - h + 1, ow = c->cols - w + 1;
     const ImageDev img = image_dev(c);
@@ -850,6 +864,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_cap = (unsigned long long)c->hit_cap;
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        // the 8 spare bytes of the candidate header carry the shader clock the kernel measured (fetched with it)
+        p.clk_out = (p.cand_on && c->cands.p) ? reinterpret_cast<float*>(c->cands.as<uint8_t>() + 8) : nullptr;
         int tg0 = 0;
         if (only_li >= 0 && !rm) {   // one template: just its group
             tg0 = only_li / (16 * mb);
@@ -867,6 +883,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
             p.ntg = 1;
             tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * sc.rm_R;
+        }
+        if (yb1 >= 0) {                     // banded launch: row blocks yb0 .. yb1 - 1 (the caller keeps the range non-empty)
+            p.yb0 = yb0;
+            p.nyb = std::min(yb1, p.nyb) - yb0;
         }
         p.n_work = p.nseg * p.nyb * p.ntg;
         const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch,
@@ -1184,6 +1204,20 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         if (!std::strcmp(v, "mfma")) c->auto_kernel = MTM_KERNEL_MFMA;
         if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
     }
+    if (const char* v = std::getenv("MTM_UPLOAD_BANDS")) {      // e.g. "0.2,0.6,1": cumulative row fractions; "1": one piece
+        std::vector<double> f;
+        for (const char* q = v; *q;) {
+            char* end = nullptr;
+            const double x = std::strtod(q, &end);
+            if (end == q) break;
+            if (x > 0.0 && x <= 1.0 && (f.empty() || x > f.back())) f.push_back(x);
+            q = *end == ',' ? end + 1 : end;
+        }
+        if (!f.empty()) {
+            f.back() = 1.0;
+            c->upload_bands = f;
+        }
+    }
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
@@ -1218,6 +1252,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->comm_pin) (void)hipHostFree(c->comm_pin);
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
+    for (hipEvent_t e : c->band_ev) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& p : c->ncc_ev) {
         (void)hipEventDestroy(p.first);
@@ -1265,14 +1300,19 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
 
 namespace {
 
-// Upload one image into `sl` and build its planar padded planes on `stream`.  `src` has tightly
-// packed rows when `src_stride` == cols * chans * elem size or any larger stride.
-int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
-                 int chans, int dtype, hipStream_t stream, int factor = 1) {
+// Geometry of the planar device copies of an image (after an optional integer downscale).
+struct SlotGeom {
+    int rows, cols, rows_alloc, pitch;
+    size_t u8_bytes;
+};
+
+// Allocates the raw + planar buffers of `sl` for an image and (re)writes their padding when the geometry is new.
+int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols, int chans, int dtype, hipStream_t stream,
+                 int factor, SlotGeom* g) {
+    (void)c;
     const size_t esz = elem_size(dtype);
     const size_t tight = (size_t)src_cols * chans * esz;
     MTMC(sl.raw.ensure(tight * src_rows));
-    HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, src_rows, hipMemcpyHostToDevice, stream));
     const int rows = src_rows / factor, cols = src_cols / factor;      // the planes hold the downscaled image
     const int rows_alloc = rows + kPadRows;
     const int pitch = (int)round_up((size_t)cols + kPadCols, 64);
@@ -1297,6 +1337,53 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
         }
         sl.geom = geom;
     }
+    g->rows = rows;
+    g->cols = cols;
+    g->rows_alloc = rows_alloc;
+    g->pitch = pitch;
+    g->u8_bytes = u8_bytes;
+    return MTM_OK;
+}
+
+// Rows [r0, r1) of a single-channel uint8 image: copy into the raw buffer and convert into the planes of `sl`
+// (prepared by prepare_slot) on `stream`.  A pageable source makes the copy call block the host until the rows
+// are staged; work queued on OTHER streams before the call runs under it.
+int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
+                     hipStream_t stream) {
+    const int cols = g.cols, nrows = r1 - r0;
+    if (nrows <= 0) return MTM_OK;
+    uint8_t* raw = sl.raw.as<uint8_t>() + (size_t)r0 * cols;
+    HIPC(hipMemcpy2DAsync(raw, (size_t)cols, (const uint8_t*)src + (size_t)r0 * src_stride, (size_t)src_stride, (size_t)cols,
+                          nrows, hipMemcpyHostToDevice, stream));
+    uint8_t* u8 = sl.u8.as<uint8_t>() + (size_t)r0 * g.pitch;
+    uint8_t* u8b = sl.u8b.as<uint8_t>() + (size_t)r0 * g.pitch;
+    float* f32 = sl.f32.as<float>() + (size_t)r0 * g.pitch;
+    int x_begin = 0;
+    if (cols >= 16) {        // 16 pixels per thread; the generic kernel takes the tail columns
+        const int cols16 = cols / 16;
+        hipLaunchKernelGGL(planarize_u8_c1_kernel, dim3((cols16 + 255) / 256, nrows), dim3(256), 0, stream, raw, nrows, cols,
+                           cols16, u8, u8b, g.pitch, f32, g.pitch);
+        x_begin = cols16 * 16;
+    }
+    if (x_begin < cols)
+        hipLaunchKernelGGL(planarize_u8_kernel, dim3((cols - x_begin + 255) / 256, nrows), dim3(256), 0, stream, raw, nrows,
+                           cols, 1, u8, u8b, g.pitch, (long long)g.pitch * g.rows_alloc, f32, g.pitch,
+                           (long long)g.pitch * g.rows_alloc, x_begin);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
+// Upload one image into `sl` and build its planar padded planes on `stream`.  `src` has tightly
+// packed rows when `src_stride` == cols * chans * elem size or any larger stride.
+int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
+                 int chans, int dtype, hipStream_t stream, int factor = 1) {
+    SlotGeom g{};
+    MTMC(prepare_slot(c, sl, src_rows, src_cols, chans, dtype, stream, factor, &g));
+    const size_t tight = (size_t)src_cols * chans * elem_size(dtype);
+    HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, src_rows, hipMemcpyHostToDevice, stream));
+    const int rows = g.rows, cols = g.cols, rows_alloc = g.rows_alloc, pitch = g.pitch;
+    const size_t u8_bytes = g.u8_bytes;
+    const bool u16_planes = dtype == MTM_U16 && chans == 1;
     const dim3 grd((cols + 255) / 256, rows);
     if (dtype == MTM_U16)
         hipLaunchKernelGGL(planarize_u16_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint16_t>(), src_cols, chans, factor,
@@ -1539,6 +1626,13 @@ struct NextImage {
     bool staged;
 };
 
+// the image of a fused "upload + search" call (mtm_find_matches_image)
+struct ImageArgs {
+    const void* px;
+    int rows, cols, chans, dtype;
+    int64_t stride;
+};
+
 // Enqueue the upload + plane conversion of the next image of a stream on the copy stream, into the
 // image slot the kernels are not reading.  Called by find_matches_impl after the kernels of the
 // current image are enqueued and before it waits for them: the PCIe transfer (and the host-side
@@ -1561,13 +1655,24 @@ int stage_next_image(mtm_ctx* c, NextImage* nx) {
 }
 
 int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
-                      int64_t* n_out, NextImage* next);
+                      int64_t* n_out, NextImage* next, const ImageArgs* up = nullptr);
 
 }  // namespace
 
 int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
                      int64_t* n_out) {
     return find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr);
+}
+
+int mtm_find_matches_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                           int mode, double score_threshold, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    if (!c) {
+        set_error("mtm_find_matches_image: null context");
+        return MTM_E_INVALID;
+    }
+    MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image"));
+    const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
+    return find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr, &up);
 }
 
 int mtm_find_matches_next(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
@@ -1598,9 +1703,90 @@ constexpr size_t kHitPrefetch = 1024;       // candidate / hit records fetched t
 
 // Asynchronous half of mtm_find_matches: statistics, score kernels, the upload of the next image and (usual
 // case) the copy of the candidate list into pinned memory are queued; nothing waits for the GPU.
-int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmState& S) {
+// Can the image of a fused call arrive in row bands (copy / layout / statistics of band k+1 under the score
+// kernel of band k)?  One unmasked single-channel uint8 size class on the MFMA kernel with the fused
+// statistics kernel; anything else uploads the image in one piece (still without a round trip to the host).
+bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
+    if (c->upload_bands.size() < 2 || a.dtype != MTM_U8 || a.chans != 1 || c->classes.size() != 1) return false;
+    const SizeClass& sc = c->classes[0];
+    if (sc.masked || !c->fuse_stats || resolved_kernel(c, sc) != MTM_KERNEL_MFMA) return false;
+    if (!(sc.w <= 768 && (double)sc.w * sc.h * 65025.0 < 4294967296.0)) return false;
+    return (size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256;
+}
+
+// The score pass of a fused call with a banded upload.  copy_stream: per band the rows' copy, their layout
+// conversion and the window statistics of the output rows that became computable; c->stream: the score kernel
+// over the row blocks whose statistics exist, behind the band's event.  With a pageable source every copy call
+// blocks the host while its rows are staged - the kernels queued before it run meanwhile.
+int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
+    const SizeClass& sc = c->classes[0];
+    if (!c->hits_only_now) MTMC(ensure_maps(c));
+    if (!c->copy_stream) HIPC(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    mtm_ctx::ImageSlot& sl = c->slot[c->cur];
+    SlotGeom g{};
+    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, MTM_U8, c->copy_stream, 1, &g));
+    const int nb = (int)c->upload_bands.size();
+    while ((int)c->band_ev.size() < nb) {
+        hipEvent_t e;
+        HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->band_ev.push_back(e);
+    }
+    const int h = sc.h, oh = a.rows - h + 1;
+    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : kMfRows;          // output rows per score-kernel row block
+    const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
+    int r_done = 0, sb_done = 0, yb_done = 0;
+    for (int k = 0; k < nb; ++k) {
+        const bool last = k == nb - 1;
+        int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
+        if (r1 <= r_done) continue;
+        MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream));
+        r_done = r1;
+        const int avail = r1 - h + 1;                            // output rows whose windows are complete
+        const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);
+        StatPlanes st;
+        c->stats_stream = c->copy_stream;
+        const int rc = launch_stats(c, sc, &st, sb_done, sb1);
+        c->stats_stream = nullptr;
+        MTMC(rc);
+        sb_done = sb1;
+        HIPC(hipEventRecord(c->band_ev[(size_t)k], c->copy_stream));
+        (void)hipStreamQuery(c->copy_stream);                    // submit now (the runtime batches commands)
+        const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
+        if (yb1 > yb_done) {
+            HIPC(hipStreamWaitEvent(c->stream, c->band_ev[(size_t)k], 0));
+            MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1));
+            (void)hipStreamQuery(c->stream);
+            yb_done = yb1;
+        }
+    }
+    return MTM_OK;
+}
+
+int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmState& S, const ImageArgs* up = nullptr) {
     HIPC(hipSetDevice(c->device));
+    bool banded = false;
+    if (up) {
+        // the geometry first (placement depends on it); the pixels follow in stream order
+        adopt_image(c, up->rows, up->cols, up->chans, up->dtype);
+        c->have_image = false;                       // until the upload is queued: an error below leaves no stale image
+        if (!c->have_templ) {
+            set_error("set the templates first");
+            return MTM_E_STATE;
+        }
+        c->have_image = true;
+    }
     MTMC(place_templates(c));
+    if (up) {
+        banded = banded_ok(c, *up);
+        if (!banded) {
+            const int rc = upload_image(c, c->slot[c->cur], up->px, up->stride, up->rows, up->cols, up->chans, up->dtype,
+                                        c->stream);
+            if (rc != MTM_OK) {
+                c->have_image = false;
+                return rc;
+            }
+        }
+    }
     const int n = (int)c->templs.size();
     const bool mode_min = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_SQDIFF_NORMED;
     // numpy compares the float32 map with the python-float threshold in float32
@@ -1663,7 +1849,16 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     }
 
     HIPC(hipEventRecord(c->ev[0], c->stream));
-    MTMC(run_score_all(c));
+    if (banded) {
+        const int rc = run_score_banded(c, *up);
+        if (rc != MTM_OK) {
+            c->have_image = false;                   // possibly half an image on the device
+            (void)hipStreamSynchronize(c->copy_stream);
+            return rc;
+        }
+    } else {
+        MTMC(run_score_all(c));
+    }
     HIPC(hipEventRecord(c->ev[1], c->stream));
     c->cand_on = false;
     // stream mode: the kernels of this image are on their way - start the upload of the next one now.
@@ -1766,6 +1961,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             const uint8_t* land = static_cast<const uint8_t*>(c->pinned);
             unsigned long long ncand = 0;
             std::memcpy(&ncand, land, sizeof(ncand));
+            std::memcpy(&c->timing.sclk_mhz, land + 8, sizeof(float));
             if (ncand <= nfetch) {
                 // everything needed is on the host: clear the counter for the next call while this one finishes
                 if (hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess) c->cands_zeroed = c->cands.p;
@@ -1954,7 +2150,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
 }
 
 int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
-                      int64_t* n_out, NextImage* next) {
+                      int64_t* n_out, NextImage* next, const ImageArgs* up) {
     if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) ||
         (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
         set_error("mtm_find_matches: bad arguments");
@@ -1965,7 +2161,7 @@ int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out
         return MTM_E_INVALID;
     }
     FmState S;
-    MTMC(fm_begin(c, mode, score_threshold, next, S));
+    MTMC(fm_begin(c, mode, score_threshold, next, S, up));
     return fm_end(c, S, out, capacity, n_out);
 }
 

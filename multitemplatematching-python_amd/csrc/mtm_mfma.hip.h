@@ -63,6 +63,7 @@ struct MfmaParams {
     int nb;                  // 64-tap blocks per template row: ceil(w / 64)
     int n_list;              // templates of this class (list order = pack order)
     int nseg, nyb, ntg;      // work grid: x segments, row blocks, template groups (of 16*MB)
+    int yb0;                 // first row block of this launch (banded launches: the image arrives in row bands)
     int n_work;
     int method;
     int lds_pitch;           // bytes per LDS tile row: (16 + 4*nb + 1) * 16
@@ -107,6 +108,8 @@ struct MfmaParams {
     unsigned long long* ext_best;
     int dbg;                 // profiling probe (MTM_MFMA_DBG): 2 = no epilogue (results invalid); the other probes
                              // are compile-time (-DMTM_PROBE_*)
+    float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
+                             // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)
 };
 
 // Per-template constants staged in LDS once per work-group (the epilogue reads them with LDS
@@ -315,6 +318,14 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if (s_item[1])
             for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    // effective shader clock under this very load (the chip clocks to its power budget: MFMA-dense code runs well
+    // below the 2.4 GHz the peak figures assume)
+    const bool clk_probe = p.clk_out != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (clk_probe) {
+        clk_t0 = __builtin_readcyclecounter();
+        clk_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     const int per_xcd = (p.n_work + 7) >> 3;
     for (int iter = 0;; ++iter) {
     int wid;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
-    const int x0 = seg * kMfSeg, y0 = yb * (RM ? 8 * p.rm_R : kMfRows);
+    const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : kMfRows);
     const int wave_rows = RM ? 2 * p.rm_R : 1;          // output rows per wave = tile-row stride between waves
 
     v4i acc[MB][16];
@@ -1048,6 +1059,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     }
     }   // epilogue scope
     }   // work-item loop
+    if (clk_probe) {
+        const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+        if (dr > 0) *p.clk_out = (float)((double)dt * 100.0 / (double)dr);
+    }
 }
 
 }  // namespace mtm

@@ -22,12 +22,27 @@ def test_north_star_workload_and_counts():
     assert img.shape == (2160, 3840) and img.dtype == np.uint8 and len(units) == 32
     assert all(u[1].shape == (64, 64) for u in units) and method == 5 and thr == 0.5
     out_px = (2160 - 63) * (3840 - 63)
-    assert bench.algorithmic_macs(img, units) == 32 * out_px * 4096 == 1038138605568
+    assert bench.score_kernel_macs(img, units) == 32 * out_px * 4096 == 1038138605568
+    assert bench.masked_stat_macs(img, units) == 0
     assert bench.algorithmic_bytes(img, units) == img.nbytes + 32 * (4096 + 4 * out_px) == 1022232704
     assert bench.algorithmic_bytes_hits_only(img, units) == img.nbytes + 32 * 4096 + 2 * 8 * out_px
     # weak scaling: 32 units per GPU
     _, units8, _, _, _, _ = bench.build_workload("north_star", 8)
     assert len(units8) == 256
+
+
+def test_masked_mac_accounting():
+    """cfg5: the timed score kernel does ONE correlation per masked unit (sum I*(T*M)); sum I^2*M is computed once per
+    distinct mask by launches outside the kernel timer and is accounted separately (a roofline fraction above 1 in
+    round 1 came from counting it inside)."""
+    import synth
+    img, units, _ = synth.make_workload(seed=5, image_hw=(300, 400), n_base=3, templ=32, scales=(16, 32), masked=True)
+    H, W = img.shape
+    per_unit = sum((H - u[1].shape[0] + 1) * (W - u[1].shape[1] + 1) * u[1].shape[0] * u[1].shape[1] for u in units)
+    assert bench.score_kernel_macs(img, units) == per_unit
+    per_mask = sum(2 * (H - s + 1) * (W - s + 1) * s * s for s in (16, 32))     # two byte planes of I^2, one mask per size
+    assert bench.masked_stat_macs(img, units) == per_mask
+    assert "cfg4" in bench.CONFIGS
 
 
 def test_pmc_traffic_table():

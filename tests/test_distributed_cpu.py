@@ -1,7 +1,8 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard the units, exchange hit records with the
-'torch' backend of MTM.distributed.HitExchange and run the global NMS; the result must equal the
-single-process pipeline.  The GPU step is replaced by the oracle (tests may use it) because this
-container has no GPU; the RCCL backend itself is exercised by bench.py --gpus N on the GPU node."""
+"""N>1 path on CPU: world_size-2 processes shard the units, exchange hit records through
+MTM.distributed.HitExchange - once over a gloo collective the test supplies ("custom" backend), once over the
+package's own socket store ("tcp" backend, no torch anywhere) - and run the global NMS; the result must equal the
+single-process pipeline.  The GPU step is replaced by the oracle (tests may use it) because this container has no
+GPU; the RCCL backend itself is exercised by bench.py --gpus N on the GPU node."""
 import os
 import socket
 import sys
@@ -20,16 +21,23 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     for p in (os.path.join(ROOT, "multitemplatematching-python_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
-    import torch.distributed as dist
     import mtm_oracle as O
     import synth
     from MTM import _lib
     from MTM.distributed import HitExchange, matchTemplates_sharded
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist = None
+    if backend == "gloo":
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        def gloo_allgather(payload):
+            parts = [None] * world
+            dist.all_gather_object(parts, payload)
+            return parts
     try:
         img, units, _ = synth.make_workload(seed=9, image_hw=(260, 420), n_base=5, templ=24)
         units.append(("big", np.ascontiguousarray(img[10:70, 20:90])))      # unequal costs
@@ -42,12 +50,16 @@ def _worker(rank, world, port, q):
                 out[i] = (names.index(h[0]), h[1][0], h[1][1], h[1][2], h[1][3], h[2])
             return out
 
-        ex = HitExchange("torch", rank, world)
+        if backend == "gloo":
+            ex = HitExchange("custom", rank, world, allgather_bytes=gloo_allgather)
+        else:
+            ex = HitExchange("tcp", rank, world)           # MASTER_ADDR / MASTER_PORT + 1
+            assert "torch" not in sys.modules
         got = matchTemplates_sharded(units, img, ex, score_threshold=0.4, maxOverlap=0.25, find_local=find_local)
         # the exchange itself: ragged counts, an empty rank, more records than the first slot holds (second
         # collective with larger slots), then small again (the slot size follows the data on every rank alike)
         ok = True
-        for n0, n1 in ((3, 0), (700, 5), (2, 1300), (0, 0), (4, 4)):
+        for n0, n1 in ((3, 0), (700, 5), (2, 1300), (0, 0), (4, 4), (9000, 17), (1, 5000)):
             n = n0 if rank == 0 else n1
             mine = np.zeros(n, dtype=_lib.HIT_DTYPE)
             mine["templ_idx"] = rank
@@ -60,7 +72,8 @@ def _worker(rank, world, port, q):
         q.put((rank, "worker failed: %r" % (e,)))
         raise
     finally:
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
 
 
 def test_shard_units_lpt():
@@ -74,12 +87,13 @@ def test_shard_units_lpt():
     assert shard_units([], 2) == [[], []]
 
 
-def test_two_rank_gloo_matches_single_process():
-    import torch.multiprocessing as mp
+@pytest.mark.parametrize("backend", ["gloo", "tcp"])
+def test_two_rank_exchange_matches_single_process(backend):
+    import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=180) for _ in procs)

@@ -553,6 +553,97 @@ def test_cfg4_full_list_and_eight_way_shards(mtm):
         assert matchTemplates_sharded(units, img, Gather(r), score_threshold=0.5, find_local=local) == full
 
 
+# ------------------------------------------------------------------------------------------------
+# one call for image + search (mtm_find_matches_image): banded upload under the score kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bands", ["0.16,0.44,0.72,1", "0.5,1", "0.03,0.06,0.5,0.51,1", "1"])
+def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
+    """mtm_find_matches_image == mtm_set_image + mtm_find_matches, whatever the band layout: plain and
+    row-multiplexed classes (band boundaries fall inside 8R-row blocks), hits-only and map mode, both peak modes,
+    and the layouts that upload in one piece (several size classes, RGB, uint16, masks)."""
+    from MTM import _lib
+    monkeypatch.setenv("MTM_UPLOAD_BANDS", bands)
+    fused, plain = _lib.Context(0), _lib.Context(0)
+    try:
+        img, units, plants = synth.make_workload(seed=21, image_hw=(1100, 1200), n_base=20, templ=32, noisy_per_unit=2)
+        rgb_img, rgb_units, _ = synth.make_workload(seed=22, image_hw=(700, 1600), n_base=3, templ=24, channels=3)
+        msk_img, msk_units, _ = synth.make_workload(seed=23, image_hw=(1050, 1100), n_base=2, templ=32, scales=(24, 40), masked=True)
+        img16 = img.astype(np.uint16) * 200 + 7
+        cases = [
+            (img, [(u[1], None) for u in units], 5, 0.5),                      # 20 templates: plain MFMA class, banded
+            (img, [(u[1], None) for u in units[:5]], 5, 0.5),                  # row-multiplexed (nt = 8, R = 2)
+            (img, [(units[0][1], None)], 3, 0.7),                              # row-multiplexed, one template (R = 16: 128-row blocks)
+            (img, [(u[1], None) for u in units[:3]] + [(np.ascontiguousarray(units[4][1][:20, :28]), None)], 1, 0.3),   # two classes
+            (rgb_img, [(u[1], None) for u in rgb_units], 5, 0.5),
+            (msk_img, [(u[1], u[2]) for u in msk_units], 3, 0.9),
+            (img16, [(u[1].astype(np.uint16) * 200 + 7, None) for u in units[:4]], 5, 0.5),
+        ]
+        for honly in (1, 0):
+            fused.set_option(_lib.OPT_HITS_ONLY, honly)
+            plain.set_option(_lib.OPT_HITS_ONLY, honly)
+            for mode in (_lib.PEAKS_LOCAL, _lib.PEAKS_GLOBAL):
+                for im, tl, method, thr in cases:
+                    a = fused.search(tl, im, method, mode, thr)
+                    plain.set_image(im)
+                    plain.set_templates(tl, method)
+                    b = plain.find_matches(mode, thr)
+                    assert len(a) == len(b) and len(a) >= len(tl), (bands, honly, mode, method, len(a), len(b))
+                    assert np.array_equal(a, b), (bands, honly, mode, method)
+                    if honly == 0 and mode == _lib.PEAKS_LOCAL:                # the maps of the banded launches, bit for bit
+                        shape = (im.shape[0] - tl[-1][0].shape[0] + 1, im.shape[1] - tl[-1][0].shape[1] + 1)
+                        assert np.array_equal(fused.last_score_map(len(tl) - 1, shape), plain.last_score_map(len(tl) - 1, shape))
+        # the banded call really ran in bands, and measured the clock it ran at
+        fused.set_option(_lib.OPT_HITS_ONLY, 1)
+        fused.search(cases[0][1], img, 5, _lib.PEAKS_LOCAL, 0.5)
+        t = fused.timing()
+        assert (t["ncc_launches"] == 1) if bands == "1" else (2 <= t["ncc_launches"] <= len(bands.split(",")))
+        assert 300.0 < t["sclk_mhz"] < 3500.0
+        # a different image through the same fused context: nothing stale survives
+        img2 = np.ascontiguousarray(img[::-1, ::-1])
+        a = fused.search(cases[0][1], img2, 5, _lib.PEAKS_LOCAL, 0.5)
+        plain.set_image(img2)
+        plain.set_templates(cases[0][1], 5)
+        assert np.array_equal(a, plain.find_matches(_lib.PEAKS_LOCAL, 0.5))
+    finally:
+        fused.close()
+        plain.close()
+
+
+def test_device_group_equals_single_context(mtm, coins, monkeypatch):
+    """Several contexts in one process (mtm_group; here all on the one GPU of the box): LPT shards, concurrent
+    upload + search per context, host merge - the hit list of the single-context call, for every shard count."""
+    from MTM import _lib
+    from MTM.distributed import shard_units, unit_cost
+    img, units, plants = synth.make_workload(seed=31, image_hw=(900, 1300), n_base=11, templ=32, noisy_per_unit=2)
+    units.append(("wide", np.ascontiguousarray(img[100:140, 200:330])))        # unequal costs
+    units.append(("tiny", np.ascontiguousarray(img[500:512, 700:716])))
+    ref = mtm.matchTemplates(units, img, score_threshold=0.5)
+    ref1 = mtm.findMatches(units, img, N_object=1)
+    for devs in ([0, 0], [0, 0, 0], [0] * 8, [0] * 16):
+        assert mtm.matchTemplates(units, img, score_threshold=0.5, devices=devs) == ref
+        assert mtm.findMatches(units, img, N_object=1, devices=devs) == ref1
+        g = _lib.engine_for(devs)
+        assert isinstance(g, _lib.Group) and len(g) == len(devs)
+        dev = g.shards([(u[1], None) for u in units], img.shape, 5)
+        exp = shard_units([unit_cost(u[1], img.shape) for u in units], len(devs))
+        assert [sorted(np.flatnonzero(dev == d).tolist()) for d in range(len(devs))] == exp
+    # masks, a difference score, a search box and an error from a worker
+    small, _ = coin_templates(coins)
+    lt = [("a", small, otsu_mask(small)), ("b", np.ascontiguousarray(small[:30, :30]))]
+    assert mtm.matchTemplates(lt, coins, method=3, score_threshold=0.8, devices=[0, 0]) == \
+        mtm.matchTemplates(lt, coins, method=3, score_threshold=0.8)
+    assert mtm.matchTemplates(lt[1:], coins, method=1, score_threshold=0.3, searchBox=(20, 10, 300, 250), devices="0,0,0") == \
+        mtm.matchTemplates(lt[1:], coins, method=1, score_threshold=0.3, searchBox=(20, 10, 300, 250))
+    with pytest.raises(_lib.MtmError, match="device 0"):
+        _lib.engine_for([0, 0]).search([(np.zeros((8, 8, 2), np.uint8), None), (small, None)], coins, 5, 0, 0.5)
+    # MTM_DEVICES selects the engine of a plain call
+    monkeypatch.setenv("MTM_DEVICES", "0,0")
+    assert isinstance(_lib.engine_for(None), _lib.Group)
+    assert mtm.matchTemplates(units, img, score_threshold=0.5) == ref
+    monkeypatch.setenv("MTM_DEVICES", "all")
+    assert mtm.matchTemplates(units, img, score_threshold=0.5) == ref
+
+
 BORDER_CALLS = {
     "sqdiff_normed": lambda im: ([("small", im[37:75, 80:121]), ("big", im[14:73, 302:367])],
                                  dict(method=1, score_threshold=0.2, maxOverlap=0)),

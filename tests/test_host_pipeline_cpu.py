@@ -37,6 +37,14 @@ class OracleContext:
         assert out.shape == tuple(shape)
         return out
 
+    def search(self, templates, image, method, mode, thr):          # the engine interface (Context / Group)
+        self.set_templates(templates, method)
+        return self.find_matches_image(image, mode, thr)
+
+    def find_matches_image(self, image, mode, thr):                 # mtm_find_matches_image
+        self.set_image(image)
+        return self._find(mode, thr)
+
     def find_matches(self, mode, thr, next_image=None):
         try:
             return self._find(mode, thr)
