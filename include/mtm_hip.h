@@ -112,13 +112,16 @@ typedef struct mtm_timing {
     float total_ms;      /* first kernel launch -> last kernel done                      */
     float score_ms;      /* window statistics + score-map kernels                        */
     float peaks_ms;      /* peak-extraction kernels                                      */
-    float ncc_kernel_ms; /* the dominant score-map kernel(s) alone                        */
+    float ncc_kernel_ms; /* the dominant score-map kernel(s) alone: time during which at least one launch ran */
     int32_t ncc_launches;
     int32_t kernel_used; /* MTM_KERNEL_* actually dispatched for the uint8 path           */
     int64_t n_hits;
     int32_t hits_only;   /* 1: the last mtm_find_matches ran without materialising the score maps */
     float   sclk_mhz;    /* shader clock the score kernel ran at, measured inside it (s_memtime ticks per
                             s_memrealtime tick x 100 MHz) by one mid-grid work-group; 0 when not measured */
+    float   ncc_sum_ms;  /* plain sum of the score-kernel launch durations (= ncc_kernel_ms unless launches of a
+                            banded call overlapped; what a profiler's per-launch average times the count gives) */
+    float   pad_;
 } mtm_timing;
 
 /* ---- device / context ------------------------------------------------------------------- */

@@ -40,7 +40,8 @@ class MtmTiming(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_float), ("score_ms", ctypes.c_float),
                 ("peaks_ms", ctypes.c_float), ("ncc_kernel_ms", ctypes.c_float),
                 ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
-                ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("sclk_mhz", ctypes.c_float)]
+                ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("sclk_mhz", ctypes.c_float),
+                ("ncc_sum_ms", ctypes.c_float), ("pad_", ctypes.c_float)]
 
 
 HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),

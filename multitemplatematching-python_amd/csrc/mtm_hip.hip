@@ -163,8 +163,14 @@ struct mtm_ctx {
     // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
     // statistics of the rows that became computable); the score kernel of a band waits for its event
     hipStream_t stats_stream = nullptr;     // non-null while a banded call queues its statistics launches
+    hipStream_t stream2 = nullptr;          // second compute stream: the score launches of consecutive bands alternate
+                                            // between `stream` and this one, so the tail of one launch (its last
+                                            // work-groups draining) is filled by the next launch instead of idling
+    hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int copy_prio = 1;                      // MTM_COPY_PRIO: 1 = the copy stream gets the highest stream priority
+    hipEvent_t stream2_done = nullptr;
     std::vector<hipEvent_t> band_ev;
-    std::vector<double> upload_bands{0.16, 0.44, 0.72, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
+    std::vector<double> upload_bands{0.12, 0.34, 0.56, 0.78, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
 
     // templates
     bool have_templ = false;
@@ -821,7 +827,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         c->ncc_ev.emplace_back(a, b);
     }
     auto& evp = c->ncc_ev[c->timing.ncc_launches];
-    HIPC(hipEventRecord(evp.first, c->stream));
+    hipStream_t ncc_s = (c->ncc_stream && kernel == MTM_KERNEL_MFMA) ? c->ncc_stream : c->stream;
+    HIPC(hipEventRecord(evp.first, ncc_s));
 
     if (kernel == MTM_KERNEL_NAIVE) {
         const dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4, n_list);
@@ -1009,7 +1016,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.stagger_sleeps = c->mfma_stagger_np;
             HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
         }
-        hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
+        hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps,
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_MFMA16) {
@@ -1118,7 +1125,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         if (c->timing.kernel_used == 0) c->timing.kernel_used = MTM_KERNEL_AUTO;
     }
     HIPC(hipGetLastError());
-    HIPC(hipEventRecord(evp.second, c->stream));
+    HIPC(hipEventRecord(evp.second, ncc_s));
     c->timing.ncc_launches++;
     return MTM_OK;
 }
@@ -1148,13 +1155,31 @@ int run_score_all(mtm_ctx* c) {
     return MTM_OK;
 }
 
+// Time during which at least one score-kernel launch of the call was running: the launches of a banded call
+// overlap (two compute streams), so their intervals are laid on the timeline of the first one and united.
 int collect_ncc_time(mtm_ctx* c) {
-    float total = 0.f;
-    for (int i = 0; i < c->timing.ncc_launches; ++i) {
-        float ms = 0.f;
-        HIPC(hipEventElapsedTime(&ms, c->ncc_ev[i].first, c->ncc_ev[i].second));
-        total += ms;
+    const int n = c->timing.ncc_launches;
+    std::vector<std::pair<float, float>> iv;
+    for (int i = 0; i < n; ++i) {
+        float a = 0.f, d = 0.f;
+        if (i > 0) HIPC(hipEventElapsedTime(&a, c->ncc_ev[0].first, c->ncc_ev[i].first));
+        HIPC(hipEventElapsedTime(&d, c->ncc_ev[i].first, c->ncc_ev[i].second));
+        iv.emplace_back(a, a + d);
     }
+    std::sort(iv.begin(), iv.end());
+    float total = 0.f, lo = 0.f, hi = -1.f, sum = 0.f;
+    for (const auto& x : iv) sum += x.second - x.first;
+    c->timing.ncc_sum_ms = sum;
+    for (const auto& x : iv) {
+        if (hi < lo || x.first > hi) {
+            if (hi >= lo) total += hi - lo;
+            lo = x.first;
+            hi = x.second;
+        } else {
+            hi = std::max(hi, x.second);
+        }
+    }
+    if (hi >= lo) total += hi - lo;
     c->timing.ncc_kernel_ms = total;
     return MTM_OK;
 }
@@ -1218,6 +1243,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
             c->upload_bands = f;
         }
     }
+    if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
@@ -1253,6 +1279,11 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->comm_pin) (void)hipHostFree(c->comm_pin);
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
     for (hipEvent_t e : c->band_ev) (void)hipEventDestroy(e);
+    if (c->stream2_done) (void)hipEventDestroy(c->stream2_done);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& p : c->ncc_ev) {
         (void)hipEventDestroy(p.first);
@@ -1487,23 +1518,43 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         }
     }
     // The same templates again (a loop of matchTemplates calls over different images): keep everything that
-    // was derived from them - statistics, size classes, device packs.  The test is on the pixel bytes.
+    // was derived from them - statistics, size classes, device packs.  The test is on the pixel bytes: the
+    // caller's rows are compared in place with the copy kept from the call that built the current state.
     {
-        std::vector<uint8_t> blob;
-        auto put = [&](const void* p, size_t n) { blob.insert(blob.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
-        put(&n_templ, sizeof(n_templ));
-        put(&method, sizeof(method));
-        for (int i = 0; i < n_templ; ++i) {
-            const mtm_templ& s = templs[i];
-            const int hdr[5] = {s.rows, s.cols, s.chans, s.dtype, s.mask ? 1 : 0};
-            put(hdr, sizeof(hdr));
-            const size_t row = (size_t)s.cols * s.chans * elem_size(s.dtype);
-            for (int y = 0; y < s.rows; ++y) {
-                put((const uint8_t*)s.px + (size_t)y * s.row_stride, row);
-                if (s.mask) put((const uint8_t*)s.mask + (size_t)y * s.mask_row_stride, row);
+        auto walk = [&](auto&& emit) {
+            emit(&n_templ, sizeof(n_templ));
+            emit(&method, sizeof(method));
+            for (int i = 0; i < n_templ; ++i) {
+                const mtm_templ& s = templs[i];
+                const int hdr[5] = {s.rows, s.cols, s.chans, s.dtype, s.mask ? 1 : 0};
+                emit(hdr, sizeof(hdr));
+                const size_t row = (size_t)s.cols * s.chans * elem_size(s.dtype);
+                if (!s.mask && s.row_stride == (int64_t)row) {      // contiguous template: one piece
+                    emit(s.px, row * s.rows);
+                    continue;
+                }
+                for (int y = 0; y < s.rows; ++y) {
+                    emit((const uint8_t*)s.px + (size_t)y * s.row_stride, row);
+                    if (s.mask) emit((const uint8_t*)s.mask + (size_t)y * s.mask_row_stride, row);
+                }
             }
+        };
+        if (c->have_templ) {
+            size_t off = 0;
+            bool same = true;
+            const std::vector<uint8_t>& old = c->templ_blob;
+            walk([&](const void* p, size_t n) {
+                if (!same) return;
+                if (off + n > old.size() || std::memcmp(old.data() + off, p, n) != 0) same = false;
+                off += n;
+            });
+            if (same && off == old.size()) return MTM_OK;
         }
-        if (c->have_templ && blob == c->templ_blob) return MTM_OK;
+        std::vector<uint8_t> blob;
+        size_t total = 0;
+        walk([&](const void*, size_t n) { total += n; });
+        blob.reserve(total);
+        walk([&](const void* p, size_t n) { blob.insert(blob.end(), (const uint8_t*)p, (const uint8_t*)p + n); });
         c->templ_blob.swap(blob);
         c->have_templ = false;          // until the new set is complete
     }
@@ -1633,13 +1684,23 @@ struct ImageArgs {
     int64_t stride;
 };
 
+// The producer side of the upload pipelines (copies, layout conversion, window statistics of a band): its short
+// kernels must not queue behind the score kernel's work-groups for a free CU, hence the highest stream priority.
+int ensure_copy_stream(mtm_ctx* c) {
+    if (c->copy_stream) return MTM_OK;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPC(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, c->copy_prio ? hi : 0));
+    return MTM_OK;
+}
+
 // Enqueue the upload + plane conversion of the next image of a stream on the copy stream, into the
 // image slot the kernels are not reading.  Called by find_matches_impl after the kernels of the
 // current image are enqueued and before it waits for them: the PCIe transfer (and the host-side
 // staging the runtime does for pageable memory) runs under the kernels.
 int stage_next_image(mtm_ctx* c, NextImage* nx) {
     if (!nx || nx->staged) return MTM_OK;
-    if (!c->copy_stream) HIPC(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    MTMC(ensure_copy_stream(c));
     if (!c->next_ready) HIPC(hipEventCreateWithFlags(&c->next_ready, hipEventDisableTiming));
     // The runtime batches stream commands and only submits them when somebody asks about the stream:
     // push the kernels of the current image out first, then (below) the copy, so that they overlap.
@@ -1721,7 +1782,7 @@ bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
 int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     const SizeClass& sc = c->classes[0];
     if (!c->hits_only_now) MTMC(ensure_maps(c));
-    if (!c->copy_stream) HIPC(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    MTMC(ensure_copy_stream(c));
     mtm_ctx::ImageSlot& sl = c->slot[c->cur];
     SlotGeom g{};
     MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, MTM_U8, c->copy_stream, 1, &g));
@@ -1734,7 +1795,13 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     const int h = sc.h, oh = a.rows - h + 1;
     const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : kMfRows;          // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
-    int r_done = 0, sb_done = 0, yb_done = 0;
+    int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
+    bool used2 = false;
+    if (!c->stream2) HIPC(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->stream2_done) HIPC(hipEventCreateWithFlags(&c->stream2_done, hipEventDisableTiming));
+    // stream2 starts behind whatever the call queued on c->stream so far (counter reset, statistics buffers ...)
+    HIPC(hipEventRecord(c->stream2_done, c->stream));
+    HIPC(hipStreamWaitEvent(c->stream2, c->stream2_done, 0));
     for (int k = 0; k < nb; ++k) {
         const bool last = k == nb - 1;
         int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
@@ -1753,11 +1820,21 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         (void)hipStreamQuery(c->copy_stream);                    // submit now (the runtime batches commands)
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
         if (yb1 > yb_done) {
-            HIPC(hipStreamWaitEvent(c->stream, c->band_ev[(size_t)k], 0));
-            MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1));
-            (void)hipStreamQuery(c->stream);
+            hipStream_t s = (n_launch & 1) ? c->stream2 : c->stream;
+            HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
+            c->ncc_stream = s;
+            const int rc2 = launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1);
+            c->ncc_stream = nullptr;
+            MTMC(rc2);
+            (void)hipStreamQuery(s);
+            used2 = used2 || s == c->stream2;
+            ++n_launch;
             yb_done = yb1;
         }
+    }
+    if (used2) {                                    // everything after the score pass is queued on c->stream
+        HIPC(hipEventRecord(c->stream2_done, c->stream2));
+        HIPC(hipStreamWaitEvent(c->stream, c->stream2_done, 0));
     }
     return MTM_OK;
 }
