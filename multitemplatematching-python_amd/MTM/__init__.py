@@ -308,6 +308,7 @@ class TemplateMatcher:
         self.score_threshold, self.maxOverlap = score_threshold, maxOverlap
         self._ctx = context or _lib.Context()
         self._uploaded_for = None      # (dtype name, channel count) the resident templates were prepared for
+        self._streaming = False        # a match_stream generator is being consumed: the context is its alone
 
     def _upload(self, image):
         units = []
@@ -347,7 +348,13 @@ class TemplateMatcher:
         kept = _nms_raw(raw, self.score_threshold, self.method == 1, self.N_object, self.maxOverlap)
         return _to_hit_list(kept, self.listTemplates, xOffset, yOffset)
 
+    def _not_streaming(self):
+        if self._streaming:
+            raise RuntimeError("TemplateMatcher: a match_stream() generator of this matcher is still being consumed; "
+                               "finish or close() it before calling match() / match_stream() again")
+
     def match(self, image: np.ndarray, searchBox: Optional[BBox] = None) -> List[Hit]:
+        self._not_streaming()
         with self._ctx.lock:
             im, xOffset, yOffset = self._prepare(image, searchBox)
             mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
@@ -360,8 +367,11 @@ class TemplateMatcher:
         of image i+1 (PCIe transfer, plane conversion) is enqueued on a
         second stream while the kernels of image i run (mtm_find_matches_next), so a stream costs
         about the kernel time per image instead of upload + kernels.  The context stays locked while
-        the generator is being consumed.
+        the generator is being consumed, and the matcher refuses other calls meanwhile - also from the
+        consuming thread, whose loop body runs between two yields while a native call is in flight on the
+        helper thread: finish the generator or close() it first.
         """
+        self._not_streaming()
         mode = _lib.PEAKS_GLOBAL if self.N_object == 1 else _lib.PEAKS_LOCAL
         it = iter(images)
         try:
@@ -373,10 +383,11 @@ class TemplateMatcher:
         # the caller's own per-image code leaves the GPU idle.
         from concurrent.futures import ThreadPoolExecutor
         with self._ctx.lock, ThreadPoolExecutor(max_workers=1, thread_name_prefix="mtm-stream") as pool:
-            cur = self._prepare(first, searchBox)
-            self._ctx.set_image(cur[0])
             pending = None          # (future of the raw hits, xOffset, yOffset) of the image in flight
+            self._streaming = True
             try:
+                cur = self._prepare(first, searchBox)
+                self._ctx.set_image(cur[0])
                 for nxt_image in it:
                     nxt = self._prepare(nxt_image, searchBox)
                     fut = pool.submit(self._ctx.find_matches, mode, self.score_threshold, nxt[0])
@@ -401,51 +412,108 @@ class TemplateMatcher:
                         pending[0].result()
                     except Exception:        # noqa: BLE001 - nothing to report to: the generator is closing
                         pass
+                self._streaming = False
 
 
 # ---------------------------------------------------------------------------------------------
 # drawing helpers (reference MTM/__init__.py:299-391), numpy only
 # ---------------------------------------------------------------------------------------------
-def _draw_boxes(canvas, listHit, boxThickness, color):
+# Label text: cv2.putText(FONT_HERSHEY_SIMPLEX, LINE_AA) in the reference (MTM/__init__.py:335, :383).  The Hershey
+# stroke tables are OpenCV data; labels are drawn here with the classic 5x7 dot-matrix font (columns, LSB = top
+# row, ASCII 32..126), scaled to the height Hershey simplex has at the same fontScale, anchored like putText
+# (org = bottom-left corner of the string).  Same place, same size, not the same glyph shapes.
+_FONT_5X7 = bytes.fromhex(
+    "0000000000" "00005f0000" "0007000700" "147f147f14" "242a7f2a12" "2313086462" "3649552250" "0005030000"
+    "001c224100" "0041221c00" "14083e0814" "08083e0808" "0050300000" "0808080808" "0060600000" "2010080402"
+    "3e5149453e" "00427f4000" "4261514946" "2141454b31" "1814127f10" "2745454539" "3c4a494930" "0171090503"
+    "3649494936" "064949291e" "0036360000" "0056360000" "0814224100" "1414141414" "0041221408" "0201510906"
+    "324979413e" "7e1111117e" "7f49494936" "3e41414122" "7f4141221c" "7f49494941" "7f09090901" "3e4149497a"
+    "7f0808087f" "00417f4100" "2040413f01" "7f08142241" "7f40404040" "7f020c027f" "7f0408107f" "3e4141413e"
+    "7f09090906" "3e4151215e" "7f09192946" "4649494931" "01017f0101" "3f4040403f" "1f2040201f" "3f4038403f"
+    "6314081463" "0708700807" "6151494543" "007f414100" "0204081020" "0041417f00" "0402010204" "4040404040"
+    "0001020400" "2054545478" "7f48444438" "3844444420" "384444487f" "3854545418" "087e090102" "0c5252523e"
+    "7f08040478" "00447d4000" "2040443d00" "7f10284400" "00417f4000" "7c04180478" "7c08040478" "3844444438"
+    "7c14141408" "081414187c" "7c08040408" "4854545420" "043f444020" "3c4040207c" "1c2040201c" "3c4030403c"
+    "4428102844" "0c5050503c" "4464544c44" "0008364100" "00007f0000" "0041360800" "0804081008")
+
+
+def _text_mask(text, scale):
+    """Boolean (rows, cols) raster of `text` in the 5x7 font, every dot a k x k block; k follows the font scale
+    (Hershey simplex is ~22 px tall at fontScale 1: k = round(22 * scale / 7), at least 1)."""
+    k = max(1, int(round(22.0 * float(scale) / 7.0)))
+    cols = []
+    for ch in str(text):
+        o = ord(ch)
+        g = _FONT_5X7[(o - 32) * 5:(o - 32) * 5 + 5] if 32 <= o <= 126 else b"\x7f\x41\x41\x41\x7f"   # box for non-ASCII
+        cols += [[(byte >> r) & 1 for r in range(7)] for byte in g] + [[0] * 7]
+    if not cols:
+        return np.zeros((0, 0), bool)
+    m = np.array(cols[:-1], dtype=bool).T                    # 7 x (6 n - 1)
+    return np.repeat(np.repeat(m, k, axis=0), k, axis=1)
+
+
+def _draw_label(canvas, text, x, y, color, scale):
+    m = _text_mask(text, scale)
+    th, tw = m.shape
+    H, W = canvas.shape[:2]
+    y0, x0 = int(y) - th, int(x)                             # putText: org is the bottom-left corner of the text
+    ya, yb, xa, xb = max(y0, 0), min(y0 + th, H), max(x0, 0), min(x0 + tw, W)
+    if ya < yb and xa < xb:
+        canvas[ya:yb, xa:xb][m[ya - y0:yb - y0, xa - x0:xb - x0]] = color
+
+
+def _draw_boxes(canvas, listHit, boxThickness, color, showLabel=False, labelColor=None, labelScale=0.5):
     H, W = canvas.shape[:2]
     t = max(int(boxThickness), 1)
     # cv2.rectangle draws a line of thickness t centred on the box outline
     lo, hi = (t - 1) // 2, t // 2
-    for _, (x, y, w, h), _ in listHit:
+    for label, (x, y, w, h), _ in listHit:
         x0, y0, x1, y1 = int(x), int(y), int(x + w), int(y + h)
         for (ya, yb, xa, xb) in ((y0 - lo, y0 + hi + 1, x0 - lo, x1 + hi + 1), (y1 - lo, y1 + hi + 1, x0 - lo, x1 + hi + 1),
                                  (y0 - lo, y1 + hi + 1, x0 - lo, x0 + hi + 1), (y0 - lo, y1 + hi + 1, x1 - lo, x1 + hi + 1)):
             ya, yb, xa, xb = max(ya, 0), min(yb, H), max(xa, 0), min(xb, W)
             if ya < yb and xa < xb:
                 canvas[ya:yb, xa:xb] = color
+        if showLabel:
+            _draw_label(canvas, label, x0, y0, labelColor, labelScale)
     return canvas
+
+
+def _rgb_to_gray(image):
+    """cv2.cvtColor(image, cv2.COLOR_RGB2GRAY) (reference MTM/__init__.py:375): OpenCV's fixed-point weights for
+    integer pixels - 8 bit: (9798 R + 19235 G + 3735 B + 2^14) >> 15, 16 bit: (4899 R + 9617 G + 1868 B + 2^13) >> 14 -
+    and float32 weights 0.299 / 0.587 / 0.114 for float images (OpenCV imgproc color.hpp, not pinned: no cv2 here)."""
+    r, g, b = image[..., 0], image[..., 1], image[..., 2]
+    if image.dtype == np.uint8:
+        v = (9798 * r.astype(np.int64) + 19235 * g.astype(np.int64) + 3735 * b.astype(np.int64) + (1 << 14)) >> 15
+        return v.astype(np.uint8)
+    if image.dtype == np.uint16:
+        v = (4899 * r.astype(np.int64) + 9617 * g.astype(np.int64) + 1868 * b.astype(np.int64) + (1 << 13)) >> 14
+        return v.astype(np.uint16)
+    f = image.astype(np.float32, copy=False)
+    return (f[..., 0] * np.float32(0.299) + f[..., 1] * np.float32(0.587) + f[..., 2] * np.float32(0.114)).astype(image.dtype)
 
 
 def drawBoxesOnRGB(image: np.ndarray, listHit: Sequence[Hit], boxThickness: int = 2,
                    boxColor: Tuple[int, int, int] = (255, 255, 00), showLabel: bool = False,
                    labelColor=(255, 255, 0), labelScale=0.5) -> np.ndarray:
-    """Return an RGB copy of the image with the hit boxes drawn (reference MTM/__init__.py:299-343).
-    Label text needs a font rasteriser (cv2.putText in the reference) and is not drawn."""
+    """Return an RGB copy of the image with the hit boxes - and, with showLabel, the template names at the top
+    left corner of each box - drawn on it (reference MTM/__init__.py:299-343).  Labels use a built-in dot-matrix
+    font instead of OpenCV's Hershey strokes: same anchor and size, different glyph shapes."""
     if image.ndim == 2:
         out = np.stack([image] * 3, axis=2)
     else:
         out = image.copy()
-    if showLabel:
-        warnings.warn("drawBoxesOnRGB: label text is not rendered by the MI355X drop-in (no cv2.putText).")
-    return _draw_boxes(out, listHit, boxThickness, np.asarray(boxColor, dtype=out.dtype))
+    return _draw_boxes(out, listHit, boxThickness, np.asarray(boxColor, dtype=out.dtype), showLabel,
+                       np.asarray(labelColor, dtype=out.dtype), labelScale)
 
 
 def drawBoxesOnGray(image: np.ndarray, listHit: Sequence[Hit], boxThickness: int = 2, boxColor: int = 255,
                     showLabel: bool = False, labelColor: int = 255, labelScale=0.5) -> np.ndarray:
-    """Return a grayscale copy of the image with the hit boxes drawn (reference MTM/__init__.py:346-391)."""
-    if image.ndim == 3:
-        # cv2.COLOR_RGB2GRAY weights
-        out = np.rint(image[..., 0] * 0.299 + image[..., 1] * 0.587 + image[..., 2] * 0.114).astype(image.dtype)
-    else:
-        out = image.copy()
-    if showLabel:
-        warnings.warn("drawBoxesOnGray: label text is not rendered by the MI355X drop-in (no cv2.putText).")
-    return _draw_boxes(out, listHit, boxThickness, boxColor)
+    """Return a grayscale copy of the image with the hit boxes (and labels) drawn on it
+    (reference MTM/__init__.py:346-391)."""
+    out = _rgb_to_gray(image) if image.ndim == 3 else image.copy()
+    return _draw_boxes(out, listHit, boxThickness, boxColor, showLabel, labelColor, labelScale)
 
 
 from . import augment  # noqa: E402,F401  (template augmentation / downscaled matching helpers)

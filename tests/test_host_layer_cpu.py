@@ -83,3 +83,56 @@ def test_draw_boxes(mtm):
     assert tuple(rgb[30, 25]) == (image[30, 25],) * 3
     gray = mtm.drawBoxesOnGray(image, hits, boxThickness=1)
     assert gray.shape == image.shape and gray[20, 10] == 255 and gray[30, 25] == image[30, 25]
+
+
+def test_draw_labels_and_gray_conversion(mtm):
+    """showLabel draws the template name with its bottom-left corner at the box corner (cv2.putText's anchor), in
+    labelColor; drawBoxesOnGray converts RGB with OpenCV's 15-bit fixed-point weights."""
+    image = np.zeros((80, 160), np.uint8)
+    hits = [("AB_90", (20, 40, 50, 30), 0.9)]
+    plain = mtm.drawBoxesOnGray(image, hits, boxThickness=1, boxColor=200)
+    lab = mtm.drawBoxesOnGray(image, hits, boxThickness=1, boxColor=200, showLabel=True, labelColor=255, labelScale=0.5)
+    text = (lab == 255)
+    assert text.any() and not (plain == 255).any()
+    ys, xs = np.nonzero(text)
+    assert ys.max() == 39 and ys.min() == 40 - 14 and xs.min() == 20          # 7 dots x 2 px tall, anchored at (x, y)
+    assert xs.max() - xs.min() + 1 == (6 * 5 - 1) * 2                         # five glyphs, 5 columns + 1 gap each
+    rgb = mtm.drawBoxesOnRGB(image, hits, showLabel=True, labelColor=(1, 2, 3))
+    assert tuple(rgb[ys[0], xs[0]]) == (1, 2, 3)
+    # a label running off the canvas is clipped, not an error
+    mtm.drawBoxesOnRGB(image, [("a very long label that does not fit at all", (150, 3, 5, 5), 1.0)], showLabel=True)
+    # RGB -> gray
+    col = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [12, 200, 77]]], np.uint8)
+    g = mtm.drawBoxesOnGray(col, [])
+    assert g.dtype == np.uint8 and g.tolist() == [[76, 150, 29, 255, (9798 * 12 + 19235 * 200 + 3735 * 77 + 16384) >> 15]]
+    assert mtm.drawBoxesOnGray(col.astype(np.float32), []).dtype == np.float32
+
+
+def test_template_matcher_refuses_reentry_while_streaming(mtm):
+    """A generator of match_stream owns the context until it is finished or closed (the lock is re-entrant, so
+    the consuming thread itself must be told)."""
+    class Ctx:
+        import threading
+        lock = threading.RLock()
+
+        def set_templates(self, t, m):
+            pass
+
+        def set_image(self, im):
+            pass
+
+        def find_matches(self, mode, thr, nxt=None):
+            return np.zeros(0, dtype=mtm._lib.HIT_DTYPE)
+        find_matches_image = lambda self, im, mode, thr: np.zeros(0, dtype=mtm._lib.HIT_DTYPE)   # noqa: E731
+
+    img = np.zeros((40, 40), np.uint8)
+    m = mtm.TemplateMatcher([("t", img[:8, :8])], context=Ctx())
+    gen = m.match_stream([img, img, img])
+    assert next(gen) == []
+    with pytest.raises(RuntimeError, match="match_stream"):
+        m.match(img)
+    with pytest.raises(RuntimeError, match="match_stream"):
+        next(m.match_stream([img]))
+    gen.close()
+    assert m.match(img) == []                 # released
+    assert list(m.match_stream([img, img])) == [[], []]
