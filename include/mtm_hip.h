@@ -152,6 +152,27 @@ int mtm_set_image_downscaled(mtm_ctx* ctx, const void* px, int rows, int cols, i
  * cv2.matchTemplate (MTM/__init__.py:92). */
 int mtm_set_templates(mtm_ctx* ctx, const mtm_templ* templs, int n_templ, int method);
 
+/* The caller's step BEFORE the hot path, on the device: the reference's users append rotated / flipped / rescaled
+ * copies of their templates to listTemplates on the host (tutorials/Tutorial2-Template_Augmentation.ipynb:313,
+ * np.rot90; multi-scale copies).  Here the caller hands over the BASES and a list of variants; every
+ * (base, variant) pair becomes one unit, base-major (unit index = base * n_variants + variant), exactly as if
+ * the copies had been passed to mtm_set_templates.  A unit is a view of a source kept on the device - the base,
+ * or an area-resized copy a kernel makes of it - read through the variant's reflection / rotation, and the
+ * operand packs of the score kernel are gathered from those views: no per-unit pixel work on the host, no
+ * per-unit upload.  uint8 bases (1-4 channels), uint8 masks (transformed like their template).
+ * Order of the steps of a variant: resize, np.fliplr, np.flipud, np.rot90(k). */
+typedef struct mtm_variant {
+    int32_t rot90;     /* 0..3 quarter turns counter-clockwise (np.rot90(a, k))                                   */
+    int32_t flip_lr;   /* 1: np.fliplr                                                                          */
+    int32_t flip_ud;   /* 1: np.flipud                                                                          */
+    int32_t rows, cols;/* > 0: area-resize the base to rows x cols first (exact rational area average, rounded
+                          half up: MTM.augment.resize_area); 0, 0 = keep the size                               */
+    int32_t down;      /* > 1: integer-factor area downscale first, OpenCV INTER_AREA rounding
+                          (MTM.augment.downscale); exclusive with rows / cols                                   */
+} mtm_variant;
+int mtm_set_templates_augmented(mtm_ctx* ctx, const mtm_templ* bases, int n_bases,
+                                const mtm_variant* variants, int n_variants, int method);
+
 /* ---- the hot path -------------------------------------------------------------------------- */
 /* cv2.matchTemplate(image, template, method, mask) for template `templ_idx`
  * (MTM/__init__.py:92, via computeScoreMap :56-92): float32 (rows-h+1, cols-w+1) to host memory. */

@@ -51,6 +51,9 @@ assert HIT_DTYPE.itemsize == ctypes.sizeof(MtmHit) == 24
 TEMPL_DTYPE = np.dtype([("px", "<u8"), ("mask", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("chans", "<i4"),
                         ("dtype", "<i4"), ("row_stride", "<i8"), ("mask_row_stride", "<i8")])
 assert TEMPL_DTYPE.itemsize == ctypes.sizeof(MtmTempl) == 48
+# mtm_variant: one augmentation of a base template (mtm_set_templates_augmented)
+VARIANT_DTYPE = np.dtype([("rot90", "<i4"), ("flip_lr", "<i4"), ("flip_ud", "<i4"), ("rows", "<i4"), ("cols", "<i4"),
+                          ("down", "<i4")])
 
 # every symbol include/mtm_hip.h declares: (restype, argtypes)
 _P = ctypes.POINTER
@@ -66,6 +69,8 @@ SYMBOLS = {
     "mtm_set_image_downscaled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     "mtm_set_templates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mtm_set_templates_augmented": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_int]),
     "mtm_score_map": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]),
     "mtm_find_matches": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                         ctypes.c_int64, _P(ctypes.c_int64)]),
@@ -251,6 +256,14 @@ class Context:
         """templates: list of (array, mask_or_None) with identical dtype policy already applied."""
         rec, keep = templ_records(templates)
         check(self._lib.mtm_set_templates(self._h, rec.ctypes.data, len(templates), int(method)), "mtm_set_templates")
+
+    def set_templates_augmented(self, bases, variants, method):
+        """bases: list of (uint8 array, uint8 mask or None); variants: VARIANT_DTYPE records.  Units are
+        base-major: unit index = base * len(variants) + variant (mtm_set_templates_augmented)."""
+        rec, keep = templ_records(bases)
+        var = np.ascontiguousarray(variants, dtype=VARIANT_DTYPE)
+        check(self._lib.mtm_set_templates_augmented(self._h, rec.ctypes.data, len(bases), var.ctypes.data, len(var),
+                                                    int(method)), "mtm_set_templates_augmented")
 
     def search(self, templates, image, method, mode, score_threshold):
         """One search = templates + image in, hit records out (the engine interface shared with Group)."""

@@ -17,6 +17,7 @@
 
 #include "mtm_device.hip.h"
 #include "mtm_mfma.hip.h"
+#include "mtm_templates.hip.h"
 #include "mtm_internal.h"
 
 using namespace mtm;
@@ -81,6 +82,13 @@ struct HostTempl {
     std::vector<double> mask;   // planar weights (binarised for uint8 masks) or empty
     TemplStats st;
     int cls = -1;
+    // uint8 template sets: the pixels live on the device as a view of a source in the arena (mtm_templates.hip.h);
+    // px / mask above stay empty until a kernel that needs host-packed weights asks for them (ensure_host_pixels)
+    bool on_device = false;
+    UnitSrc src{};
+    double sum_t = 0.0;                 // sum over all channels of T (masked: T * M): bias term of the MFMA path
+    double mask_ones = 0.0;             // set mask pixels (channel 0)
+    unsigned long long mask_key = 0;    // identifies the (transformed) mask: equal keys = equal masks
 };
 
 struct SizeClass {
@@ -167,6 +175,7 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
     int copy_prio = 1;                      // MTM_COPY_PRIO: 1 = the copy stream gets the highest stream priority
     hipEvent_t stream2_done = nullptr;
     std::vector<hipEvent_t> band_ev;
@@ -183,6 +192,7 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
+    DevBuf tsrc, usrc_dev, tsums_dev, tgather;      // template source arena, unit views, source sums, gather scratch
     DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq;
 
     // options
@@ -388,6 +398,74 @@ void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
 
 int resolved_kernel(const mtm_ctx* c, const SizeClass& sc);
 
+// Pixels (and binary mask) of a device-resident uint8 template as the planar float64 arrays the host-side packers
+// take: one gather kernel + one copy.  Only the fallback kernels (float64, dot4) ever need it.
+int ensure_host_pixels(mtm_ctx* c, int i) {
+    HostTempl& t = c->templs[(size_t)i];
+    if (!t.on_device || !t.px.empty()) return MTM_OK;
+    const size_t n = (size_t)t.chans * t.rows * t.cols;
+    MTMC(c->tgather.ensure(2 * n));
+    uint8_t* dpx = c->tgather.as<uint8_t>();
+    uint8_t* dmk = t.masked ? dpx + n : nullptr;
+    hipLaunchKernelGGL(gather_unit_kernel, dim3((t.cols + 63) / 64, t.rows, t.chans), dim3(64), 0, c->stream,
+                       c->tsrc.as<uint8_t>(), t.src, dpx, dmk);
+    HIPC(hipGetLastError());
+    std::vector<uint8_t> host(2 * n);
+    HIPC(hipMemcpyAsync(host.data(), dpx, (t.masked ? 2 : 1) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    t.px.resize(n);
+    for (size_t k = 0; k < n; ++k) t.px[k] = (double)host[k];
+    if (t.masked) {
+        t.mask.resize(n);
+        for (size_t k = 0; k < n; ++k) t.mask[k] = host[n + k] ? 1.0 : 0.0;
+    }
+    return MTM_OK;
+}
+
+// A packs of one MFMA class gathered on the device from the unit views (pack_units_kernel); layouts as the host
+// packers above.  The class's template list must already be in c->tlist.
+int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
+    const uint8_t* arena = c->tsrc.as<uint8_t>();
+    const UnitSrc* units = c->usrc_dev.as<UnitSrc>();
+    const int* tl = c->tlist.as<int>() + sc.tlist_off;
+    PackParams p{};
+    p.h = sc.h;
+    p.w = sc.w;
+    p.nb = (sc.w + 63) / 64;
+    p.n = (int)sc.members.size();
+    auto launch = [&](long long off) {
+        hipLaunchKernelGGL(pack_units_kernel, dim3((unsigned)((p.n_chunks + 255) / 256)), dim3(256), 0, c->stream, p, arena,
+                           units, tl, c->apacks.as<uint8_t>() + off);
+    };
+    if (sc.mask_rm_off >= 0) {            // the binary mask as the single "template" of the sum I^2 M pass
+        p.mode = 2;
+        p.chans = 1;
+        p.nt = 1;
+        p.R = 16;
+        p.masked = 0;
+        p.cstride = rm_pack_bytes(sc.h, sc.w, 16);
+        p.n_chunks = p.cstride / 16;
+        launch(sc.mask_rm_off);
+    }
+    p.masked = sc.masked ? 1 : 0;
+    if (sc.rm_R > 0) {
+        p.mode = 1;
+        p.chans = sc.masked ? 1 : c->chans;
+        p.nt = sc.rm_nt;
+        p.R = sc.rm_R;
+        p.cstride = rm_pack_bytes(sc.h, sc.w, sc.rm_R);
+        p.n_chunks = p.cstride * p.chans / 16;
+    } else {
+        p.mode = 0;
+        p.chans = c->chans;
+        p.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
+        p.n_chunks = p.group_bytes * mfma_groups_alloc(p.n) / 16;
+    }
+    launch(sc.apack_off);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
 int place_templates(mtm_ctx* c) {
     if (!c->have_image || !c->have_templ) {
         set_error("set the image and the templates first");
@@ -448,8 +526,8 @@ int place_templates(mtm_ctx* c) {
         d.templ2_mask2_sum = t.st.templ2_mask2_sum;
         d.all_ones = t.st.all_ones;
         {
-            double sum_t = 0.0;      // exact: integers
-            if (t.dtype == MTM_U8)
+            double sum_t = t.sum_t;  // exact: integers
+            if (t.dtype == MTM_U8 && !t.on_device)
                 for (size_t k = 0; k < t.px.size(); ++k) sum_t += t.masked ? t.px[k] * t.mask[k] : t.px[k];
             d.mfma_k = 128.0 * sum_t - 16384.0 * (double)t.rows * (double)t.cols * (double)t.chans;
         }
@@ -487,6 +565,13 @@ int place_templates(mtm_ctx* c) {
             p_off += dot_pack_bytes(sc.h, sc.w, 1);
         }
     }
+    // templates that live on the device but are matched by a kernel with host-packed operands: fetch their pixels
+    for (int i = 0; i < n; ++i) {
+        const int kern = class_kernel[(size_t)c->templs[i].cls];
+        const bool mfma_dev = kern == MTM_KERNEL_MFMA && !(classes[(size_t)c->templs[i].cls].masked_int &&
+                                                           classes[(size_t)c->templs[i].cls].mask_pack_off >= 0);
+        if (c->templs[i].on_device && !mfma_dev) MTMC(ensure_host_pixels(c, i));
+    }
     // weights (float64): K1 = T (or T*M^2), K2 = M^2
     std::vector<double> wts(w_off);
     std::vector<uint8_t> packs(p_off);
@@ -520,8 +605,10 @@ int place_templates(mtm_ctx* c) {
         if (sc.masked && c->row_mux && c->fuse_stats) {
             sc.mask_rm_off = (long long)a_off;
             a_off += (size_t)rm_pack_bytes(sc.h, sc.w, 16);
-            sc.mask_ones = 0.0;
-            for (double m : c->templs[sc.members[0]].mask) sc.mask_ones += m > 0.0 ? 1.0 : 0.0;
+            const HostTempl& m0 = c->templs[sc.members[0]];
+            sc.mask_ones = m0.on_device ? m0.mask_ones : 0.0;
+            if (!m0.on_device)
+                for (double m : m0.mask) sc.mask_ones += m > 0.0 ? 1.0 : 0.0;
         }
         if (sc.rm_R > 0) {
             sc.group_bytes = -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
@@ -544,9 +631,22 @@ int place_templates(mtm_ctx* c) {
         sc.tsum_off = (long long)ts_off;
         ts_off += 2 * (size_t)sc.n_pad;
     }
-    std::vector<uint8_t> apacks(a_off);
+    // classes whose members all live on the device are packed there (after the uploads below)
+    std::vector<char> dev_pack(classes.size(), 0);
+    bool any_host_pack = false;
+    for (size_t k = 0; k < classes.size(); ++k) {
+        if (class_kernel[k] != MTM_KERNEL_MFMA && class_kernel[k] != MTM_KERNEL_MFMA16) continue;
+        bool all_dev = class_kernel[k] == MTM_KERNEL_MFMA;
+        for (int m : classes[k].members) all_dev = all_dev && c->templs[(size_t)m].on_device;
+        dev_pack[k] = all_dev ? 1 : 0;
+        any_host_pack = any_host_pack || !all_dev;
+    }
+    std::vector<uint8_t> apacks(any_host_pack ? a_off : 0);
     std::vector<double> tsums(ts_off);
     for (size_t k = 0; k < classes.size(); ++k) {
+        if (dev_pack[k]) continue;
+        if (class_kernel[k] == MTM_KERNEL_MFMA)
+            for (int m : classes[k].members) MTMC(ensure_host_pixels(c, m));
         if (class_kernel[k] == MTM_KERNEL_MFMA && classes[k].mask_rm_off >= 0)
             pack_mask_rm(c, classes[k], apacks.data() + classes[k].mask_rm_off);
         if (class_kernel[k] == MTM_KERNEL_MFMA && classes[k].rm_R > 0)
@@ -571,7 +671,9 @@ int place_templates(mtm_ctx* c) {
     MTMC(c->weights.ensure(sizeof(double) * std::max<size_t>(1, w_off)));
     MTMC(c->packs.ensure(std::max<size_t>(4, p_off)));
     MTMC(c->apacks.ensure(std::max<size_t>(16, a_off) + 16384));     // the K loop requests up to two steps past a pack
-    if (a_off) HIPC(hipMemcpyAsync(c->apacks.p, apacks.data(), a_off, hipMemcpyHostToDevice, c->stream));
+    // host-packed classes (device-packed regions of the same arena are written afterwards, in stream order, by
+    // pack_units_kernel below)
+    if (a_off && any_host_pack) HIPC(hipMemcpyAsync(c->apacks.p, apacks.data(), a_off, hipMemcpyHostToDevice, c->stream));
     // the score-map arena (4 bytes per pixel and template) is only allocated when something writes maps:
     // mtm_find_matches in hits-only mode never does (ensure_maps, called by the launch paths)
     HIPC(hipMemcpyAsync(c->td.p, td_host.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
@@ -582,6 +684,9 @@ int place_templates(mtm_ctx* c) {
     if (p_off) HIPC(hipMemcpyAsync(c->packs.p, packs.data(), p_off, hipMemcpyHostToDevice, c->stream));
     MTMC(c->tsum.ensure(sizeof(double) * std::max<size_t>(2, ts_off)));
     if (ts_off) HIPC(hipMemcpyAsync(c->tsum.p, tsums.data(), sizeof(double) * ts_off, hipMemcpyHostToDevice, c->stream));
+    // device-side packing: gathers the A operands straight from the unit views (the template list is in place)
+    for (size_t k = 0; k < classes.size(); ++k)
+        if (dev_pack[k]) MTMC(pack_class_on_device(c, classes[k]));
     HIPC(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
     c->classes.swap(classes);
     c->td_host.swap(td_host);
@@ -1244,6 +1349,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         }
     }
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
+    if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
@@ -1271,6 +1377,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
+    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})
@@ -1503,19 +1610,286 @@ int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int
     return mtm_set_image_downscaled(c, px, rows, cols, chans, dtype, row_stride_bytes, 1);
 }
 
+namespace {
+
+// unit (y, x) -> source (row, col) of a view, composed from the augmentation steps (numpy semantics)
+struct View {
+    int ay = 1, by = 0, cy = 0, ax = 0, bx = 1, cx = 0, h = 0, w = 0;
+    void fliplr() {                  // new(y, x) = cur(y, w - 1 - x)
+        cy += by * (w - 1);
+        cx += bx * (w - 1);
+        by = -by;
+        bx = -bx;
+    }
+    void flipud() {                  // new(y, x) = cur(h - 1 - y, x)
+        cy += ay * (h - 1);
+        cx += ax * (h - 1);
+        ay = -ay;
+        ax = -ax;
+    }
+    void rot90() {                   // np.rot90: new(i, j) = cur(j, w - 1 - i); new dims (w, h)
+        const int nay = -by, nby = ay, ncy = cy + by * (w - 1);
+        const int nax = -bx, nbx = ax, ncx = cx + bx * (w - 1);
+        ay = nay; by = nby; cy = ncy;
+        ax = nax; bx = nbx; cx = ncx;
+        std::swap(h, w);
+    }
+};
+
+inline unsigned long long fnv(unsigned long long h, const void* p, size_t n) {
+    const uint8_t* b = (const uint8_t*)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
+// uint8 template sets, plain or augmented: the bases go to the device source arena (planar), resized copies are
+// made there, every unit becomes a view (UnitSrc), statistics come from exact sums per source - on the host for
+// the bases (one pass over the bytes that are being copied anyway), by a device reduction for resized copies.
+// No per-unit pixel work on the host, no per-unit upload.
+int set_templates_device(mtm_ctx* c, const mtm_templ* bases, int n_bases, const mtm_variant* variants, int n_var,
+                         int method, std::vector<HostTempl>& hts) {
+    HIPC(hipSetDevice(c->device));
+    static const mtm_variant kIdentity = {0, 0, 0, 0, 0, 0};
+    if (n_var <= 0) {
+        variants = &kIdentity;
+        n_var = 1;
+    }
+    struct Source {
+        long long off = 0, moff = -1;
+        int sh = 0, sw = 0, chans = 0;
+        bool on_host = false;                       // sums computed on the host
+        double s[kMaxChans] = {0, 0, 0, 0}, sq[kMaxChans] = {0, 0, 0, 0}, sm[kMaxChans] = {0, 0, 0, 0},
+               sqm[kMaxChans] = {0, 0, 0, 0}, mones = 0.0;
+        unsigned long long mask_hash = 0;
+    };
+    std::vector<Source> srcs;
+    std::vector<uint8_t> stage;                     // host image of the arena prefix (the bases)
+    auto alloc = [&](size_t& cursor, size_t bytes) {
+        const size_t off = cursor;
+        cursor = round_up(cursor + bytes, 16);
+        return (long long)off;
+    };
+    size_t cursor = 0;
+    // ---- bases: planarise into the staging image, exact sums on the way
+    for (int b = 0; b < n_bases; ++b) {
+        const mtm_templ& t = bases[b];
+        Source sc;
+        sc.sh = t.rows;
+        sc.sw = t.cols;
+        sc.chans = t.chans;
+        sc.on_host = true;
+        const size_t plane = (size_t)t.rows * t.cols, n = plane * t.chans;
+        sc.off = alloc(cursor, n);
+        if (t.mask) sc.moff = alloc(cursor, n);
+        stage.resize(cursor);
+        uint8_t* dpx = stage.data() + sc.off;
+        uint8_t* dmk = t.mask ? stage.data() + sc.moff : nullptr;
+        unsigned long long mh = 1469598103934665603ull;
+        for (int ch = 0; ch < t.chans; ++ch) {
+            unsigned long long s = 0, sq = 0, sm = 0, sqm = 0, ones = 0;
+            for (int y = 0; y < t.rows; ++y) {
+                const uint8_t* rp = (const uint8_t*)t.px + (size_t)y * t.row_stride + ch;
+                const uint8_t* mp = t.mask ? (const uint8_t*)t.mask + (size_t)y * t.mask_row_stride + ch : nullptr;
+                uint8_t* o = dpx + ch * plane + (size_t)y * t.cols;
+                uint8_t* om = dmk ? dmk + ch * plane + (size_t)y * t.cols : nullptr;
+                for (int x = 0; x < t.cols; ++x) {
+                    const unsigned v = rp[(size_t)x * t.chans];
+                    o[x] = (uint8_t)v;
+                    s += v;
+                    sq += v * v;
+                    if (mp) {
+                        // the arena keeps the mask bytes as given (a resized mask is the resize of THOSE bytes);
+                        // every reader binarises: CV_8U masks are binary masks (matchTemplateMask)
+                        om[x] = mp[(size_t)x * t.chans];
+                        const unsigned m = om[x] > 0 ? 1u : 0u;
+                        sm += v * m;
+                        sqm += v * v * m;
+                        ones += m;
+                    }
+                }
+                if (om) mh = fnv(mh, om, (size_t)t.cols);
+            }
+            sc.s[ch] = (double)s;
+            sc.sq[ch] = (double)sq;
+            sc.sm[ch] = (double)sm;
+            sc.sqm[ch] = (double)sqm;
+            if (ch == 0) sc.mones = (double)ones;
+        }
+        sc.mask_hash = t.mask ? mh : 0ull;
+        srcs.push_back(sc);
+    }
+    // ---- resized copies: one source per (base, resize rule), shared by the variants that use it
+    struct Resize { int rows, cols, down; };
+    std::vector<Resize> rules;
+    std::vector<int> rule_of_var((size_t)n_var, -1);
+    for (int v = 0; v < n_var; ++v) {
+        const mtm_variant& q = variants[v];
+        if (q.rot90 < 0 || q.rot90 > 3 || q.rows < 0 || q.cols < 0 || q.down < 0 || ((q.rows > 0) != (q.cols > 0)) ||
+            (q.rows > 0 && q.down > 1)) {
+            set_error("mtm_set_templates_augmented: bad variant " + std::to_string(v));
+            return MTM_E_INVALID;
+        }
+        if (q.rows == 0 && q.down <= 1) continue;
+        for (size_t r = 0; r < rules.size(); ++r)
+            if (rules[r].rows == q.rows && rules[r].cols == q.cols && rules[r].down == (q.down > 1 ? q.down : 0)) rule_of_var[(size_t)v] = (int)r;
+        if (rule_of_var[(size_t)v] < 0) {
+            rule_of_var[(size_t)v] = (int)rules.size();
+            rules.push_back(Resize{q.rows, q.cols, q.down > 1 ? q.down : 0});
+        }
+    }
+    const size_t n_host_src = srcs.size();
+    for (int b = 0; b < n_bases; ++b)
+        for (size_t r = 0; r < rules.size(); ++r) {
+            const Source& base = srcs[(size_t)b];
+            Source sc;
+            sc.chans = base.chans;
+            sc.sh = rules[r].down ? base.sh / rules[r].down : rules[r].rows;
+            sc.sw = rules[r].down ? base.sw / rules[r].down : rules[r].cols;
+            if (sc.sh < 1 || sc.sw < 1) {
+                set_error("mtm_set_templates_augmented: a resize leaves no pixel of base " + std::to_string(b));
+                return MTM_E_INVALID;
+            }
+            const size_t n = (size_t)sc.sh * sc.sw * sc.chans;
+            sc.off = alloc(cursor, n);
+            if (base.moff >= 0) sc.moff = alloc(cursor, n);
+            const int key[4] = {sc.sh, sc.sw, rules[r].down, 0};
+            sc.mask_hash = base.moff >= 0 ? fnv(base.mask_hash, key, sizeof(key)) : 0ull;
+            srcs.push_back(sc);
+        }
+    MTMC(c->tsrc.ensure(std::max<size_t>(16, cursor)));
+    if (!stage.empty()) HIPC(hipMemcpyAsync(c->tsrc.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
+    uint8_t* arena = c->tsrc.as<uint8_t>();
+    for (int b = 0; b < n_bases; ++b)
+        for (size_t r = 0; r < rules.size(); ++r) {
+            const Source& base = srcs[(size_t)b];
+            const Source& d = srcs[n_host_src + (size_t)b * rules.size() + r];
+            const dim3 grd((d.sw + 63) / 64, d.sh, d.chans);
+            for (int pass = 0; pass < (base.moff >= 0 ? 2 : 1); ++pass) {
+                const uint8_t* sp = arena + (pass ? base.moff : base.off);
+                uint8_t* dp = arena + (pass ? d.moff : d.off);
+                if (rules[r].down)
+                    hipLaunchKernelGGL(downscale_int_kernel, grd, dim3(64), 0, c->stream, sp, base.sh, base.sw, dp, rules[r].down,
+                                       d.chans);
+                else
+                    hipLaunchKernelGGL(resize_area_kernel, grd, dim3(64), 0, c->stream, sp, base.sh, base.sw, dp, d.sh, d.sw,
+                                       d.chans);
+            }
+        }
+    // exact sums of the device-made sources: one reduction, one small copy back
+    if (srcs.size() > n_host_src) {
+        const size_t nd = srcs.size() - n_host_src;
+        std::vector<SourceDesc> desc(nd);
+        for (size_t k = 0; k < nd; ++k) {
+            const Source& d = srcs[n_host_src + k];
+            desc[k] = SourceDesc{d.off, d.moff, d.sh, d.sw, d.chans, 0};
+        }
+        MTMC(c->tsums_dev.ensure(sizeof(SourceDesc) * nd + sizeof(unsigned long long) * kSumsPerSource * nd));
+        SourceDesc* ddesc = c->tsums_dev.as<SourceDesc>();
+        unsigned long long* dsums = reinterpret_cast<unsigned long long*>(c->tsums_dev.as<uint8_t>() + sizeof(SourceDesc) * nd);
+        HIPC(hipMemcpyAsync(ddesc, desc.data(), sizeof(SourceDesc) * nd, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(source_sums_kernel, dim3((unsigned)nd), dim3(256), 0, c->stream, arena, ddesc, dsums);
+        HIPC(hipGetLastError());
+        std::vector<unsigned long long> sums((size_t)kSumsPerSource * nd);
+        HIPC(hipMemcpyAsync(sums.data(), dsums, sizeof(unsigned long long) * sums.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        for (size_t k = 0; k < nd; ++k) {
+            Source& d = srcs[n_host_src + k];
+            const unsigned long long* q = sums.data() + k * kSumsPerSource;
+            for (int ch = 0; ch < d.chans; ++ch) {
+                d.s[ch] = (double)q[4 * ch + 0];
+                d.sq[ch] = (double)q[4 * ch + 1];
+                d.sm[ch] = (double)q[4 * ch + 2];
+                d.sqm[ch] = (double)q[4 * ch + 3];
+            }
+            d.mones = (double)q[4 * kMaxChans];
+        }
+    }
+    // ---- units: base-major, variants in the order given
+    const int n_units = n_bases * n_var;
+    hts.assign((size_t)n_units, HostTempl{});
+    std::vector<UnitSrc> units((size_t)n_units);
+    for (int b = 0; b < n_bases; ++b)
+        for (int v = 0; v < n_var; ++v) {
+            const mtm_variant& q = variants[v];
+            const Source& sc = rule_of_var[(size_t)v] < 0 ? srcs[(size_t)b]
+                                                          : srcs[n_host_src + (size_t)b * rules.size() + (size_t)rule_of_var[(size_t)v]];
+            View vw;
+            vw.h = sc.sh;
+            vw.w = sc.sw;
+            if (q.flip_lr) vw.fliplr();
+            if (q.flip_ud) vw.flipud();
+            for (int k = 0; k < q.rot90; ++k) vw.rot90();
+            const int ui = b * n_var + v;
+            UnitSrc& u = units[(size_t)ui];
+            u = UnitSrc{sc.off, sc.moff, sc.sh, sc.sw, vw.ay, vw.by, vw.cy, vw.ax, vw.bx, vw.cx, vw.h, vw.w, sc.chans, 0};
+            HostTempl& t = hts[(size_t)ui];
+            t.rows = vw.h;
+            t.cols = vw.w;
+            t.chans = sc.chans;
+            t.dtype = MTM_U8;
+            t.masked = sc.moff >= 0;
+            t.on_device = true;
+            t.src = u;
+            double tm2 = 0.0;
+            for (int ch = 0; ch < sc.chans; ++ch) {
+                t.sum_t += t.masked ? sc.sm[ch] : sc.s[ch];
+                tm2 += sc.sqm[ch];
+            }
+            t.mask_ones = sc.mones;
+            t.st = templ_stats_from_sums(sc.s, sc.sq, tm2, t.masked, t.rows, t.cols, t.chans, method);
+            if (t.masked) {
+                const int key[8] = {vw.ay, vw.by, vw.cy, vw.ax, vw.bx, vw.cx, vw.h, vw.w};
+                t.mask_key = fnv(sc.mask_hash, key, sizeof(key));
+                if (t.mask_key == 0) t.mask_key = 1;
+            }
+        }
+    MTMC(c->usrc_dev.ensure(sizeof(UnitSrc) * std::max<size_t>(1, units.size())));
+    if (!units.empty())
+        HIPC(hipMemcpyAsync(c->usrc_dev.p, units.data(), sizeof(UnitSrc) * units.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));      // `stage` and `units` go out of scope
+    return MTM_OK;
+}
+
+int set_templates_impl(mtm_ctx* c, const mtm_templ* templs, int n_templ, const mtm_variant* variants, int n_var, int method,
+                       const char* who);
+
+}  // namespace
+
 int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int method) {
-    if (!c || n_templ < 0 || (n_templ > 0 && !templs) || method < 0 || method > 5) {
-        set_error("mtm_set_templates: bad arguments");
+    return set_templates_impl(c, templs, n_templ, nullptr, 0, method, "mtm_set_templates");
+}
+
+int mtm_set_templates_augmented(mtm_ctx* c, const mtm_templ* bases, int n_bases, const mtm_variant* variants, int n_variants,
+                                int method) {
+    if (n_variants < 1 || !variants) {
+        set_error("mtm_set_templates_augmented: at least one variant is needed");
         return MTM_E_INVALID;
     }
-    MTM_NOT_IN_FLIGHT(c, "mtm_set_templates");
+    return set_templates_impl(c, bases, n_bases, variants, n_variants, method, "mtm_set_templates_augmented");
+}
+
+namespace {
+
+int set_templates_impl(mtm_ctx* c, const mtm_templ* templs, int n_templ, const mtm_variant* variants, int n_var, int method,
+                       const char* who) {
+    if (!c || n_templ < 0 || (n_templ > 0 && !templs) || method < 0 || method > 5) {
+        set_error(std::string(who) + ": bad arguments");
+        return MTM_E_INVALID;
+    }
+    MTM_NOT_IN_FLIGHT(c, who);
+    bool all_u8 = true;
     for (int i = 0; i < n_templ; ++i) {
         const mtm_templ& s = templs[i];
         if (!s.px || s.rows <= 0 || s.cols <= 0 || s.chans < 1 || s.chans > kMaxChans ||
             (s.dtype != MTM_U8 && s.dtype != MTM_F32 && s.dtype != MTM_U16)) {
-            set_error("mtm_set_templates: bad template " + std::to_string(i));
+            set_error(std::string(who) + ": bad template " + std::to_string(i));
             return MTM_E_INVALID;
         }
+        all_u8 = all_u8 && s.dtype == MTM_U8;
+    }
+    if (n_var > 0 && !all_u8) {
+        set_error("mtm_set_templates_augmented takes uint8 bases (augment other pixel types on the host)");
+        return MTM_E_INVALID;
     }
     // The same templates again (a loop of matchTemplates calls over different images): keep everything that
     // was derived from them - statistics, size classes, device packs.  The test is on the pixel bytes: the
@@ -1524,6 +1898,8 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         auto walk = [&](auto&& emit) {
             emit(&n_templ, sizeof(n_templ));
             emit(&method, sizeof(method));
+            emit(&n_var, sizeof(n_var));
+            if (n_var > 0) emit(variants, sizeof(mtm_variant) * (size_t)n_var);
             for (int i = 0; i < n_templ; ++i) {
                 const mtm_templ& s = templs[i];
                 const int hdr[5] = {s.rows, s.cols, s.chans, s.dtype, s.mask ? 1 : 0};
@@ -1558,7 +1934,16 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         c->templ_blob.swap(blob);
         c->have_templ = false;          // until the new set is complete
     }
-    std::vector<HostTempl> hts((size_t)n_templ);
+    std::vector<HostTempl> hts;
+    if (all_u8 && c->templ_on_device) {
+        const int rc = set_templates_device(c, templs, n_templ, variants, n_var, method, hts);
+        if (rc != MTM_OK) {
+            c->templ_blob.clear();
+            return rc;
+        }
+        n_templ = (int)hts.size();
+    } else {
+    hts.assign((size_t)n_templ, HostTempl{});
     for (int i = 0; i < n_templ; ++i) {
         const mtm_templ& s = templs[i];
         HostTempl& t = hts[i];
@@ -1595,6 +1980,7 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
         t.st = compute_templ_stats(t.px.data(), t.masked ? t.mask.data() : nullptr, t.rows, t.cols, t.chans,
                                    method, s.dtype == MTM_U8 || s.dtype == MTM_U16);
     }
+    }   // host path
     // size classes, in order of first appearance
     std::vector<SizeClass> classes;
     // masked templates only share a class (and its masked window statistics) when their masks are equal
@@ -1605,6 +1991,7 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
             std::memcpy(&bits, &v, 8);
             hsh = (hsh ^ bits) * 1099511628211ull;
         }
+        if (t.on_device) return t.masked ? t.mask_key : 0ull;
         return t.masked ? hsh : 0ull;
     };
     std::map<std::tuple<int, int, bool, unsigned long long>, int> index;
@@ -1633,6 +2020,8 @@ int mtm_set_templates(mtm_ctx* c, const mtm_templ* templs, int n_templ, int meth
     c->placed = false;
     return MTM_OK;
 }
+
+}  // namespace
 
 int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_bytes) {
     if (!c || !out) {

@@ -23,11 +23,7 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 // ---------------------------------------------------------------------------------------------
 TemplStats compute_templ_stats(const double* px, const double* mask, int rows, int cols, int chans,
                                int method, bool integer) {
-    TemplStats st;
-    const double n = (double)rows * (double)cols;
-    st.inv_area = 1.0 / ((double)rows * (double)cols);
     const size_t plane = (size_t)rows * cols;
-
     if (mask != nullptr) {
         // matchTemplateMask: templ2_mask2_sum = norm(templ.mul(mask), NORM_L2SQR)
         double s = 0.0;
@@ -36,11 +32,9 @@ TemplStats compute_templ_stats(const double* px, const double* mask, int rows, i
                 const double v = px[c * plane + i] * mask[c * plane + i];
                 s += v * v;
             }
-        st.templ2_mask2_sum = s;
-        return st;
+        return templ_stats_from_sums(nullptr, nullptr, s, true, rows, cols, chans, method);
     }
-
-    double mean[4] = {0, 0, 0, 0}, sdv[4] = {0, 0, 0, 0};
+    double sum[4] = {0, 0, 0, 0}, sumsq[4] = {0, 0, 0, 0};
     for (int c = 0; c < chans && c < 4; ++c) {
         double s = 0.0, sq = 0.0;
         if (integer) {
@@ -59,8 +53,27 @@ TemplStats compute_templ_stats(const double* px, const double* mask, int rows, i
                 sq += v * v;
             }
         }
-        mean[c] = s / n;
-        const double var = sq / n - mean[c] * mean[c];
+        sum[c] = s;
+        sumsq[c] = sq;
+    }
+    return templ_stats_from_sums(sum, sumsq, 0.0, false, rows, cols, chans, method);
+}
+
+// The same from the per-channel sums (sum v, sum v^2) - or, masked, from sum (v*m)^2 alone: what the device
+// reduction over a template source delivers (exact integers for uint8 pixels).
+TemplStats templ_stats_from_sums(const double* sum, const double* sumsq, double templ2_mask2_sum, bool masked, int rows,
+                                 int cols, int chans, int method) {
+    TemplStats st;
+    const double n = (double)rows * (double)cols;
+    st.inv_area = 1.0 / ((double)rows * (double)cols);
+    if (masked) {
+        st.templ2_mask2_sum = templ2_mask2_sum;
+        return st;
+    }
+    double mean[4] = {0, 0, 0, 0}, sdv[4] = {0, 0, 0, 0};
+    for (int c = 0; c < chans && c < 4; ++c) {
+        mean[c] = sum[c] / n;
+        const double var = sumsq[c] / n - mean[c] * mean[c];
         sdv[c] = std::sqrt(std::max(var, 0.0));
     }
     if (method == MTM_TM_CCORR) return st;

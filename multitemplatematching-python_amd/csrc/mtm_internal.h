@@ -27,6 +27,10 @@ struct TemplStats {
 TemplStats compute_templ_stats(const double* px, const double* mask, int rows, int cols, int chans,
                                int method, bool integer);
 
+// the same from the per-channel sums (sum v, sum v^2), or - masked - from sum((v*m)^2) alone
+TemplStats templ_stats_from_sums(const double* sum, const double* sumsq, double templ2_mask2_sum, bool masked, int rows,
+                                 int cols, int chans, int method);
+
 // scipy.signal.find_peaks(x, height=h)[0]
 std::vector<int> find_peaks_1d(const float* x, int n, int stride, float height, bool negate);
 

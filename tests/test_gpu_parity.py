@@ -644,6 +644,138 @@ def test_device_group_equals_single_context(mtm, coins, monkeypatch):
     assert mtm.matchTemplates(units, img, score_threshold=0.5) == ref
 
 
+# ------------------------------------------------------------------------------------------------
+# templates on the device: views of device-resident sources, device-side packing, on-device augmentation
+# ------------------------------------------------------------------------------------------------
+def test_device_resident_templates_equal_host_packing(mtm, coins, monkeypatch):
+    """uint8 template sets live on the device (views + pack_units_kernel) by default; MTM_TEMPL_ON_DEVICE=0 keeps
+    the host packers.  Same hit records and the same score maps, bit for bit, on every route a class can take:
+    plain / row-multiplexed MFMA packs, masked (T*M packs + the mask pack of the sum I^2 M pass), RGB, several
+    size classes, and the kernels with host-packed operands (dot4, float64 / naive: pixels fetched back)."""
+    from MTM import _lib
+    monkeypatch.setenv("MTM_TEMPL_ON_DEVICE", "0")
+    host = _lib.Context(0)
+    monkeypatch.setenv("MTM_TEMPL_ON_DEVICE", "1")
+    dev = _lib.Context(0)
+    try:
+        img, units, _ = synth.make_workload(seed=41, image_hw=(420, 700), n_base=19, templ=24, noisy_per_unit=1)
+        rgb_img, rgb_units, _ = synth.make_workload(seed=42, image_hw=(300, 520), n_base=5, templ=20, channels=3)
+        msk_img, msk_units, _ = synth.make_workload(seed=43, image_hw=(400, 640), n_base=3, templ=32, scales=(24, 40), masked=True)
+        small, big = coin_templates(coins)
+        strided = coins[10:90:2, 20:140:3]                                     # non-contiguous rows
+        cases = [
+            (img, [(u[1], None) for u in units], 5),
+            (img, [(u[1], None) for u in units[:7]], 3),
+            (img, [(units[0][1], None), (np.ascontiguousarray(units[1][1][:17, :23]), None), (units[2][1], None)], 1),
+            (rgb_img, [(u[1], None) for u in rgb_units], 5),
+            (rgb_img, [(u[1], None) for u in rgb_units] * 4, 4),
+            (msk_img, [(u[1], u[2]) for u in msk_units], 3),
+            (msk_img, [(u[1], u[2]) for u in msk_units], 0),
+            (coins, [(small, otsu_mask(small)), (big, None), (strided, None)], 3),
+            (coins, [(np.full((9, 9), 7, np.uint8), None), (small, None)], 5),   # constant template: all-ones map
+        ]
+        for kernel in ("auto", "dot4", "naive"):
+            for cx in (host, dev):
+                cx.set_option(_lib.OPT_KERNEL, KERNELS[kernel])
+                cx.set_option(_lib.OPT_HITS_ONLY, 0)
+            for im, tl, method in cases:
+                thr = {0: 1e7, 1: 0.35, 3: 0.9, 4: 1e5, 5: 0.5}[method]
+                a = dev.search(tl, im, method, _lib.PEAKS_LOCAL, thr)
+                b = host.search(tl, im, method, _lib.PEAKS_LOCAL, thr)
+                assert np.array_equal(a, b), (kernel, method, len(a), len(b))
+                for i in (0, len(tl) - 1):
+                    shape = (im.shape[0] - tl[i][0].shape[0] + 1, im.shape[1] - tl[i][0].shape[1] + 1)
+                    ma, mb = dev.last_score_map(i, shape), host.last_score_map(i, shape)
+                    assert np.array_equal(ma, mb, equal_nan=True), (kernel, method, i)
+    finally:
+        host.close()
+        dev.close()
+
+
+def test_augmentation_on_device(mtm, ctx, coins):
+    """MTM.augment.matchTemplatesAugmented(bases, variants, image) == matchTemplates(expand(bases, variants), image):
+    rotations, mirrors, exact area resizes and integer downscales built as device views, never on the host; the
+    device resize equals the numpy one byte for byte (checked through constant-free score maps)."""
+    A = mtm.augment
+    img, base_units, _ = synth.make_workload(seed=51, image_hw=(500, 760), n_base=5, templ=32, rotations=1, noisy_per_unit=1)
+    bases = [(u[0].split("_")[0], u[1]) for u in base_units]
+    # plant rotated / mirrored / resized copies so that every variant has something to find
+    spec_all = A.variants(angles=(0, 90, 180, 270), flip_lr=True, flip_ud=True)
+    for k, (name, t) in enumerate(A.expand(bases[:2], spec_all)):
+        y, x = 40 + 48 * (k // 12), 30 + 58 * (k % 12)
+        img[y:y + t.shape[0], x:x + t.shape[1]] = t
+    specs = [
+        A.variants(angles=(0, 90, 180, 270)),
+        spec_all,
+        A.variants(sizes=(20, (24, 40), 48), angles=(0, 90)),
+        A.variants(factors=(1, 2, 3), flip_lr=True),
+    ]
+    for row, spec in enumerate(specs[2:]):
+        for k, (name, t) in enumerate(A.expand(bases[2:3], spec)):
+            y, x = 200 + 100 * row, 30 + 60 * k
+            img[y:y + t.shape[0], x:x + t.shape[1]] = t
+    for spec in specs:
+        for method, thr in ((5, 0.6), (1, 0.3), (3, 0.93)):
+            got = A.matchTemplatesAugmented(bases, spec, img, method=method, score_threshold=thr)
+            exp = mtm.matchTemplates(A.expand(bases, spec), img, method=method, score_threshold=thr)
+            assert got == exp and len(got) > 0, (len(spec), method, len(got), len(exp))
+        assert A.matchTemplatesAugmented(bases, spec, img, N_object=1) == mtm.matchTemplates(A.expand(bases, spec), img, N_object=1)
+        sb = (16, 8, 600, 400)
+        assert A.matchTemplatesAugmented(bases, spec, img, score_threshold=0.6, searchBox=sb) == \
+            mtm.matchTemplates(A.expand(bases, spec), img, score_threshold=0.6, searchBox=sb)
+    # masks travel with their template (method 3), RGB bases, and the fallback kernels (pixels fetched back)
+    small, big = coin_templates(coins)
+    mb = [("s", small, otsu_mask(small)), ("b", np.ascontiguousarray(big[:50, :50]), otsu_mask(np.ascontiguousarray(big[:50, :50])))]
+    spec = A.variants(angles=(0, 90), sizes=(28, 36), flip_lr=True)
+    assert A.matchTemplatesAugmented(mb, spec, coins, method=3, score_threshold=0.85) == \
+        mtm.matchTemplates(A.expand(mb, spec), coins, method=3, score_threshold=0.85)
+    with pytest.warns(UserWarning, match="not supporting the use of Mask"):
+        a = A.matchTemplatesAugmented(mb, spec, coins, method=5, score_threshold=0.4)
+    assert a == mtm.matchTemplates(A.expand([t[:2] for t in mb], spec), coins, method=5, score_threshold=0.4)
+    rgb = np.stack([coins, np.roll(coins, 3, axis=1), 255 - coins], axis=2)
+    rb = [("c", np.ascontiguousarray(rgb[37:75, 80:121]))]
+    spec = A.variants(angles=(0, 90, 180, 270), sizes=((30, 34),))
+    assert A.matchTemplatesAugmented(rb, spec, rgb, score_threshold=0.4) == mtm.matchTemplates(A.expand(rb, spec), rgb, score_threshold=0.4)
+    for kernel in ("dot4", "naive"):
+        set_kernel(ctx, kernel)
+        try:
+            spec = A.variants(angles=(0, 270), sizes=(24,))
+            assert A.matchTemplatesAugmented(bases[:2], spec, img, score_threshold=0.6) == \
+                mtm.matchTemplates(A.expand(bases[:2], spec), img, score_threshold=0.6)
+        finally:
+            set_kernel(ctx, "auto")
+    # other pixel types: expanded on the host, same answer
+    f_img, f_bases = img.astype(np.float32), [(n, t.astype(np.float32)) for n, t in bases[:2]]
+    spec = A.variants(angles=(0, 180))
+    assert A.matchTemplatesAugmented(f_bases, spec, f_img, score_threshold=0.6) == \
+        mtm.matchTemplates(A.expand(f_bases, spec), f_img, score_threshold=0.6)
+
+
+def test_cfg3_and_cfg5_from_bases_only(mtm):
+    """BASELINE configs[2] and configs[4] submitted the way they are described - 32 bases x 4 rotations, 16 bases
+    x 5 scales (masked) - as bases + an augmentation spec: hit lists identical to the host-augmented lists."""
+    A = mtm.augment
+    img, units, plants = synth.make_config("cfg3")
+    bases = [(u[0][:-2], u[1]) for u in units[::4]]                     # labels "<i>_0" -> "<i>"
+    spec = A.variants(angles=(0, 90, 180, 270))
+    assert [u[0] for u in A.expand(bases, spec)] == [u[0] for u in units]
+    got = A.matchTemplatesAugmented(bases, spec, img, score_threshold=0.5)
+    assert got == mtm.matchTemplates(units, img, score_threshold=0.5)
+    assert {(h[0], h[1]) for h in got} == {(p[0], p[1]) for p in plants}
+    img, units, plants = synth.make_config("cfg5")
+    sides = (32, 56, 80, 104, 128)
+    kw = synth.CONFIGS["cfg5"]
+    bases = [(str(b), synth.rand_u8(kw["seed"], 1000 + b, (64, 64)), synth._disc_mask(64)) for b in range(kw["n_base"])]
+    assert len(bases) == 16 and len(units) == 80
+    spec = A.variants(sizes=sides)
+    host_units = A.expand(bases, spec)
+    for hu, u in zip(host_units, units):
+        assert np.array_equal(hu[1], u[1])                              # the templates are synth's own resizes
+    got = A.matchTemplatesAugmented(bases, spec, img, method=3, score_threshold=0.9)
+    exp = mtm.matchTemplates(host_units, img, method=3, score_threshold=0.9)
+    assert got == exp and len(got) >= len(plants)
+
+
 BORDER_CALLS = {
     "sqdiff_normed": lambda im: ([("small", im[37:75, 80:121]), ("big", im[14:73, 302:367])],
                                  dict(method=1, score_threshold=0.2, maxOverlap=0)),
