@@ -175,11 +175,13 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
+                                            // streams (their tails overlap; per-launch durations then overlap too)
     int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
     int copy_prio = 1;                      // MTM_COPY_PRIO: 1 = the copy stream gets the highest stream priority
     hipEvent_t stream2_done = nullptr;
     std::vector<hipEvent_t> band_ev;
-    std::vector<double> upload_bands{0.12, 0.34, 0.56, 0.78, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
+    std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
 
     // templates
     bool have_templ = false;
@@ -1349,6 +1351,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         }
     }
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
+    if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
@@ -2209,7 +2212,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         (void)hipStreamQuery(c->copy_stream);                    // submit now (the runtime batches commands)
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
         if (yb1 > yb_done) {
-            hipStream_t s = (n_launch & 1) ? c->stream2 : c->stream;
+            hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
             HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
             c->ncc_stream = s;
             const int rc2 = launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1);
