@@ -98,6 +98,8 @@ struct SizeClass {
     bool all_u16 = true;
     bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
     int rm_nt = 0, rm_R = 0;    // > 0: row-multiplexed MFMA mode (<= 16 templates: nt x R = 16 A rows)
+    bool r2 = false;            // two-row MFMA variant (> 16 templates, w <= 64, one channel, methods 2..5): packs of
+                                // h + 1 rows per 16-template group (the last row zero)
     long long mask_rm_off = -1; // masked class: row-multiplexed pack (1 "template" = the binary mask, R = 16) in apacks
     double mask_ones = 0.0;     // number of set mask pixels
     int n_pad = 0;              // members rounded up to a multiple of 16 (uint16 packs)
@@ -175,6 +177,7 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int mfma_r2 = 1;                        // MTM_MFMA_R2: two-row variant of the MFMA kernel where it applies
     int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
                                             // streams (their tails overlap; per-launch durations then overlap too)
     int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
@@ -381,8 +384,9 @@ void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, doub
 
 void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
     const int h = sc.h, w = sc.w, nb = (w + 63) / 64, chans = c->chans;
-    const long long gb = mfma_group_bytes(h, w, chans);
-    std::memset(out, 0, (size_t)gb * mfma_groups_alloc((int)sc.members.size()));
+    // two-row variant: groups of h + 1 rows (one channel), the extra row stays zero
+    const long long gb = sc.r2 ? sc.group_bytes : mfma_group_bytes(h, w, chans);
+    std::memset(out, 0, (size_t)gb * (sc.r2 ? ((int)sc.members.size() + 15) / 16 : mfma_groups_alloc((int)sc.members.size())));
     for (size_t li = 0; li < sc.members.size(); ++li) {
         const HostTempl& t = c->templs[sc.members[li]];
         uint8_t* g = out + (li / 16) * gb;
@@ -393,7 +397,7 @@ void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
                     const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
                     const size_t k = ((size_t)ch * h + dy) * w + dx;
                     const uint8_t v = (uint8_t)(t.masked ? t.px[k] * t.mask[k] : t.px[k]);   // masked: T*M, M in {0,1}
-                    g[((((size_t)ch * h + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                    g[((((size_t)ch * (sc.r2 ? h + 1 : h) + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
                 }
     }
 }
@@ -432,6 +436,7 @@ int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
     const int* tl = c->tlist.as<int>() + sc.tlist_off;
     PackParams p{};
     p.h = sc.h;
+    p.hv = sc.h;
     p.w = sc.w;
     p.nb = (sc.w + 63) / 64;
     p.n = (int)sc.members.size();
@@ -457,6 +462,12 @@ int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
         p.R = sc.rm_R;
         p.cstride = rm_pack_bytes(sc.h, sc.w, sc.rm_R);
         p.n_chunks = p.cstride * p.chans / 16;
+    } else if (sc.r2) {
+        p.mode = 0;
+        p.chans = 1;
+        p.h = sc.h + 1;                      // rows per group in the pack; row h is zero (hv = valid template rows)
+        p.group_bytes = sc.group_bytes;
+        p.n_chunks = p.group_bytes * ((p.n + 15) / 16) / 16;
     } else {
         p.mode = 0;
         p.chans = c->chans;
@@ -508,6 +519,8 @@ int place_templates(mtm_ctx* c) {
             sc.rm_nt = nt;
             sc.rm_R = 16 / nt;
         }
+        sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && n_cls > 16 && sc.w <= 64 &&
+                c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
     }
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
@@ -616,6 +629,12 @@ int place_templates(mtm_ctx* c) {
             sc.group_bytes = -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
             sc.apack_off = (long long)a_off;
             a_off += (size_t)rm_pack_bytes(sc.h, sc.w, sc.rm_R) * (sc.masked ? 1 : c->chans);
+            continue;
+        }
+        if (sc.r2) {
+            sc.group_bytes = mfma_group_bytes(sc.h + 1, sc.w, 1);        // h + 1 rows, the last one zero
+            sc.apack_off = (long long)a_off;
+            a_off += (size_t)sc.group_bytes * (((int)sc.members.size() + 15) / 16);
             continue;
         }
         sc.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
@@ -947,7 +966,9 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         // request (mtm_score_map) computes its group and stores only that template
         const int n_all = (int)sc.members.size();
         const bool rm = sc.rm_R > 0;
+        const bool r2 = sc.r2;
         const int mb = (n_all > 16 || rm) ? 2 : 1;
+        const int tgsz = r2 ? 16 : 16 * mb;          // templates per work item
         MfmaParams p{};
         p.img = c->slot[c->cur].u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
         p.pitch = img.u8_pitch;
@@ -961,7 +982,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.n_list = n_all;
         p.nseg = (ow + kMfSeg - 1) / kMfSeg;
         p.nyb = (oh + kMfRows - 1) / kMfRows;
-        p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
+        p.ntg = (n_all + tgsz - 1) / tgsz;
+        if (r2) p.nyb = (oh + 2 * kMfRows - 1) / (2 * kMfRows);
         p.method = c->method;
         p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
         p.cpr = p.lds_pitch / 16;
@@ -982,10 +1004,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.clk_out = (p.cand_on && c->cands.p) ? reinterpret_cast<float*>(c->cands.as<uint8_t>() + 8) : nullptr;
         int tg0 = 0;
         if (only_li >= 0 && !rm) {   // one template: just its group
-            tg0 = only_li / (16 * mb);
+            tg0 = only_li / tgsz;
             p.ntg = 1;
         }
-        int tile_rows = std::min(h, kMfChunkH) + kMfRows - 1;
+        int tile_rows = r2 ? std::min(h + 1, kMfChunkR2) + (kMfRows - 1) * 2 : std::min(h, kMfChunkH) + kMfRows - 1;
         if (rm) {
             p.rm_R = sc.rm_R;
             p.rm_nt = sc.rm_nt;
@@ -1008,7 +1030,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
         // statistics prefetch region: (channels + 2) planes per wave (RM loads its statistics directly)
-        size_t lds = (size_t)p.st_off + (rm ? 0 : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
+        size_t lds = (size_t)p.st_off + (rm ? 0 : r2 ? (size_t)kMfRows * 2 * 4 * 1024
+                                                     : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
         const bool ext = c->ext_now && only_li < 0;      // find_matches_impl checked the class
         if (ext) {
             p.ext_off = (int)lds;                         // 4 waves x 32 keys
@@ -1020,12 +1043,12 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off +
-                            (rm ? (long long)sc.rm_R * p.nb * 1024 : (long long)tg0 * mb * sc.group_bytes);
+                            (rm ? (long long)sc.rm_R * p.nb * 1024 : (long long)tg0 * (r2 ? 1 : mb) * sc.group_bytes);
         // with a group offset the kernel's list positions must stay class-relative: shift the list
         // pointer and the counts instead (positions inside the kernel are relative to tg0)
-        p.n_list = n_all - tg0 * 16 * mb;
-        if (only_li >= 0) p.only_li = only_li - tg0 * 16 * mb;
-        const int* tl_k = tl_class + tg0 * 16 * mb;
+        p.n_list = n_all - tg0 * tgsz;
+        if (only_li >= 0) p.only_li = only_li - tg0 * tgsz;
+        const int* tl_k = tl_class + tg0 * tgsz;
         using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
 #define MTM_MF_ROW(MB, X, M) {ncc_mfma_kernel<MB, -1, X, false>, ncc_mfma_kernel<MB, 0, X, M>, ncc_mfma_kernel<MB, 1, X, M>, \
                              ncc_mfma_kernel<MB, 2, X, M>, ncc_mfma_kernel<MB, 3, X, M>, ncc_mfma_kernel<MB, 4, X, false>,  \
@@ -1076,9 +1099,16 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                           ncc_mfma_kernel<2, 4, X, false, true, 3, true>, ncc_mfma_kernel<2, 5, X, false, true, 3, true>}
         static const MfmaFn kMfmaRmExtC3Fns[2][6] = {MTM_MF_RMEXTC3(false), MTM_MF_RMEXTC3(true)};
 #undef MTM_MF_RMEXTC3
+        // two-row variant (methods 2..5), plain and with the fused global extremum
+#define MTM_MF_R2(X, E) {ncc_mfma_kernel<2, 2, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 3, X, false, false, 1, E, true>,   \
+                        ncc_mfma_kernel<2, 4, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 5, X, false, false, 1, E, true>}
+        static const MfmaFn kMfmaR2Fns[2][2][4] = {{MTM_MF_R2(false, false), MTM_MF_R2(true, false)},
+                                                   {MTM_MF_R2(false, true), MTM_MF_R2(true, true)}};
+#undef MTM_MF_R2
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
         const int xd = c->exact_div ? 1 : 0;
-        const MfmaFn fn = (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
+        const MfmaFn fn = r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
+                        : (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
                         : ext ? (c->chans == 3 ? kMfmaExtC3Fns[xd][mb - 1][c->method] : kMfmaExtFns[xd][mb - 1][c->method])
                         : (rm && c->chans == 3) ? kMfmaRmC3Fns[c->exact_div ? 1 : 0][c->method]
                         : c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
@@ -1352,6 +1382,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     }
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
@@ -2185,7 +2216,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         c->band_ev.push_back(e);
     }
     const int h = sc.h, oh = a.rows - h + 1;
-    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : kMfRows;          // output rows per score-kernel row block
+    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? 2 * kMfRows : kMfRows);   // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
     int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
     bool used2 = false;

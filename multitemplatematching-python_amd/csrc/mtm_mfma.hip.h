@@ -36,6 +36,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kMfSeg = 256;          // output pixels per wave (16 phases x 16 columns)
 constexpr int kMfRows = 4;           // output rows per work-group (one per wave)
 constexpr int kMfChunkH = 64;        // template rows per LDS tile
+constexpr int kMfChunkR2 = 72;       // K steps per LDS tile of the two-row variant (h + 1 steps: 64-row templates in one tile)
 // Epilogue buffer of one wave: [8 templates][kMfEpiPitch] int32.  Pixel column xl = 16 j + c is
 // stored at physical column 16 j + ((c + 4 * ((j >> 1) & 3)) & 15): 4-pixel groups stay contiguous
 // and 16-byte aligned (one ds_read_b128 per lane and template, conflict-free), while the
@@ -284,7 +285,14 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
-template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false, int CH = 1, bool EXT = false>
+// R2 (two-row variant; classes of more than 16 templates up to 64 wide, one channel, methods 2..5): the two MFMA
+// groups of a wave are the SAME 16 templates on two consecutive output rows y, y + 1 instead of 32 templates on one
+// row.  Image row r is template row r - y for the first and r - y - 1 for the second, so the second group's A operand
+// is the one the first group used one step earlier: it stays in registers.  A K step then needs ONE 1 KiB template
+// load instead of two (the B operand and its byte shifts were shared already); a wave walks h + 1 image rows (the
+// first / last step use a zero operand for one of the rows) and a work-group covers 8 output rows.
+template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false, int CH = 1, bool EXT = false,
+          bool R2 = false>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
@@ -293,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
     static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && !MASKED), "fused extremum: unmasked compile-time-method paths");
+    static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
@@ -342,8 +351,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
-    const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : kMfRows);
-    const int wave_rows = RM ? 2 * p.rm_R : 1;          // output rows per wave = tile-row stride between waves
+    const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : (R2 ? 2 * kMfRows : kMfRows));
+    const int wave_rows = RM ? 2 * p.rm_R : (R2 ? 2 : 1);   // output rows per wave = tile-row stride between waves
+    constexpr int kTG = R2 ? 16 : 16 * MB;              // templates per work item
 
     v4i acc[MB][16];
 #pragma unroll
@@ -353,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
     MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
-    if (METHOD != kMfRaw && threadIdx.x < (RM ? p.rm_nt : 16 * MB)) {
-        const int li = tg * MB * 16 + threadIdx.x;
+    if (METHOD != kMfRaw && threadIdx.x < (RM ? p.rm_nt : kTG)) {
+        const int li = tg * kTG + threadIdx.x;
         if (li < p.n_list) {
             const TemplDev& T = td[tlist[li]];
             MfTemplConst k;
@@ -395,7 +405,23 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                                          METHOD == MTM_TM_CCOEFF_NORMED);
     constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
-    if constexpr (C1 && METHOD != kMfRaw && !RM) {
+    if constexpr (R2) {
+        // two rows per wave, S1 and sqrt only (methods 2..5 need no sum2): [row][S1, sqrt][half][lane][16 B]
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int xc = min(x0 + 4 * lane, st.pitch - 4);
+        uint8_t* sbase = smem + p.st_off + wave * (2 * 4 * 1024);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const size_t sidx = (size_t)min(y0 + 2 * wave + r, p.oh - 1) * st.pitch + xc;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(st.t[0] + sidx + 2 * hh), (lptr_t)(sbase + (4 * r + hh) * 1024), 16, 0, 0);
+                if (kNormed)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(st.sq + sidx + 2 * hh), (lptr_t)(sbase + (4 * r + 2 + hh) * 1024), 16, 0, 0);
+            }
+        }
+    } else if constexpr (C1 && METHOD != kMfRaw && !RM) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
@@ -414,13 +440,15 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
 
-    const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
+    const uint8_t* apack_g = apack + (long long)tg * (R2 ? 1 : MB) * p.group_bytes + (size_t)lane * 16;
 
     for (int c = 0; c < p.chans; ++c) {
         const uint8_t* plane = p.img + c * p.plane;
-        const int krows = RM ? p.rm_steps : p.h;        // image rows a wave walks (K steps / nb)
-        for (int cy0 = 0; cy0 < krows; cy0 += kMfChunkH) {
-            const int ch = min(kMfChunkH, krows - cy0);
+        const int krows = RM ? p.rm_steps : (R2 ? p.h + 1 : p.h);        // image rows a wave walks (K steps / nb)
+        constexpr int kChunk = R2 ? kMfChunkR2 : kMfChunkH;
+        v4i r2_prev = v4i{0, 0, 0, 0};      // R2: the A operand of the previous step (the int8 zero before template row 0)
+        for (int cy0 = 0; cy0 < krows; cy0 += kChunk) {
+            const int ch = min(kChunk, krows - cy0);
             // ---- stage (ch + 3) rows of the int8 image plane by LDS-DMA: the tile is one linear
             // array of 16-byte chunks [row][cpr]; wave-instruction k of the work-group fills chunks
             // 64 k .. 64 k + 63 (LDS destination = wave-uniform base + lane * 16), each lane
@@ -453,6 +481,53 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
+            if constexpr (R2) {
+                // ---- K loop of the two-row variant (nb == 1: one step per image row).  B operands alternate between
+                // two register sets, A operands rotate through three (this step's, the previous step's - the second
+                // row's operand - and the one being loaded), so the body is unrolled six times; every request runs
+                // one step ahead and up to six steps past the end of the chunk (pack slack / inside the LDS
+                // allocation; never used).
+                const uint8_t* aptr = apack_g + (size_t)cy0 * 1024;
+                const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
+                int loff = 0;
+                v4i qx, qy, qx2, qy2, aA, aB, aC = r2_prev;
+                if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+#define MTM_R2_LOAD(QA, QB, A)                                              \
+                QA = *reinterpret_cast<const v4i*>(lbase + loff);           \
+                QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);      \
+                A = *reinterpret_cast<const v4i*>(aptr);
+#define MTM_R2_STEP(QA, QB, ACUR, APREV, QA2, QB2, ANEXT)                   \
+                {                                                           \
+                    aptr += 1024;                                           \
+                    loff += p.lds_pitch;                                    \
+                    MTM_R2_LOAD(QA2, QB2, ANEXT)                            \
+                    __builtin_amdgcn_sched_barrier(0);                      \
+                    const v4i ar_[2] = {ACUR, APREV};                       \
+                    mfma_step<2>(acc, QA, QB, ar_);                         \
+                    __builtin_amdgcn_sched_barrier(0);                      \
+                }
+                MTM_R2_LOAD(qx, qy, aA)           // step 0 of the chunk; aC = the step before it
+                int ks = 0;
+                for (; ks + 6 <= ch; ks += 6) {
+                    MTM_R2_STEP(qx, qy, aA, aC, qx2, qy2, aB)
+                    MTM_R2_STEP(qx2, qy2, aB, aA, qx, qy, aC)
+                    MTM_R2_STEP(qx, qy, aC, aB, qx2, qy2, aA)
+                    MTM_R2_STEP(qx2, qy2, aA, aC, qx, qy, aB)
+                    MTM_R2_STEP(qx, qy, aB, aA, qx2, qy2, aC)
+                    MTM_R2_STEP(qx2, qy2, aC, aB, qx, qy, aA)
+                }
+                // remainder (0..5 steps), same rotation; r2_prev = the operand of the chunk's last step
+                r2_prev = aC;
+                if (ks < ch) { MTM_R2_STEP(qx, qy, aA, aC, qx2, qy2, aB) r2_prev = aA; }
+                if (ks + 1 < ch) { MTM_R2_STEP(qx2, qy2, aB, aA, qx, qy, aC) r2_prev = aB; }
+                if (ks + 2 < ch) { MTM_R2_STEP(qx, qy, aC, aB, qx2, qy2, aA) r2_prev = aC; }
+                if (ks + 3 < ch) { MTM_R2_STEP(qx2, qy2, aA, aC, qx, qy, aB) r2_prev = aA; }
+                if (ks + 4 < ch) { MTM_R2_STEP(qx, qy, aB, aA, qx2, qy2, aC) r2_prev = aB; }
+#undef MTM_R2_LOAD
+#undef MTM_R2_STEP
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                __builtin_amdgcn_s_setprio(0);
+            } else {
             // ---- K loop: template rows of this chunk x 64-tap blocks, software pipelined with two
             // register sets: the operands of the next step (2 LDS chunks + MB packed template rows)
             // are requested before the 16*MB MFMAs of the current step issue.  sched_barrier keeps
@@ -533,6 +608,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // before compiler-generated code reads the accumulators (hipcc does not see asm MFMAs)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             __builtin_amdgcn_s_setprio(0);
+            }   // !R2
         }
     }
 
@@ -550,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     asm volatile("" : "+v"(tid_e));
     const int wave = tid_e >> 6, lane = tid_e & 63;
     const int j = lane & 15, q = lane >> 4;
-    const int y = y0 + wave;
+    const int y = y0 + (R2 ? 2 : 1) * wave;             // R2: the wave's first row; MFMA group mb is row y + mb
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
     if (p.dbg & 2) {            // probe: no epilogue (keep the accumulators observable)
         int sum = 0;
@@ -835,17 +911,19 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // such calls skip the screen instead of tracking the minima as well)
             if (p.hits_only && (EXT || p.cand_thr_lo >= 0.0)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint8_t* sw = smem + p.st_off + wave * mf_stat_bytes_per_wave(1);
+                const uint8_t* sw0 = smem + p.st_off + wave * (R2 ? 2 * 4 * 1024 : mf_stat_bytes_per_wave(1));
                 bool pass = false;
                 // one MFMA group (4 templates of this lane) at a time: 4 x (K, 128 - mean, running extremes)
                 // stay in registers next to the 64 * MB accumulators
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
+                    const uint8_t* sw = sw0 + (R2 ? mb * 4 * 1024 : 0);       // R2: group mb = the wave's row mb
+                    constexpr int kSqPlane = R2 ? 2 : 4;                     // 1 KiB planes: [S1 x 2][(S2 x 2)][sqrt x 2]
                     double kk[4], mm[4], umax[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int lt = 16 * mb + 4 * q + e;
-                        const bool live = tg * MB * 16 + lt < p.n_list;     // beyond the list: zero-padded A rows
+                        const int lt = (R2 ? 0 : 16 * mb) + 4 * q + e;
+                        const bool live = tg * kTG + lt < p.n_list;     // beyond the list: zero-padded A rows
                         const MfTemplConst& T = tcl[lt];
                         kk[e] = live ? T.mfma_k : 0.0;
                         mm[e] = live ? (METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0) : 0.0;
@@ -857,8 +935,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const int L = 4 * j + g;
                         const double2 sa = *reinterpret_cast<const double2*>(sw + 0 * 1024 + L * 16);
                         const double2 sb = *reinterpret_cast<const double2*>(sw + 1 * 1024 + L * 16);
-                        const double2 qa = *reinterpret_cast<const double2*>(sw + 4 * 1024 + L * 16);
-                        const double2 qb = *reinterpret_cast<const double2*>(sw + 5 * 1024 + L * 16);
+                        const double2 qa = *reinterpret_cast<const double2*>(sw + kSqPlane * 1024 + L * 16);
+                        const double2 qb = *reinterpret_cast<const double2*>(sw + (kSqPlane + 1) * 1024 + L * 16);
                         const double s1g[4] = {sa.x, sa.y, sb.x, sb.y}, sqg[4] = {qa.x, qa.y, qb.x, qb.y};
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4) {
@@ -876,8 +954,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     // threshold < 1, tested anyway)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int lt = 16 * mb + 4 * q + e;
-                        const bool live = tg * MB * 16 + lt < p.n_list;
+                        const int lt = (R2 ? 0 : 16 * mb) + 4 * q + e;
+                        const bool live = tg * kTG + lt < p.n_list;
                         const double tn = tcl[lt].templ_norm;
                         // extremum mode: the template's own running best is the threshold (negative or none
                         // yet: no screen for this template)
@@ -894,9 +972,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // accumulators of the next template are requested before the current one is normalised)
         // and branch-free apart from wave-uniform tests.
         double ps1[4][CH], pp1[4], psum2[4], psq[4], prsq[4];
-        {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint8_t* sl = smem + p.st_off + wave * mf_stat_bytes_per_wave(CH) + lane * 16;
+        // statistics of the lane's four pixels: from the LDS prefetch into registers (R2: per row, inside the loop)
+        auto load_stats = [&](int r2_row) {
+            const uint8_t* sl = smem + p.st_off + (R2 ? wave * (2 * 4 * 1024) + r2_row * (4 * 1024)
+                                                      : wave * mf_stat_bytes_per_wave(CH)) + lane * 16;
+            constexpr int kSq = R2 ? 2 : 2 * CH + 2;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -907,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 }
                 double2 b = make_double2(0.0, 0.0), d = make_double2(0.0, 0.0);
                 if (kNeedSum2) b = *reinterpret_cast<const double2*>(sl + (2 * CH + hh) * 1024);
-                if (kNormed) d = *reinterpret_cast<const double2*>(sl + (2 * CH + 2 + hh) * 1024);
+                if (kNormed) d = *reinterpret_cast<const double2*>(sl + (kSq + hh) * 1024);
                 psum2[2 * hh] = b.x;
                 psum2[2 * hh + 1] = b.y;
                 psq[2 * hh] = d.x;
@@ -922,21 +1002,26 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
-        }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!R2) load_stats(0);
         __syncthreads();              // every wave is done reading the image tile: the buffers alias it
         if (!wave_has_work) continue;                       // wave-uniform; no work-group barrier below
-        const bool lane_on = y < p.oh && xq < p.ow;
+        const bool col_on = xq < p.ow;
         unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
         if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
+            const int yrow = y + (R2 ? mb : 0);
+            const bool lane_on = yrow < p.oh && col_on;
+            if constexpr (R2) load_stats(mb);
 #pragma unroll 1
             for (int round = 0; round < 2; ++round) {
                 if ((q >> 1) == round) put(acc[mb]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS writes above, reads below
                 __builtin_amdgcn_wave_barrier();
                 if (lane_on) {
-                    const int lt0 = mb * 16 + 8 * round;                  // template inside this work item
+                    const int lt0 = (R2 ? 0 : mb * 16) + 8 * round;       // template inside this work item
                     MfTemplConst Tn = tcl[lt0];
                     v4i an = *reinterpret_cast<const v4i*>(&epi[rd_off]);
 #pragma unroll 2
@@ -949,7 +1034,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             Tn = tcl[lt0 + s8 + 1];
                             an = *reinterpret_cast<const v4i*>(&epi[(s8 + 1) * kMfEpiPitch + rd_off]);
                         }
-                        const int li = tg * MB * 16 + lt0 + s8;
+                        const int li = tg * kTG + lt0 + s8;
                         if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;   // wave-uniform
                         const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
                         if (kNormed && p.hits_only) {
@@ -992,23 +1077,23 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                         }
                         if constexpr (EXT) {
-                            ext_update(out, y, T.ext_hi, &ext_slot[lt0 + s8]);
+                            ext_update(out, yrow, T.ext_hi, &ext_slot[lt0 + s8]);
                         } else if (p.cand_on) {
-                            // cheap any-of-4 test; emit() repeats the exact per-pixel test (rare)
+                            // cheap any-of-4 test; emit_at() repeats the exact per-pixel test (rare)
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit(out, li);
+                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, yrow);
                         }
-                        if (!p.hits_only) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
+                        if (!p.hits_only) store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, out);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (EXT && lane < 16 * MB) {       // one global atomic per template this wave improved
+        if (EXT && lane < kTG) {       // one global atomic per template this wave improved
             const unsigned long long key = ext_slot[lane];
-            const int li = tg * MB * 16 + lane;
+            const int li = tg * kTG + lane;
             if (key && li < p.n_list) atomicMax(&p.ext_best[2 * tlist[li] + p.cand_min], key);
         }
     } else {

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void source_sums_kernel(const uint8_t* __restr
 // `masked`: bytes are T * M (M binary).
 // ---------------------------------------------------------------------------------------------
 struct PackParams {
-    int mode, h, w, nb, chans, n;        // n = templates of the class
+    int mode, h, w, nb, chans, n;        // h = rows per group in the pack, n = templates of the class
+    int hv;                              // valid template rows (rows hv .. h - 1 of a group stay zero: two-row variant)
     int nt, R;                           // RM
     long long group_bytes, cstride;      // plain: bytes per 16-template group; RM: bytes per channel
     int masked, pad_;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void pack_units_kernel(PackParams p, const uin
         li = t;
     }
     uint32_t wds[4] = {0u, 0u, 0u, 0u};
-    if (li >= 0 && li < p.n && dy >= 0 && dy < p.h) {
+    if (li >= 0 && li < p.n && dy >= 0 && dy < p.hv) {
         const UnitSrc u = units[tl[li]];
 #pragma unroll
         for (int byte = 0; byte < 16; ++byte) {
