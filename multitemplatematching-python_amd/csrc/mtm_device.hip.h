@@ -766,6 +766,66 @@ __global__ __launch_bounds__(256) void ncc16_combine_kernel(Ncc16Params p, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// Large uint8 templates on the int8 matrix cores.  The int32 accumulator of ncc_mfma_kernel holds
+// |sum (I-128)(T-128)| <= 16384 * w * h * C only for w*h*C <= 131071 (and its LDS tile wants w <= 256), so a larger
+// template is cut into slabs - row ranges x column blocks x channels - each within those limits.  Every slab is a
+// template of its own correlated (RAW mode: biased int32 accumulators) against the image shifted by the slab's
+// offset; the slabs of a template add up to its full biased correlation, and
+//   sum I*T = sum_slabs a_s + 128 * S1 + 128 * sum(T) - 16384 * w * h * C
+// with S1 the window sum over the WHOLE template window (the slabs' window sums add up to it) - exact integers,
+// summed here in float64 (< 2^53) and normalised by finish_unmasked like every other kernel.
+// raw layout: [slab][template (list position)][oh][pitch] int32.
+// ---------------------------------------------------------------------------------------------
+struct SlabParams {
+    mtm_hit* cand_hits;
+    unsigned long long* cand_counter;
+    unsigned long long cand_cap;
+    float cand_thr;
+    int cand_min, cand_on, hits_only;
+    int w, h, chans;
+    const int* raw;
+    long long raw_slab;        // ints per slab block: n_list * raw_map
+    long long raw_map;         // ints per template map: oh * pitch
+    int n_slabs;
+    int oh, ow, pitch;
+    int n_list;
+    int method;
+};
+
+__global__ __launch_bounds__(256) void slab_combine_kernel(SlabParams p, const TemplDev* __restrict__ td,
+                                                           const int* __restrict__ tlist, StatPlanes st,
+                                                           float* __restrict__ maps, int only_li) {
+    const int li = blockIdx.z;
+    if (only_li >= 0 && li != only_li) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= p.ow || y >= p.oh) return;
+    const TemplDev T = td[tlist[li]];
+    const size_t o = (size_t)li * p.raw_map + (size_t)y * p.pitch + x;
+    long long a = 0;
+    for (int k = 0; k < p.n_slabs; ++k) a += (long long)p.raw[(size_t)k * p.raw_slab + o];
+    const size_t sidx = (size_t)y * st.pitch + x;
+    double s1 = 0.0;
+    for (int c = 0; c < p.chans; ++c) s1 += st.t[c][sidx];
+    const double corr = ((double)a + 128.0 * s1) + T.mfma_k;
+    const float out = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
+    if (p.cand_on && (p.cand_min ? -out : out) > p.cand_thr) {
+        const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+        if (slot < p.cand_cap) {
+            mtm_hit hrec;
+            hrec.templ_idx = tlist[li];
+            hrec.x = x;
+            hrec.y = y;
+            hrec.w = p.w;
+            hrec.h = p.h;
+            hrec.score = out;
+            p.cand_hits[slot] = hrec;
+        }
+    }
+    if (!p.hits_only) maps[T.map_off + (size_t)y * T.map_pitch + x] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // NAIVE score-map kernel: one thread per output pixel, float64 FMA chain over the window.
 // Generic (uint8 or float32 pixels, masks, any size); it is the in-library cross-check for the
 // tiled kernels and the fallback for shapes they do not take.

@@ -98,6 +98,14 @@ struct SizeClass {
     bool all_u16 = true;
     bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
     int rm_nt = 0, rm_R = 0;    // > 0: row-multiplexed MFMA mode (<= 16 templates: nt x R = 16 A rows)
+    // large templates (w > 256 or w*h*C > 131071) on the MFMA kernel: cut into slabs (slab_combine_kernel)
+    struct Slab {
+        int r0, r1, c0, c1, ch;
+        long long apack_off;    // this slab's packs in the apack arena
+        int tlist_off;          // its view list (unit-table indices) in the device tlist
+    };
+    std::vector<Slab> slabs;
+    int slab_nt = 0, slab_R = 0;    // > 0: row-multiplexed raw launches (<= 16 templates); 0: plain raw launches
     bool r2 = false;            // two-row MFMA variant (> 16 templates, w <= 64, one channel, methods 2..5): packs of
                                 // h + 1 rows per 16-template group (the last row zero)
     long long mask_rm_off = -1; // masked class: row-multiplexed pack (1 "template" = the binary mask, R = 16) in apacks
@@ -197,6 +205,10 @@ struct mtm_ctx {
     std::vector<int> list2d;        // templates with a 2-D score map
     int list2d_off = 0;
     size_t maps_floats = 0;
+    std::vector<UnitSrc> usrc_host;                 // the unit views (device copy: usrc_dev), slab views appended at placement
+    size_t usrc_units = 0;                          // entries that are units (the rest are slab views)
+    int slab_mfma = 1;                              // MTM_SLAB_MFMA: large templates as slabs on the MFMA kernel
+    DevBuf slab_raw;                                // raw int32 maps of the slabs
     DevBuf tsrc, usrc_dev, tsums_dev, tgather;      // template source arena, unit views, source sums, gather scratch
     DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq;
 
@@ -296,7 +308,28 @@ void pack_template_dot4(const HostTempl& t, uint8_t* out) {
 // 64*b + 16*q .. +15 of template i, biased to int8 (T ^ 0x80); taps beyond the template width and
 // templates beyond the list are 0 (the signed zero), so they add nothing.
 constexpr int kMfmaMaxW = 256;
+// Slab layout of a large unmasked uint8 class (empty: not slab-able).  Column blocks are multiples of 64 taps wide
+// (the LDS-DMA tile staging wants 16-byte aligned image offsets): 128 for the row-multiplexed raw launches of
+// <= 16 templates (their LDS tile is 6R rows taller), 256 otherwise; row ranges keep rows * width <= 131071.
+std::vector<SizeClass::Slab> slab_layout(const mtm_ctx* c, const SizeClass& sc) {
+    std::vector<SizeClass::Slab> out;
+    if (!c->slab_mfma || sc.masked || !sc.all_u8 || c->dtype != MTM_U8) return out;
+    for (int m : sc.members)
+        if (!c->templs[(size_t)m].on_device) return out;
+    const int cw = sc.members.size() <= 16 ? 128 : 256;
+    const int rows_max = 131071 / std::min(cw, ((sc.w + 63) / 64) * 64);
+    const int nrb = (sc.h + rows_max - 1) / rows_max, rh = (sc.h + nrb - 1) / nrb;
+    for (int ch = 0; ch < c->chans; ++ch)
+        for (int r0 = 0; r0 < sc.h; r0 += rh)
+            for (int c0 = 0; c0 < sc.w; c0 += cw)
+                out.push_back(SizeClass::Slab{r0, std::min(sc.h, r0 + rh), c0, std::min(sc.w, c0 + cw), ch, 0, 0});
+    if (out.size() > 24) out.clear();            // absurdly large: the VALU kernel takes it
+    return out;
+}
+
 bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
+    if (c->dtype == MTM_U8 && sc.all_u8 && !sc.masked && (sc.w > kMfmaMaxW || (long long)c->chans * sc.w * sc.h > 131071))
+        return !slab_layout(c, sc).empty();
     if (!(c->dtype == MTM_U8 && sc.all_u8 && sc.w <= kMfmaMaxW && (long long)c->chans * sc.w * sc.h <= 131071))
         return false;
     // masked: single channel, sum I^2*M must fit the uint32 dot4 accumulator (w*h*255^2 < 2^32)
@@ -454,6 +487,30 @@ int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
         p.n_chunks = p.cstride / 16;
         launch(sc.mask_rm_off);
     }
+    if (!sc.slabs.empty()) {               // every slab is a class of its own: its view list, its dimensions
+        for (const auto& sl : sc.slabs) {
+            p.h = p.hv = sl.r1 - sl.r0;
+            p.w = sl.c1 - sl.c0;
+            p.nb = (p.w + 63) / 64;
+            p.chans = 1;
+            p.masked = 0;
+            tl = c->tlist.as<int>() + sl.tlist_off;
+            if (sc.slab_R > 0) {
+                p.mode = 1;
+                p.nt = sc.slab_nt;
+                p.R = sc.slab_R;
+                p.cstride = rm_pack_bytes(p.h, p.w, sc.slab_R);
+                p.n_chunks = p.cstride / 16;
+            } else {
+                p.mode = 0;
+                p.group_bytes = mfma_group_bytes(p.h, p.w, 1);
+                p.n_chunks = p.group_bytes * mfma_groups_alloc(p.n) / 16;
+            }
+            launch(sl.apack_off);
+        }
+        HIPC(hipGetLastError());
+        return MTM_OK;
+    }
     p.masked = sc.masked ? 1 : 0;
     if (sc.rm_R > 0) {
         p.mode = 1;
@@ -519,8 +576,29 @@ int place_templates(mtm_ctx* c) {
             sc.rm_nt = nt;
             sc.rm_R = 16 / nt;
         }
-        sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && n_cls > 16 && sc.w <= 64 &&
-                c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
+        sc.slabs.clear();
+        sc.slab_nt = sc.slab_R = 0;
+        const bool big = sc.w > kMfmaMaxW || (long long)c->chans * sc.w * sc.h > 131071;
+        if (class_kernel[k] == MTM_KERNEL_MFMA && big) {
+            sc.slabs = slab_layout(c, sc);
+            sc.rm_nt = sc.rm_R = 0;
+            if (n_cls <= 16) {                     // row-multiplexed raw launches: nt templates x R rows per MFMA group
+                int nt = 1;
+                while (nt < (int)n_cls) nt <<= 1;
+                int hs = 0, ws = 0;
+                for (const auto& sl : sc.slabs) {
+                    hs = std::max(hs, sl.r1 - sl.r0);
+                    ws = std::max(ws, sl.c1 - sl.c0);
+                }
+                const size_t lds_pitch = (size_t)(16 + 4 * ((ws + 63) / 64) + 1) * 16;
+                auto tile_bytes = [&](int R) { return (size_t)(std::min(hs + 2 * R - 1, kMfChunkH) + 6 * R) * lds_pitch; };
+                while (nt < 16 && tile_bytes(16 / nt) > 72 * 1024) nt <<= 1;
+                sc.slab_nt = nt;
+                sc.slab_R = 16 / nt;
+            }
+        }
+        sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
+                sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
     }
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
@@ -631,6 +709,16 @@ int place_templates(mtm_ctx* c) {
             a_off += (size_t)rm_pack_bytes(sc.h, sc.w, sc.rm_R) * (sc.masked ? 1 : c->chans);
             continue;
         }
+        if (!sc.slabs.empty()) {              // one pack per slab (a template of its own, one channel)
+            sc.apack_off = (long long)a_off;
+            for (auto& sl : sc.slabs) {
+                sl.apack_off = (long long)a_off;
+                const int hs = sl.r1 - sl.r0, ws = sl.c1 - sl.c0;
+                a_off += sc.slab_R > 0 ? (size_t)rm_pack_bytes(hs, ws, sc.slab_R)
+                                       : (size_t)mfma_group_bytes(hs, ws, 1) * mfma_groups_alloc((int)sc.members.size());
+            }
+            continue;
+        }
         if (sc.r2) {
             sc.group_bytes = mfma_group_bytes(sc.h + 1, sc.w, 1);        // h + 1 rows, the last one zero
             sc.apack_off = (long long)a_off;
@@ -686,6 +774,29 @@ int place_templates(mtm_ctx* c) {
         if (td_host[i].oh > 1 && td_host[i].ow > 1) list2d.push_back(i);
     const int list2d_off = (int)tlist_host.size();
     tlist_host.insert(tlist_host.end(), list2d.begin(), list2d.end());
+    // slab views: windows into the units of a large-template class, appended to the unit table (a view of a view:
+    // the offsets move, the orientation stays)
+    std::vector<UnitSrc> units_all(c->usrc_host.begin(), c->usrc_host.begin() + (long)std::min(c->usrc_units, c->usrc_host.size()));
+    for (SizeClass& sc : classes)
+        for (auto& sl : sc.slabs) {
+            sl.tlist_off = (int)tlist_host.size();
+            for (int m : sc.members) {
+                UnitSrc v = c->templs[(size_t)m].src;
+                v.off += (long long)sl.ch * v.sh * v.sw;
+                v.moff = -1;
+                v.cy += v.ay * sl.r0 + v.by * sl.c0;
+                v.cx += v.ax * sl.r0 + v.bx * sl.c0;
+                v.h = sl.r1 - sl.r0;
+                v.w = sl.c1 - sl.c0;
+                v.chans = 1;
+                tlist_host.push_back((int)units_all.size());
+                units_all.push_back(v);
+            }
+        }
+    if (units_all.size() > c->usrc_units) {
+        MTMC(c->usrc_dev.ensure(sizeof(UnitSrc) * units_all.size()));
+        HIPC(hipMemcpyAsync(c->usrc_dev.p, units_all.data(), sizeof(UnitSrc) * units_all.size(), hipMemcpyHostToDevice, c->stream));
+    }
 
     MTMC(c->td.ensure(sizeof(TemplDev) * n));
     MTMC(c->tlist.ensure(sizeof(int) * std::max<size_t>(1, tlist_host.size())));
@@ -709,6 +820,7 @@ int place_templates(mtm_ctx* c) {
     for (size_t k = 0; k < classes.size(); ++k)
         if (dev_pack[k]) MTMC(pack_class_on_device(c, classes[k]));
     HIPC(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
+    if (units_all.size() > c->usrc_units) c->usrc_host.swap(units_all);
     c->classes.swap(classes);
     c->td_host.swap(td_host);
     c->tlist_host.swap(tlist_host);
@@ -961,6 +1073,97 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         hipLaunchKernelGGL(ncc_naive_kernel, grd, blk, 0, c->stream, img, td, tl, c->weights.as<double>(), st,
                            c->method, sc.masked ? 1 : 0, maps);
         c->timing.kernel_used = MTM_KERNEL_NAIVE;
+    } else if (kernel == MTM_KERNEL_MFMA && !sc.slabs.empty()) {
+        // large templates: one RAW launch per slab (a template of its own against the image shifted by the slab's
+        // offset), then slab_combine_kernel adds the slabs up, restores the bias terms and normalises
+        const int n_all = (int)sc.members.size();
+        const int map_pitch = (int)round_up((size_t)ow, 4);
+        const long long raw_map = (long long)oh * map_pitch;
+        const int S = (int)sc.slabs.size();
+        MTMC(c->slab_raw.ensure(sizeof(int) * (size_t)S * n_all * (size_t)raw_map));
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        const bool rmr = sc.slab_R > 0;
+        for (int k = 0; k < S; ++k) {
+            const SizeClass::Slab& sl = sc.slabs[(size_t)k];
+            const int hs = sl.r1 - sl.r0, ws = sl.c1 - sl.c0;
+            MfmaParams p{};
+            p.img = c->slot[c->cur].u8b.as<uint8_t>() + (size_t)sl.ch * img.u8_plane + (size_t)sl.r0 * img.u8_pitch + sl.c0;
+            p.pitch = img.u8_pitch;
+            p.plane = img.u8_plane;
+            p.chans = 1;
+            p.h = hs;
+            p.w = ws;
+            p.oh = oh;
+            p.ow = ow;
+            p.nb = (ws + 63) / 64;
+            p.n_list = n_all;
+            p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+            p.method = c->method;
+            p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+            p.cpr = p.lds_pitch / 16;
+            p.cpr_rstep = 256 / p.cpr;
+            p.cpr_dstep = 256 % p.cpr;
+            p.only_li = -1;
+            p.raw_map = raw_map;
+            p.raw_pitch = map_pitch;
+            p.raw_out = c->slab_raw.as<int>() + (size_t)k * n_all * (size_t)raw_map;
+            int tile_rows;
+            if (rmr) {
+                const int R = sc.slab_R;
+                p.rm_R = R;
+                p.rm_nt = sc.slab_nt;
+                while ((1 << p.rm_log2nt) < sc.slab_nt) ++p.rm_log2nt;
+                p.rm_steps = hs + 2 * R - 1;
+                p.rm_cstride = rm_pack_bytes(hs, ws, R);
+                p.nyb = (oh + 8 * R - 1) / (8 * R);
+                p.ntg = 1;
+                p.group_bytes = -(long long)R * p.nb * 1024;
+                tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * R;
+            } else {
+                p.nyb = (oh + kMfRows - 1) / kMfRows;
+                p.ntg = (n_all + 31) / 32;
+                p.group_bytes = mfma_group_bytes(hs, ws, 1);
+                tile_rows = std::min(hs, kMfChunkH) + kMfRows - 1;
+            }
+            p.n_work = p.nseg * p.nyb * p.ntg;
+            const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
+                                    ~(size_t)15;
+            p.tc_off = (int)lds_main;
+            p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+            const size_t lds = (size_t)p.st_off + (rmr ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);
+            const int grid = ((p.n_work + 7) / 8) * 8;
+            const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
+            if (rmr)
+                hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false, true>), dim3(grid), dim3(256), lds, c->stream, p, td,
+                                   c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+            else
+                hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td,
+                                   c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+        }
+        SlabParams q{};
+        q.raw = c->slab_raw.as<int>();
+        q.raw_slab = (long long)n_all * raw_map;
+        q.raw_map = raw_map;
+        q.n_slabs = S;
+        q.oh = oh;
+        q.ow = ow;
+        q.pitch = map_pitch;
+        q.n_list = n_all;
+        q.method = c->method;
+        q.w = w;
+        q.h = h;
+        q.chans = c->chans;
+        q.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        q.cand_min = c->cand_min ? 1 : 0;
+        q.cand_thr = c->cand_thr;
+        q.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        q.cand_counter = c->cands.as<unsigned long long>();
+        q.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        q.hits_only = (q.cand_on && c->hits_only_now) ? 1 : 0;
+        hipLaunchKernelGGL(slab_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
+                           c->tlist.as<int>() + sc.tlist_off, st, maps, only_li);
+        c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_MFMA) {
         // the MFMA kernel works on whole 16-template groups of the class list; a single-template
         // request (mtm_score_map) computes its group and stores only that template
@@ -1383,6 +1586,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
@@ -1411,7 +1615,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
-    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather}) b->release();
+    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})
@@ -1880,7 +2084,9 @@ int set_templates_device(mtm_ctx* c, const mtm_templ* bases, int n_bases, const 
     MTMC(c->usrc_dev.ensure(sizeof(UnitSrc) * std::max<size_t>(1, units.size())));
     if (!units.empty())
         HIPC(hipMemcpyAsync(c->usrc_dev.p, units.data(), sizeof(UnitSrc) * units.size(), hipMemcpyHostToDevice, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));      // `stage` and `units` go out of scope
+    HIPC(hipStreamSynchronize(c->stream));      // `stage` goes out of scope
+    c->usrc_units = units.size();
+    c->usrc_host.swap(units);
     return MTM_OK;
 }
 
@@ -2193,7 +2399,7 @@ constexpr size_t kHitPrefetch = 1024;       // candidate / hit records fetched t
 bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
     if (c->upload_bands.size() < 2 || a.dtype != MTM_U8 || a.chans != 1 || c->classes.size() != 1) return false;
     const SizeClass& sc = c->classes[0];
-    if (sc.masked || !c->fuse_stats || resolved_kernel(c, sc) != MTM_KERNEL_MFMA) return false;
+    if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != MTM_KERNEL_MFMA) return false;
     if (!(sc.w <= 768 && (double)sc.w * sc.h * 65025.0 < 4294967296.0)) return false;
     return (size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256;
 }
@@ -2308,7 +2514,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3)) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
-            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && !sc.masked;
+            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && !sc.masked && sc.slabs.empty();
         if (ok) {
             MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
             HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)n, c->stream));

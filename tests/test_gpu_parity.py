@@ -776,6 +776,51 @@ def test_cfg3_and_cfg5_from_bases_only(mtm):
     assert got == exp and len(got) >= len(plants)
 
 
+def test_large_templates_as_slabs_on_mfma(mtm, ctx):
+    """Templates beyond the int32 accumulator / LDS tile limits of the MFMA kernel (w > 256 or w*h*C > 131071; the
+    reference's own benchmark matches a 414 x 400 template, tutorials/Benchmark.ipynb:203) are cut into slabs, every
+    slab runs on the matrix cores in raw mode and slab_combine_kernel adds them up - exact integers: the maps equal
+    the dot4 kernel's bit for bit and the oracle's to 1e-6, for one template (row-multiplexed raw launches), a few,
+    more than 16 (plain raw launches) and RGB."""
+    from MTM import _lib
+    img = synth.rand_u8(61, 0, (900, 1100))
+    big = np.ascontiguousarray(img[100:514, 300:700]).copy()              # 414 x 400, an exact copy in the image
+    noisy = np.clip(big.astype(np.int32) + (synth.rand_u8(61, 9, big.shape).astype(np.int32) % 61) - 30, 0, 255).astype(np.uint8)
+    wide = np.ascontiguousarray(img[600:640, 200:900])                    # 40 x 700: wider than three tiles
+    cases = [
+        ([("big", big)], img),
+        ([("big", big), ("big180", np.ascontiguousarray(np.rot90(big, 2))), ("noisy", noisy)], img),
+        ([("wide", wide)], img),
+        ([("t%d" % k, np.ascontiguousarray(img[20 * k:20 * k + 300, 10 * k:10 * k + 450])) for k in range(18)], img),
+    ]
+    rgb = synth.rand_u8(62, 0, (500, 640, 3))
+    cases.append(([("rgb", np.ascontiguousarray(rgb[50:290, 100:330]))], rgb))        # 240 x 230 x 3 = 165,600 taps
+    for lt, im in cases:
+        for method, thr in ((5, 0.5), (3, 0.9), (1, 0.3)):
+            res = {}
+            for kernel in ("auto", "dot4"):
+                set_kernel(ctx, kernel)
+                try:
+                    res[kernel] = (mtm.findMatches(lt, im, method=method, score_threshold=thr),
+                                   mtm.computeScoreMap(lt[-1][1], im, method), ctx.timing()["kernel_used"])
+                finally:
+                    set_kernel(ctx, "auto")
+            assert res["auto"][2] == 3 and res["dot4"][2] == 2                 # matrix cores vs VALU fallback
+            assert res["auto"][0] == res["dot4"][0] and len(res["auto"][0]) >= 1, (len(lt), method)
+            assert np.array_equal(res["auto"][1], res["dot4"][1])
+        map_close(res["auto"][1], O.compute_score_map(lt[-1][1], im, 1), tol=1e-6)
+        exp = O.match_templates(lt, im, method=5, score_threshold=0.5)
+        assert_hits_equal(canon(mtm.matchTemplates(lt, im, method=5, score_threshold=0.5)), canon(exp), tol=1e-5)
+        assert mtm.findMatches(lt, im, N_object=1) == [h for h in mtm.findMatches(lt, im, N_object=1, devices=[0, 0])]
+    # maps materialised == hits only
+    ctx.set_option(_lib.OPT_HITS_ONLY, 0)
+    try:
+        a = mtm.findMatches(cases[1][0], img, score_threshold=0.4)
+    finally:
+        ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+    assert a == mtm.findMatches(cases[1][0], img, score_threshold=0.4)
+
+
 BORDER_CALLS = {
     "sqdiff_normed": lambda im: ([("small", im[37:75, 80:121]), ("big", im[14:73, 302:367])],
                                  dict(method=1, score_threshold=0.2, maxOverlap=0)),
