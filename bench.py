@@ -490,8 +490,8 @@ def main():
                      "kernel_ms_per_step": round(k_step, 4),
                      "algorithmic_macs_per_step": int(macs), "algorithmic_macs_per_launch": int(macs / max(launches, 1)),
                      "achieved_tmacs": round(tmacs, 2),
-                     "launch_note": "the image arrives in row bands: one launch per band over that band's rows, alternating between "
-                                    "two streams; kernel_ms_per_step = time during which at least one of them runs" if launches > 1
+                     "launch_note": "the image arrives in row bands: one launch per band over that band's rows (they run under the "
+                                    "copy / layout / statistics kernels of the next band)" if launches > 1
                                     and len({u[1].shape[:2] for u in my_units}) == 1 else "one launch per size class"})
         msm = masked_stat_macs(img, my_units)
         if msm:
