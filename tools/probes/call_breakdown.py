@@ -2,7 +2,7 @@
 """Where one MTM.matchTemplates call (numpy in -> hits out) spends its wall-clock on the bench workload:
 Python host layer / native call / GPU kernels (HIP events).  GPU box."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 import synth, MTM

@@ -3,7 +3,7 @@
 random image (the bench workload), constant image (every B operand byte equal), constant image AND constant
 templates.  Kernel time (HIP events) and the shader clock measured inside the kernel.  GPU box."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 import synth

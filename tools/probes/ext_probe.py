@@ -3,7 +3,7 @@
 (= 0) on the bench workload, on BASELINE config 2 (1080p x 8, row-multiplexed) and on RGB; GPU time per call
 from the library's events and wall time.  GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "multitemplatematching-python_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "multitemplatematching-python_amd"))
 import numpy as np, synth
 from MTM import _lib
 cases = (("4K x 32 grey", (2160, 3840), 32, 1), ("1080p x 8 grey", (1080, 1920), 8, 1),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the uint8, uint16 (byte-plane MFMA) and float32 (float64 kernel) paths at 1080p x 8 and 4K x 32 (GPU box)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 import synth

@@ -2,7 +2,7 @@
 """Device-memory stability: many uploads of varying sizes, template sets, searches on one context and on
 short-lived contexts; rocm-smi memory use before / after (GPU box)."""
 import os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 from MTM import _lib

@@ -5,7 +5,7 @@
 call, numpy in -> hits out, median of 20.  MTM_KERNEL=dot4 gives the VALU fallback the large templates took before
 the slab decomposition.  GPU box."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 import synth, MTM

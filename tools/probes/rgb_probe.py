@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time for RGB (3-channel uint8) inputs vs grayscale (GPU box)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 import synth

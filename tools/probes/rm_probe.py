@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time for few-template calls, row-multiplexed mode on/off (GPU box): MTM_ROW_MUX=0/1."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
 import numpy as np
 import synth

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/variants_probe.sh <variant.so>[:ENV=VAL[,ENV=VAL...]] ...   (GPU box)
+# usage: tools/probes/variants_probe.sh <variant.so>[:ENV=VAL[,ENV=VAL...]] ...   (GPU box)
 # steady-clock kernel time of the north-star launch for each library build (build/variants/*.so,
 # made with MTM_EXTRA_FLAGS=-DMTM_PROBE_*); the scratch copy's in-tree library is overwritten
 for spec in "$@"; do
