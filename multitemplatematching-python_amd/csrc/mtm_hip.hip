@@ -2175,7 +2175,7 @@ int set_templates_impl(mtm_ctx* c, const mtm_templ* templs, int n_templ, const m
         c->have_templ = false;          // until the new set is complete
     }
     std::vector<HostTempl> hts;
-    if (all_u8 && c->templ_on_device) {
+    if (all_u8 && (c->templ_on_device || n_var > 0)) {       // augmented sets only exist as device views
         const int rc = set_templates_device(c, templs, n_templ, variants, n_var, method, hts);
         if (rc != MTM_OK) {
             c->templ_blob.clear();

@@ -596,8 +596,9 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
         fused.set_option(_lib.OPT_HITS_ONLY, 1)
         fused.search(cases[0][1], img, 5, _lib.PEAKS_LOCAL, 0.5)
         t = fused.timing()
-        assert (t["ncc_launches"] == 1) if bands == "1" else (2 <= t["ncc_launches"] <= len(bands.split(",")))
-        assert 300.0 < t["sclk_mhz"] < 3500.0
+        if not any(os.environ.get(k) for k in ("MTM_FUSE_PEAKS", "MTM_FUSE_STATS", "MTM_KERNEL")):   # (tools/alt_modes.sh)
+            assert (t["ncc_launches"] == 1) if bands == "1" else (2 <= t["ncc_launches"] <= len(bands.split(",")))
+            assert 300.0 < t["sclk_mhz"] < 3500.0
         # a different image through the same fused context: nothing stale survives
         img2 = np.ascontiguousarray(img[::-1, ::-1])
         a = fused.search(cases[0][1], img2, 5, _lib.PEAKS_LOCAL, 0.5)
@@ -805,7 +806,8 @@ def test_large_templates_as_slabs_on_mfma(mtm, ctx):
                                    mtm.computeScoreMap(lt[-1][1], im, method), ctx.timing()["kernel_used"])
                 finally:
                     set_kernel(ctx, "auto")
-            assert res["auto"][2] == 3 and res["dot4"][2] == 2                 # matrix cores vs VALU fallback
+            if not os.environ.get("MTM_SLAB_MFMA") and not os.environ.get("MTM_TEMPL_ON_DEVICE"):
+                assert res["auto"][2] == 3 and res["dot4"][2] == 2             # matrix cores vs VALU fallback
             assert res["auto"][0] == res["dot4"][0] and len(res["auto"][0]) >= 1, (len(lt), method)
             assert np.array_equal(res["auto"][1], res["dot4"][1])
         map_close(res["auto"][1], O.compute_score_map(lt[-1][1], im, 1), tol=1e-6)
