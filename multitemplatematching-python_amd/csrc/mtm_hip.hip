@@ -1302,6 +1302,16 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                           ncc_mfma_kernel<2, 4, X, false, true, 3, true>, ncc_mfma_kernel<2, 5, X, false, true, 3, true>}
         static const MfmaFn kMfmaRmExtC3Fns[2][6] = {MTM_MF_RMEXTC3(false), MTM_MF_RMEXTC3(true)};
 #undef MTM_MF_RMEXTC3
+        // fused global extremum of masked classes (binary uint8 mask, methods 0..3; reciprocal-normalisation builds only:
+        // MTM_OPT_EXACT_DIV calls keep the maps + extremum_kernel route)
+#define MTM_MF_EXTM(MB) {ncc_mfma_kernel<MB, 0, false, true, false, 1, true>, ncc_mfma_kernel<MB, 1, false, true, false, 1, true>,   \
+                        ncc_mfma_kernel<MB, 2, false, true, false, 1, true>, ncc_mfma_kernel<MB, 3, false, true, false, 1, true>}
+        static const MfmaFn kMfmaExtMaskedFns[2][4] = {MTM_MF_EXTM(1), MTM_MF_EXTM(2)};
+#undef MTM_MF_EXTM
+        static const MfmaFn kMfmaRmExtMaskedFns[4] = {ncc_mfma_kernel<2, 0, false, true, true, 1, true>,
+                                                      ncc_mfma_kernel<2, 1, false, true, true, 1, true>,
+                                                      ncc_mfma_kernel<2, 2, false, true, true, 1, true>,
+                                                      ncc_mfma_kernel<2, 3, false, true, true, 1, true>};
         // two-row variant (methods 2..5), plain and with the fused global extremum
 #define MTM_MF_R2(X, E) {ncc_mfma_kernel<2, 2, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 3, X, false, false, 1, E, true>,   \
                         ncc_mfma_kernel<2, 4, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 5, X, false, false, 1, E, true>}
@@ -1311,6 +1321,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
         const int xd = c->exact_div ? 1 : 0;
         const MfmaFn fn = r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
+                        : (ext && sc.masked) ? (rm ? kMfmaRmExtMaskedFns[c->method] : kMfmaExtMaskedFns[mb - 1][c->method])
                         : (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
                         : ext ? (c->chans == 3 ? kMfmaExtC3Fns[xd][mb - 1][c->method] : kMfmaExtFns[xd][mb - 1][c->method])
                         : (rm && c->chans == 3) ? kMfmaRmC3Fns[c->exact_div ? 1 : 0][c->method]
@@ -2514,7 +2525,8 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3)) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
-            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && !sc.masked && sc.slabs.empty();
+            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() &&
+                 (!sc.masked || (!c->exact_div && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED));
         if (ok) {
             MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
             HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)n, c->stream));

@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                           unsigned int* __restrict__ sched) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
-    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && !MASKED), "fused extremum: unmasked compile-time-method paths");
+    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw), "fused extremum: compile-time-method paths");
     static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

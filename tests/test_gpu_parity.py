@@ -1361,6 +1361,36 @@ def test_fused_global_extremum(mtm, n_templ, row_mux):
 # mtm_find_matches_async / _wait == mtm_find_matches (the same call split at its first synchronisation)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
+def test_fused_global_extremum_masked(mtm, ctx, coins):
+    """N_object == 1 on masked classes (binary uint8 masks, methods 0..3): the per-template extremum comes out of the
+    score kernel's epilogue (no maps, no extremum_kernel) - same record as the maps + extremum_kernel route and as the
+    oracle, for row-multiplexed (<= 16 templates) and plain (> 16) classes."""
+    from MTM import _lib
+    small, big = coin_templates(coins)
+    m_small, m_big = otsu_mask(small), ((big > 120) * 255).astype(np.uint8)
+    few = [("s", small, m_small), ("b", big, m_big), ("s2", np.ascontiguousarray(small[::-1]), m_small)]
+    many = [("t%d" % k, np.ascontiguousarray(coins[5 * k:5 * k + 30, 7 * k:7 * k + 34]), ((coins[5 * k:5 * k + 30, 7 * k:7 * k + 34] > 90) * 255).astype(np.uint8))
+            for k in range(5)]
+    many = many + [("u%d" % k, np.ascontiguousarray(coins[40 + 3 * k:70 + 3 * k, 100 + 4 * k:134 + 4 * k]), many[0][2]) for k in range(19)]   # 20 share a mask
+    for lt in (few, many):
+        for method in (0, 1, 2, 3):
+            res = []
+            for honly in (1, 0):
+                ctx.set_option(_lib.OPT_HITS_ONLY, honly)
+                try:
+                    res.append(mtm.findMatches(lt, coins, method=method, N_object=1))
+                    res.append(ctx.timing()["hits_only"])
+                finally:
+                    ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+            assert res[0] == res[2] and len(res[0]) == len(lt), (method, len(lt))
+            if not any(os.environ.get(k) for k in ("MTM_EXACT_DIV", "MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY")):
+                assert res[1] == 1 and res[3] == 0            # fused route really ran
+            exp = O.find_matches(lt, coins, method=method, N_object=1)
+            assert [(h[0], h[1]) for h in res[0]] == [(h[0], h[1]) for h in exp]
+            assert_hits_equal(res[0], hits_json(exp), tol=1e-5)
+
+
+@pytest.mark.gpu
 def test_find_matches_async(mtm, coins):
     lib = mtm._lib
     small, big = coin_templates(coins)
