@@ -65,6 +65,10 @@ extern "C" {
 #define MTM_KERNEL_MFMA16 4  /* reported in mtm_timing.kernel_used only: uint16 pixels as four byte-plane
                                 correlations on the MFMA kernel (selected by MTM_KERNEL_AUTO / _MFMA) */
 
+#define MTM_KERNEL_MFMA_F32 5 /* reported in mtm_timing.kernel_used only: float32 pixels as two bfloat16 pieces on the
+                                bf16 matrix cores, ~1e-5 of the normalised score (selected by MTM_KERNEL_AUTO /
+                                _MFMA for unmasked float32 image + templates; MTM_F32_MFMA=0: float64 kernel) */
+
 #define MTM_OPT_KERNEL      1
 #define MTM_OPT_PEAK_BORDER 2
 #define MTM_OPT_HIT_CAPACITY 3

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
 STAMP = LIB + ".stamp"
 SOURCES = ["mtm_hip.hip", "mtm_host.cpp", "mtm_group.cpp"]
-DEPS = SOURCES + ["mtm_device.hip.h", "mtm_mfma.hip.h", "mtm_templates.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
+DEPS = SOURCES + ["mtm_device.hip.h", "mtm_mfma.hip.h", "mtm_templates.hip.h", "mtm_bf16.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
                   os.path.join("..", "..", "include", "mtm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default"]

@@ -1,0 +1,238 @@
+// float32 images on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).
+//
+// The reference casts every non-uint8 input to float32 and lets cv2 correlate it with a float64 DFT
+// (MTM/__init__.py:71-74 -> cv2.matchTemplate, :92).  The exact float64 VALU kernel (ncc_f64_kernel) reproduces that
+// to rounding but runs at the fp64 vector rate - 50 ms at 4K x 32 templates against 0.7 ms for uint8.  This kernel
+// computes the same sliding dot products on the matrix cores to ~1e-5 of the normalised score (north_star's
+// tolerance is 1e-4):
+//
+//   * every float is split into two bfloat16 pieces, v = v0 + v1 (v0 = RNE(v), v1 = RNE(v - v0): 16 significant
+//     bits), and  I*T ~ I0*T0 + I0*T1 + I1*T0  - three bf16 MFMAs into one float32 accumulator; the dropped terms are
+//     <= 2^-17 |I||T| each;
+//   * what makes 16 bits enough is CENTRING, which is free: templates are packed as Tc = T - mean(T), so
+//     sum I*T = sum I*Tc + mean(T)*S1 with S1 the (float64) window sum the statistics pass provides, and because
+//     sum(Tc) = 0 ANY constant may be subtracted from the image inside a window without changing sum I*Tc.  A
+//     work-group subtracts the mean of a sample of its own image tile while it stages the tile, so the pieces
+//     carry the local contrast, not the local brightness;
+//   * float32 accumulation of 128 MFMA results per 64 x 64 template (the K = 32 sums inside an MFMA are exact
+//     products added in wide precision): ~1e-6 relative.
+//
+// GEMM mapping as in ncc_mfma_kernel with 2-byte elements: one MFMA = 16 templates x 16 pixels x 32 taps; the 16
+// pixels of an MFMA are 8 apart (x_j = x0 + 8 j + c, phase c = 0..7), all 8 phases of a lane read the same two
+// aligned 16-byte LDS chunks of a piece plane, shifted by c elements: even c are whole-dword shifts, odd c one
+// v_alignbyte_b32 by 2 bytes.  A wave owns 128 consecutive pixels of one output row for 16 * MB templates
+// (32 * MB accumulator VGPRs); a work-group = 4 waves = 4 rows sharing the two piece tiles.
+// Unmasked templates only (float masks keep the float64 kernel); w <= 256.
+#pragma once
+#include "mtm_device.hip.h"
+
+namespace mtm {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i_b __attribute__((ext_vector_type(4)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+constexpr int kBfSeg = 128;          // output pixels per wave (8 phases x 16 columns)
+constexpr int kBfRows = 4;           // output rows per work-group
+constexpr int kBfMaxW = 256;
+
+struct Bf16Params {
+    const float* img;        // planar padded float32 image
+    int pitch;               // floats per row
+    long long plane;         // floats per plane
+    int chans;
+    int rows, cols;          // image size (the planes are zero padded beyond it)
+    int h, w, oh, ow;
+    int nkb;                 // 32-tap blocks per template row
+    int chunk_h;             // template rows per LDS tile
+    int lds_cols;            // elements per tile row: 128 + 32 * nkb
+    int n_list;
+    int nseg, nyb, ntg, n_work;
+    int method;
+    long long group_bytes;   // bytes of one 16-template pack of ONE piece: chans * h * nkb * 1024
+    long long piece_bytes;   // bytes between the T0 packs and the T1 packs
+    int only_li;
+    // fused peak candidates / hits-only, as in the other score kernels
+    mtm_hit* cand_hits;
+    unsigned long long* cand_counter;
+    unsigned long long cand_cap;
+    float cand_thr;
+    int cand_min, cand_on, hits_only;
+};
+
+// round-to-nearest-even bfloat16 bits of a finite float
+__device__ __forceinline__ uint32_t bf16_rne(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
+}
+__host__ __device__ inline float bf16_to_float(uint32_t h) {
+    const uint32_t b = h << 16;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+
+template <int MB>
+__global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const TemplDev* __restrict__ td,
+                                                          const int* __restrict__ tlist,
+                                                          const uint8_t* __restrict__ apack, StatPlanes st,
+                                                          float* __restrict__ maps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_bf[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const int per_xcd = (p.n_work + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= p.n_work) return;
+    const int tg = wid % p.ntg;
+    const int rest = wid / p.ntg;
+    const int seg = rest % p.nseg, yb = rest / p.nseg;
+    const int x0 = seg * kBfSeg, y0 = yb * kBfRows;
+
+    v4f acc[MB][8];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[mb][c] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    const int row_bytes = p.lds_cols * 2;
+    const int tile_rows_max = p.chunk_h + kBfRows - 1;
+    uint8_t* thi = smem_bf;
+    uint8_t* tlo = smem_bf + (size_t)tile_rows_max * row_bytes;
+    float* s_mu = reinterpret_cast<float*>(smem_bf + 2 * (size_t)tile_rows_max * row_bytes);
+    const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
+
+    for (int c = 0; c < p.chans; ++c) {
+        const float* plane = p.img + c * p.plane;
+        // The constant subtracted from this channel's pixels: the mean of an 8 x 8 sample grid over the work item's whole
+        // image patch.  ANY constant is exact - but it must be ONE constant for all rows of the template (the taps
+        // of a channel sum to zero only over the whole template, not over a chunk of its rows); the mean is the
+        // accurate one.
+        __syncthreads();                        // previous channel's tile fully consumed (s_mu is rewritten)
+        if (wave == 0) {
+            // (samples are clamped into the image: the zero padding beyond it would drag the constant away from the
+            // pixels that matter, and the pieces would spend their bits on the difference)
+            const int sr = min(y0 + (lane >> 3) * (p.h + kBfRows - 2) / 7, p.rows - 1);
+            const int sc = min(x0 + (lane & 7) * (p.lds_cols - 1) / 7, p.cols - 1);
+            float v = plane[(size_t)sr * p.pitch + sc];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) *s_mu = v * (1.0f / 64.0f);
+        }
+        __syncthreads();
+        const float mu = *s_mu;
+        for (int cy0 = 0; cy0 < p.h; cy0 += p.chunk_h) {
+            const int ch = min(p.chunk_h, p.h - cy0);
+            const int trows = ch + kBfRows - 1;
+            const float* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
+            __syncthreads();                    // previous tile fully consumed
+            // stage: two adjacent pixels per thread and step -> one dword per piece plane
+            const int pairs = p.lds_cols >> 1;
+            for (int e = threadIdx.x; e < trows * pairs; e += 256) {
+                const int r = e / pairs, cp = e - r * pairs;
+                const float2 v = *reinterpret_cast<const float2*>(grow + (size_t)r * p.pitch + 2 * cp);
+                const float a = v.x - mu, b = v.y - mu;
+                const uint32_t a0 = bf16_rne(a), b0 = bf16_rne(b);
+                const uint32_t a1 = bf16_rne(a - bf16_to_float(a0)), b1 = bf16_rne(b - bf16_to_float(b0));
+                *reinterpret_cast<uint32_t*>(thi + (size_t)r * row_bytes + 4 * cp) = a0 | (b0 << 16);
+                *reinterpret_cast<uint32_t*>(tlo + (size_t)r * row_bytes + 4 * cp) = a1 | (b1 << 16);
+            }
+            __syncthreads();
+            // K loop: template rows of this chunk x 32-tap blocks
+            const uint8_t* aptr = apack_g + ((size_t)(c * p.h + cy0) * p.nkb) * 1024;
+            const int lane_off = wave * row_bytes + (j + q) * 16;
+            for (int dy = 0; dy < ch; ++dy) {
+                for (int kb = 0; kb < p.nkb; ++kb) {
+                    const int off = lane_off + dy * row_bytes + kb * 64;
+                    const v4i_b h0 = *reinterpret_cast<const v4i_b*>(thi + off);
+                    const v4i_b h1 = *reinterpret_cast<const v4i_b*>(thi + off + 16);
+                    const v4i_b l0 = *reinterpret_cast<const v4i_b*>(tlo + off);
+                    const v4i_b l1 = *reinterpret_cast<const v4i_b*>(tlo + off + 16);
+                    v4i_b a0[MB], a1[MB];
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        a0[mb] = *reinterpret_cast<const v4i_b*>(aptr + mb * p.group_bytes);
+                        a1[mb] = *reinterpret_cast<const v4i_b*>(aptr + p.piece_bytes + mb * p.group_bytes);
+                    }
+                    aptr += 1024;
+                    const int W[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                    const int V[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+                    int EW[7], EV[7];
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) {
+                        EW[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)W[m + 1], (uint32_t)W[m], 2);
+                        EV[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)V[m + 1], (uint32_t)V[m], 2);
+                    }
+#pragma unroll
+                    for (int ph = 0; ph < 8; ++ph) {
+                        const int k = ph >> 1;
+                        const v4i_b bh = (ph & 1) ? v4i_b{EW[k], EW[k + 1], EW[k + 2], EW[k + 3]} : v4i_b{W[k], W[k + 1], W[k + 2], W[k + 3]};
+                        const v4i_b bl = (ph & 1) ? v4i_b{EV[k], EV[k + 1], EV[k + 2], EV[k + 3]} : v4i_b{V[k], V[k + 1], V[k + 2], V[k + 3]};
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            v4f a = acc[mb][ph];
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
+                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bl), a, 0, 0, 0);
+                            acc[mb][ph] = a;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane (j, q) holds pixels x0 + 8 j + 0..7 of row y for templates 16 mb + 4 q + e
+    const int y = y0 + wave;
+    const int xq = x0 + 8 * j;
+    if (y >= p.oh || xq >= p.ow) return;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int li = tg * MB * 16 + mb * 16 + 4 * q + e;
+            if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;
+            const int tglob = tlist[li];
+            const TemplDev T = td[tglob];
+            float out[8];
+#pragma unroll
+            for (int ph = 0; ph < 8; ++ph) {
+                const int x = min(xq + ph, p.ow - 1);
+                const size_t sidx = (size_t)y * st.pitch + x;
+                double corr = (double)acc[mb][ph][e];
+                for (int cc = 0; cc < p.chans; ++cc) corr += T.centre[cc] * st.t[cc][sidx];
+                out[ph] = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
+            }
+            if (p.cand_on) {
+#pragma unroll
+                for (int ph = 0; ph < 8; ++ph) {
+                    const float v = p.cand_min ? -out[ph] : out[ph];
+                    if (xq + ph < p.ow && v > p.cand_thr) {
+                        const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+                        if (slot < p.cand_cap) {
+                            mtm_hit hrec;
+                            hrec.templ_idx = tglob;
+                            hrec.x = xq + ph;
+                            hrec.y = y;
+                            hrec.w = p.w;
+                            hrec.h = p.h;
+                            hrec.score = out[ph];
+                            p.cand_hits[slot] = hrec;
+                        }
+                    }
+                }
+            }
+            if (!p.hits_only) {
+                float* orow = maps + T.map_off + (size_t)y * T.map_pitch + xq;
+                if (xq + 7 < p.ow) {
+                    *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
+                    *reinterpret_cast<float4*>(orow + 4) = make_float4(out[4], out[5], out[6], out[7]);
+                } else {
+#pragma unroll
+                    for (int ph = 0; ph < 8; ++ph)
+                        if (xq + ph < p.ow) orow[ph] = out[ph];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace mtm

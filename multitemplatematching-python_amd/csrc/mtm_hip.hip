@@ -18,6 +18,7 @@
 #include "mtm_device.hip.h"
 #include "mtm_mfma.hip.h"
 #include "mtm_templates.hip.h"
+#include "mtm_bf16.hip.h"
 #include "mtm_internal.h"
 
 using namespace mtm;
@@ -96,6 +97,8 @@ struct SizeClass {
     bool masked = false;
     bool all_u8 = true;
     bool all_u16 = true;
+    bool all_f32 = true;
+    bool bf16_ok = false;       // float32 class on the bf16 matrix cores (ncc_bf16_kernel)
     bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
     int rm_nt = 0, rm_R = 0;    // > 0: row-multiplexed MFMA mode (<= 16 templates: nt x R = 16 A rows)
     // large templates (w > 256 or w*h*C > 131071) on the MFMA kernel: cut into slabs (slab_combine_kernel)
@@ -185,6 +188,7 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int f32_mfma = 1;                       // MTM_F32_MFMA: unmasked float32 classes on the bf16 matrix cores
     int mfma_r2 = 1;                        // MTM_MFMA_R2: two-row variant of the MFMA kernel where it applies
     int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
                                             // streams (their tails overlap; per-launch durations then overlap too)
@@ -388,6 +392,52 @@ bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
            (long long)sc.w * sc.h <= 131071;
 }
 
+// float32 image + float32 templates, no mask: two bfloat16 pieces per value on the bf16 matrix cores
+bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
+    return c->f32_mfma && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW;
+}
+inline int bf16_nkb(int w) { return (w + 31) / 32; }
+long long bf16_group_bytes(int h, int w, int chans) { return (long long)chans * h * bf16_nkb(w) * 1024; }
+
+// A packs of a float32 class for ncc_bf16_kernel: [piece 0 | piece 1][group of 16][ch][dy][32-tap block][lane = 16 q + i]
+// [8 bf16]: lane (i, q) holds taps 32 kb + 8 q .. + 7 of template i, centred by its channel mean and split
+// v = v0 + v1 (bfloat16, round to nearest even).  centre[] receives the means (TemplDev::centre).
+void pack_class_bf16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, std::vector<TemplDev>& td_host) {
+    const int h = sc.h, w = sc.w, nkb = bf16_nkb(w), chans = c->chans;
+    const long long gb = bf16_group_bytes(h, w, chans);
+    const int groups = mfma_groups_alloc((int)sc.members.size());
+    const long long piece = gb * groups;
+    std::memset(out, 0, (size_t)(2 * piece));
+    auto rne = [](float v) {
+        uint32_t b;
+        std::memcpy(&b, &v, 4);
+        return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+    };
+    for (size_t li = 0; li < sc.members.size(); ++li) {
+        const HostTempl& t = c->templs[sc.members[li]];
+        TemplDev& d = td_host[(size_t)sc.members[li]];
+        uint8_t* g = out + (li / 16) * gb;
+        const int i = (int)(li % 16);
+        const size_t plane = (size_t)h * w;
+        for (int ch = 0; ch < chans; ++ch) {
+            double mean = 0.0;
+            for (size_t k = 0; k < plane; ++k) mean += t.px[ch * plane + k];
+            mean /= (double)plane;
+            d.centre[ch] = mean;
+            for (int dy = 0; dy < h; ++dy)
+                for (int dx = 0; dx < w; ++dx) {
+                    const float v = (float)(t.px[ch * plane + (size_t)dy * w + dx] - mean);
+                    const uint16_t v0 = rne(v);
+                    const uint16_t v1 = rne(v - bf16_to_float(v0));
+                    const int kb = dx / 32, q = (dx % 32) / 8, e = dx % 8;
+                    const size_t o = ((((size_t)ch * h + dy) * nkb + kb) * 64 + (16 * q + i)) * 16 + 2 * e;
+                    std::memcpy(g + o, &v0, 2);
+                    std::memcpy(g + piece + o, &v1, 2);
+                }
+        }
+    }
+}
+
 // A packs of a uint16 class: 2 * n_pad pseudo-templates, [high bytes of member 0..n_pad-1][low bytes ...],
 // same lane order as pack_class_mfma.  Also the byte sums of every member (bias terms of the combine).
 void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, double* tsum) {
@@ -557,6 +607,7 @@ int place_templates(mtm_ctx* c) {
     for (size_t k = 0; k < classes.size(); ++k) {
         classes[k].mfma_ok = mfma_class_ok(c, classes[k]);
         classes[k].mfma16_ok = mfma16_class_ok(c, classes[k]);
+        classes[k].bf16_ok = bf16_class_ok(c, classes[k]);
         classes[k].n_pad = (int)round_up(classes[k].members.size(), 16);
         class_kernel[k] = resolved_kernel(c, classes[k]);
         // row-multiplexed mode: uint8 class of <= 16 templates (one channel, masked or not, or unmasked RGB) whose
@@ -729,6 +780,13 @@ int place_templates(mtm_ctx* c) {
         sc.apack_off = (long long)a_off;
         a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
     }
+    for (size_t k = 0; k < classes.size(); ++k) {
+        SizeClass& sc = classes[k];
+        if (class_kernel[k] != MTM_KERNEL_MFMA_F32) continue;
+        sc.group_bytes = bf16_group_bytes(sc.h, sc.w, c->chans);
+        sc.apack_off = (long long)a_off;
+        a_off += (size_t)(2 * sc.group_bytes * mfma_groups_alloc((int)sc.members.size()));
+    }
     size_t ts_off = 0;
     for (size_t k = 0; k < classes.size(); ++k) {
         SizeClass& sc = classes[k];
@@ -744,7 +802,8 @@ int place_templates(mtm_ctx* c) {
     std::vector<char> dev_pack(classes.size(), 0);
     bool any_host_pack = false;
     for (size_t k = 0; k < classes.size(); ++k) {
-        if (class_kernel[k] != MTM_KERNEL_MFMA && class_kernel[k] != MTM_KERNEL_MFMA16) continue;
+        if (class_kernel[k] != MTM_KERNEL_MFMA && class_kernel[k] != MTM_KERNEL_MFMA16 && class_kernel[k] != MTM_KERNEL_MFMA_F32)
+            continue;
         bool all_dev = class_kernel[k] == MTM_KERNEL_MFMA;
         for (int m : classes[k].members) all_dev = all_dev && c->templs[(size_t)m].on_device;
         dev_pack[k] = all_dev ? 1 : 0;
@@ -764,6 +823,7 @@ int place_templates(mtm_ctx* c) {
             pack_class_mfma(c, classes[k], apacks.data() + classes[k].apack_off);
         if (class_kernel[k] == MTM_KERNEL_MFMA16)
             pack_class_mfma16(c, classes[k], apacks.data() + classes[k].apack_off, tsums.data() + classes[k].tsum_off);
+        if (class_kernel[k] == MTM_KERNEL_MFMA_F32) pack_class_bf16(c, classes[k], apacks.data() + classes[k].apack_off, td_host);
     }
     // template lists: one per class, then the list of templates with a 2-D score map
     for (SizeClass& sc : classes) {
@@ -844,7 +904,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
     st.pitch = (int)round_up((size_t)ow, 4);
     *out = st;
     const int rk = resolved_kernel(c, sc);
-    const bool want_t_always = rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16;
+    const bool want_t_always = rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16 || rk == MTM_KERNEL_MFMA_F32;
     const bool masked_mfma = sc.masked && rk == MTM_KERNEL_MFMA;
     if ((sc.masked && !masked_mfma) || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // none needed
     const int num_type = masked_mfma ? 0
@@ -1440,6 +1500,55 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         hipLaunchKernelGGL(ncc16_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
                            c->tlist.as<int>() + sc.tlist_off, ts, ts + n_pad, st, maps, only_li);
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
+    } else if (kernel == MTM_KERNEL_MFMA_F32) {
+        const int n_all = (int)sc.members.size();
+        const int mb = n_all > 16 ? 2 : 1;
+        Bf16Params p{};
+        p.img = img.f32;
+        p.pitch = img.f32_pitch;
+        p.plane = img.f32_plane;
+        p.chans = c->chans;
+        p.rows = c->rows;
+        p.cols = c->cols;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nkb = bf16_nkb(w);
+        p.chunk_h = p.nkb <= 2 ? 64 : 32;
+        p.lds_cols = kBfSeg + 32 * p.nkb;
+        p.n_list = n_all;
+        p.nseg = (ow + kBfSeg - 1) / kBfSeg;
+        p.nyb = (oh + kBfRows - 1) / kBfRows;
+        p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
+        p.method = c->method;
+        p.group_bytes = sc.group_bytes;
+        p.piece_bytes = sc.group_bytes * mfma_groups_alloc(n_all);
+        p.only_li = only_li;
+        int tg0 = 0;
+        if (only_li >= 0) {
+            tg0 = only_li / (16 * mb);
+            p.ntg = 1;
+            p.n_list = n_all - tg0 * 16 * mb;
+            p.only_li = only_li - tg0 * 16 * mb;
+        }
+        p.n_work = p.nseg * p.nyb * p.ntg;
+        p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.cand_min = c->cand_min ? 1 : 0;
+        p.cand_thr = c->cand_thr;
+        p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        p.cand_counter = c->cands.as<unsigned long long>();
+        p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        const size_t lds = 2 * (size_t)(p.chunk_h + kBfRows - 1) * p.lds_cols * 2 + 16;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
+        const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16 * mb;
+        if (mb == 2)
+            hipLaunchKernelGGL(ncc_bf16_kernel<2>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        else
+            hipLaunchKernelGGL(ncc_bf16_kernel<1>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        c->timing.kernel_used = MTM_KERNEL_MFMA_F32;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
         const DotVariant& v = kDotVariants[wide ? kDotWideVariant : c->dot_variant];
@@ -1484,6 +1593,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
 int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
     const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
     int kernel = c->opt_kernel;
+    if (c->dtype == MTM_F32) {
+        if ((kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) && sc.bf16_ok) return MTM_KERNEL_MFMA_F32;
+        return kernel == MTM_KERNEL_NAIVE ? MTM_KERNEL_NAIVE : MTM_KERNEL_AUTO;
+    }
     if (c->dtype == MTM_U16) {
         if ((kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) && sc.mfma16_ok) return MTM_KERNEL_MFMA16;
         return kernel == MTM_KERNEL_NAIVE ? MTM_KERNEL_NAIVE : MTM_KERNEL_AUTO;
@@ -1597,6 +1710,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
@@ -2262,6 +2376,7 @@ int set_templates_impl(mtm_ctx* c, const mtm_templ* templs, int n_templ, const m
         sc.members.push_back(i);
         sc.all_u8 = sc.all_u8 && hts[i].dtype == MTM_U8;
         sc.all_u16 = sc.all_u16 && hts[i].dtype == MTM_U16;
+        sc.all_f32 = sc.all_f32 && hts[i].dtype == MTM_F32;
         hts[i].cls = it->second;
     }
     c->templs.swap(hts);
@@ -2515,7 +2630,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
     for (const SizeClass& sc : c->classes) {
         const int rk = resolved_kernel(c, sc);
-        fused = fused && (rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16);
+        fused = fused && (rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16 || rk == MTM_KERNEL_MFMA_F32);
     }
     c->cand_on = false;
     c->hits_only_now = false;

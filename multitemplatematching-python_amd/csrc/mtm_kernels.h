@@ -18,6 +18,8 @@ struct TemplDev {
     double templ_sum2;
     double templ2_mask2_sum;
     double mfma_k;          // 128*sum(T) - 16384*w*h*C: bias correction of the int8 MFMA path
+    double centre[kMaxChans];   // float32 templates on the bf16 matrix cores: the per-channel mean the packed template
+                                // was centred by (sum I*T = sum I*(T - centre) + centre * S1)
     long long map_off;      // float offset of this template's score map in the map arena
     long long k1_off;       // double offset of K1 (T, or T*M^2) in the weight arena, planar [C][h][w]
     long long k2_off;       // double offset of K2 (M^2) or -1

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the uint8, uint16 (byte-plane MFMA) and float32 (float64 kernel) paths at 1080p x 8 and 4K x 32 (GPU box)."""
+"""Timing of the uint8, uint16 (byte-plane MFMA) and float32 (bf16-piece MFMA kernel; MTM_F32_MFMA=0: float64 kernel)
+paths at 1080p x 8 and 4K x 32 (GPU box)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
