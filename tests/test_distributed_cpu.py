@@ -109,3 +109,34 @@ def test_two_rank_exchange_matches_single_process(backend):
     exp = O.match_templates(units, img, score_threshold=0.4, maxOverlap=0.25)
     key = lambda h: (-float(h[2]), h[0], tuple(h[1]))    # noqa: E731
     assert sorted(res[0], key=key) == sorted([(h[0], tuple(h[1]), float(h[2])) for h in exp], key=key)
+
+
+def _store_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
+    from MTM.distributed import TcpStore
+    st = TcpStore(rank, world, addr="127.0.0.1", port=port)
+    try:
+        uid = st.broadcast(b"id-from-rank-0" * 9 if rank == 0 else None)
+        parts = st.allgather(bytes([rank]) * (rank * 1000 + 3))
+        parts2 = st.allgather(b"")                      # empty payloads, second round on the same connections
+        q.put((rank, uid, [len(p) for p in parts], [p[:1] for p in parts], parts2))
+    finally:
+        st.close()
+
+
+def test_tcp_store_three_ranks():
+    """The package's own bootstrap / host exchange (no torch): broadcast of the RCCL id and a ragged all-gather."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_store_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, uid, lens, heads, parts2 in res:
+        assert uid == b"id-from-rank-0" * 9 and lens == [3, 1003, 2003] and heads == [b"\x00", b"\x01", b"\x02"]
+        assert parts2 == [b"", b"", b""]

@@ -169,3 +169,48 @@ def test_augment_helpers_and_downscaled_matching(mtm):
         assert got == exp and len(got) > 3
     with pytest.raises(ValueError, match="larger than image"):
         A.matchTemplatesDownscaled([("all", coins)], coins[:200], 2)
+
+
+def test_augmentation_spec_and_host_expansion(mtm):
+    """MTM.augment.variants / expand (the host reference of mtm_set_templates_augmented): order, labels and pixels of
+    the copies; resize_area is the exact area average (identity, integer factors = block means rounded half up)."""
+    A = mtm.augment
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (12, 20), dtype=np.uint8)
+    m = (a > 100).astype(np.uint8) * 255
+    spec = A.variants(angles=(0, 90, 180, 270))
+    assert [s for s, _ in spec] == ["_0", "_90", "_180", "_270"]
+    ex = A.expand([("t", a, m)], spec)
+    assert [e[0] for e in ex] == ["t_0", "t_90", "t_180", "t_270"]
+    for k, e in enumerate(ex):
+        assert np.array_equal(e[1], np.rot90(a, k)) and np.array_equal(e[2], np.rot90(m, k)) and e[1].flags.c_contiguous
+    # the tutorial's own augmentation (rotations helper) is the same list
+    assert all(np.array_equal(x[1], y[1]) and x[0] == y[0] for x, y in zip(ex, A.rotations([("t", a, m)])))
+    spec = A.variants(flip_lr=True, flip_ud=True, sizes=((6, 10), 8), angles=(0, 90))
+    assert [s for s, _ in spec] == ["_s6x10_0", "_s6x10_90", "_s6x10_lr_0", "_s6x10_lr_90", "_s6x10_ud_0", "_s6x10_ud_90",
+                                    "_s8x8_0", "_s8x8_90", "_s8x8_lr_0", "_s8x8_lr_90", "_s8x8_ud_0", "_s8x8_ud_90"]
+    ex = A.expand([("t", a)], spec)
+    small = A.resize_area(a, 6, 10)
+    assert np.array_equal(ex[0][1], small) and np.array_equal(ex[3][1], np.rot90(np.fliplr(small)))
+    assert np.array_equal(ex[4][1], np.flipud(small)) and ex[7][1].shape == (8, 8)
+    # resize_area: identity; integer factors = block means rounded half up; constant images stay constant; RGB per channel
+    assert np.array_equal(A.resize_area(a, 12, 20), a)
+    blocks = a.reshape(6, 2, 10, 2).astype(np.int64).sum(axis=(1, 3))
+    assert np.array_equal(A.resize_area(a, 6, 10), ((2 * blocks + 4) // 8).astype(np.uint8))
+    assert np.array_equal(A.resize_area(np.full((7, 9), 201, np.uint8), 13, 4), np.full((13, 4), 201, np.uint8))
+    rgb = rng.integers(0, 256, (10, 14, 3), dtype=np.uint8)
+    up = A.resize_area(rgb, 15, 21)
+    assert up.shape == (15, 21, 3) and all(np.array_equal(up[..., c], A.resize_area(np.ascontiguousarray(rgb[..., c]), 15, 21)) for c in range(3))
+    # integer downscale factors go through MTM.augment.downscale (OpenCV's INTER_AREA rounding)
+    ex = A.expand([("t", a)], A.variants(factors=(1, 2)))
+    assert [e[0] for e in ex] == ["t_d1", "t_d2"] and np.array_equal(ex[0][1], a) and np.array_equal(ex[1][1], A.downscale(a, 2))
+    with pytest.raises(ValueError):
+        A.variants(angles=(45,))
+    with pytest.raises(ValueError):
+        A.variants(sizes=(8,), factors=(2,))
+    # matchTemplatesAugmented == matchTemplates(expand(...)) through the (oracle-backed) host pipeline for non-uint8 input
+    coins = load_coins().astype(np.float32)
+    small_t, _ = coin_templates(coins)
+    spec = A.variants(angles=(0, 180))
+    assert A.matchTemplatesAugmented([("s", small_t)], spec, coins, score_threshold=0.6) == \
+        mtm.matchTemplates(A.expand([("s", small_t)], spec), coins, score_threshold=0.6)
