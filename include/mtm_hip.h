@@ -277,7 +277,9 @@ int      mtm_group_last_hits(mtm_group* g, mtm_hit* out, int64_t capacity, int64
 int mtm_comm_unique_id(void* id_out /* MTM_COMM_ID_BYTES */);
 int mtm_comm_init(mtm_ctx* ctx, const void* id, int n_ranks, int rank);
 /* all-gather: every rank contributes n_local hits; out receives the concatenation in rank order.
- * counts_out[n_ranks] receives the per-rank counts.  Collective call. */
+ * counts_out[n_ranks] receives the per-rank counts.  Collective call with a deadline: if the other ranks do not
+ * arrive within MTM_COMM_TIMEOUT_S seconds (environment; default 300, 0 = wait for ever) the communicator is
+ * aborted (ncclCommAbort), the call returns MTM_E_COMM and the context goes back to single-rank operation. */
 int mtm_comm_allgather_hits(mtm_ctx* ctx, const mtm_hit* local, int64_t n_local,
                             mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out);
 /* The result of the last mtm_comm_allgather_hits again (no communication): the way to collect it after

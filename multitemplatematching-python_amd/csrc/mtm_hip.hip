@@ -6,13 +6,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
 #include <tuple>
-#include <unordered_map>
 #include <vector>
 
 #include "mtm_device.hip.h"
@@ -261,6 +262,9 @@ struct mtm_ctx {
     ncclComm_t comm = nullptr;
     int n_ranks = 1, rank = 0;
     long long comm_slot_hits = 512;
+    double comm_timeout_s = 300.0;      // deadline of one hit exchange (MTM_COMM_TIMEOUT_S; 0 = none)
+    std::vector<unsigned long long> vh_keys;   // host verification of the candidate list: open-addressing table
+    std::vector<int> vh_vals;
     DevBuf comm_send, comm_recv;
     std::vector<long long> comm_last_counts;   // per-rank counts of the last exchange (mtm_comm_last_gather)
     size_t comm_last_slot = 0;                 //   and its slot size in bytes; the slots are still in comm_pin
@@ -1711,6 +1715,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
+    if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
@@ -2799,12 +2804,30 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 // everything needed is on the host: clear the counter for the next call while this one finishes
                 if (hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess) c->cands_zeroed = c->cands.p;
                 const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(land + 16);
-                std::unordered_map<unsigned long long, int> where;
-                where.reserve((size_t)ncand * 2 + 8);
+                // open-addressing table over the candidates (key -> index), kept in the context between calls
+                size_t tsize = 64;
+                while (tsize < 2 * (size_t)ncand + 8) tsize <<= 1;
+                std::vector<unsigned long long>& hk = c->vh_keys;
+                std::vector<int>& hv = c->vh_vals;
+                hk.assign(tsize, 0ull);
+                hv.resize(tsize);
+                const size_t tmask = tsize - 1;
                 auto key = [](int t, int y, int x) {
                     return ((unsigned long long)(t + 1) << 42) | ((unsigned long long)y << 21) | (unsigned long long)x;
                 };
-                for (int i = 0; i < (int)ncand; ++i) where.emplace(key(cd[i].templ_idx, cd[i].y, cd[i].x), i);
+                auto slot_of = [&](unsigned long long k) {
+                    size_t sidx = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & tmask;
+                    while (hk[sidx] != 0ull && hk[sidx] != k) sidx = (sidx + 1) & tmask;
+                    return sidx;
+                };
+                for (int i = 0; i < (int)ncand; ++i) {
+                    const unsigned long long k = key(cd[i].templ_idx, cd[i].y, cd[i].x);
+                    const size_t sidx = slot_of(k);
+                    if (hk[sidx] == 0ull) {         // (a pixel is listed once; keep the first if it ever were not)
+                        hk[sidx] = k;
+                        hv[sidx] = i;
+                    }
+                }
                 const float padv = (c->opt_border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
                 for (int i = 0; i < (int)ncand; ++i) {
                     const mtm_hit& h = cd[i];
@@ -2819,8 +2842,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                                 mx = fmaxf(mx, padv);
                                 continue;
                             }
-                            const auto it = where.find(key(h.templ_idx, yy, xx));
-                            if (it != where.end()) mx = fmaxf(mx, mode_min ? -cd[it->second].score : cd[it->second].score);
+                            const size_t sidx = slot_of(key(h.templ_idx, yy, xx));
+                            if (hk[sidx] != 0ull) mx = fmaxf(mx, mode_min ? -cd[hv[sidx]].score : cd[hv[sidx]].score);
                         }
                     if (v == mx) {
                         hits.push_back(h);
@@ -3083,6 +3106,7 @@ struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -3102,6 +3126,7 @@ int load_rccl() {
     g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(lib, "ncclAllGather"));
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(lib, "ncclCommAbort"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         set_error("librccl.so lacks an expected symbol");
@@ -3191,7 +3216,31 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
         HIPC(hipMemcpyAsync(c->comm_send.p, mine, mine_bytes, hipMemcpyHostToDevice, c->stream));
         NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream));
         HIPC(hipMemcpyAsync(gathered, c->comm_recv.p, slot * R, hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
+        // A rank that never arrives (crashed, or took another branch) must not hang the others for ever: the
+        // exchange has a deadline (MTM_COMM_TIMEOUT_S, default 300 s; 0 = wait without limit), after which the
+        // communicator is aborted - the queued collective is cancelled, the context stays usable without it.
+        if (c->comm_timeout_s > 0.0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t qs;
+            int spins = 0;
+            while ((qs = hipStreamQuery(c->stream)) == hipErrorNotReady) {
+                if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->comm_timeout_s) {
+                    if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+                    else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+                    c->comm = nullptr;
+                    c->n_ranks = 1;
+                    c->rank = 0;
+                    (void)hipStreamSynchronize(c->stream);
+                    set_error("mtm_comm_allgather_hits: no answer from the other ranks within the deadline "
+                              "(MTM_COMM_TIMEOUT_S); communicator aborted");
+                    return MTM_E_COMM;
+                }
+            }
+            HIPC(qs);
+        } else {
+            HIPC(hipStreamSynchronize(c->stream));
+        }
         all = gathered;
         long long mx = 0;
         for (int r = 0; r < R; ++r) {
