@@ -60,6 +60,15 @@ struct Bf16Params {
     int cand_min, cand_on, hits_only;
 };
 
+// Per-template constants of a work item, staged in LDS once (the epilogue reads them as LDS broadcasts).
+struct BfTemplConst {
+    double mean[kMaxChans];
+    double centre[kMaxChans];
+    double templ_norm, templ_sum2;
+    long long map_off;
+    int map_pitch, all_ones, tglob, pad_;
+};
+
 // round-to-nearest-even bfloat16 bits of a finite float
 __device__ __forceinline__ uint32_t bf16_rne(float v) {
     const uint32_t b = __float_as_uint(v);
@@ -70,6 +79,69 @@ __host__ __device__ inline float bf16_to_float(uint32_t h) {
     float f;
     __builtin_memcpy(&f, &b, 4);
     return f;
+}
+
+// finish_unmasked on values already in registers (same arithmetic, same order)
+__device__ __forceinline__ float bf_finish(int method, double corr, const double (&t)[kMaxChans], double sum2, double sq,
+                                           const BfTemplConst& T, int chans) {
+    if (T.all_ones) return 1.0f;
+    if (method == MTM_TM_CCORR) return (float)corr;
+    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    const bool normed = (method == MTM_TM_SQDIFF_NORMED) || (method == MTM_TM_CCORR_NORMED) ||
+                        (method == MTM_TM_CCOEFF_NORMED);
+    double num = corr;
+    if (num_type == 1) {
+#pragma unroll
+        for (int c = 0; c < kMaxChans; ++c)
+            if (c < chans) num -= t[c] * T.mean[c];
+    } else if (num_type == 2) {
+        num = sum2 - 2.0 * num + T.templ_sum2;
+        num = fmax(num, 0.0);
+    }
+    if (normed) {
+        const double tt = sq * T.templ_norm;
+        const double an = fabs(num);
+        if (an < tt) num = num / tt;
+        else if (an < tt * 1.125) num = (num > 0.0) ? 1.0 : -1.0;
+        else num = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
+    }
+    return (float)num;
+}
+
+// One K step: 32 taps x 8 phases x MB template groups x 3 piece products.  h0/h1 (l0/l1): the lane's two aligned
+// 16-byte chunks of the first (second) piece plane; a0 / a1: the packed template pieces.
+template <int MB>
+__device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const v4i_b h1, const v4i_b l0, const v4i_b l1,
+                                        const v4i_b (&a0)[MB], const v4i_b (&a1)[MB]) {
+    const int W[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const int V[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    int EW[7], EV[7];
+#pragma unroll
+    for (int m = 0; m < 7; ++m) {
+        EW[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)W[m + 1], (uint32_t)W[m], 2);
+        EV[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)V[m + 1], (uint32_t)V[m], 2);
+    }
+#pragma unroll
+    for (int ph = 0; ph < 8; ++ph) {
+        const int k = ph >> 1;
+        const v4i_b bh = (ph & 1) ? v4i_b{EW[k], EW[k + 1], EW[k + 2], EW[k + 3]} : v4i_b{W[k], W[k + 1], W[k + 2], W[k + 3]};
+        const v4i_b bl = (ph & 1) ? v4i_b{EV[k], EV[k + 1], EV[k + 2], EV[k + 3]} : v4i_b{V[k], V[k + 1], V[k + 2], V[k + 3]};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            v4f a = acc[mb][ph];
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bl), a, 0, 0, 0);
+            acc[mb][ph] = a;
+        }
+    }
+}
+
+// LDS: [piece tile 0][piece tile 1][16 B: the subtracted constant][32 BfTemplConst]; the K loop requests operands up
+// to two steps past a chunk (never used): those reads stay inside this allocation.
+__host__ __device__ inline size_t bf16_lds_bytes(int chunk_h, int lds_cols) {
+    return 2 * (size_t)(chunk_h + kBfRows - 1) * lds_cols * 2 + 16 + 32 * sizeof(BfTemplConst);
 }
 
 template <int MB>
@@ -99,7 +171,31 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     uint8_t* thi = smem_bf;
     uint8_t* tlo = smem_bf + (size_t)tile_rows_max * row_bytes;
     float* s_mu = reinterpret_cast<float*>(smem_bf + 2 * (size_t)tile_rows_max * row_bytes);
+    BfTemplConst* tcl = reinterpret_cast<BfTemplConst*>(smem_bf + 2 * (size_t)tile_rows_max * row_bytes + 16);
     const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
+
+    // per-template constants -> LDS (ordered before the epilogue by the staging barriers)
+    if (threadIdx.x < 16 * MB) {
+        const int li = tg * MB * 16 + threadIdx.x;
+        if (li < p.n_list) {
+            const int tglob = tlist[li];
+            const TemplDev& T = td[tglob];
+            BfTemplConst k;
+#pragma unroll
+            for (int cc = 0; cc < kMaxChans; ++cc) {
+                k.mean[cc] = T.mean[cc];
+                k.centre[cc] = T.centre[cc];
+            }
+            k.templ_norm = T.templ_norm;
+            k.templ_sum2 = T.templ_sum2;
+            k.map_off = T.map_off;
+            k.map_pitch = T.map_pitch;
+            k.all_ones = T.all_ones;
+            k.tglob = tglob;
+            k.pad_ = 0;
+            tcl[threadIdx.x] = k;
+        }
+    }
 
     for (int c = 0; c < p.chans; ++c) {
         const float* plane = p.img + c * p.plane;
@@ -124,111 +220,151 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             const int trows = ch + kBfRows - 1;
             const float* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
             __syncthreads();                    // previous tile fully consumed
-            // stage: two adjacent pixels per thread and step -> one dword per piece plane
-            const int pairs = p.lds_cols >> 1;
-            for (int e = threadIdx.x; e < trows * pairs; e += 256) {
-                const int r = e / pairs, cp = e - r * pairs;
-                const float2 v = *reinterpret_cast<const float2*>(grow + (size_t)r * p.pitch + 2 * cp);
-                const float a = v.x - mu, b = v.y - mu;
-                const uint32_t a0 = bf16_rne(a), b0 = bf16_rne(b);
-                const uint32_t a1 = bf16_rne(a - bf16_to_float(a0)), b1 = bf16_rne(b - bf16_to_float(b0));
-                *reinterpret_cast<uint32_t*>(thi + (size_t)r * row_bytes + 4 * cp) = a0 | (b0 << 16);
-                *reinterpret_cast<uint32_t*>(tlo + (size_t)r * row_bytes + 4 * cp) = a1 | (b1 << 16);
-            }
-            __syncthreads();
-            // K loop: template rows of this chunk x 32-tap blocks
-            const uint8_t* aptr = apack_g + ((size_t)(c * p.h + cy0) * p.nkb) * 1024;
-            const int lane_off = wave * row_bytes + (j + q) * 16;
-            for (int dy = 0; dy < ch; ++dy) {
-                for (int kb = 0; kb < p.nkb; ++kb) {
-                    const int off = lane_off + dy * row_bytes + kb * 64;
-                    const v4i_b h0 = *reinterpret_cast<const v4i_b*>(thi + off);
-                    const v4i_b h1 = *reinterpret_cast<const v4i_b*>(thi + off + 16);
-                    const v4i_b l0 = *reinterpret_cast<const v4i_b*>(tlo + off);
-                    const v4i_b l1 = *reinterpret_cast<const v4i_b*>(tlo + off + 16);
-                    v4i_b a0[MB], a1[MB];
+            // stage: two adjacent pixels per thread and step -> one dword per piece plane; (row, pair) advance
+            // without divisions, four requests in flight per thread
+            {
+                const int pairs = p.lds_cols >> 1;
+                const int rstep = 256 / pairs, cstep = 256 - rstep * pairs;
+                int r = threadIdx.x / pairs, cp = threadIdx.x - r * pairs;
+                while (r < trows) {
+                    float2 v[4];
+                    int rr[4], cc[4];
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
-                        a0[mb] = *reinterpret_cast<const v4i_b*>(aptr + mb * p.group_bytes);
-                        a1[mb] = *reinterpret_cast<const v4i_b*>(aptr + p.piece_bytes + mb * p.group_bytes);
-                    }
-                    aptr += 1024;
-                    const int W[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                    const int V[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-                    int EW[7], EV[7];
-#pragma unroll
-                    for (int m = 0; m < 7; ++m) {
-                        EW[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)W[m + 1], (uint32_t)W[m], 2);
-                        EV[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)V[m + 1], (uint32_t)V[m], 2);
-                    }
-#pragma unroll
-                    for (int ph = 0; ph < 8; ++ph) {
-                        const int k = ph >> 1;
-                        const v4i_b bh = (ph & 1) ? v4i_b{EW[k], EW[k + 1], EW[k + 2], EW[k + 3]} : v4i_b{W[k], W[k + 1], W[k + 2], W[k + 3]};
-                        const v4i_b bl = (ph & 1) ? v4i_b{EV[k], EV[k + 1], EV[k + 2], EV[k + 3]} : v4i_b{V[k], V[k + 1], V[k + 2], V[k + 3]};
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            v4f a = acc[mb][ph];
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
-                            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bl), a, 0, 0, 0);
-                            acc[mb][ph] = a;
+                    for (int u = 0; u < 4; ++u) {
+                        rr[u] = r;
+                        cc[u] = cp;
+                        if (r < trows) v[u] = *reinterpret_cast<const float2*>(grow + (size_t)r * p.pitch + 2 * cp);
+                        r += rstep;
+                        cp += cstep;
+                        if (cp >= pairs) {
+                            cp -= pairs;
+                            ++r;
                         }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (rr[u] >= trows) break;
+                        const float a = v[u].x - mu, b = v[u].y - mu;
+                        const uint32_t a0 = bf16_rne(a), b0 = bf16_rne(b);
+                        const uint32_t a1 = bf16_rne(a - bf16_to_float(a0)), b1 = bf16_rne(b - bf16_to_float(b0));
+                        *reinterpret_cast<uint32_t*>(thi + (size_t)rr[u] * row_bytes + 4 * cc[u]) = a0 | (b0 << 16);
+                        *reinterpret_cast<uint32_t*>(tlo + (size_t)rr[u] * row_bytes + 4 * cc[u]) = a1 | (b1 << 16);
                     }
                 }
             }
+            __syncthreads();
+            // K loop: template rows of this chunk x 32-tap blocks, software pipelined with two register sets: the
+            // operands of the next step (4 LDS chunks + 2 MB packed template rows) are requested before the 24 MB
+            // MFMAs of the current one issue; the loop body is branch-free and requests up to two steps past the
+            // chunk (pack arena slack / inside the LDS allocation; never used).
+            const uint8_t* aptr = apack_g + ((size_t)(c * p.h + cy0) * p.nkb) * 1024;
+            const int nsteps = ch * p.nkb;
+            const int row_adv = row_bytes - (p.nkb - 1) * 64;
+            int loff = wave * row_bytes + (j + q) * 16;
+            int kb_i = 0;
+            v4i_b hA0, hA1, lA0, lA1, hB0, hB1, lB0, lB1, aA0[MB], aA1[MB], aB0[MB], aB1[MB];
+#define MTM_BF_LOAD(H0, H1, L0, L1, A0, A1)                                                    \
+            H0 = *reinterpret_cast<const v4i_b*>(thi + loff);                                  \
+            H1 = *reinterpret_cast<const v4i_b*>(thi + loff + 16);                             \
+            L0 = *reinterpret_cast<const v4i_b*>(tlo + loff);                                  \
+            L1 = *reinterpret_cast<const v4i_b*>(tlo + loff + 16);                             \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                \
+                A0[mb] = *reinterpret_cast<const v4i_b*>(aptr + mb * p.group_bytes);           \
+                A1[mb] = *reinterpret_cast<const v4i_b*>(aptr + p.piece_bytes + mb * p.group_bytes); \
+            }
+#define MTM_BF_ADVANCE()                                        \
+            {                                                   \
+                aptr += 1024;                                   \
+                const bool wrap_ = kb_i + 1 == p.nkb;           \
+                loff += wrap_ ? row_adv : 64;                   \
+                kb_i = wrap_ ? 0 : kb_i + 1;                    \
+            }
+            MTM_BF_LOAD(hA0, hA1, lA0, lA1, aA0, aA1)
+            int ks = 0;
+            for (; ks + 2 <= nsteps; ks += 2) {
+                MTM_BF_ADVANCE()
+                MTM_BF_LOAD(hB0, hB1, lB0, lB1, aB0, aB1)
+                __builtin_amdgcn_sched_barrier(0);
+                bf_step<MB>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
+                __builtin_amdgcn_sched_barrier(0);
+                MTM_BF_ADVANCE()
+                MTM_BF_LOAD(hA0, hA1, lA0, lA1, aA0, aA1)
+                __builtin_amdgcn_sched_barrier(0);
+                bf_step<MB>(acc, hB0, hB1, lB0, lB1, aB0, aB1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks < nsteps) bf_step<MB>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
+#undef MTM_BF_LOAD
+#undef MTM_BF_ADVANCE
         }
     }
 
-    // ---- epilogue: lane (j, q) holds pixels x0 + 8 j + 0..7 of row y for templates 16 mb + 4 q + e
+    // ---- epilogue: lane (j, q) holds pixels x0 + 8 j + 0..7 of row y for templates 16 mb + 4 q + e.  Statistics of
+    // four pixels at a time in registers (they do not depend on the template), constants from LDS.
     const int y = y0 + wave;
     const int xq = x0 + 8 * j;
     if (y >= p.oh || xq >= p.ow) return;
+    const int method = p.method;
+    const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
+    const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+    for (int half = 0; half < 2; ++half) {
+        if (xq + 4 * half >= p.ow) break;
+        double ts[4][kMaxChans], s2[4], sq[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int li = tg * MB * 16 + mb * 16 + 4 * q + e;
-            if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;
-            const int tglob = tlist[li];
-            const TemplDev T = td[tglob];
-            float out[8];
+        for (int i = 0; i < 4; ++i) {
+            const int x = min(xq + 4 * half + i, p.ow - 1);
+            const size_t sidx = (size_t)y * st.pitch + x;
 #pragma unroll
-            for (int ph = 0; ph < 8; ++ph) {
-                const int x = min(xq + ph, p.ow - 1);
-                const size_t sidx = (size_t)y * st.pitch + x;
-                double corr = (double)acc[mb][ph][e];
-                for (int cc = 0; cc < p.chans; ++cc) corr += T.centre[cc] * st.t[cc][sidx];
-                out[ph] = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
-            }
-            if (p.cand_on) {
+            for (int cc = 0; cc < kMaxChans; ++cc) ts[i][cc] = cc < p.chans ? st.t[cc][sidx] : 0.0;
+            s2[i] = need_sum2 ? st.sum2[sidx] : 0.0;
+            sq[i] = normed ? st.sq[sidx] : 0.0;
+        }
 #pragma unroll
-                for (int ph = 0; ph < 8; ++ph) {
-                    const float v = p.cand_min ? -out[ph] : out[ph];
-                    if (xq + ph < p.ow && v > p.cand_thr) {
-                        const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
-                        if (slot < p.cand_cap) {
-                            mtm_hit hrec;
-                            hrec.templ_idx = tglob;
-                            hrec.x = xq + ph;
-                            hrec.y = y;
-                            hrec.w = p.w;
-                            hrec.h = p.h;
-                            hrec.score = out[ph];
-                            p.cand_hits[slot] = hrec;
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lt = mb * 16 + 4 * q + e, li = tg * MB * 16 + lt;
+                if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;
+                const BfTemplConst& T = tcl[lt];
+                float out[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double corr = (double)acc[mb][4 * half + i][e];
+#pragma unroll
+                    for (int cc = 0; cc < kMaxChans; ++cc)
+                        if (cc < p.chans) corr += T.centre[cc] * ts[i][cc];
+                    out[i] = bf_finish(method, corr, ts[i], s2[i], sq[i], T, p.chans);
+                }
+                const int xb = xq + 4 * half;
+                if (p.cand_on) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = p.cand_min ? -out[i] : out[i];
+                        if (xb + i < p.ow && v > p.cand_thr) {
+                            const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+                            if (slot < p.cand_cap) {
+                                mtm_hit hrec;
+                                hrec.templ_idx = T.tglob;
+                                hrec.x = xb + i;
+                                hrec.y = y;
+                                hrec.w = p.w;
+                                hrec.h = p.h;
+                                hrec.score = out[i];
+                                p.cand_hits[slot] = hrec;
+                            }
                         }
                     }
                 }
-            }
-            if (!p.hits_only) {
-                float* orow = maps + T.map_off + (size_t)y * T.map_pitch + xq;
-                if (xq + 7 < p.ow) {
-                    *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
-                    *reinterpret_cast<float4*>(orow + 4) = make_float4(out[4], out[5], out[6], out[7]);
-                } else {
+                if (!p.hits_only) {
+                    float* orow = maps + T.map_off + (size_t)y * T.map_pitch + xb;
+                    if (xb + 3 < p.ow) {
+                        *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
+                    } else {
 #pragma unroll
-                    for (int ph = 0; ph < 8; ++ph)
-                        if (xq + ph < p.ow) orow[ph] = out[ph];
+                        for (int i = 0; i < 4; ++i)
+                            if (xb + i < p.ow) orow[i] = out[i];
+                    }
                 }
             }
         }

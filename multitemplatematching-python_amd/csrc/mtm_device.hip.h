@@ -113,7 +113,7 @@ __global__ void planarize_f32_down_kernel(const float* __restrict__ raw, int src
 }
 
 // uint16 images (single channel): exact integer matching through the int8 matrix cores needs the two
-// bytes of every pixel as separate int8 planes (hi ^ 0x80, lo ^ 0x80; see ncc16_combine_kernel).  Also
+// bytes of every pixel as separate int8 planes (hi ^ 0x80, lo ^ 0x80; see the kMfU16 pass of ncc_mfma_kernel).  Also
 // writes the unbiased high-byte plane (window sums of the high bytes) and the float32 plane (window
 // statistics, float64 fallback kernel).  f > 1: area-downscaled first, rounding as for uint8 with the
 // uint16 saturation.  `hi_lo` may be null (multi-channel uint16 images only take the float64 kernel).
@@ -704,66 +704,12 @@ __global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restri
 // uint16 images and templates on the int8 matrix cores, exactly.
 //   I = 256 Ih + Il, T = 256 Th + Tl  (bytes)  =>
 //   sum I*T = 65536 R_hh + 256 (R_hl + R_lh) + R_ll,   R_xy = sum I_x * T_y   (uint8 x uint8)
-// ncc_mfma_kernel in RAW mode stores the biased int8 accumulators a_xy = sum (I_x - 128)(T_y - 128) of
-// the four byte-plane pairs; here R_xy = a_xy + 128 S1_x + 128 sum(T_y) - 16384 A is rebuilt (S1_x the
-// window sum of byte plane x; S1_lo = S1 - 256 S1_hi), combined in float64 (all terms are integers
-// < 2^53: exact) and normalised by finish_unmasked like every other kernel.
-// raw layout: [image plane x (2)][template plane y (2)][template (n_pad)][oh][pitch] int32.
+// Two launches of ncc_mfma_kernel over the image's byte planes, each against [T_hi | T_lo] of 16 templates per work
+// item: the high-byte pass stores its biased accumulators a_hh, a_hl (RAW mode), the low-byte pass (kMfU16) reads
+// them back in its epilogue, rebuilds R_xy = a_xy + 128 S1_x + 128 sum(T_y) - 16384 A (S1_x the window sum of byte
+// plane x; S1_lo = S1 - 256 S1_hi), combines in float64 (all terms are integers < 2^53: exact) and normalises like
+// every other kernel.  See mtm_mfma.hip.h.
 // ---------------------------------------------------------------------------------------------
-struct Ncc16Params {
-    // fused peak candidates / hits-only, as in the MFMA epilogue (mtm_find_matches)
-    mtm_hit* cand_hits;
-    unsigned long long* cand_counter;
-    unsigned long long cand_cap;
-    float cand_thr;
-    int cand_min, cand_on, hits_only;
-    int w, h;
-    const int* raw;
-    long long raw_plane;       // ints per (x, y) pair block: n_pad * oh * pitch
-    long long raw_map;         // ints per template map: oh * pitch
-    const double* s1_hi;       // window sums of the high-byte plane (pitch = st.pitch)
-    int oh, ow, pitch;         // pitch of the raw maps (= map_pitch of the class)
-    int n_list;
-    int method;
-    double area;
-};
-
-__global__ __launch_bounds__(256) void ncc16_combine_kernel(Ncc16Params p, const TemplDev* __restrict__ td,
-                                                            const int* __restrict__ tlist,
-                                                            const double* __restrict__ tsum_hi,
-                                                            const double* __restrict__ tsum_lo, StatPlanes st,
-                                                            float* __restrict__ maps, int only_li) {
-    const int li = blockIdx.z;
-    if (only_li >= 0 && li != only_li) return;
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= p.ow || y >= p.oh) return;
-    const TemplDev T = td[tlist[li]];
-    const size_t o = (size_t)li * p.raw_map + (size_t)y * p.pitch + x;
-    const double a_hh = (double)p.raw[0 * p.raw_plane + o], a_hl = (double)p.raw[1 * p.raw_plane + o];
-    const double a_lh = (double)p.raw[2 * p.raw_plane + o], a_ll = (double)p.raw[3 * p.raw_plane + o];
-    const size_t sidx = (size_t)y * st.pitch + x;
-    const double s1 = st.t[0][sidx], s1h = p.s1_hi[sidx], s1l = s1 - 256.0 * s1h;
-    const double kh = 128.0 * tsum_hi[li] - 16384.0 * p.area, kl = 128.0 * tsum_lo[li] - 16384.0 * p.area;
-    const double r_hh = a_hh + 128.0 * s1h + kh, r_hl = a_hl + 128.0 * s1h + kl;
-    const double r_lh = a_lh + 128.0 * s1l + kh, r_ll = a_ll + 128.0 * s1l + kl;
-    const double corr = 65536.0 * r_hh + 256.0 * (r_hl + r_lh) + r_ll;
-    const float out = finish_unmasked(p.method, corr, st, sidx, T, 1);
-    if (p.cand_on && (p.cand_min ? -out : out) > p.cand_thr) {
-        const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
-        if (slot < p.cand_cap) {
-            mtm_hit hrec;
-            hrec.templ_idx = tlist[li];
-            hrec.x = x;
-            hrec.y = y;
-            hrec.w = p.w;
-            hrec.h = p.h;
-            hrec.score = out;
-            p.cand_hits[slot] = hrec;
-        }
-    }
-    if (!p.hits_only) maps[T.map_off + (size_t)y * T.map_pitch + x] = out;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Large uint8 templates on the int8 matrix cores.  The int32 accumulator of ncc_mfma_kernel holds

@@ -390,7 +390,8 @@ void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
 }
 
 // uint16 image + uint16 templates, one channel, no mask: four uint8 byte-plane correlations on the int8
-// MFMA kernel (raw mode) + ncc16_combine_kernel.  Same int32 accumulator bound as the uint8 path.
+// MFMA kernel (a raw pass over the high bytes, a finishing pass over the low bytes).  Same int32 accumulator bound
+// as the uint8 path.
 bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
     return c->dtype == MTM_U16 && sc.all_u16 && c->chans == 1 && !sc.masked && sc.w <= kMfmaMaxW &&
            (long long)sc.w * sc.h <= 131071;
@@ -442,8 +443,10 @@ void pack_class_bf16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, std::v
     }
 }
 
-// A packs of a uint16 class: 2 * n_pad pseudo-templates, [high bytes of member 0..n_pad-1][low bytes ...],
-// same lane order as pack_class_mfma.  Also the byte sums of every member (bias terms of the combine).
+// A packs of a uint16 class: 2 * n_pad pseudo-templates in 16-template groups [high bytes of members 16 g .. 16 g + 15]
+// [low bytes of the same members] - one work item of ncc_mfma_kernel (32 pseudo-templates) holds both byte planes of
+// 16 templates.  Same lane order as pack_class_mfma.  Also the byte sums of every member (bias terms of the
+// combination): tsum[li] high bytes, tsum[n_pad + li] low bytes.
 void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, double* tsum) {
     const int h = sc.h, w = sc.w, nb = (w + 63) / 64, n_pad = sc.n_pad;
     const long long gb = mfma_group_bytes(h, w, 1);
@@ -452,9 +455,8 @@ void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, doub
     for (size_t li = 0; li < sc.members.size(); ++li) {
         const HostTempl& t = c->templs[sc.members[li]];
         for (int part = 0; part < 2; ++part) {
-            const size_t pi = (size_t)part * n_pad + li;
-            uint8_t* g = out + (pi / 16) * gb;
-            const int i = (int)(pi % 16);
+            uint8_t* g = out + (2 * (li / 16) + (size_t)part) * gb;
+            const int i = (int)(li % 16);
             double sum = 0.0;
             for (int dy = 0; dy < h; ++dy)
                 for (int dx = 0; dx < w; ++dx) {
@@ -464,7 +466,7 @@ void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, doub
                     const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
                     g[(((size_t)dy * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
                 }
-            tsum[pi] = sum;
+            tsum[(size_t)part * n_pad + li] = sum;
         }
     }
 }
@@ -982,14 +984,6 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
                            c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
                            inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
     }
-    if (rk == MTM_KERNEL_MFMA16) {
-        // window sums of the high-byte plane (bias terms of the byte-plane correlations)
-        MTMC(c->stats_hi.ensure(sizeof(double) * plane));
-        const int owg = stats_u8_owg(w);
-        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
-        hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, h, w, oh, ow, owg, inv_area, 0,
-                           0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr, st.pitch);
-    }
     HIPC(hipGetLastError());
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
     st.sum2 = sum2;
@@ -1435,12 +1429,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_MFMA16) {
-        // uint16: raw byte-plane correlations (2 launches: image high / low bytes x [T_hi..., T_lo...]),
-        // then the exact float64 combination + normalisation
+        // uint16: two launches over the image's byte planes x [T_hi | T_lo] of 16 templates per work item.  The first
+        // (high bytes) stores its raw accumulators, the second (low bytes) reads them back in its epilogue and
+        // finishes the exact 16-bit correlation + normalisation there (kMfU16).
         const int n_all = (int)sc.members.size(), n_pad = sc.n_pad;
         const int map_pitch = (int)round_up((size_t)ow, 4);
         const long long raw_map = (long long)oh * map_pitch;
-        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(4LL * n_pad * raw_map)));
+        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(2LL * n_pad * raw_map)));
         MfmaParams p{};
         p.pitch = img.u8_pitch;
         p.plane = img.u8_plane;
@@ -1454,7 +1449,6 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.nseg = (ow + kMfSeg - 1) / kMfSeg;
         p.nyb = (oh + kMfRows - 1) / kMfRows;
         p.ntg = n_pad / 16;
-        p.n_work = p.nseg * p.nyb * p.ntg;
         p.method = c->method;
         p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
         p.cpr = p.lds_pitch / 16;
@@ -1464,6 +1458,14 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.only_li = -1;
         p.raw_map = raw_map;
         p.raw_pitch = map_pitch;
+        p.raw_out = c->raw16.as<int>();
+        int tg0 = 0;
+        if (only_li >= 0) {                 // one template: just its group of 16
+            tg0 = only_li / 16;
+            p.ntg = 1;
+            p.raw_out += (size_t)32 * tg0 * raw_map;
+        }
+        p.n_work = p.nseg * p.nyb * p.ntg;
         const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
@@ -1473,36 +1475,31 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
         const uint8_t* planes = c->slot[c->cur].u8b.as<uint8_t>();
-        for (int x = 0; x < 2; ++x) {
-            p.img = planes + (size_t)x * img.u8_plane;
-            p.raw_out = c->raw16.as<int>() + (size_t)x * 2 * n_pad * raw_map;
-            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td,
-                               c->tlist.as<int>() + sc.tlist_off, c->apacks.as<uint8_t>() + sc.apack_off, st, maps,
-                               c->sched.as<unsigned int>());
-        }
-        Ncc16Params q{};
-        q.raw = c->raw16.as<int>();
-        q.raw_plane = (long long)n_pad * raw_map;
-        q.raw_map = raw_map;
-        q.s1_hi = c->stats_hi.as<double>();
-        q.oh = oh;
-        q.ow = ow;
-        q.pitch = map_pitch;
-        q.n_list = n_all;
-        q.method = c->method;
-        q.area = (double)h * (double)w;
-        q.w = w;
-        q.h = h;
-        q.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
-        q.cand_min = c->cand_min ? 1 : 0;
-        q.cand_thr = c->cand_thr;
-        q.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
-        q.cand_counter = c->cands.as<unsigned long long>();
-        q.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
-        q.hits_only = (q.cand_on && c->hits_only_now) ? 1 : 0;
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * 2 * sc.group_bytes;
+        const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16;
+        p.img = planes;                                         // high bytes: raw accumulators
+        hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap,
+                           st, maps, c->sched.as<unsigned int>());
+        p.img = planes + (size_t)img.u8_plane;                  // low bytes: finish
+        p.n_list = n_all - tg0 * 16;                            // list positions inside the kernel are relative to tg0
+        p.only_li = only_li >= 0 ? only_li - tg0 * 16 : -1;
         const double* ts = c->tsum.as<double>() + sc.tsum_off;
-        hipLaunchKernelGGL(ncc16_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
-                           c->tlist.as<int>() + sc.tlist_off, ts, ts + n_pad, st, maps, only_li);
+        p.u16_tsum = ts + tg0 * 16;
+        p.u16_npad = n_pad;
+        p.u16_area = (double)h * (double)w;
+        p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        p.cand_min = c->cand_min ? 1 : 0;
+        p.cand_thr = c->cand_thr;
+        p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        p.cand_counter = c->cands.as<unsigned long long>();
+        p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        if (c->exact_div)
+            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfU16, true, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k,
+                               ap, st, maps, c->sched.as<unsigned int>());
+        else
+            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfU16, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k,
+                               ap, st, maps, c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32) {
         const int n_all = (int)sc.members.size();
@@ -1544,7 +1541,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
-        const size_t lds = 2 * (size_t)(p.chunk_h + kBfRows - 1) * p.lds_cols * 2 + 16;
+        const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
         const int grid = ((p.n_work + 7) / 8) * 8;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
         const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16 * mb;

@@ -51,8 +51,12 @@ constexpr int kMfStatPlaneBytes = 2 * 1024;                // one statistics pla
 constexpr int kMfStatBytesPerWave = 3 * kMfStatPlaneBytes;   // single channel: S1, S2, sqrt
 __host__ __device__ constexpr int mf_stat_bytes_per_wave(int ch) { return (ch + 2) * kMfStatPlaneBytes; }
 // METHOD value of the raw mode: the biased int8 accumulators are stored as they are (uint16 images:
-// four byte-plane correlations combined by ncc16_combine_kernel).
+// the first of two byte-plane passes, see kMfU16; sum I^2 M of masked classes; slabs).
 constexpr int kMfRaw = 6;
+// METHOD value of the second byte-plane pass of uint16 images: the low-byte plane against [T_hi | T_lo] of 16
+// templates per work item; the epilogue reads the first pass's raw accumulators (high-byte plane, kMfRaw) of the
+// same templates and finishes the exact 16-bit correlation there - no second set of raw maps, no combine kernel.
+constexpr int kMfU16 = 7;
 
 struct MfmaParams {
     const uint8_t* img;      // planar padded image, bytes already biased to int8 (^ 0x80)
@@ -96,7 +100,7 @@ struct MfmaParams {
     long long rm_cstride;    // bytes between the packs of two channels (RM with 3 channels)
     const double* rm_rsq;    // 1 / sqrt plane of the class (0 for flat windows), pitch = st.pitch
     int* raw_out;            // METHOD == kMfRaw: int32 accumulators of list position li at raw_out + li * raw_map
-    long long raw_map;       //   (+ y * raw_pitch + x); see ncc16_combine_kernel
+    long long raw_map;       //   (+ y * raw_pitch + x); kMfU16: the raw maps of the first pass (read)
     int raw_pitch;
     double cand_thr_lo;      // cand_thr minus 8 float32 ulps (hits-only pre-test in float64)
     int hits_only;           // 1: candidates only, the score maps are not written (mtm_find_matches
@@ -109,6 +113,11 @@ struct MfmaParams {
     unsigned long long* ext_best;
     int dbg;                 // profiling probe (MTM_MFMA_DBG): 2 = no epilogue (results invalid); the other probes
                              // are compile-time (-DMTM_PROBE_*)
+    // METHOD == kMfU16: byte sums of the templates ([0 .. npad) high bytes, [npad .. 2 npad) low bytes, class list
+    // order), template area
+    const double* u16_tsum;
+    int u16_npad, u16_pad_;
+    double u16_area;
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)
 };
@@ -237,6 +246,25 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
     return (an < tt) ? qf : r2;
 }
 
+// finish_lean with the method chosen at run time (one channel): `corr` is the exact correlation.
+template <bool EXACT_DIV>
+__device__ __forceinline__ float finish_rt(int method, double corr, double s1, double sum2, double sq, double rsq,
+                                           const MfTemplConst& T) {
+    const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
+    double num = corr;
+    if (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) num = corr - s1 * T.mean[0];
+    if (method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
+    if (!normed) return (float)num;
+    const double tt = sq * T.templ_norm;
+    float qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
+    asm volatile("" : "+v"(qf));
+    const double an = fabs(num);
+    const float satf = (num > 0.0) ? 1.0f : -1.0f;
+    const float other = (method == MTM_TM_SQDIFF_NORMED) ? 1.0f : 0.0f;
+    const float r2 = (an < tt * 1.125) ? satf : other;
+    return (an < tt) ? qf : r2;
+}
+
 // Masked templates (OpenCV's matchTemplateMask, binary uint8 mask, reference MTM/__init__.py:78,:216):
 // c1 = sum I*(T*M) comes from the MFMA accumulator exactly like an unmasked correlation (the packed
 // template is T*M), c2 = sum I^2*M from the MASKSQ dot4 pass.  No guards, as in OpenCV: 0/0 is NaN.
@@ -300,7 +328,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                           unsigned int* __restrict__ sched) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
-    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw), "fused extremum: compile-time-method paths");
+    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && METHOD != kMfU16), "fused extremum: compile-time-method paths");
+    static_assert(METHOD != kMfU16 || (MB == 2 && !MASKED && !RM && CH == 1 && !R2), "uint16 finishing pass");
     static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -363,8 +392,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
     MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
-    if (METHOD != kMfRaw && threadIdx.x < (RM ? p.rm_nt : kTG)) {
-        const int li = tg * kTG + threadIdx.x;
+    constexpr int kTGc = METHOD == kMfU16 ? 16 : kTG;   // templates with constants (uint16: both groups are the same 16)
+    if (METHOD != kMfRaw && threadIdx.x < (RM ? p.rm_nt : kTGc)) {
+        const int li = tg * kTGc + threadIdx.x;
         if (li < p.n_list) {
             const TemplDev& T = td[tlist[li]];
             MfTemplConst k;
@@ -373,6 +403,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.templ_norm = T.templ_norm;
             k.templ_sum2 = T.templ_sum2;
             k.mfma_k = T.mfma_k;
+            if constexpr (METHOD == kMfU16) {
+                // bias of the 16-bit combination: 257 (256 K_hi + K_lo), K_y = 128 sum(T_y) - 16384 A (exact integers)
+                const double kh = 128.0 * p.u16_tsum[li] - 16384.0 * p.u16_area;
+                const double kl = 128.0 * p.u16_tsum[p.u16_npad + li] - 16384.0 * p.u16_area;
+                k.mfma_k = 257.0 * (256.0 * kh + kl);
+            }
             k.rtempl_norm = T.templ_norm > 0.0 ? 1.0 / T.templ_norm : 0.0;
 #pragma unroll
             for (int cc = 0; cc < kMaxChans; ++cc) k.m128[cc] = 128.0 - T.mean[cc];
@@ -421,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     __builtin_amdgcn_global_load_lds((gptr_t)(st.sq + sidx + 2 * hh), (lptr_t)(sbase + (4 * r + 2 + hh) * 1024), 16, 0, 0);
             }
         }
-    } else if constexpr (C1 && METHOD != kMfRaw && !RM) {
+    } else if constexpr (C1 && METHOD != kMfRaw && METHOD != kMfU16 && !RM) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
@@ -895,6 +931,112 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+        }
+    } else if constexpr (METHOD == kMfU16) {
+        // ---- uint16 finishing pass.  This work item holds a_lh = acc[0] (I_lo x T_hi) and a_ll = acc[1] (I_lo x T_lo)
+        // of templates 16 tg .. 16 tg + 15; a_hh / a_hl of the same templates were stored by the raw pass over the
+        // high-byte plane at list positions 32 tg + t and 32 tg + 16 + t.  With R_xy = a_xy + 128 S1_x + K_y
+        // (K_y = 128 sum(T_y) - 16384 A, S1_x the window sum of byte plane x):
+        //   sum I*T = 65536 R_hh + 256 (R_hl + R_lh) + R_ll
+        //           = 65536 a_hh + 256 (a_hl + a_lh) + a_ll  +  32896 S1  +  257 (256 K_hi + K_lo)
+        // because 256 S1_hi + S1_lo = S1, the window sum of the 16-bit image the statistics pass provides - the byte
+        // planes need no sums of their own.  Every term is an integer < 2^53: exact in float64 in any order.  Then the
+        // common normalisation (run-time method).  Four stages of 4 templates: the lanes with q == stage put both
+        // accumulators of their 4 templates into the wave's buffer (rows 0-3 / 4-7).
+        __syncthreads();              // every wave is done reading the image tile: the buffers alias it
+        const bool lane_on = y < p.oh && xq < p.ow;
+        const int method = p.method;
+        const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
+        const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
+        double us1[4] = {0.0, 0.0, 0.0, 0.0}, up1[4], usum2[4] = {0.0, 0.0, 0.0, 0.0}, usq[4] = {0.0, 0.0, 0.0, 0.0}, ursq[4];
+        if (lane_on) {
+            const size_t sidx = (size_t)y * st.pitch + xq;       // pitch is a multiple of 4: the 4 values exist
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
+                us1[2 * hh] = a.x, us1[2 * hh + 1] = a.y;
+                if (need_sum2) {
+                    const double2 d = *reinterpret_cast<const double2*>(st.sum2 + sidx + 2 * hh);
+                    usum2[2 * hh] = d.x, usum2[2 * hh + 1] = d.y;
+                }
+                if (normed) {
+                    const double2 d = *reinterpret_cast<const double2*>(st.sq + sidx + 2 * hh);
+                    usq[2 * hh] = d.x, usq[2 * hh + 1] = d.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            up1[i] = 32896.0 * us1[i];
+            ursq[i] = (normed && usq[i] > 0.0) ? 1.0 / usq[i] : 0.0;
+        }
+        // the raw accumulators of the first pass are requested one template ahead (they do not depend on the LDS staging)
+        const int* rbase = p.raw_out + (size_t)(32 * tg) * p.raw_map + (size_t)y * p.raw_pitch + xq;
+        const int n_here = min(16, p.n_list - tg * 16);
+        v4i hhn = v4i{0, 0, 0, 0}, hln = v4i{0, 0, 0, 0};
+        if (lane_on && n_here > 0) {
+            hhn = *reinterpret_cast<const v4i*>(rbase);                 // raw_pitch is a multiple of 4
+            hln = *reinterpret_cast<const v4i*>(rbase + 16 * p.raw_map);
+        }
+#pragma unroll 1
+        for (int stage = 0; stage < 4; ++stage) {
+            if (q == stage) {
+                int* dst = &epi[16 * j];
+                const int rot = mf_epi_rot(j);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int col = (c + rot) & 15;
+                    dst[0 * kMfEpiPitch + col] = acc[0][c].x;
+                    dst[1 * kMfEpiPitch + col] = acc[0][c].y;
+                    dst[2 * kMfEpiPitch + col] = acc[0][c].z;
+                    dst[3 * kMfEpiPitch + col] = acc[0][c].w;
+                    dst[4 * kMfEpiPitch + col] = acc[MB - 1][c].x;
+                    dst[5 * kMfEpiPitch + col] = acc[MB - 1][c].y;
+                    dst[6 * kMfEpiPitch + col] = acc[MB - 1][c].z;
+                    dst[7 * kMfEpiPitch + col] = acc[MB - 1][c].w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane_on) {
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) {
+                    const int lt = 4 * stage + e, li = tg * 16 + lt;
+                    if (lt >= n_here) break;                                     // wave-uniform
+                    const v4i hh4 = hhn, hl4 = hln;
+                    if (lt + 1 < n_here) {
+                        hhn = *reinterpret_cast<const v4i*>(rbase + (size_t)(lt + 1) * p.raw_map);
+                        hln = *reinterpret_cast<const v4i*>(rbase + (size_t)(lt + 17) * p.raw_map);
+                    }
+                    if (p.only_li >= 0 && li != p.only_li) continue;
+                    const MfTemplConst T = tcl[lt];
+                    const v4i lh4 = *reinterpret_cast<const v4i*>(&epi[e * kMfEpiPitch + rd_off]);
+                    const v4i ll4 = *reinterpret_cast<const v4i*>(&epi[(4 + e) * kMfEpiPitch + rd_off]);
+                    const int a_lh[4] = {lh4.x, lh4.y, lh4.z, lh4.w}, a_ll[4] = {ll4.x, ll4.y, ll4.z, ll4.w};
+                    const int a_hh[4] = {hh4.x, hh4.y, hh4.z, hh4.w}, a_hl[4] = {hl4.x, hl4.y, hl4.z, hl4.w};
+                    float out[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double mid = (double)a_hl[i] + (double)a_lh[i];
+                        const double a = fma(65536.0, (double)a_hh[i], fma(256.0, mid, (double)a_ll[i]));
+                        const double corr = a + (up1[i] + T.mfma_k);
+                        out[i] = finish_rt<EXACT_DIV>(method, corr, us1[i], usum2[i], usq[i], ursq[i], T);
+                    }
+                    {
+                        const bool ones = T.all_ones != 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
+                    }
+                    if (p.cand_on) {
+                        const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                        const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                        if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, y);
+                    }
+                    if (!p.hits_only) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     } else if constexpr (C1) {
         // ---- hits-only screen, straight from the accumulator registers (no LDS transposition): in this

@@ -1242,6 +1242,53 @@ def test_uint16_exact_path(mtm, ctx, coins):
     assert_hits_equal(got, hits_json(exp), tol=1e-6)
 
 
+def test_uint16_many_templates(mtm):
+    """uint16 classes of more than 16 templates: several work-item groups ([T_hi | T_lo] of 16 templates each), a
+    partly filled last group, two size classes; every map (one-template launches and last_score_map of a whole-set
+    call) and the hit lists against the oracle on the float32 cast; hits-only == maps."""
+    from MTM import _lib
+    rng = np.random.default_rng(4242)
+    H, W = 150, 333
+    img = rng.integers(0, 65536, (H, W), dtype=np.uint16)
+    img[70:100, 40:120] = 777
+    lt = []
+    for i in range(37):
+        y, x = int(rng.integers(0, H - 20)), int(rng.integers(0, W - 70))
+        t = img[y:y + 20, x:x + 70].copy()                     # two 64-tap blocks
+        if i % 3 == 0:
+            t = np.clip(t.astype(np.int64) + rng.integers(-2000, 2000, t.shape), 0, 65535).astype(np.uint16)
+        lt.append(("w%d" % i, t))
+    for i in range(18):
+        y, x = int(rng.integers(0, H - 70)), int(rng.integers(0, W - 12))
+        lt.append(("t%d" % i, img[y:y + 70, x:x + 12].copy()))  # two 64-row chunks
+    f32img = img.astype(np.float32)
+    c = _lib.Context(0)
+    try:
+        for method in (5, 1, 3):
+            c.set_image(img)
+            c.set_templates([(t, None) for _, t in lt], method)
+            for idx in (0, 15, 16, 31, 36, 37, 54):
+                t = lt[idx][1]
+                got = c.score_map(idx, (H - t.shape[0] + 1, W - t.shape[1] + 1))
+                assert c.timing()["kernel_used"] == 4
+                map_close(got, O.match_template(f32img, t.astype(np.float32), method), tol=1e-6)
+            thr = {5: 0.6, 1: 0.15, 3: 0.95}[method]
+            c.set_option(_lib.OPT_HITS_ONLY, 0)
+            hm = c.find_matches(_lib.PEAKS_LOCAL, thr)
+            for idx in (3, 20, 36, 40):
+                t = lt[idx][1]
+                map_close(c.last_score_map(idx, (H - t.shape[0] + 1, W - t.shape[1] + 1)),
+                          O.match_template(f32img, t.astype(np.float32), method), tol=1e-6)
+            c.set_option(_lib.OPT_HITS_ONLY, 1)
+            hh = c.find_matches(_lib.PEAKS_LOCAL, thr)
+            assert len(hm) >= 40 and sorted(map(tuple, hm.tolist())) == sorted(map(tuple, hh.tolist()))
+        got = mtm.findMatches(lt, img, method=5, score_threshold=0.6)
+        exp = O.find_matches(_as_f32(lt), f32img, method=5, score_threshold=0.6)
+        assert_hits_equal(hits_json(got), hits_json(exp), tol=1e-6, ordered=False)
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # row-multiplexed MFMA mode (classes of <= 16 templates: A rows = templates x output rows)
 # ------------------------------------------------------------------------------------------------
