@@ -25,6 +25,7 @@
 // Unmasked templates only (float masks keep the float64 kernel); w <= 256.
 #pragma once
 #include "mtm_device.hip.h"
+#include "mtm_mfma.hip.h"
 
 namespace mtm {
 
@@ -58,6 +59,10 @@ struct Bf16Params {
     unsigned long long cand_cap;
     float cand_thr;
     int cand_min, cand_on, hits_only;
+    // fused global extremum (mtm_find_matches, MTM_PEAKS_GLOBAL): nothing is stored, every wave keeps the best
+    // (ordered score, ~index) key per template in LDS and merges it into ext_best[2 * template + cand_min]
+    int ext_on, ext_pad_;
+    unsigned long long* ext_best;
 };
 
 // Per-template constants of a work item, staged in LDS once (the epilogue reads them as LDS broadcasts).
@@ -138,10 +143,11 @@ __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const
     }
 }
 
-// LDS: [piece tile 0][piece tile 1][16 B: the subtracted constant][32 BfTemplConst]; the K loop requests operands up
+// LDS: [piece tile 0][piece tile 1][16 B: the subtracted constant][32 BfTemplConst][4 waves x 32 extremum keys]; the K loop requests operands up
 // to two steps past a chunk (never used): those reads stay inside this allocation.
 __host__ __device__ inline size_t bf16_lds_bytes(int chunk_h, int lds_cols) {
-    return 2 * (size_t)(chunk_h + kBfRows - 1) * lds_cols * 2 + 16 + 32 * sizeof(BfTemplConst);
+    return 2 * (size_t)(chunk_h + kBfRows - 1) * lds_cols * 2 + 16 + 32 * sizeof(BfTemplConst) +
+           (size_t)kBfRows * 32 * sizeof(unsigned long long);
 }
 
 template <int MB>
@@ -173,6 +179,8 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     float* s_mu = reinterpret_cast<float*>(smem_bf + 2 * (size_t)tile_rows_max * row_bytes);
     BfTemplConst* tcl = reinterpret_cast<BfTemplConst*>(smem_bf + 2 * (size_t)tile_rows_max * row_bytes + 16);
     const uint8_t* apack_g = apack + (long long)tg * MB * p.group_bytes + (size_t)lane * 16;
+    unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(tcl + 32) + wave * 32;
+    if (lane < 32) ext_slot[lane] = 0ull;       // wave-private; ordered before the epilogue by the staging barriers
 
     // per-template constants -> LDS (ordered before the epilogue by the staging barriers)
     if (threadIdx.x < 16 * MB) {
@@ -303,10 +311,11 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     // four pixels at a time in registers (they do not depend on the template), constants from LDS.
     const int y = y0 + wave;
     const int xq = x0 + 8 * j;
-    if (y >= p.oh || xq >= p.ow) return;
+    const bool lane_on = y < p.oh && xq < p.ow;
     const int method = p.method;
     const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
     const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
+    if (lane_on) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (xq + 4 * half >= p.ow) break;
@@ -337,7 +346,21 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     out[i] = bf_finish(method, corr, ts[i], s2[i], sq[i], T, p.chans);
                 }
                 const int xb = xq + 4 * half;
-                if (p.cand_on) {
+                if (p.ext_on) {
+                    // cv2.minMaxLoc: the first index wins ties, NaN never wins
+                    unsigned long long bestk = 0ull;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = out[i];
+                        if (xb + i < p.ow && v == v) {
+                            const uint32_t o = mf_float_order(v);
+                            const unsigned long long key = ((unsigned long long)(p.cand_min ? ~o : o) << 32) |
+                                                           (unsigned long long)(0xFFFFFFFFu - (uint32_t)(y * p.ow + xb + i));
+                            bestk = key > bestk ? key : bestk;
+                        }
+                    }
+                    if (bestk) atomicMax(&ext_slot[lt], bestk);
+                } else if (p.cand_on) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float v = p.cand_min ? -out[i] : out[i];
@@ -367,6 +390,16 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     }
                 }
             }
+        }
+    }
+    }
+    if (p.ext_on) {                 // one global atomic per template this wave improved
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16 * MB) {
+            const unsigned long long key = ext_slot[lane];
+            const int li = tg * MB * 16 + lane;
+            if (key && li < p.n_list) atomicMax(&p.ext_best[2 * tlist[li] + p.cand_min], key);
         }
     }
 }

@@ -1494,12 +1494,21 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
-        if (c->exact_div)
-            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfU16, true, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k,
-                               ap, st, maps, c->sched.as<unsigned int>());
-        else
-            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfU16, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k,
-                               ap, st, maps, c->sched.as<unsigned int>());
+        size_t lds2 = lds;
+        const bool ext = c->ext_now && only_li < 0;      // fused global extremum (find_matches_impl checked the classes)
+        if (ext) {
+            p.ext_off = (int)lds2;                        // 4 waves x 32 keys
+            lds2 += (size_t)kMfRows * 32 * sizeof(unsigned long long);
+            p.ext_best = c->counters.as<unsigned long long>();
+            p.cand_on = 1;
+            p.hits_only = 1;
+        }
+        using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
+        static const MfmaFn kU16Fns[2][2] = {
+            {ncc_mfma_kernel<2, kMfU16, false, false>, ncc_mfma_kernel<2, kMfU16, true, false>},
+            {ncc_mfma_kernel<2, kMfU16, false, false, false, 1, true>, ncc_mfma_kernel<2, kMfU16, true, false, false, 1, true>}};
+        hipLaunchKernelGGL(kU16Fns[ext ? 1 : 0][c->exact_div ? 1 : 0], dim3(grid), dim3(256), lds2, c->stream, p, td, tl_k, ap,
+                           st, maps, c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32) {
         const int n_all = (int)sc.members.size();
@@ -1541,6 +1550,12 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        if (c->ext_now && only_li < 0) {                  // fused global extremum (find_matches_impl checked the classes)
+            p.ext_on = 1;
+            p.ext_best = c->counters.as<unsigned long long>();
+            p.cand_on = 1;
+            p.hits_only = 1;
+        }
         const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
         const int grid = ((p.n_work + 7) / 8) * 8;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
@@ -2637,13 +2652,15 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     c->cand_on = false;
     c->hits_only_now = false;
     c->ext_now = false;
-    // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the unmasked
-    // 1- or 3-channel MFMA kernel (plain or row-multiplexed); same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
+    // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the 1- or 3-channel MFMA kernel
+    // (plain, two-row or row-multiplexed; binary masks with the reciprocal normalisation), the uint16 byte-plane passes
+    // or the float32 kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
     if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3)) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
-            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() &&
-                 (!sc.masked || (!c->exact_div && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED));
+            ok = ok && ((resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() &&
+                         (!sc.masked || (!c->exact_div && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED))) ||
+                        resolved_kernel(c, sc) == MTM_KERNEL_MFMA16 || resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32);
         if (ok) {
             MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
             HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)n, c->stream));

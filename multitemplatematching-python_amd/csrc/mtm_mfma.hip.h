@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                           unsigned int* __restrict__ sched) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
-    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw && METHOD != kMfU16), "fused extremum: compile-time-method paths");
+    static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw), "fused extremum: compile-time-method paths");
     static_assert(METHOD != kMfU16 || (MB == 2 && !MASKED && !RM && CH == 1 && !R2), "uint16 finishing pass");
     static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -970,6 +970,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             up1[i] = 32896.0 * us1[i];
             ursq[i] = (normed && usq[i] > 0.0) ? 1.0 / usq[i] : 0.0;
         }
+        unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
+        if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
         // the raw accumulators of the first pass are requested one template ahead (they do not depend on the LDS staging)
         const int* rbase = p.raw_out + (size_t)(32 * tg) * p.raw_map + (size_t)y * p.raw_pitch + xq;
         const int n_here = min(16, p.n_list - tg * 16);
@@ -1027,7 +1029,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                         for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                     }
-                    if (p.cand_on) {
+                    if constexpr (EXT) {
+                        ext_update(out, y, T.ext_hi, &ext_slot[lt]);
+                    } else if (p.cand_on) {
                         const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                         const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                         if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, y);
@@ -1037,6 +1041,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+        if (EXT && lane < 16) {        // one global atomic per template this wave improved
+            const unsigned long long key = ext_slot[lane];
+            const int li = tg * 16 + lane;
+            if (key && li < p.n_list) atomicMax(&p.ext_best[2 * tlist[li] + p.cand_min], key);
         }
     } else if constexpr (C1) {
         // ---- hits-only screen, straight from the accumulator registers (no LDS transposition): in this

@@ -1493,6 +1493,69 @@ def test_fused_global_extremum_masked(mtm, ctx, coins):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["uint16", "float32"])
+def test_fused_global_extremum_uint16_float32(mtm, dtype):
+    """N_object == 1 on uint16 (byte-plane passes) and float32 (bf16-piece kernel) classes: the extremum comes out of
+    the score kernel's epilogue - the same record as the maps + extremum_kernel route, and the oracle's; several
+    work-item groups, exact copies (ties: the first index wins), a constant template, all methods."""
+    from MTM import _lib
+    rng = np.random.default_rng(515)
+    H, W = 140, 300
+    top = 65536 if dtype == "uint16" else 256
+    img = rng.integers(0, top, (H, W)).astype(dtype)
+    if dtype == "float32":
+        img = img * np.float32(3.25) + np.float32(100.0)
+    tile = img[10:34, 20:60].copy()
+    for (y, x) in ((90, 200), (50, 130)):
+        img[y:y + 24, x:x + 40] = tile                        # exact copies
+    lt = [("tile", tile)]
+    for i in range(20):
+        y, x = int(rng.integers(0, H - 24)), int(rng.integers(0, W - 40))
+        t = img[y:y + 24, x:x + 40].copy()
+        if i % 2:
+            t = np.clip(t.astype(np.float64) + rng.integers(-top // 10, top // 10, t.shape), 0, None).astype(dtype)
+        lt.append(("t%d" % i, t))
+    lt.append(("const", np.full((24, 40), 77, dtype)))
+    lt += [("n%d" % i, img[5 * i:5 * i + 9, 11 * i:11 * i + 70].copy()) for i in range(3)]     # a second size class
+    f32img = img.astype(np.float32)
+    c = _lib.Context(0)
+    try:
+        c.set_image(img)
+        for method in (5, 3, 1, 0, 2, 4):
+            c.set_templates([(t, None) for _, t in lt], method)
+            res = []
+            for honly in (1, 0):
+                c.set_option(_lib.OPT_HITS_ONLY, honly)
+                res.append(c.find_matches(_lib.PEAKS_GLOBAL, 0.5).copy())
+                tm = c.timing()
+                if not any(os.environ.get(k) for k in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY", "MTM_F32_MFMA")):
+                    assert tm["kernel_used"] == (4 if dtype == "uint16" else 5) and tm["hits_only"] == honly, tm
+            c.set_option(_lib.OPT_HITS_ONLY, 1)
+            assert res[0].tobytes() == res[1].tobytes(), (dtype, method)
+            r = res[0]
+            assert len(r) == len(lt) and list(r["templ_idx"]) == list(range(len(lt)))
+            exp = O.find_matches([(n, t.astype(np.float32)) for n, t in lt], f32img, method=method, N_object=1)
+            got = [(lt[int(q["templ_idx"])][0], (int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"])), q["score"]) for q in r]
+            tol = 1e-6 if dtype == "uint16" else 5e-5
+            if method in (1, 3, 5):
+                # near-ties between different positions may resolve differently within the tolerance: compare scores,
+                # and positions wherever the oracle's best is isolated
+                for g, e in zip(got, exp):
+                    assert g[0] == e[0] and abs(float(g[2]) - float(e[2])) <= tol, (method, g, e)
+                assert [g[1] for g in got[:1]] == [tuple(e[1]) for e in exp[:1]]      # the tile: first of three exact copies
+            else:
+                # raw sums of ~1e11..1e13: the oracle's float64 FFT carries absolute noise there (the uint16 integer path is
+                # the exact one), which only shows where SQDIFF cancels to ~0
+                ev = np.array([e[2] for e in exp], np.float64)
+                gv = np.array([g[2] for g in got], np.float64)
+                rel = 1e-5 if dtype == "float32" else 1e-6     # float32: ~1e-6 of the sums that cancel in SQDIFF
+                bad = np.abs(gv - ev) > rel * np.abs(ev) + rel * np.abs(ev).max()
+                assert not bad.any(), (method, [(lt[i][0], gv[i], ev[i]) for i in np.flatnonzero(bad)])
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_find_matches_async(mtm, coins):
     lib = mtm._lib
     small, big = coin_templates(coins)
