@@ -191,8 +191,16 @@ def cpu_baseline(img, units, method, thr, n_sample):
     n_sample = n_sample or min(len(units), max(4, min(workers, 64 if fast else 16)))
     sample = units[:n_sample]
     t0 = time.perf_counter()
+    reps = []
     if impl == "cxx":
-        hits, info = mtm_cpu.find_matches(sample, img, method, thr, n_threads=workers)
+        # ~0.5 s per pass: several passes (about 10 s of CPU work in total), the median pass is reported
+        for _ in range(7):
+            t1 = time.perf_counter()
+            hits, info = mtm_cpu.find_matches(sample, img, method, thr, n_threads=workers)
+            O.NMS(hits, thr, method == 1, float("inf"), 0.25)
+            reps.append(time.perf_counter() - t1)
+            if time.perf_counter() - t0 > 20.0:
+                break
         what = "C++ port of the cv2 pipeline (oracle/cpu/mtm_cpu.cpp: 512x512 float32 DFT blocks, shared image spectra)"
     else:
         from concurrent.futures import ThreadPoolExecutor
@@ -206,6 +214,9 @@ def cpu_baseline(img, units, method, thr, n_sample):
         what = "numpy float32-DFT port of the cv2 pipeline" if fast else "exact float64 numpy oracle"
     O.NMS(hits, thr, method == 1, float("inf"), 0.25)
     dt = time.perf_counter() - t0
+    if reps:
+        dt = float(np.median(reps))
+        what += ", median of %d passes" % len(reps)
     mpx = img.shape[0] * img.shape[1] * n_sample / 1e6
     model = "unknown"
     try:
@@ -213,10 +224,11 @@ def cpu_baseline(img, units, method, thr, n_sample):
             model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), model)
     except OSError:
         pass
-    return {"value": round(mpx / dt, 3), "unit": "Mpx-corr/s", "cores": min(workers, n_sample) if impl == "cxx" else workers,
+    used = min(workers, n_sample) if impl == "cxx" else workers          # the C++ port runs one thread per template
+    return {"value": round(mpx / dt, 3), "unit": "Mpx-corr/s", "cores": used,
             "kind": "port", "cpu_model": model, "host_cores": cores,
             "sample": "%d of %d templates on the full %dx%d image, %s, %d worker threads of %d host cores, %.2f s"
-                      % (n_sample, len(units), img.shape[1], img.shape[0], what, workers, cores, dt),
+                      % (n_sample, len(units), img.shape[1], img.shape[0], what, used, cores, dt),
             "seconds": round(dt, 3)}
 
 
@@ -410,6 +422,23 @@ def main():
                                      "value": rate(float(np.median(st)) * 1e3),
                                      "note": "every call gets template bytes the library has not seen in the previous call: "
                                              "statistics, packing and upload of the templates are inside the call"}
+        call()
+        # (a2) the same per-call metric with the image in page-locked memory (MTM.pinned_empty): no staging copy, the
+        # rows cross PCIe as plain DMA transfers behind the call
+        pimg = MTM.pinned_empty(img.shape, img.dtype)
+        pimg[...] = img
+        for _ in range(3):
+            hp = MTM.matchTemplates(units, pimg, method=method, score_threshold=thr, maxOverlap=0.25)
+        st = []
+        for _ in range(max(10, min(args.steps, 40))):
+            t1 = time.perf_counter()
+            hp = MTM.matchTemplates(units, pimg, method=method, score_threshold=thr, maxOverlap=0.25)
+            st.append(time.perf_counter() - t1)
+            note_timing()
+        extras["pinned_image"] = {"median_ms_per_call": round(float(np.median(st)) * 1e3, 4),
+                                  "value": rate(float(np.median(st)) * 1e3), "identical_hits": hp == hits,
+                                  "note": "the image array lives in page-locked host memory (MTM.pinned_empty)"}
+        del pimg
         call()
         # (b) inputs resident in HBM: round 1's headline (pipelined) and the same call by call
         ctx.set_image(img)

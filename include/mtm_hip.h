@@ -22,6 +22,7 @@
 #ifndef MTM_HIP_H
 #define MTM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -135,6 +136,12 @@ const char* mtm_last_error(void);
 int         mtm_ctx_create(mtm_ctx** out, int device_id);
 void        mtm_ctx_destroy(mtm_ctx* ctx);
 int         mtm_set_option(mtm_ctx* ctx, int option, int64_t value);
+/* Page-locked host memory for pixel buffers (optional).  The reference's caller hands over whatever numpy holds
+ * (MTM/__init__.py:247 `image`) - pageable memory, which the runtime stages through its own pinned buffers while the
+ * upload call blocks.  An image kept in memory from mtm_host_alloc crosses PCIe as a plain DMA transfer behind the call
+ * (MTM.pinned_empty wraps it as a numpy array).  NULL on failure (message in mtm_last_error). */
+void*       mtm_host_alloc(size_t bytes);
+void        mtm_host_free(void* p);
 
 /* ---- inputs ------------------------------------------------------------------------------ */
 /* Upload the search image (already cropped to searchBox by the host layer, MTM/__init__.py:140-144)

@@ -21,7 +21,9 @@ from . import _lib
 from .NMS import NMS, Hit
 from .version import __version__
 
-__all__ = ["NMS", "Hit", "matchTemplates", "findMatches", "computeScoreMap", "TemplateMatcher", "drawBoxesOnRGB",
+pinned_empty = _lib.pinned_empty        # numpy arrays in page-locked memory (faster uploads); optional
+
+__all__ = ["NMS", "Hit", "matchTemplates", "findMatches", "computeScoreMap", "TemplateMatcher", "pinned_empty", "drawBoxesOnRGB",
            "drawBoxesOnGray", "TM_SQDIFF", "TM_SQDIFF_NORMED", "TM_CCORR", "TM_CCORR_NORMED",
            "TM_CCOEFF", "TM_CCOEFF_NORMED", "__version__"]
 

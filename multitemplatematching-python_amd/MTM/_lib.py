@@ -20,6 +20,7 @@ BORDER_CONSTANT, BORDER_NEAREST = 0, 1
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
 OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY = 1, 2, 3, 4, 5, 6
 E_OVERFLOW = -5
+E_HIP = -2
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 
@@ -99,6 +100,8 @@ SYMBOLS = {
                                               ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
                                               _P(ctypes.c_int64)]),
     "mtm_group_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
+    "mtm_host_free": (None, [ctypes.c_void_p]),
     "mtm_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "mtm_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mtm_comm_allgather_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
@@ -204,6 +207,33 @@ def templ_records(templates):
         rec["px"], rec["mask"], rec["rows"], rec["cols"] = px, mk, rows, cols
         rec["chans"], rec["dtype"], rec["row_stride"], rec["mask_row_stride"] = ch, dt, rs, ms
     return rec, keep
+
+
+class _PinnedBlock:
+    """Owner of one mtm_host_alloc block (freed with the last numpy view of it)."""
+
+    def __init__(self, nbytes):
+        lib = load()
+        self.ptr = lib.mtm_host_alloc(int(nbytes))
+        if not self.ptr:
+            check(E_HIP, "mtm_host_alloc")
+        self.nbytes = int(nbytes)
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr and _lib is not None:
+            _lib.mtm_host_free(ptr)
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """An uninitialised numpy array in page-locked host memory (mtm_host_alloc): images kept in such arrays are
+    uploaded by plain DMA transfers, without the staging copy pageable memory needs."""
+    dtype = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(v) for v in shape)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    block = _PinnedBlock(max(n, 1))
+    return np.asarray(block)[:n].view(dtype).reshape(shape)       # the views keep `block` alive
 
 
 class Context:

@@ -1681,6 +1681,20 @@ int mtm_device_count(void) {
     return n;
 }
 
+void* mtm_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error(std::string("mtm_host_alloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void mtm_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (!out) {
         set_error("mtm_ctx_create: null output");

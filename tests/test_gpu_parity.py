@@ -1556,6 +1556,28 @@ def test_fused_global_extremum_uint16_float32(mtm, dtype):
 
 
 @pytest.mark.gpu
+def test_pinned_image_arrays(mtm, coins):
+    """MTM.pinned_empty: numpy arrays in page-locked memory behave like any other array (same hits, views, dtypes);
+    the block is released with its last view."""
+    small, big = coin_templates(coins)
+    lt = [("s", small), ("b", big)]
+    ref = mtm.matchTemplates(lt, coins, score_threshold=0.5)
+    p = mtm.pinned_empty(coins.shape, coins.dtype)
+    assert p.shape == coins.shape and p.dtype == coins.dtype and p.flags.c_contiguous and p.flags.writeable
+    p[...] = coins
+    assert mtm.matchTemplates(lt, p, score_threshold=0.5) == ref
+    assert mtm.matchTemplates(lt, p[:, ::-1][:, ::-1], score_threshold=0.5) == ref           # a view of it
+    big_img = np.tile(coins, (5, 6))                      # banded upload path (>= 1 Mpx)
+    pb = mtm.pinned_empty(big_img.shape)
+    pb[...] = big_img
+    assert mtm.matchTemplates(lt, pb, score_threshold=0.8) == mtm.matchTemplates(lt, big_img, score_threshold=0.8)
+    p16 = mtm.pinned_empty((40, 50, 3), np.uint16)
+    assert p16.shape == (40, 50, 3) and p16.dtype == np.uint16 and p16.nbytes == 40 * 50 * 3 * 2
+    assert mtm.pinned_empty(0).size == 0
+    del p, pb, p16
+
+
+@pytest.mark.gpu
 def test_find_matches_async(mtm, coins):
     lib = mtm._lib
     small, big = coin_templates(coins)
