@@ -234,7 +234,9 @@ struct mtm_ctx {
     int row_mux = 1;           // MTM_ROW_MUX: row-multiplexed MFMA mode for classes of <= 16 templates
     int hits_only = 1;         // MTM_OPT_HITS_ONLY: mtm_find_matches does not materialise the score maps when
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
-    int hits_only_backoff = 0; // calls left in map mode after a candidate-list overflow (dense maps)
+    int backoff_len = 16;      // length of the next back-off period: doubles with every overflow in a row (<= 1024), reset by a
+                               // call whose candidates fitted
+    int fuse_backoff = 0;      // calls left without fused candidates (map mode + full peak pass: maps known to be dense)
     bool hits_only_now = false;
     bool maps_valid = false;   // the map arena holds every score map of the last mtm_find_matches (mtm_last_score_map)
     FmState fm;                         // mtm_find_matches_async -> mtm_find_matches_wait
@@ -1818,7 +1820,8 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
             return MTM_OK;
         case MTM_OPT_HITS_ONLY:
             c->hits_only = value ? 1 : 0;
-            c->hits_only_backoff = 0;
+            c->fuse_backoff = 0;
+            c->backoff_len = 16;
             return MTM_OK;
         case MTM_OPT_DOT4_VARIANT:
             if (value < 0 || value >= kNumDotVariants || kDotVariants[value].wide) break;
@@ -2657,8 +2660,14 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     c->timing = mtm_timing{};
     c->maps_valid = false;
 
-    // fused peak candidates: only when every class runs the MFMA kernel
+    // fused peak candidates: only when every class runs the MFMA kernel - and not while the maps of this context are
+    // known to be dense (the last attempts overflowed the candidate list: smooth images at a low threshold), where the
+    // full peak pass over the maps is the cheaper route
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
+    if (fused && c->fuse_backoff > 0) {
+        --c->fuse_backoff;
+        fused = false;
+    }
     for (const SizeClass& sc : c->classes) {
         const int rk = resolved_kernel(c, sc);
         fused = fused && (rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16 || rk == MTM_KERNEL_MFMA_F32);
@@ -2698,10 +2707,6 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         c->cand_thr = mode_min ? -thr : thr;
         // hits-only: single-channel MFMA classes, every map 2-D, no recent candidate overflow
         bool honly = c->hits_only && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n;
-        if (honly && c->hits_only_backoff > 0) {
-            --c->hits_only_backoff;
-            honly = false;
-        }
         c->hits_only_now = honly;
     }
     // hash table of the candidate positions (hits-only verification on the device: only when the
@@ -2936,17 +2941,21 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             std::memcpy(tflags.data(), host_buf.data() + 2 * sizeof(count), sizeof(int) * n);
             if (use_fused && (int64_t)ncand > cand_cap) {
                 use_fused = false;                  // dense maps: candidate list overflowed
+                // the next calls on this context go straight to map mode + full peak pass; the period doubles while
+                // the retries keep overflowing
+                c->fuse_backoff = c->backoff_len;
+                c->backoff_len = std::min(2 * c->backoff_len, 1024);
                 if (c->hits_only_now) {
-                    // no maps in memory: compute them (this call pays twice; the next calls on this
-                    // context start in map mode)
+                    // no maps in memory: compute them (this call pays twice - the overflowed launch left early)
                     c->hits_only_now = false;
-                    c->hits_only_backoff = 16;
+                    c->cand_on = false;
                     c->timing.ncc_launches = 0;
                     MTMC(run_score_all(c));
                     HIPC(hipEventRecord(c->ev[1], c->stream));
                 }
                 continue;
             }
+            if (use_fused) c->backoff_len = 16;     // the candidates fitted
             if ((int64_t)count <= c->hit_cap) {
                 hits.resize((size_t)count);
                 const size_t got = std::min<size_t>((size_t)count, first);
@@ -3007,13 +3016,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
         }
         // deterministic order: template, then descending quality, then row-major position
-        std::sort(hits.begin(), hits.end(), [&](const mtm_hit& a, const mtm_hit& b) {
-            if (a.templ_idx != b.templ_idx) return a.templ_idx < b.templ_idx;
-            const float qa = mode_min ? -a.score : a.score, qb = mode_min ? -b.score : b.score;
-            if (qa != qb) return qa > qb;
-            if (a.y != b.y) return a.y < b.y;
-            return a.x < b.x;
-        });
+        sort_hits(hits, mode_min);
     }
     HIPC(hipEventSynchronize(c->ev[2]));       // already complete: every path above synchronised the stream
     HIPC(hipEventElapsedTime(&c->timing.score_ms, c->ev[0], c->ev[1]));

@@ -146,14 +146,105 @@ static inline float rect_overlap(const mtm_hit& a, const mtm_hit& b) {
     return 1.0f - (float)dist;
 }
 
+namespace {
+
+// float -> uint32 whose unsigned order is the float order (-0 == +0 must be normalised by the caller; NaN sorts high)
+inline uint32_t float_order(float v) {
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Stable LSD radix sort (8-bit digits) of `rec` by the `key_bytes` low bytes of Rec::key(), ascending.  Digits that are
+// the same in every record cost one histogram pass and no move.
+template <typename Rec, int KEY_BYTES>
+void radix_sort(std::vector<Rec>& rec) {
+    std::vector<Rec> tmp(rec.size());
+    Rec* src = rec.data();
+    Rec* dst = tmp.data();
+    const size_t n = rec.size();
+    for (int d = 0; d < KEY_BYTES; ++d) {
+        size_t hist[256] = {0};
+        for (size_t i = 0; i < n; ++i) ++hist[src[i].digit(d)];
+        if (hist[src[0].digit(d)] == n) continue;
+        size_t sum = 0;
+        for (int b = 0; b < 256; ++b) {
+            const size_t c = hist[b];
+            hist[b] = sum;
+            sum += c;
+        }
+        for (size_t i = 0; i < n; ++i) dst[hist[src[i].digit(d)]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != rec.data()) std::memcpy(rec.data(), src, n * sizeof(Rec));
+}
+
+struct HitRec {           // ascending (templ, ~order(quality), y, x)
+    uint64_t lo;          // [~order(quality) : 32][y : 16][x : 16]
+    uint32_t templ;
+    uint32_t idx;
+    unsigned digit(int d) const { return d < 8 ? (unsigned)(lo >> (8 * d)) & 255u : (unsigned)(templ >> (8 * (d - 8))) & 255u; }
+};
+
+struct ScoreRec {         // ascending ~order(score) = descending score
+    uint32_t key, idx;
+    unsigned digit(int d) const { return (key >> (8 * d)) & 255u; }
+};
+
+}  // namespace
+
+void sort_hits(std::vector<mtm_hit>& hits, bool mode_min) {
+    const size_t n = hits.size();
+    bool radix = n >= 512;
+    for (size_t i = 0; i < n && radix; ++i)
+        radix = hits[i].x >= 0 && hits[i].x < 65536 && hits[i].y >= 0 && hits[i].y < 65536 && hits[i].templ_idx >= 0 &&
+                hits[i].score == hits[i].score;
+    if (!radix) {
+        std::sort(hits.begin(), hits.end(), [&](const mtm_hit& a, const mtm_hit& b) {
+            if (a.templ_idx != b.templ_idx) return a.templ_idx < b.templ_idx;
+            const float qa = mode_min ? -a.score : a.score, qb = mode_min ? -b.score : b.score;
+            if (qa != qb) return qa > qb;
+            if (a.y != b.y) return a.y < b.y;
+            return a.x < b.x;
+        });
+        return;
+    }
+    std::vector<HitRec> rec(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float q = (mode_min ? -hits[i].score : hits[i].score) + 0.0f;      // -0 -> +0: equal qualities, equal keys
+        rec[i].lo = ((uint64_t)(~float_order(q)) << 32) | ((uint64_t)(uint32_t)hits[i].y << 16) | (uint32_t)hits[i].x;
+        rec[i].templ = (uint32_t)hits[i].templ_idx;
+        rec[i].idx = (uint32_t)i;
+    }
+    radix_sort<HitRec, 12>(rec);
+    std::vector<mtm_hit> out(n);
+    for (size_t i = 0; i < n; ++i) out[i] = hits[rec[i].idx];
+    hits.swap(out);
+}
+
 void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_threshold,
                float nms_threshold, std::vector<int32_t>& keep) {
     std::vector<int32_t> cand;
     cand.reserve((size_t)n);
+    bool radix = n >= 512;
     for (int64_t i = 0; i < n; ++i)
-        if (scores[i] > score_threshold) cand.push_back((int32_t)i);
-    std::stable_sort(cand.begin(), cand.end(),
-                     [&](int32_t a, int32_t b) { return scores[a] > scores[b]; });
+        if (scores[i] > score_threshold) {            // (false for NaN)
+            cand.push_back((int32_t)i);
+        }
+    if (radix) {
+        // descending score, ties in input order: a stable radix sort on the ordered bits (-0 normalised: -0 == +0 in the
+        // comparison-based sort below)
+        std::vector<ScoreRec> rec(cand.size());
+        for (size_t k = 0; k < cand.size(); ++k) {
+            rec[k].key = ~float_order(scores[cand[k]] + 0.0f);
+            rec[k].idx = (uint32_t)cand[k];
+        }
+        if (!rec.empty()) radix_sort<ScoreRec, 4>(rec);
+        for (size_t k = 0; k < cand.size(); ++k) cand[k] = (int32_t)rec[k].idx;
+    } else {
+        std::stable_sort(cand.begin(), cand.end(),
+                         [&](int32_t a, int32_t b) { return scores[a] > scores[b]; });
+    }
     keep.clear();
 
     // Same greedy decisions as OpenCV's NMSFast_ (a candidate is kept iff its overlap with EVERY kept

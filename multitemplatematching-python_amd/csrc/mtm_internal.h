@@ -38,4 +38,9 @@ std::vector<int> find_peaks_1d(const float* x, int n, int stride, float height, 
 void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_threshold,
                float nms_threshold, std::vector<int32_t>& keep);
 
+// The order in which mtm_find_matches returns its records: template, then descending quality (score, or -score for the
+// difference methods), then row-major position.  Deterministic whatever order the GPU appended them in; thousands
+// of records (smooth images at a low threshold) are sorted by an LSD radix sort on the same key.
+void sort_hits(std::vector<mtm_hit>& hits, bool mode_min);
+
 }  // namespace mtm

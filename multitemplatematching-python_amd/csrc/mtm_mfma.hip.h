@@ -377,6 +377,14 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     }
     if (wid >= p.n_work) break;
+    if (!EXT && METHOD != kMfRaw && p.hits_only) {
+        // hits-only launch whose candidate list overflowed: the call will be repeated with the maps in memory
+        // (dense maps), nothing this launch still computes is used - leave (work-group-uniform decision)
+        if (threadIdx.x == 0)
+            s_item[2] = __hip_atomic_load(p.cand_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > p.cand_cap ? 1 : 0;
+        __syncthreads();
+        if (s_item[2]) break;
+    }
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
@@ -674,6 +682,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         continue;
     }
     const int xq = x0 + 4 * lane;                       // first of this lane's 4 pixels
+    // is the candidate list full already?  (dense maps; see emit_at)
+    bool emit_full = false;
+    if (!EXT && METHOD != kMfRaw && p.cand_on)
+        emit_full = __hip_atomic_load(p.cand_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > p.cand_cap;   // strictly: the overflow is on record
     const int rd_off = 16 * (lane >> 2) + ((4 * (lane & 3) + mf_epi_rot(lane >> 2)) & 15);
     // registers e = 0..3 of phase c hold templates 4 (q & 1) + e of a stage, pixel 16 j + c
     auto put = [&](const v4i (&blk)[16]) {
@@ -688,7 +700,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             dst[3 * kMfEpiPitch + col] = blk[c].w;
         }
     };
-    // append the outputs above the threshold to the candidate list (rare)
+    // append the outputs above the threshold to the candidate list.  Rare on sparse maps, massive on smooth ones (a
+    // photograph at threshold 0.5: millions), so the list slots of a wave come from ONE atomic: the lanes that reach
+    // this point (the call sits under a divergent any-of-4 test) count their candidates with four ballots, the first
+    // of them reserves the total.  Once the list is full (emit_full, sampled when the epilogue starts) nothing is
+    // appended or counted any more - the host only needs to see count > capacity to fall back to the full peak pass.
     auto emit_at = [&](const float (&out)[4], int li, int yrow) {
         unsigned m = 0;
 #pragma unroll
@@ -696,11 +712,28 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             const float v = p.cand_min ? -out[i] : out[i];
             if (xq + i < p.ow && v > p.cand_thr) m |= 1u << i;
         }
+        if (emit_full) m = 0;
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64((m & 1u) != 0), b1 = __builtin_amdgcn_ballot_w64((m & 2u) != 0);
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64((m & 4u) != 0), b3 = __builtin_amdgcn_ballot_w64((m & 8u) != 0);
+        const unsigned n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+        const unsigned total = n0 + n1 + n2 + n3;
+        if (total == 0) return;                                     // uniform over the lanes that are here
+        const int leader = (int)__builtin_ctzll(act);
+        unsigned long long base = 0ull;
+        if (lane == leader) base = atomicAdd(p.cand_counter, (unsigned long long)total);
+        const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader);
+        const uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+        base = ((unsigned long long)bhi << 32) | blo;
         if (m) {
             const int tglob = tlist[li];
+            const unsigned long long bb[4] = {b0, b1, b2, b3};
+            const unsigned pre[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+#pragma unroll
             for (int i = 0; i < 4; ++i)
                 if ((m >> i) & 1u) {
-                    const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
+                    const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bb[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb[i], 0u));
+                    const unsigned long long slot = base + pre[i] + below;
                     if (slot < p.cand_cap) {
                         mtm_hit hrec;
                         hrec.templ_idx = tglob;

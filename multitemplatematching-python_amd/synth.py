@@ -46,6 +46,32 @@ def rand_int(seed, stream, n, lo, hi):
     return (lo + (r % np.uint64(hi - lo)).astype(np.int64)).astype(np.int64)
 
 
+def smooth_u8(seed, shape, scales=(4, 16, 64), weights=(1.0, 1.5, 2.0), noise=0.15):
+    """uint8 image with the statistics of a photograph - neighbouring pixels correlated: box-filtered white noise at
+    several scales plus a little sensor noise, stretched to 0..255.  Score maps of such images are smooth: at the
+    reference's default threshold (0.5) a template has thousands of pixels above it, where a white-noise image
+    (rand_u8, make_workload) has none besides the planted copies."""
+    rng = np.random.default_rng(seed)
+    acc = np.zeros(shape, np.float64)
+    for k, wgt in zip(scales, weights):
+        n = rng.standard_normal((shape[0] + k, shape[1] + k))
+        c = np.cumsum(np.cumsum(n, axis=0), axis=1)
+        acc += wgt * (c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k])[:shape[0], :shape[1]] / k
+    acc += noise * rng.standard_normal(shape)
+    acc = (acc - acc.min()) / (acc.max() - acc.min())
+    return np.round(acc * 255).astype(np.uint8)
+
+
+def cut_templates(seed, image, n, side):
+    """[(label, crop)] - n side x side crops of `image` at seeded positions."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        y, x = int(rng.integers(0, image.shape[0] - side)), int(rng.integers(0, image.shape[1] - side))
+        out.append(("t%d" % i, image[y:y + side, x:x + side].copy()))
+    return out
+
+
 def _resize_area(a, side):
     """Own area-average resize of a square uint8 array to side x side (no cv2), in exact integer
     arithmetic so that every numpy/BLAS build produces the same bytes: output pixel i integrates

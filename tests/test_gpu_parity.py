@@ -1720,6 +1720,58 @@ def test_context_state_sequences(mtm, seed):
             assert_hits_equal(hits_json(names), hits_json(exp), tol=1e-5, ordered=False)
 
 
+def test_dense_maps_candidate_overflow(mtm):
+    """Smooth images at a low threshold: far more pixels above the threshold than the candidate list holds.  The
+    overflowing hits-only launch leaves early, the call is repeated with the maps in memory and the full peak pass;
+    the following calls go there directly (back-off), later ones retry.  Every call returns the oracle's hits - also
+    when the image turns sparse again, and with the wave-aggregated candidate append of the score kernel in between."""
+    from MTM import _lib
+    dense = synth.smooth_u8(7, (300, 520), scales=(3, 9, 27), noise=0.1)
+    rng = np.random.default_rng(8)
+    sparse = rng.integers(0, 256, dense.shape, dtype=np.uint8)
+    lt = []
+    for i in range(20):                                   # two work-item groups
+        y, x = int(rng.integers(0, 300 - 24)), int(rng.integers(0, 520 - 32))
+        lt.append(("t%d" % i, dense[y:y + 24, x:x + 32].copy()))
+        sparse[y:y + 24, x:x + 32] = lt[-1][1]
+    exp_dense = hits_json(O.find_matches(lt, dense, method=5, score_threshold=0.3))
+    exp_sparse = hits_json(O.find_matches(lt, sparse, method=5, score_threshold=0.3))
+    assert len(exp_dense) > 3000 and 20 <= len(exp_sparse) < 200
+    c = _lib.Context(0)
+    try:
+        c.set_option(_lib.OPT_HIT_CAPACITY, 2048)             # candidate list of 2048 records: the dense image overflows it
+        c.set_templates([(t, None) for _, t in lt], 5)
+        modes = []
+        for k, (im, exp) in enumerate([(dense, exp_dense)] * 3 + [(sparse, exp_sparse)] * 2 + [(dense, exp_dense)] * 20 +
+                                      [(sparse, exp_sparse)] * 3):
+            raw = c.find_matches_image(im, _lib.PEAKS_LOCAL, 0.3)
+            modes.append(c.timing()["hits_only"])
+            got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in raw]
+            assert len(got) == len(exp), (k, len(got), len(exp))
+            assert_hits_equal(hits_json(got), exp, tol=1e-6, ordered=False)
+            # the records' order: template, descending score, row-major position (thousands: the radix sort)
+            keys = [(int(r["templ_idx"]), -float(r["score"]), int(r["y"]), int(r["x"])) for r in raw]
+            assert keys == sorted(keys), k
+        if not any(os.environ.get(v) for v in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY")):
+            assert modes[0] == 0 and modes[1] == 0            # overflow -> maps; then the back-off period
+            for _ in range(80):                               # sparse again: hits-only is back once the period ran out
+                raw = c.find_matches_image(sparse, _lib.PEAKS_LOCAL, 0.3)
+                assert len(raw) == len(exp_sparse)
+                if c.timing()["hits_only"] == 1:
+                    break
+            assert c.timing()["hits_only"] == 1
+        # a list that holds everything: same hits from the hits-only route (device hash verification)
+        c.set_option(_lib.OPT_HIT_CAPACITY, 1 << 18)
+        c.set_option(_lib.OPT_HITS_ONLY, 1)                   # (also clears the back-off)
+        raw = c.find_matches_image(dense, _lib.PEAKS_LOCAL, 0.3)
+        got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in raw]
+        assert_hits_equal(hits_json(got), exp_dense, tol=1e-6, ordered=False)
+        if not any(os.environ.get(v) for v in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY")):
+            assert c.timing()["hits_only"] == 1
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # RGB uint8: the compile-time-method epilogue with per-channel window sums (CH = 3)
 # ------------------------------------------------------------------------------------------------

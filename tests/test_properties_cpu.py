@@ -47,6 +47,14 @@ def test_nms_dense_grid_path(MTM, seed, n):
     got = MTM.NMS(hits, 0.2, False, float("inf"), ov)
     exp = O.NMS(hits, 0.2, False, float("inf"), ov)
     assert [(tuple(h[1]), float(h[2])) for h in got] == [(tuple(h[1]), float(h[2])) for h in exp]
+    # many equal scores (ties keep the input order: the radix sort of long lists is stable), both sort directions,
+    # a signed zero among them
+    tied = [(h[0], h[1], np.float32(round(float(h[2]) * 20) / 20)) for h in hits]
+    tied[0] = (tied[0][0], tied[0][1], np.float32(-0.0))
+    for ascending, thr in ((False, 0.2), (True, 0.7)):
+        got = MTM.NMS(tied, thr, ascending, float("inf"), ov)
+        exp = O.NMS(tied, thr, ascending, float("inf"), ov)
+        assert [(tuple(h[1]), float(h[2])) for h in got] == [(tuple(h[1]), float(h[2])) for h in exp]
 
 
 @settings(max_examples=200, **COMMON)
