@@ -285,22 +285,26 @@ void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_
         }
         return;
     }
-    std::vector<int32_t> head((size_t)(gw * gh), -1), next((size_t)n, -1);
+    // Lists are kept in insertion order (head = the cell's best box): a candidate of a dense cluster is almost always
+    // suppressed by the cluster's top, which is then the first box it meets; the own cell is visited first.
+    std::vector<int32_t> head((size_t)(gw * gh), -1), tail((size_t)(gw * gh), -1), next((size_t)n, -1);
+    static const int kOrder[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
     for (int32_t idx : cand) {
         const mtm_hit& b = hits[idx];
         const long long cx = fdiv(b.x, cell) - cx0 + 1, cy = fdiv(b.y, cell) - cy0 + 1;
         bool ok = true;
-        for (long long gy = cy - 1; gy <= cy + 1 && ok; ++gy)
-            for (long long gx = cx - 1; gx <= cx + 1 && ok; ++gx)
-                for (int32_t k = head[(size_t)(gy * gw + gx)]; k >= 0; k = next[k])
-                    if (!(rect_overlap(b, hits[k]) <= nms_threshold)) {
-                        ok = false;
-                        break;
-                    }
+        for (int o = 0; o < 9 && ok; ++o)
+            for (int32_t k = head[(size_t)((cy + kOrder[o][0]) * gw + cx + kOrder[o][1])]; k >= 0; k = next[k])
+                if (!(rect_overlap(b, hits[k]) <= nms_threshold)) {
+                    ok = false;
+                    break;
+                }
         if (ok) {
             keep.push_back(idx);
-            next[idx] = head[(size_t)(cy * gw + cx)];
-            head[(size_t)(cy * gw + cx)] = idx;
+            const size_t cellidx = (size_t)(cy * gw + cx);
+            if (tail[cellidx] >= 0) next[tail[cellidx]] = idx;
+            else head[cellidx] = idx;
+            tail[cellidx] = idx;
         }
     }
 }
