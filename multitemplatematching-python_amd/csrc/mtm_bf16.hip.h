@@ -361,21 +361,21 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     }
                     if (bestk) atomicMax(&ext_slot[lt], bestk);
                 } else if (p.cand_on) {
+                    // any-of-4 first (rare on sparse maps); the append itself takes one atomic per wave
+                    const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                    const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                    if ((p.cand_min ? -lo : hi) > p.cand_thr) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v = p.cand_min ? -out[i] : out[i];
-                        if (xb + i < p.ow && v > p.cand_thr) {
-                            const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
-                            if (slot < p.cand_cap) {
-                                mtm_hit hrec;
-                                hrec.templ_idx = T.tglob;
-                                hrec.x = xb + i;
-                                hrec.y = y;
-                                hrec.w = p.w;
-                                hrec.h = p.h;
-                                hrec.score = out[i];
-                                p.cand_hits[slot] = hrec;
-                            }
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = p.cand_min ? -out[i] : out[i];
+                            mtm_hit hrec;
+                            hrec.templ_idx = T.tglob;
+                            hrec.x = xb + i;
+                            hrec.y = y;
+                            hrec.w = p.w;
+                            hrec.h = p.h;
+                            hrec.score = out[i];
+                            cand_append(xb + i < p.ow && v > p.cand_thr, p.cand_counter, p.cand_cap, p.cand_hits, hrec);
                         }
                     }
                 }

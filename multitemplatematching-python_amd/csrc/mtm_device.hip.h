@@ -722,6 +722,27 @@ __global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restri
 // summed here in float64 (< 2^53) and normalised by finish_unmasked like every other kernel.
 // raw layout: [slab][template (list position)][oh][pitch] int32.
 // ---------------------------------------------------------------------------------------------
+// Append `rec` to the candidate list for every lane with `pred` - one atomic per wave (ballot + leader), so that
+// smooth score maps with millions of candidates do not serialise on the counter.  Call from wave-convergent or
+// divergent code alike (lanes that are not here count as pred = false).  Slots beyond `cap` are counted, not written.
+__device__ __forceinline__ void cand_append(bool pred, unsigned long long* counter, unsigned long long cap, mtm_hit* list,
+                                            const mtm_hit& rec) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(pred);
+    if (b == 0ull) return;                                      // uniform over the lanes that are here
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    const int leader = (int)__builtin_ctzll(act);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned long long base = 0ull;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(b));
+    const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader);
+    const uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+    if (pred) {
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + below;
+        if (slot < cap) list[slot] = rec;
+    }
+}
+
 struct SlabParams {
     mtm_hit* cand_hits;
     unsigned long long* cand_counter;
@@ -755,18 +776,15 @@ __global__ __launch_bounds__(256) void slab_combine_kernel(SlabParams p, const T
     for (int c = 0; c < p.chans; ++c) s1 += st.t[c][sidx];
     const double corr = ((double)a + 128.0 * s1) + T.mfma_k;
     const float out = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
-    if (p.cand_on && (p.cand_min ? -out : out) > p.cand_thr) {
-        const unsigned long long slot = atomicAdd(p.cand_counter, 1ull);
-        if (slot < p.cand_cap) {
-            mtm_hit hrec;
-            hrec.templ_idx = tlist[li];
-            hrec.x = x;
-            hrec.y = y;
-            hrec.w = p.w;
-            hrec.h = p.h;
-            hrec.score = out;
-            p.cand_hits[slot] = hrec;
-        }
+    if (p.cand_on) {
+        mtm_hit hrec;
+        hrec.templ_idx = tlist[li];
+        hrec.x = x;
+        hrec.y = y;
+        hrec.w = p.w;
+        hrec.h = p.h;
+        hrec.score = out;
+        cand_append((p.cand_min ? -out : out) > p.cand_thr, p.cand_counter, p.cand_cap, p.cand_hits, hrec);
     }
     if (!p.hits_only) maps[T.map_off + (size_t)y * T.map_pitch + x] = out;
 }

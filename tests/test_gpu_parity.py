@@ -1772,6 +1772,42 @@ def test_dense_maps_candidate_overflow(mtm):
         c.close()
 
 
+@pytest.mark.parametrize("kind", ["uint16", "float32", "slabs"])
+def test_dense_maps_other_kernels(mtm, kind):
+    """The same dense regime on the kernels with their own candidate append (uint16 finishing pass, float32 kernel,
+    slab combination): a candidate list that overflows, one that holds everything, and map mode return the same
+    records; uint16 / slabs also equal the oracle's."""
+    from MTM import _lib
+    dense = synth.smooth_u8(17, (260, 480), scales=(3, 9, 27), noise=0.1)
+    if kind == "slabs":
+        lt = [("wide", dense[30:50, 40:40 + 300].copy()), ("wide2", dense[200:220, 100:100 + 300].copy())]   # w > 256
+        img = dense
+    else:
+        lt = synth.cut_templates(3, dense, 20, 28)
+        img = dense.astype(np.uint16) * 201 + 7 if kind == "uint16" else dense.astype(np.float32) * np.float32(1.5) + np.float32(3)
+        lt = [(n, (t.astype(np.uint16) * 201 + 7) if kind == "uint16" else t.astype(np.float32) * np.float32(1.5) + np.float32(3))
+              for n, t in lt]
+    c = _lib.Context(0)
+    try:
+        c.set_templates([(t, None) for _, t in lt], 5)
+        res = {}
+        small = 64 if kind == "slabs" else 1024
+        for name, cap, honly in (("maps", 1 << 18, 0), ("list_holds", 1 << 18, 1), ("overflow", small, 1), ("overflow_again", small, 1)):
+            c.set_option(_lib.OPT_HIT_CAPACITY, cap)
+            c.set_option(_lib.OPT_HITS_ONLY, honly)
+            res[name] = c.find_matches_image(img, _lib.PEAKS_LOCAL, 0.3).copy()
+        n = len(res["maps"])
+        assert n > (15 if kind == "slabs" else 2000), n
+        for name in ("list_holds", "overflow", "overflow_again"):
+            assert res[name].tobytes() == res["maps"].tobytes(), (kind, name, len(res[name]), n)
+        if kind != "float32":
+            exp = O.find_matches([(a, b.astype(np.float32)) for a, b in lt], img.astype(np.float32), method=5, score_threshold=0.3)
+            got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in res["maps"]]
+            assert_hits_equal(hits_json(got), hits_json(exp), tol=1e-6, ordered=False)
+    finally:
+        c.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # RGB uint8: the compile-time-method epilogue with per-channel window sums (CH = 3)
 # ------------------------------------------------------------------------------------------------
