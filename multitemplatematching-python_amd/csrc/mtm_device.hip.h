@@ -33,7 +33,7 @@ __global__ void planarize_u8_kernel(const uint8_t* __restrict__ raw, int rows, i
         const uint8_t v = p[c];
         u8[c * u8_plane + (size_t)y * u8_pitch + x] = v;
         u8b[c * u8_plane + (size_t)y * u8_pitch + x] = v ^ 0x80;
-        f32[c * f32_plane + (size_t)y * f32_pitch + x] = (float)v;
+        if (f32 != nullptr) f32[c * f32_plane + (size_t)y * f32_pitch + x] = (float)v;
     }
 }
 
@@ -61,11 +61,22 @@ __global__ __launch_bounds__(256) void planarize_u8_c1_kernel(const uint8_t* __r
     *reinterpret_cast<uint4*>(u8 + o) = make_uint4(w[0], w[1], w[2], w[3]);
     *reinterpret_cast<uint4*>(u8b + o) = make_uint4(w[0] ^ 0x80808080u, w[1] ^ 0x80808080u, w[2] ^ 0x80808080u,
                                                     w[3] ^ 0x80808080u);
+    if (f32 == nullptr) return;         // banded uploads: no consumer of the float32 plane in that call (u8_to_f32_kernel later)
     float* fo = f32 + (size_t)y * f32_pitch + 16 * (size_t)g;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         *reinterpret_cast<float4*>(fo + 4 * k) = make_float4((float)(w[k] & 255u), (float)((w[k] >> 8) & 255u),
                                                              (float)((w[k] >> 16) & 255u), (float)(w[k] >> 24));
+}
+
+// The float32 plane of a uint8 image from its padded uint8 plane (4 pixels per thread), when a later call needs it
+// (float64 / naive kernels, the generic statistics) after an upload that skipped it.
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ u8, float* __restrict__ f32, size_t n4) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n4) return;
+    const uint32_t w = reinterpret_cast<const uint32_t*>(u8)[g];
+    reinterpret_cast<float4*>(f32)[g] = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u),
+                                                    (float)(w >> 24));
 }
 
 // Integer-factor area downscale fused with the layout conversion (reference use:

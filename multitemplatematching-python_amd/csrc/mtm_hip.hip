@@ -176,6 +176,7 @@ struct mtm_ctx {
     struct ImageSlot {
         DevBuf raw, u8, u8b, f32;
         long long geom = -1;        // (rows, cols, chans, dtype) the padding was initialised for
+        bool f32_valid = true;      // false after a banded uint8 upload: the float32 plane was skipped (ensure_f32_plane)
     } slot[2];
     int cur = 0;
     DevBuf sq_planes;           // [high byte of I^2][the same ^ 0x80][low byte ^ 0x80] of the current uint8 image
@@ -189,6 +190,7 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int skip_f32 = 1;                       // MTM_SKIP_F32: banded uploads leave the float32 plane out (rebuilt on demand)
     int f32_mfma = 1;                       // MTM_F32_MFMA: unmasked float32 classes on the bf16 matrix cores
     int mfma_r2 = 1;                        // MTM_MFMA_R2: two-row variant of the MFMA kernel where it applies
     int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
@@ -901,6 +903,18 @@ int place_templates(mtm_ctx* c) {
 
 int resolved_kernel(const mtm_ctx* c, const SizeClass& sc);
 
+// The float32 plane of the current image, if the upload skipped it (banded uint8 uploads do: single channel).
+int ensure_f32_plane(mtm_ctx* c) {
+    mtm_ctx::ImageSlot& sl = c->slot[c->cur];
+    if (sl.f32_valid) return MTM_OK;
+    const size_t n4 = (size_t)c->u8_pitch * c->rows_alloc / 4;         // pitch is a multiple of 64
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, sl.u8.as<uint8_t>(),
+                       sl.f32.as<float>(), n4);
+    HIPC(hipGetLastError());
+    sl.f32_valid = true;
+    return MTM_OK;
+}
+
 // Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
 // `sb0`, `sb1`: range of kStatBand4-row output blocks to compute (banded image upload; fused single-channel
 // kernel only), sb1 < 0 = all.
@@ -970,15 +984,18 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
             hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
                                c->stream, img.u8, img.u8_pitch, img.u8_plane, c->cols, w, ow, c->hs1.as<uint32_t>(),
                                c->hs2.as<uint32_t>(), hs_pitch, hs_plane);
-        else
+        else {
+            MTMC(ensure_f32_plane(c));
             hipLaunchKernelGGL(hsum_kernel<uint32_t>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
                                img.f32_plane, c->rows, w, ow, c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(),
                                hs_pitch, hs_plane);
+        }
         hipLaunchKernelGGL((vsum_stats_kernel<uint32_t, unsigned long long>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
                            ow, inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq,
                            st.pitch);
     } else {
+        MTMC(ensure_f32_plane(c));
         hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
                            img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
                            hs_plane);
@@ -1130,6 +1147,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
 
     if (kernel == MTM_KERNEL_NAIVE) {
         const dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4, n_list);
+        MTMC(ensure_f32_plane(c));
         hipLaunchKernelGGL(ncc_naive_kernel, grd, blk, 0, c->stream, img, td, tl, c->weights.as<double>(), st,
                            c->method, sc.masked ? 1 : 0, maps);
         c->timing.kernel_used = MTM_KERNEL_NAIVE;
@@ -1594,6 +1612,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     } else {
         const int ntx = (ow + kF64BX - 1) / kF64BX, nty = (oh + kF64BY - 1) / kF64BY;
         const dim3 grd(ntx * nty, n_list);
+        MTMC(ensure_f32_plane(c));
         if (sc.masked)
             hipLaunchKernelGGL(ncc_f64_kernel<true>, grd, dim3(256), 0, c->stream, img, td, tl,
                                c->weights.as<double>(), st, c->method, maps, ntx);
@@ -1743,6 +1762,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
@@ -1884,7 +1904,7 @@ int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols,
 // (prepared by prepare_slot) on `stream`.  A pageable source makes the copy call block the host until the rows
 // are staged; work queued on OTHER streams before the call runs under it.
 int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool skip_f32) {
     const int cols = g.cols, nrows = r1 - r0;
     if (nrows <= 0) return MTM_OK;
     uint8_t* raw = sl.raw.as<uint8_t>() + (size_t)r0 * cols;
@@ -1892,7 +1912,10 @@ int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src,
                           nrows, hipMemcpyHostToDevice, stream));
     uint8_t* u8 = sl.u8.as<uint8_t>() + (size_t)r0 * g.pitch;
     uint8_t* u8b = sl.u8b.as<uint8_t>() + (size_t)r0 * g.pitch;
-    float* f32 = sl.f32.as<float>() + (size_t)r0 * g.pitch;
+    // no float32 plane here: nothing in a banded call reads it (33 of the 50 MB this conversion would write at 4K);
+    // ensure_f32_plane() makes it from the uint8 plane if a later call on this image needs it
+    float* f32 = skip_f32 ? nullptr : sl.f32.as<float>() + (size_t)r0 * g.pitch;
+    sl.f32_valid = !skip_f32;
     int x_begin = 0;
     if (cols >= 16) {        // 16 pixels per thread; the generic kernel takes the tail columns
         const int cols16 = cols / 16;
@@ -1914,6 +1937,7 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
                  int chans, int dtype, hipStream_t stream, int factor = 1) {
     SlotGeom g{};
     MTMC(prepare_slot(c, sl, src_rows, src_cols, chans, dtype, stream, factor, &g));
+    sl.f32_valid = true;
     const size_t tight = (size_t)src_cols * chans * elem_size(dtype);
     HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, src_rows, hipMemcpyHostToDevice, stream));
     const int rows = g.rows, cols = g.cols, rows_alloc = g.rows_alloc, pitch = g.pitch;
@@ -2595,7 +2619,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         const bool last = k == nb - 1;
         int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
         if (r1 <= r_done) continue;
-        MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream));
+        MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
         r_done = r1;
         const int avail = r1 - h + 1;                            // output rows whose windows are complete
         const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);

@@ -605,6 +605,25 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
         plain.set_image(img2)
         plain.set_templates(cases[0][1], 5)
         assert np.array_equal(a, plain.find_matches(_lib.PEAKS_LOCAL, 0.5))
+        # the image of a banded call stays usable by everything else: the float64 / naive kernels and the generic
+        # statistics read the float32 plane, which the banded upload leaves out and the library rebuilds on demand
+        t0 = cases[0][1][0][0]
+        shape = (img2.shape[0] - t0.shape[0] + 1, img2.shape[1] - t0.shape[1] + 1)
+        for kern in (1, 0):                                # naive kernel; automatic choice (matrix cores)
+            for c_ in (fused, plain):
+                c_.set_option(_lib.OPT_KERNEL, kern)
+                c_.set_templates(cases[0][1][:3], 5)
+            m_f, m_p = fused.score_map(0, shape), plain.score_map(0, shape)
+            assert np.array_equal(m_f, m_p), kern
+        msk = [(t0, (t0 > 100).astype(np.uint8))]
+        for c_ in (fused, plain):
+            c_.set_templates(msk, 5)                       # masked + method 5 is not a matrix-core case: float64 kernel
+        fused.search(cases[0][1], img2, 5, _lib.PEAKS_LOCAL, 0.5)      # (banded upload again)
+        fused.set_templates(msk, 3)
+        plain.set_templates(msk, 3)
+        fused.set_option(_lib.OPT_KERNEL, 1)
+        plain.set_option(_lib.OPT_KERNEL, 1)
+        assert np.array_equal(fused.score_map(0, shape), plain.score_map(0, shape))
     finally:
         fused.close()
         plain.close()
