@@ -253,6 +253,7 @@ class Context:
         self.device = device
         self.lock = threading.RLock()
         self._keep = []
+        self._rec_key, self._rec, self._rec_keep = None, None, None
         k = os.environ.get("MTM_KERNEL")
         if k:
             self.set_option(OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[k.lower()])
@@ -282,9 +283,21 @@ class Context:
         check(self._lib.mtm_set_image_downscaled(self._h, ptr, a.shape[0], a.shape[1], chans, _dtype_code(a), stride,
                                                  int(downscale)), "mtm_set_image")
 
+    def _records(self, templates):
+        """templ_records(templates), memoised on the identity (and shape) of the arrays: a caller that passes the same
+        template objects call after call - the usual loop over images - pays for the marshalling once.  The arrays are
+        kept referenced, so an id cannot be recycled; changed PIXELS are the library's business (it compares the bytes
+        with the copy it packed from in every mtm_set_templates)."""
+        key = [(id(t), t.shape, id(m)) for t, m in templates]
+        if key != self._rec_key:
+            self._rec, keep = templ_records(templates)
+            self._rec_keep = (keep, [t for t, _ in templates], [m for _, m in templates])
+            self._rec_key = key
+        return self._rec
+
     def set_templates(self, templates, method):
         """templates: list of (array, mask_or_None) with identical dtype policy already applied."""
-        rec, keep = templ_records(templates)
+        rec = self._records(templates)
         check(self._lib.mtm_set_templates(self._h, rec.ctypes.data, len(templates), int(method)), "mtm_set_templates")
 
     def set_templates_augmented(self, bases, variants, method):

@@ -42,6 +42,11 @@ def coins():
     return load_coins()
 
 
+def hits_of(oracle_hits):
+    """Oracle hits in the package's output form (tuples, np.float32 scores)."""
+    return [(h[0], tuple(int(v) for v in h[1]), np.float32(h[2])) for h in oracle_hits]
+
+
 def set_kernel(ctx, name):
     ctx.set_option(1, KERNELS[name])
 
@@ -1591,6 +1596,25 @@ def test_fused_global_extremum_uint16_float32(mtm, dtype):
                 assert not bad.any(), (method, [(lt[i][0], gv[i], ev[i]) for i in np.flatnonzero(bad)])
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_same_template_objects_call_after_call(mtm, coins):
+    """The Python layer memoises the marshalling of the template list on the identity of its arrays; the pixels are
+    still compared by the library in every call: a template changed IN PLACE, or given another shape in place, is a
+    new template."""
+    small, big = coin_templates(coins)
+    a, b = small.copy(), np.ascontiguousarray(big[:40, :60])
+    lt = [("a", a), ("b", b)]
+    first = mtm.matchTemplates(lt, coins, score_threshold=0.5)
+    assert mtm.matchTemplates(lt, coins, score_threshold=0.5) == first == hits_of(O.match_templates(lt, coins, score_threshold=0.5))
+    a[...] = coins[150:150 + a.shape[0], 200:200 + a.shape[1]]          # same object, other pixels
+    second = mtm.matchTemplates(lt, coins, score_threshold=0.5)
+    assert second == hits_of(O.match_templates(lt, coins, score_threshold=0.5)) and second != first
+    b.shape = (60, 40)                                                  # same object, same bytes, other geometry
+    third = mtm.matchTemplates(lt, coins, score_threshold=0.5)
+    assert third == hits_of(O.match_templates(lt, coins, score_threshold=0.5))
+    assert all(h[1][2:] == (40, 60) for h in third if h[0] == "b")
 
 
 @pytest.mark.gpu
