@@ -401,9 +401,13 @@ bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
            (long long)sc.w * sc.h <= 131071;
 }
 
-// float32 image + float32 templates, no mask: two bfloat16 pieces per value on the bf16 matrix cores
+// float32 image + float32 templates, no mask: two bfloat16 pieces per value on the bf16 matrix cores - for the
+// NORMALISED methods, whose outputs are O(1) and stay within ~1e-5 of the float64 result.  The raw sums (TM_SQDIFF,
+// TM_CCORR, TM_CCOEFF) are as accurate relative to the sums they are built from (~1e-7), but they can cancel to
+// values far smaller than those sums (an exact copy: SQDIFF = 0), where no relative bound holds: float64 kernel.
 bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
-    return c->f32_mfma && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW;
+    const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED || c->method == MTM_TM_CCOEFF_NORMED;
+    return c->f32_mfma && normed && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW;
 }
 inline int bf16_nkb(int w) { return (w + 31) / 32; }
 long long bf16_group_bytes(int h, int w, int chans) { return (long long)chans * h * bf16_nkb(w) * 1024; }
