@@ -103,6 +103,8 @@ real = benign = 0
 t0 = time.time()
 for seed in range(first, first + count):
     img, lt, method, thr, n_obj, box = make_case(seed)
+    if os.environ.get("FUZZ_DTYPES") and str(img.dtype) not in os.environ["FUZZ_DTYPES"].split(","):
+        continue
     oimg, olt = as_oracle(img, lt)
     kw = dict(method=method, N_object=n_obj, searchBox=box)
     if thr is not None:
