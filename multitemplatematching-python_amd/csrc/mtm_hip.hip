@@ -102,6 +102,7 @@ struct SizeClass {
     bool bf16_ok = false;       // float32 class on the bf16 matrix cores (ncc_bf16_kernel)
     bool mfma16_ok = false;     // uint16 class on the int8 MFMA path (byte-plane decomposition)
     int rm_nt = 0, rm_R = 0;    // > 0: row-multiplexed MFMA mode (<= 16 templates: nt x R = 16 A rows)
+    int kp_nseg = 0;            // > 0: packed K (MfmaParams::kp_nseg): ceil(w / 16) segments per template row, 4 per MFMA step
     // large templates (w > 256 or w*h*C > 131071) on the MFMA kernel: cut into slabs (slab_combine_kernel)
     struct Slab {
         int r0, r1, c0, c1, ch;
@@ -190,6 +191,7 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int kpack = 1;                          // MTM_KPACK: packed K for template widths that are not multiples of 64
     int skip_f32 = 1;                       // MTM_SKIP_F32: banded uploads leave the float32 plane out (rebuilt on demand)
     int f32_mfma = 1;                       // MTM_F32_MFMA: unmasked float32 classes on the bf16 matrix cores
     int mfma_r2 = 1;                        // MTM_MFMA_R2: two-row variant of the MFMA kernel where it applies
@@ -349,12 +351,20 @@ bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
     return true;
 }
 long long mfma_group_bytes(int h, int w, int chans) { return (long long)chans * h * ((w + 63) / 64) * 1024; }
+// packed K: MFMA steps (1 KiB of A operand each) of `rows` stream rows of nseg 16-tap segments
+inline int kp_blocks(int rows, int nseg) { return (rows * nseg + 3) / 4; }
 int mfma_groups_alloc(int n) { return (((n + 15) / 16) + 1) & ~1; }     // multiple of MB = 2
 
 // Row-multiplexed packs (<= 16 uint8 templates, one channel, no mask): steps sp' = 0 .. h + 3R - 2, A row
 // i = (template i % nt, row offset i / nt) holds template row sp' - R - i / nt (zero outside 0..h-1).
 // MFMA group 0 of step s reads pack step s + R, group 1 (the wave's next R output rows) pack step s.
 long long rm_pack_bytes(int h, int w, int R) { return (long long)(h + 3 * R - 1) * ((w + 63) / 64) * 1024; }
+// bytes of one channel of a class's row-multiplexed pack.  Packed K: the two MFMA groups have packs of their own
+// (group g, image row r of the h + 2R - 1 a wave walks: template row r - g R - rho), kp_blocks steps each - the shifted
+// reuse of one pack (classic layout) would need R rows to be a whole number of 4-segment steps.
+long long class_rm_pack_bytes(const SizeClass& sc) {
+    return sc.kp_nseg ? 2LL * kp_blocks(sc.h + 2 * sc.rm_R - 1, sc.kp_nseg) * 1024 : rm_pack_bytes(sc.h, sc.w, sc.rm_R);
+}
 
 // the binary mask of a masked class as the single "template" (nt = 1, R = 16) of the sum I^2 M pass
 void pack_mask_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
@@ -374,10 +384,28 @@ void pack_mask_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
 }
 
 void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
-    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, R = sc.rm_R, nt = sc.rm_nt;
-    const int chans = sc.masked ? 1 : c->chans;                 // one pack per channel, rm_pack_bytes apart
-    const size_t cstride = (size_t)rm_pack_bytes(h, w, R);
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, R = sc.rm_R, nt = sc.rm_nt, nseg = sc.kp_nseg;
+    const int chans = sc.masked ? 1 : c->chans;                 // one pack per channel, class_rm_pack_bytes apart
+    const size_t cstride = (size_t)class_rm_pack_bytes(sc);
     std::memset(out, 0, cstride * chans);
+    if (nseg) {                                  // packed K: [ch][group g][step][lane][16], stream row r: dy = r - g R - rho
+        const size_t gbytes = cstride / 2;
+        for (int ch = 0; ch < chans; ++ch)
+            for (int g = 0; g < 2; ++g)
+                for (int r = 0; r < h + 2 * R - 1; ++r)
+                    for (int i = 0; i < 16; ++i) {
+                        const int t = i % nt, rho = i / nt, dy = r - g * R - rho;
+                        if (t >= (int)sc.members.size() || dy < 0 || dy >= h) continue;
+                        const HostTempl& ht = c->templs[sc.members[(size_t)t]];
+                        for (int dx = 0; dx < w; ++dx) {
+                            const size_t k = ((size_t)ch * h + dy) * w + dx;
+                            const int sidx = r * nseg + dx / 16;
+                            out[ch * cstride + g * gbytes + (((size_t)(sidx / 4) * 64) + (16 * (sidx % 4) + i)) * 16 + dx % 16] =
+                                (uint8_t)ht.px[k] ^ 0x80;
+                        }
+                    }
+        return;
+    }
     for (int ch = 0; ch < chans; ++ch)
         for (int sp = 0; sp < h + 3 * R - 1; ++sp)
             for (int i = 0; i < 16; ++i) {
@@ -385,10 +413,11 @@ void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
                 if (t >= (int)sc.members.size() || dy < 0 || dy >= h) continue;
                 const HostTempl& ht = c->templs[sc.members[(size_t)t]];
                 for (int dx = 0; dx < w; ++dx) {
-                    const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
                     const size_t k = ((size_t)ch * h + dy) * w + dx;
                     const uint8_t v = (uint8_t)(ht.masked ? ht.px[k] * ht.mask[k] : ht.px[k]);   // masked: T*M, M in {0,1}
-                    out[ch * cstride + (((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                    const size_t blk = (size_t)sp * nb + dx / 64;
+                    const int q = (dx % 64) / 16;
+                    out[ch * cstride + ((blk * 64) + (16 * q + i)) * 16 + dx % 16] = v ^ 0x80;
                 }
             }
 }
@@ -480,9 +509,9 @@ void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, doub
 }
 
 void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
-    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, chans = c->chans;
-    // two-row variant: groups of h + 1 rows (one channel), the extra row stays zero
-    const long long gb = sc.r2 ? sc.group_bytes : mfma_group_bytes(h, w, chans);
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, chans = c->chans, nseg = sc.kp_nseg;
+    // two-row variant: groups of h + 1 rows (one channel), the extra row stays zero; packed K: kp_blocks steps per channel
+    const long long gb = (sc.r2 || nseg) ? sc.group_bytes : mfma_group_bytes(h, w, chans);
     std::memset(out, 0, (size_t)gb * (sc.r2 ? ((int)sc.members.size() + 15) / 16 : mfma_groups_alloc((int)sc.members.size())));
     for (size_t li = 0; li < sc.members.size(); ++li) {
         const HostTempl& t = c->templs[sc.members[li]];
@@ -494,6 +523,11 @@ void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
                     const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
                     const size_t k = ((size_t)ch * h + dy) * w + dx;
                     const uint8_t v = (uint8_t)(t.masked ? t.px[k] * t.mask[k] : t.px[k]);   // masked: T*M, M in {0,1}
+                    if (nseg) {                                  // packed K: segment dy * nseg + dx / 16 of the row stream
+                        const int sidx = dy * nseg + dx / 16;
+                        g[((((size_t)ch * kp_blocks(h, nseg) + sidx / 4) * 64) + (16 * (sidx % 4) + i)) * 16 + byte] = v ^ 0x80;
+                        continue;
+                    }
                     g[((((size_t)ch * (sc.r2 ? h + 1 : h) + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
                 }
     }
@@ -576,12 +610,14 @@ int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
         return MTM_OK;
     }
     p.masked = sc.masked ? 1 : 0;
+    p.nseg = sc.kp_nseg;
     if (sc.rm_R > 0) {
         p.mode = 1;
         p.chans = sc.masked ? 1 : c->chans;
         p.nt = sc.rm_nt;
         p.R = sc.rm_R;
-        p.cstride = rm_pack_bytes(sc.h, sc.w, sc.rm_R);
+        p.cstride = class_rm_pack_bytes(sc);
+        p.kblocks = (int)(p.cstride / 2048);             // packed K: steps per MFMA group ([ch][group][step])
         p.n_chunks = p.cstride * p.chans / 16;
     } else if (sc.r2) {
         p.mode = 0;
@@ -592,7 +628,8 @@ int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
     } else {
         p.mode = 0;
         p.chans = c->chans;
-        p.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
+        p.group_bytes = sc.group_bytes;                  // (packed K: chans * kp_blocks steps)
+        p.kblocks = sc.kp_nseg ? kp_blocks(sc.h, sc.kp_nseg) : 0;
         p.n_chunks = p.group_bytes * mfma_groups_alloc(p.n) / 16;
     }
     launch(sc.apack_off);
@@ -664,6 +701,20 @@ int place_templates(mtm_ctx* c) {
         }
         sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
                 sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
+        // packed K: unmasked one-channel uint8 classes on the plain or row-multiplexed tiling whose width leaves part
+        // of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
+        // this one whole MFMA steps).
+        sc.kp_nseg = 0;
+        {
+            const int nseg = (sc.w + 15) / 16;
+            const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED ||
+                                c->method == MTM_TM_CCOEFF_NORMED;       // the instantiated variants (ncc_mfma_kernel<.., KP>)
+            if (c->kpack && class_kernel[k] == MTM_KERNEL_MFMA && !sc.masked && sc.slabs.empty() && nseg % 4 != 0 &&
+                c->chans == 1 && normed) {
+                sc.kp_nseg = nseg;
+                sc.r2 = false;
+            }
+        }
     }
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
@@ -769,9 +820,10 @@ int place_templates(mtm_ctx* c) {
                 for (double m : m0.mask) sc.mask_ones += m > 0.0 ? 1.0 : 0.0;
         }
         if (sc.rm_R > 0) {
-            sc.group_bytes = -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
+            sc.group_bytes = sc.kp_nseg ? class_rm_pack_bytes(sc) / 2          // packed K: a pack per MFMA group
+                                        : -(long long)sc.rm_R * ((sc.w + 63) / 64) * 1024;
             sc.apack_off = (long long)a_off;
-            a_off += (size_t)rm_pack_bytes(sc.h, sc.w, sc.rm_R) * (sc.masked ? 1 : c->chans);
+            a_off += (size_t)class_rm_pack_bytes(sc) * (sc.masked ? 1 : c->chans);
             continue;
         }
         if (!sc.slabs.empty()) {              // one pack per slab (a template of its own, one channel)
@@ -790,7 +842,8 @@ int place_templates(mtm_ctx* c) {
             a_off += (size_t)sc.group_bytes * (((int)sc.members.size() + 15) / 16);
             continue;
         }
-        sc.group_bytes = mfma_group_bytes(sc.h, sc.w, c->chans);
+        sc.group_bytes = sc.kp_nseg ? (long long)c->chans * kp_blocks(sc.h, sc.kp_nseg) * 1024
+                                    : mfma_group_bytes(sc.h, sc.w, c->chans);
         sc.apack_off = (long long)a_off;
         a_off += (size_t)sc.group_bytes * mfma_groups_alloc((int)sc.members.size());
     }
@@ -1299,7 +1352,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.rm_log2nt = 0;
             while ((1 << p.rm_log2nt) < sc.rm_nt) ++p.rm_log2nt;
             p.rm_steps = h + 2 * sc.rm_R - 1;
-            p.rm_cstride = rm_pack_bytes(h, w, sc.rm_R);
+            p.rm_cstride = class_rm_pack_bytes(sc);
             p.rm_rsq = c->stats_rsq.as<double>();
             p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
             p.ntg = 1;
@@ -1327,8 +1380,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         }
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
+        p.kp_nseg = sc.kp_nseg;
+        p.kp_blocks = sc.kp_nseg ? kp_blocks(h, sc.kp_nseg) : 0;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off +
-                            (rm ? (long long)sc.rm_R * p.nb * 1024 : (long long)tg0 * (r2 ? 1 : mb) * sc.group_bytes);
+                            (rm ? (sc.kp_nseg ? 0LL : (long long)sc.rm_R * p.nb * 1024)
+                                : (long long)tg0 * (r2 ? 1 : mb) * sc.group_bytes);
         // with a group offset the kernel's list positions must stay class-relative: shift the list
         // pointer and the counts instead (positions inside the kernel are relative to tg0)
         p.n_list = n_all - tg0 * tgsz;
@@ -1400,9 +1456,25 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         static const MfmaFn kMfmaR2Fns[2][2][4] = {{MTM_MF_R2(false, false), MTM_MF_R2(true, false)},
                                                    {MTM_MF_R2(false, true), MTM_MF_R2(true, true)}};
 #undef MTM_MF_R2
+        // packed-K variants (one channel, unmasked, the normalised methods 1 / 3 / 5): [extremum][exact division][..]
+#define MTM_MF_KP(MB, X, E) {ncc_mfma_kernel<MB, 1, X, false, false, 1, E, false, true>,                              \
+                            ncc_mfma_kernel<MB, 3, X, false, false, 1, E, false, true>,                              \
+                            ncc_mfma_kernel<MB, 5, X, false, false, 1, E, false, true>}
+#define MTM_MF_RMKP(X, E) {ncc_mfma_kernel<2, 1, X, false, true, 1, E, false, true>,                                  \
+                          ncc_mfma_kernel<2, 3, X, false, true, 1, E, false, true>,                                  \
+                          ncc_mfma_kernel<2, 5, X, false, true, 1, E, false, true>}
+        static const MfmaFn kMfmaKpFns[2][2][2][3] = {
+            {{MTM_MF_KP(1, false, false), MTM_MF_KP(2, false, false)}, {MTM_MF_KP(1, true, false), MTM_MF_KP(2, true, false)}},
+            {{MTM_MF_KP(1, false, true), MTM_MF_KP(2, false, true)}, {MTM_MF_KP(1, true, true), MTM_MF_KP(2, true, true)}}};
+        static const MfmaFn kMfmaRmKpFns[2][2][3] = {{MTM_MF_RMKP(false, false), MTM_MF_RMKP(true, false)},
+                                                     {MTM_MF_RMKP(false, true), MTM_MF_RMKP(true, true)}};
+#undef MTM_MF_KP
+#undef MTM_MF_RMKP
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
         const int xd = c->exact_div ? 1 : 0;
-        const MfmaFn fn = r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
+        const MfmaFn fn = sc.kp_nseg ? (rm ? kMfmaRmKpFns[ext ? 1 : 0][xd][(c->method - 1) / 2]
+                                           : kMfmaKpFns[ext ? 1 : 0][xd][mb - 1][(c->method - 1) / 2])
+                        : r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
                         : (ext && sc.masked) ? (rm ? kMfmaRmExtMaskedFns[c->method] : kMfmaExtMaskedFns[mb - 1][c->method])
                         : (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
                         : ext ? (c->chans == 3 ? kMfmaExtC3Fns[xd][mb - 1][c->method] : kMfmaExtFns[xd][mb - 1][c->method])
@@ -1767,6 +1839,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);

@@ -113,6 +113,13 @@ struct MfmaParams {
     unsigned long long* ext_best;
     int dbg;                 // profiling probe (MTM_MFMA_DBG): 2 = no epilogue (results invalid); the other probes
                              // are compile-time (-DMTM_PROBE_*)
+    // Packed K (kp_nseg > 0; plain and row-multiplexed tilings of unmasked uint8 classes whose width is not a multiple
+    // of 64): the K dimension is the STREAM of 16-tap segments of the template rows (kp_nseg = ceil(w / 16) per row),
+    // four consecutive segments per MFMA wherever the rows end - lane group q of step b holds segment 4 b + q, i.e.
+    // image row (4 b + q) / nseg, taps 16 ((4 b + q) % nseg) .. + 15.  A 41-wide template then walks 3 segments per
+    // row instead of a whole 64-tap block (the other 23 taps multiplied zeros), a 65-wide one 5 instead of 8.
+    int kp_nseg;
+    int kp_blocks;           // plain tiling: MFMA steps per channel = ceil(h * nseg / 4) (row-multiplexed: rm_cstride / 1024)
     // METHOD == kMfU16: byte sums of the templates ([0 .. npad) high bytes, [npad .. 2 npad) low bytes, class list
     // order), template area
     const double* u16_tsum;
@@ -320,7 +327,7 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 // load instead of two (the B operand and its byte shifts were shared already); a wave walks h + 1 image rows (the
 // first / last step use a zero operand for one of the rows) and a work-group covers 8 output rows.
 template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = false, int CH = 1, bool EXT = false,
-          bool R2 = false>
+          bool R2 = false, bool KP = false>
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
@@ -330,6 +337,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
     static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw), "fused extremum: compile-time-method paths");
     static_assert(METHOD != kMfU16 || (MB == 2 && !MASKED && !RM && CH == 1 && !R2), "uint16 finishing pass");
+    // packed K is a compile-time variant (its own instantiations): two K loops in one kernel - a run-time choice -
+    // push the register allocator of the 256-VGPR kernel into spilling accumulators
+    static_assert(!KP || (!R2 && !MASKED && CH == 1 && METHOD >= 0 && METHOD != kMfRaw && METHOD != kMfU16), "packed K");
     static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -571,6 +581,54 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #undef MTM_R2_STEP
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
                 __builtin_amdgcn_s_setprio(0);
+            } else if constexpr (KP) {
+            // ---- K loop over the segment stream (packed K, see MfmaParams): as below, but every lane group q walks
+            // its own (row, segment) position - five VALU instructions of bookkeeping per step instead of scalar ones
+            const int nseg = p.kp_nseg;
+            const uint8_t* aptr = apack_g + (RM ? (size_t)c * p.rm_cstride : (size_t)c * p.kp_blocks * 1024) +
+                                  (size_t)((cy0 * nseg) >> 2) * 1024;           // cy0 is a multiple of 64
+            const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + j * 16;
+            const int nsteps = (ch * nseg + 3) >> 2;
+            const int drow = 4 / nseg, dseg = 4 - drow * nseg;                 // uniform: stream advance of one step
+            const int adv = drow * p.lds_pitch + dseg * 16, wrapfix = p.lds_pitch - nseg * 16;
+            int seg = q % nseg;                                                 // this lane group's segment of step 0
+            int loff = (q / nseg) * p.lds_pitch + seg * 16;
+            v4i qa0, qb0, qa1, qb1, a0[MB], a1[MB];
+#define MTM_KP_ADVANCE()                                            \
+            {                                                       \
+                aptr += 1024;                                       \
+                seg += dseg;                                        \
+                const bool wrap_ = seg >= nseg;                     \
+                seg -= wrap_ ? nseg : 0;                            \
+                loff += adv + (wrap_ ? wrapfix : 0);                \
+            }
+#define MTM_KP_LOAD(QA, QB, A)                                                          \
+            QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
+            QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
+            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
+                A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
+            if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+            MTM_KP_LOAD(qa0, qb0, a0)            // step 0
+            int ks = 0;
+            for (; ks + 2 <= nsteps; ks += 2) {
+                MTM_KP_ADVANCE()
+                MTM_KP_LOAD(qa1, qb1, a1)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step<MB>(acc, qa0, qb0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                MTM_KP_ADVANCE()
+                MTM_KP_LOAD(qa0, qb0, a0)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_step<MB>(acc, qa1, qb1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks < nsteps) {
+                mfma_step<MB>(acc, qa0, qb0, a0);
+            }
+#undef MTM_KP_ADVANCE
+#undef MTM_KP_LOAD
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            __builtin_amdgcn_s_setprio(0);
             } else {
             // ---- K loop: template rows of this chunk x 64-tap blocks, software pipelined with two
             // register sets: the operands of the next step (2 LDS chunks + MB packed template rows)

@@ -140,8 +140,11 @@ struct PackParams {
     int hv;                              // valid template rows (rows hv .. h - 1 of a group stay zero: two-row variant)
     int nt, R;                           // RM
     long long group_bytes, cstride;      // plain: bytes per 16-template group; RM: bytes per channel
-    int masked, pad_;
+    int masked;
+    int nseg;                            // > 0: packed K (MfmaParams::kp_nseg): [ch][block b][lane][16], lane group q of block b =
+                                         // segment 4 b + q of the row stream (row (4 b + q) / nseg, taps 16 ((4 b + q) % nseg) ..)
     long long n_chunks;
+    int kblocks, pad_;                   // packed K: blocks per channel
 };
 
 __global__ __launch_bounds__(256) void pack_units_kernel(PackParams p, const uint8_t* __restrict__ arena,
@@ -151,9 +154,27 @@ __global__ __launch_bounds__(256) void pack_units_kernel(PackParams p, const uin
     if (k >= p.n_chunks) return;
     const int lane = (int)(k & 63), i = lane & 15, q = lane >> 4;
     long long r = k >> 6;
-    const int b = (int)(r % p.nb);
-    r /= p.nb;
     int li = -1, dy = -1, ch = 0;
+    int b = 0, qtap = q;                 // 16-tap segment of the row: dx = 64 b + 16 qtap + byte
+    if (p.nseg > 0) {
+        const int bb = (int)(r % p.kblocks);
+        r /= p.kblocks;
+        const int sidx = 4 * bb + q, srow = sidx / p.nseg;
+        qtap = sidx - srow * p.nseg;
+        if (p.mode == 0) {
+            dy = srow;
+            ch = (int)(r % p.chans);
+            li = 16 * (int)(r / p.chans) + i;
+        } else {                         // row-multiplexed: [ch][MFMA group g][step]; stream row r: template row r - g R - rho
+            const int g = (int)(r & 1);
+            ch = (int)(r >> 1);
+            const int t = i % p.nt, rho = i / p.nt;
+            dy = srow - g * p.R - rho;
+            li = t;
+        }
+    } else {
+    b = (int)(r % p.nb);
+    r /= p.nb;
     if (p.mode == 0) {
         dy = (int)(r % p.h);
         r /= p.h;
@@ -168,12 +189,13 @@ __global__ __launch_bounds__(256) void pack_units_kernel(PackParams p, const uin
         dy = sp - p.R - rho;
         li = t;
     }
+    }
     uint32_t wds[4] = {0u, 0u, 0u, 0u};
     if (li >= 0 && li < p.n && dy >= 0 && dy < p.hv) {
         const UnitSrc u = units[tl[li]];
 #pragma unroll
         for (int byte = 0; byte < 16; ++byte) {
-            const int dx = 64 * b + 16 * q + byte;
+            const int dx = 64 * b + 16 * qtap + byte;
             if (dx < p.w) {
                 unsigned v;
                 if (p.mode == 2) v = unit_mask(arena, u, 0, dy, dx);
