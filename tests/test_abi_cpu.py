@@ -105,3 +105,22 @@ def test_nms_edge_cases(lib):
     assert MTM.NMS(two, maxOverlap=0.5) == [two[0]]          # identical boxes: IoU 1 > 0.5
     assert MTM.NMS(two, maxOverlap=1.0) == two
     assert MTM.NMS(two, scoreThreshold=0.95) == []
+
+
+def test_score_kernel_does_not_spill_accumulators():
+    """ncc_mfma_kernel holds 128 accumulator VGPRs next to inline-asm MFMA steps; an instantiation whose register
+    allocation tips over starts spilling accumulators around those steps - slow, and (seen once, DESIGN 4.1 "packed K")
+    wrong.  The healthy instantiations spill a few prologue / epilogue values only: at most ~160 bytes of scratch."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    import build as mtm_build
+    mtm_build.build()
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = [k for k in kr.kernels(mtm_build.LIB) if "ncc_mfma_kernel" in k["name"]]
+    assert len(ks) >= 100
+    worst = max(ks, key=lambda k: k["scratch"])
+    assert worst["scratch"] <= 200, worst
+    assert all(k["vgpr"] <= 256 for k in ks)

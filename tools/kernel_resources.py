@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Registers / scratch / LDS of every kernel in libmtm_hip.so (gfx950 code object unbundled from the fat binary,
+metadata read with llvm-readelf).  Usage: tools/kernel_resources.py [path/to/libmtm_hip.so] [name filter]
+The score kernel must not spill accumulators (packed K): tests/test_abi_cpu.py checks its scratch."""
+import os, re, struct, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def code_object(so_path, arch="gfx950"):
+    blob = open(so_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos = blob.find(magic)
+    while pos >= 0:
+        n = struct.unpack_from("<Q", blob, pos + len(magic))[0]
+        q = pos + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if arch in triple and size > 0:
+                return blob[pos + off:pos + off + size]
+        pos = blob.find(magic, pos + 1)
+    raise RuntimeError("no %s code object in %s" % (arch, so_path))
+
+
+def kernels(so_path):
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(code_object(so_path))
+        f.flush()
+        notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    out = []
+    for blk in notes.split("- .agpr_count")[1:]:
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        out.append({"name": re.search(r"\.name:\s+(\S+)", blk).group(1), "vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"),
+                    "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size")})
+    return out
+
+
+if __name__ == "__main__":
+    so = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else os.path.join(ROOT, "multitemplatematching-python_amd", "MTM", "libmtm_hip.so")
+    flt = sys.argv[-1] if len(sys.argv) > 1 and not os.path.exists(sys.argv[-1]) else ""
+    ks = [k for k in kernels(so) if flt in k["name"]]
+    for k in sorted(ks, key=lambda k: -k["scratch"])[:400]:
+        print("%4d vgpr %4d sgpr %5d B scratch  %s" % (k["vgpr"], k["sgpr"], k["scratch"], k["name"][:150]))
+    print("%d kernels; max scratch %d B" % (len(ks), max(k["scratch"] for k in ks)))
