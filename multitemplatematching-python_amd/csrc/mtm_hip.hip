@@ -400,8 +400,9 @@ void pack_class_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
                         for (int dx = 0; dx < w; ++dx) {
                             const size_t k = ((size_t)ch * h + dy) * w + dx;
                             const int sidx = r * nseg + dx / 16;
+                            const uint8_t v = (uint8_t)(ht.masked ? ht.px[k] * ht.mask[k] : ht.px[k]);   // masked: T*M
                             out[ch * cstride + g * gbytes + (((size_t)(sidx / 4) * 64) + (16 * (sidx % 4) + i)) * 16 + dx % 16] =
-                                (uint8_t)ht.px[k] ^ 0x80;
+                                v ^ 0x80;
                         }
                     }
         return;
@@ -701,16 +702,16 @@ int place_templates(mtm_ctx* c) {
         }
         sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
                 sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
-        // packed K: unmasked one-channel uint8 classes on the plain or row-multiplexed tiling whose width leaves part
-        // of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
+        // packed K: one-channel uint8 classes (masked or not) on the plain or row-multiplexed tiling whose width leaves
+        // part of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
         // this one whole MFMA steps).
         sc.kp_nseg = 0;
         {
             const int nseg = (sc.w + 15) / 16;
             const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED ||
                                 c->method == MTM_TM_CCOEFF_NORMED;       // the instantiated variants (ncc_mfma_kernel<.., KP>)
-            if (c->kpack && class_kernel[k] == MTM_KERNEL_MFMA && !sc.masked && sc.slabs.empty() && nseg % 4 != 0 &&
-                c->chans == 1 && normed) {
+            if (c->kpack && class_kernel[k] == MTM_KERNEL_MFMA && sc.slabs.empty() && nseg % 4 != 0 && c->chans == 1 &&
+                normed && (!sc.masked || c->method != MTM_TM_CCOEFF_NORMED)) {
                 sc.kp_nseg = nseg;
                 sc.r2 = false;
             }
@@ -1468,12 +1469,24 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             {{MTM_MF_KP(1, false, true), MTM_MF_KP(2, false, true)}, {MTM_MF_KP(1, true, true), MTM_MF_KP(2, true, true)}}};
         static const MfmaFn kMfmaRmKpFns[2][2][3] = {{MTM_MF_RMKP(false, false), MTM_MF_RMKP(true, false)},
                                                      {MTM_MF_RMKP(false, true), MTM_MF_RMKP(true, true)}};
+        // masked packed-K variants (methods 1 / 3; the fused extremum only with the reciprocal normalisation)
+#define MTM_MF_KPM(MB, X, E) {ncc_mfma_kernel<MB, 1, X, true, false, 1, E, false, true>, ncc_mfma_kernel<MB, 3, X, true, false, 1, E, false, true>}
+#define MTM_MF_RMKPM(X, E) {ncc_mfma_kernel<2, 1, X, true, true, 1, E, false, true>, ncc_mfma_kernel<2, 3, X, true, true, 1, E, false, true>}
+        static const MfmaFn kMfmaKpMaskedFns[2][2][2] = {{MTM_MF_KPM(1, false, false), MTM_MF_KPM(2, false, false)},
+                                                         {MTM_MF_KPM(1, true, false), MTM_MF_KPM(2, true, false)}};
+        static const MfmaFn kMfmaKpMaskedExtFns[2][2] = {MTM_MF_KPM(1, false, true), MTM_MF_KPM(2, false, true)};
+        static const MfmaFn kMfmaRmKpMaskedFns[2][2] = {MTM_MF_RMKPM(false, false), MTM_MF_RMKPM(true, false)};
+        static const MfmaFn kMfmaRmKpMaskedExtFns[2] = MTM_MF_RMKPM(false, true);
+#undef MTM_MF_KPM
+#undef MTM_MF_RMKPM
 #undef MTM_MF_KP
 #undef MTM_MF_RMKP
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
         const int xd = c->exact_div ? 1 : 0;
-        const MfmaFn fn = sc.kp_nseg ? (rm ? kMfmaRmKpFns[ext ? 1 : 0][xd][(c->method - 1) / 2]
-                                           : kMfmaKpFns[ext ? 1 : 0][xd][mb - 1][(c->method - 1) / 2])
+        const int m2 = (c->method - 1) / 2;               // methods 1 / 3 / 5 -> 0 / 1 / 2
+        const MfmaFn fn = (sc.kp_nseg && sc.masked) ? (ext ? (rm ? kMfmaRmKpMaskedExtFns[m2] : kMfmaKpMaskedExtFns[mb - 1][m2])
+                                                           : (rm ? kMfmaRmKpMaskedFns[xd][m2] : kMfmaKpMaskedFns[xd][mb - 1][m2]))
+                        : sc.kp_nseg ? (rm ? kMfmaRmKpFns[ext ? 1 : 0][xd][m2] : kMfmaKpFns[ext ? 1 : 0][xd][mb - 1][m2])
                         : r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
                         : (ext && sc.masked) ? (rm ? kMfmaRmExtMaskedFns[c->method] : kMfmaExtMaskedFns[mb - 1][c->method])
                         : (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
