@@ -702,16 +702,16 @@ int place_templates(mtm_ctx* c) {
         }
         sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
                 sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
-        // packed K: one-channel uint8 classes (masked or not) on the plain or row-multiplexed tiling whose width leaves
-        // part of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
+        // packed K: uint8 classes (one channel, masked or not; RGB) on the plain or row-multiplexed tiling whose width
+        // leaves part of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
         // this one whole MFMA steps).
         sc.kp_nseg = 0;
         {
             const int nseg = (sc.w + 15) / 16;
             const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED ||
                                 c->method == MTM_TM_CCOEFF_NORMED;       // the instantiated variants (ncc_mfma_kernel<.., KP>)
-            if (c->kpack && class_kernel[k] == MTM_KERNEL_MFMA && sc.slabs.empty() && nseg % 4 != 0 && c->chans == 1 &&
-                normed && (!sc.masked || c->method != MTM_TM_CCOEFF_NORMED)) {
+            if (c->kpack && class_kernel[k] == MTM_KERNEL_MFMA && sc.slabs.empty() && nseg % 4 != 0 && normed &&
+                (c->chans == 1 || (c->chans == 3 && !sc.masked)) && (!sc.masked || c->method != MTM_TM_CCOEFF_NORMED)) {
                 sc.kp_nseg = nseg;
                 sc.r2 = false;
             }
@@ -1479,6 +1479,20 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         static const MfmaFn kMfmaRmKpMaskedExtFns[2] = MTM_MF_RMKPM(false, true);
 #undef MTM_MF_KPM
 #undef MTM_MF_RMKPM
+        // RGB packed-K variants
+#define MTM_MF_KP3(MB, X, E) {ncc_mfma_kernel<MB, 1, X, false, false, 3, E, false, true>,                             \
+                             ncc_mfma_kernel<MB, 3, X, false, false, 3, E, false, true>,                             \
+                             ncc_mfma_kernel<MB, 5, X, false, false, 3, E, false, true>}
+#define MTM_MF_RMKP3(X, E) {ncc_mfma_kernel<2, 1, X, false, true, 3, E, false, true>,                                 \
+                           ncc_mfma_kernel<2, 3, X, false, true, 3, E, false, true>,                                 \
+                           ncc_mfma_kernel<2, 5, X, false, true, 3, E, false, true>}
+        static const MfmaFn kMfmaKpC3Fns[2][2][2][3] = {
+            {{MTM_MF_KP3(1, false, false), MTM_MF_KP3(2, false, false)}, {MTM_MF_KP3(1, true, false), MTM_MF_KP3(2, true, false)}},
+            {{MTM_MF_KP3(1, false, true), MTM_MF_KP3(2, false, true)}, {MTM_MF_KP3(1, true, true), MTM_MF_KP3(2, true, true)}}};
+        static const MfmaFn kMfmaRmKpC3Fns[2][2][3] = {{MTM_MF_RMKP3(false, false), MTM_MF_RMKP3(true, false)},
+                                                       {MTM_MF_RMKP3(false, true), MTM_MF_RMKP3(true, true)}};
+#undef MTM_MF_KP3
+#undef MTM_MF_RMKP3
 #undef MTM_MF_KP
 #undef MTM_MF_RMKP
         const bool c3 = c->chans == 3 && !sc.masked && !rm;
@@ -1486,6 +1500,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int m2 = (c->method - 1) / 2;               // methods 1 / 3 / 5 -> 0 / 1 / 2
         const MfmaFn fn = (sc.kp_nseg && sc.masked) ? (ext ? (rm ? kMfmaRmKpMaskedExtFns[m2] : kMfmaKpMaskedExtFns[mb - 1][m2])
                                                            : (rm ? kMfmaRmKpMaskedFns[xd][m2] : kMfmaKpMaskedFns[xd][mb - 1][m2]))
+                        : (sc.kp_nseg && c->chans == 3) ? (rm ? kMfmaRmKpC3Fns[ext ? 1 : 0][xd][m2]
+                                                              : kMfmaKpC3Fns[ext ? 1 : 0][xd][mb - 1][m2])
                         : sc.kp_nseg ? (rm ? kMfmaRmKpFns[ext ? 1 : 0][xd][m2] : kMfmaKpFns[ext ? 1 : 0][xd][mb - 1][m2])
                         : r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
                         : (ext && sc.masked) ? (rm ? kMfmaRmExtMaskedFns[c->method] : kMfmaExtMaskedFns[mb - 1][c->method])
