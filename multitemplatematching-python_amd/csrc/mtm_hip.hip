@@ -486,8 +486,8 @@ void pack_class_bf16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, std::v
 // 16 templates.  Same lane order as pack_class_mfma.  Also the byte sums of every member (bias terms of the
 // combination): tsum[li] high bytes, tsum[n_pad + li] low bytes.
 void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, double* tsum) {
-    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, n_pad = sc.n_pad;
-    const long long gb = mfma_group_bytes(h, w, 1);
+    const int h = sc.h, w = sc.w, nb = (w + 63) / 64, n_pad = sc.n_pad, nseg = sc.kp_nseg;
+    const long long gb = sc.group_bytes;
     std::memset(out, 0, (size_t)gb * (2 * n_pad / 16));
     for (int k = 0; k < 2 * n_pad; ++k) tsum[k] = 0.0;
     for (size_t li = 0; li < sc.members.size(); ++li) {
@@ -502,6 +502,11 @@ void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, doub
                     const uint8_t v = part == 0 ? (uint8_t)(v16 >> 8) : (uint8_t)(v16 & 255u);
                     sum += v;
                     const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
+                    if (nseg) {                                  // packed K: segment dy * nseg + dx / 16 of the row stream
+                        const int sidx = dy * nseg + dx / 16;
+                        g[(((size_t)(sidx / 4)) * 64 + (16 * (sidx % 4) + i)) * 16 + byte] = v ^ 0x80;
+                        continue;
+                    }
                     g[(((size_t)dy * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
                 }
             tsum[(size_t)part * n_pad + li] = sum;
@@ -860,7 +865,11 @@ int place_templates(mtm_ctx* c) {
         SizeClass& sc = classes[k];
         sc.tsum_off = -1;
         if (class_kernel[k] != MTM_KERNEL_MFMA16) continue;
-        sc.group_bytes = mfma_group_bytes(sc.h, sc.w, 1);
+        {   // packed K for the two byte-plane passes (widths that are not multiples of 64), as for uint8 classes
+            const int nseg = (sc.w + 15) / 16;
+            sc.kp_nseg = (c->kpack && nseg % 4 != 0) ? nseg : 0;
+        }
+        sc.group_bytes = sc.kp_nseg ? (long long)kp_blocks(sc.h, sc.kp_nseg) * 1024 : mfma_group_bytes(sc.h, sc.w, 1);
         sc.apack_off = (long long)a_off;
         a_off += (size_t)sc.group_bytes * (2 * sc.n_pad / 16);
         sc.tsum_off = (long long)ts_off;
@@ -1603,8 +1612,14 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * 2 * sc.group_bytes;
         const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16;
         p.img = planes;                                         // high bytes: raw accumulators
-        hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap,
-                           st, maps, c->sched.as<unsigned int>());
+        p.kp_nseg = sc.kp_nseg;
+        p.kp_blocks = sc.kp_nseg ? kp_blocks(h, sc.kp_nseg) : 0;
+        if (sc.kp_nseg)
+            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false, false, 1, false, false, true>), dim3(grid), dim3(256),
+                               lds, c->stream, p, td, tl_k, ap, st, maps, c->sched.as<unsigned int>());
+        else
+            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k,
+                               ap, st, maps, c->sched.as<unsigned int>());
         p.img = planes + (size_t)img.u8_plane;                  // low bytes: finish
         p.n_list = n_all - tg0 * 16;                            // list positions inside the kernel are relative to tg0
         p.only_li = only_li >= 0 ? only_li - tg0 * 16 : -1;
@@ -1629,11 +1644,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.hits_only = 1;
         }
         using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
-        static const MfmaFn kU16Fns[2][2] = {
-            {ncc_mfma_kernel<2, kMfU16, false, false>, ncc_mfma_kernel<2, kMfU16, true, false>},
-            {ncc_mfma_kernel<2, kMfU16, false, false, false, 1, true>, ncc_mfma_kernel<2, kMfU16, true, false, false, 1, true>}};
-        hipLaunchKernelGGL(kU16Fns[ext ? 1 : 0][c->exact_div ? 1 : 0], dim3(grid), dim3(256), lds2, c->stream, p, td, tl_k, ap,
-                           st, maps, c->sched.as<unsigned int>());
+        static const MfmaFn kU16Fns[2][2][2] = {
+            {{ncc_mfma_kernel<2, kMfU16, false, false>, ncc_mfma_kernel<2, kMfU16, true, false>},
+             {ncc_mfma_kernel<2, kMfU16, false, false, false, 1, true>, ncc_mfma_kernel<2, kMfU16, true, false, false, 1, true>}},
+            {{ncc_mfma_kernel<2, kMfU16, false, false, false, 1, false, false, true>,
+              ncc_mfma_kernel<2, kMfU16, true, false, false, 1, false, false, true>},
+             {ncc_mfma_kernel<2, kMfU16, false, false, false, 1, true, false, true>,
+              ncc_mfma_kernel<2, kMfU16, true, false, false, 1, true, false, true>}}};             // [packed K][extremum][exact]
+        hipLaunchKernelGGL(kU16Fns[sc.kp_nseg ? 1 : 0][ext ? 1 : 0][c->exact_div ? 1 : 0], dim3(grid), dim3(256), lds2, c->stream,
+                           p, td, tl_k, ap, st, maps, c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32) {
         const int n_all = (int)sc.members.size();

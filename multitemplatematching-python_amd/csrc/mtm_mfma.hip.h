@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     static_assert(METHOD != kMfU16 || (MB == 2 && !MASKED && !RM && CH == 1 && !R2), "uint16 finishing pass");
     // packed K is a compile-time variant (its own instantiations): two K loops in one kernel - a run-time choice -
     // push the register allocator of the 256-VGPR kernel into spilling accumulators
-    static_assert(!KP || (!R2 && METHOD >= 0 && METHOD != kMfRaw && METHOD != kMfU16), "packed K");
+    static_assert(!KP || (!R2 && METHOD >= 0 && (METHOD != kMfRaw || !RM)), "packed K");
     static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
