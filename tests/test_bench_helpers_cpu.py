@@ -50,3 +50,21 @@ def test_pmc_traffic_table():
     m = bench.pmc_traffic(3, "north_star", 1, hits_only=False)
     assert t and m and 1.0 <= t / 135151376 < 1.3 and 1.0 <= m / 1022232704 < 1.3   # no wasted re-reads
     assert bench.pmc_traffic(3, "cfg5", 1) is None
+
+
+def test_synthetic_smooth_image_and_crops():
+    """synth.smooth_u8 / cut_templates (the photograph-like workload of bench.py's extra and of the dense-map tests):
+    seeded, full byte range, neighbouring pixels correlated; crops are copies at in-range positions."""
+    import synth
+    a = synth.smooth_u8(7, (120, 200))
+    assert a.dtype == np.uint8 and a.shape == (120, 200) and a.min() == 0 and a.max() == 255
+    assert np.array_equal(a, synth.smooth_u8(7, (120, 200))) and not np.array_equal(a, synth.smooth_u8(8, (120, 200)))
+    d = np.abs(np.diff(a.astype(np.int32), axis=1)).mean()
+    w = np.abs(np.diff(synth.rand_u8(7, 0, (120, 200)).astype(np.int32), axis=1)).mean()
+    assert d < 0.35 * w                                     # far smoother than white noise
+    lt = synth.cut_templates(3, a, 5, 24)
+    assert [n for n, _ in lt] == ["t0", "t1", "t2", "t3", "t4"]
+    for _, t in lt:
+        assert t.shape == (24, 24) and t.flags.c_contiguous and t.base is None
+        pos = [(y, x) for y in range(120 - 24 + 1) for x in range(200 - 24 + 1) if a[y, x] == t[0, 0] and np.array_equal(a[y:y + 24, x:x + 24], t)]
+        assert pos
