@@ -4,22 +4,31 @@ tests and by hand:  python multitemplatematching-python_amd/build.py [--force]
 
 hipcc cross-compiles without a GPU.  The built .so is git-ignored but travels to the GPU box with
 the gpurun snapshot.
+
+The library is several translation units (the ~300 instantiations of the MFMA score kernel alone are four of
+them): every unit is compiled to an object of its own, in parallel, and only the units whose inputs changed
+are recompiled (objects and their stamps live in csrc/build/, git-ignored).
 """
 import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["mtm_hip.hip", "mtm_host.cpp", "mtm_group.cpp"]
-DEPS = SOURCES + ["mtm_device.hip.h", "mtm_mfma.hip.h", "mtm_templates.hip.h", "mtm_bf16.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
-                  os.path.join("..", "..", "include", "mtm_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+SOURCES = ["mtm_hip.hip", "mtm_mfma_plain.hip", "mtm_mfma_rm.hip", "mtm_mfma_ext.hip", "mtm_mfma_kp.hip", "mtm_bf16.hip",
+           "mtm_host.cpp", "mtm_group.cpp"]
+HEADERS = ["mtm_device.hip.h", "mtm_device_util.hip.h", "mtm_mfma.hip.h", "mtm_mfma_params.h", "mtm_templates.hip.h",
+           "mtm_bf16.hip.h", "mtm_bf16_params.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
+           os.path.join("..", "..", "include", "mtm_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default"]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl", "-pthread"]
 
 
 def _hipcc():
@@ -33,15 +42,45 @@ def _extra_flags():
     return os.environ.get("MTM_EXTRA_FLAGS", "").split()     # experiments only (e.g. -DMTM_PROBE_NO_A)
 
 
-def _digest():
+def _file_digest(h, path):
+    if os.path.exists(path):
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+
+
+def _unit_digest(src):
+    """Everything an object depends on: its source, every header, the flags."""
     h = hashlib.sha256()
-    for f in DEPS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p):
-            with open(p, "rb") as fh:
-                h.update(fh.read())
+    _file_digest(h, os.path.join(CSRC, src))
+    for f in HEADERS:
+        _file_digest(h, os.path.join(CSRC, f))
     h.update(" ".join(FLAGS + _extra_flags()).encode())
     return h.hexdigest()
+
+
+def _digest():
+    h = hashlib.sha256()
+    for src in SOURCES:
+        h.update(_unit_digest(src).encode())
+    h.update(" ".join(LINK_FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src, force, verbose):
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    stamp = obj + ".stamp"
+    dig = _unit_digest(src)
+    if not force and os.path.exists(obj) and os.path.exists(stamp):
+        with open(stamp) as f:
+            if f.read().strip() == dig:
+                return obj
+    cmd = [_hipcc()] + FLAGS + _extra_flags() + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return obj
 
 
 def build(force=False, verbose=False):
@@ -50,9 +89,13 @@ def build(force=False, verbose=False):
         with open(STAMP) as f:
             if f.read().strip() == dig:
                 return LIB
-    cmd = [_hipcc()] + FLAGS + _extra_flags() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-ldl", "-pthread"]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = max(1, min(len(SOURCES), int(os.environ.get("MTM_BUILD_JOBS", os.cpu_count() or 1))))
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        objs = list(pool.map(lambda s: _compile(s, force, verbose), SOURCES))
+    cmd = [_hipcc()] + objs + ["-o", LIB] + LINK_FLAGS
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     with open(STAMP, "w") as f:
         f.write(dig)

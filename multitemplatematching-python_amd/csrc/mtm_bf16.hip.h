@@ -24,68 +24,16 @@
 // (32 * MB accumulator VGPRs); a work-group = 4 waves = 4 rows sharing the two piece tiles.
 // Unmasked templates only (float masks keep the float64 kernel); w <= 256.
 #pragma once
-#include "mtm_device.hip.h"
-#include "mtm_mfma.hip.h"
+#include "mtm_device_util.hip.h"
+#include "mtm_bf16_params.h"
 
 namespace mtm {
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef int v4i_b __attribute__((ext_vector_type(4)));
-typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
-
-constexpr int kBfSeg = 128;          // output pixels per wave (8 phases x 16 columns)
-constexpr int kBfRows = 4;           // output rows per work-group
-constexpr int kBfMaxW = 256;
-
-struct Bf16Params {
-    const float* img;        // planar padded float32 image
-    int pitch;               // floats per row
-    long long plane;         // floats per plane
-    int chans;
-    int rows, cols;          // image size (the planes are zero padded beyond it)
-    int h, w, oh, ow;
-    int nkb;                 // 32-tap blocks per template row
-    int chunk_h;             // template rows per LDS tile
-    int lds_cols;            // elements per tile row: 128 + 32 * nkb
-    int n_list;
-    int nseg, nyb, ntg, n_work;
-    int method;
-    long long group_bytes;   // bytes of one 16-template pack of ONE piece: chans * h * nkb * 1024
-    long long piece_bytes;   // bytes between the T0 packs and the T1 packs
-    int only_li;
-    // fused peak candidates / hits-only, as in the other score kernels
-    mtm_hit* cand_hits;
-    unsigned long long* cand_counter;
-    unsigned long long cand_cap;
-    float cand_thr;
-    int cand_min, cand_on, hits_only;
-    // fused global extremum (mtm_find_matches, MTM_PEAKS_GLOBAL): nothing is stored, every wave keeps the best
-    // (ordered score, ~index) key per template in LDS and merges it into ext_best[2 * template + cand_min]
-    int ext_on, ext_pad_;
-    unsigned long long* ext_best;
-};
-
-// Per-template constants of a work item, staged in LDS once (the epilogue reads them as LDS broadcasts).
-struct BfTemplConst {
-    double mean[kMaxChans];
-    double centre[kMaxChans];
-    double templ_norm, templ_sum2;
-    long long map_off;
-    int map_pitch, all_ones, tglob, pad_;
-};
 
 // round-to-nearest-even bfloat16 bits of a finite float
 __device__ __forceinline__ uint32_t bf16_rne(float v) {
     const uint32_t b = __float_as_uint(v);
     return (b + 0x7FFFu + ((b >> 16) & 1u)) >> 16;
 }
-__host__ __device__ inline float bf16_to_float(uint32_t h) {
-    const uint32_t b = h << 16;
-    float f;
-    __builtin_memcpy(&f, &b, 4);
-    return f;
-}
-
 // finish_unmasked on values already in registers (same arithmetic, same order)
 __device__ __forceinline__ float bf_finish(int method, double corr, const double (&t)[kMaxChans], double sum2, double sq,
                                            const BfTemplConst& T, int chans) {
@@ -141,13 +89,6 @@ __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const
             acc[mb][ph] = a;
         }
     }
-}
-
-// LDS: [piece tile 0][piece tile 1][16 B: the subtracted constant][32 BfTemplConst][4 waves x 32 extremum keys]; the K loop requests operands up
-// to two steps past a chunk (never used): those reads stay inside this allocation.
-__host__ __device__ inline size_t bf16_lds_bytes(int chunk_h, int lds_cols) {
-    return 2 * (size_t)(chunk_h + kBfRows - 1) * lds_cols * 2 + 16 + 32 * sizeof(BfTemplConst) +
-           (size_t)kBfRows * 32 * sizeof(unsigned long long);
 }
 
 template <int MB>

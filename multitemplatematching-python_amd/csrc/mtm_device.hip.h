@@ -13,6 +13,7 @@
 
 #include "mtm_kernels.h"
 #include "../../include/mtm_hip.h"
+#include "mtm_device_util.hip.h"
 
 namespace mtm {
 
@@ -623,49 +624,6 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// normalisation epilogue (common_matchTemplate / matchTemplateMask), float64 -> float32
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float finish_unmasked(int method, double corr, const StatPlanes& st,
-                                                 size_t sidx, const TemplDev& T, int chans) {
-    if (T.all_ones) return 1.0f;
-    if (method == MTM_TM_CCORR) return (float)corr;
-    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
-                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
-    const bool normed = (method == MTM_TM_SQDIFF_NORMED) || (method == MTM_TM_CCORR_NORMED) ||
-                        (method == MTM_TM_CCOEFF_NORMED);
-    double num = corr;
-    if (num_type == 1) {
-#pragma unroll
-        for (int c = 0; c < kMaxChans; ++c)
-            if (c < chans) num -= st.t[c][sidx] * T.mean[c];
-    } else if (num_type == 2) {
-        num = st.sum2[sidx] - 2.0 * num + T.templ_sum2;
-        num = fmax(num, 0.0);
-    }
-    if (normed) {
-        const double t = st.sq[sidx] * T.templ_norm;
-        const double an = fabs(num);
-        if (an < t) num = num / t;
-        else if (an < t * 1.125) num = (num > 0.0) ? 1.0 : -1.0;
-        else num = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
-    }
-    return (float)num;
-}
-
-__device__ __forceinline__ float finish_masked(int method, double c_i_tm2, double c_i2_m2,
-                                               const TemplDev& T) {
-    const double tms = T.templ2_mask2_sum;
-    double res;
-    switch (method) {
-        case MTM_TM_SQDIFF:        res = -2.0 * c_i_tm2 + c_i2_m2 + tms; break;
-        case MTM_TM_SQDIFF_NORMED: res = (-2.0 * c_i_tm2 + c_i2_m2 + tms) / sqrt(tms * c_i2_m2); break;
-        case MTM_TM_CCORR:         res = c_i_tm2; break;
-        default:                   res = c_i_tm2 / sqrt(tms * c_i2_m2); break;   // TM_CCORR_NORMED
-    }
-    return (float)res;
-}
-
-// ---------------------------------------------------------------------------------------------
 // Masked templates: sum I^2 * M over every window on the matrix cores.  I^2 is a 16-bit number; its two
 // bytes are image planes of their own (square_planes_kernel), the binary mask is the "template" of a
 // row-multiplexed raw correlation (one template, 16 output rows per MFMA), and masksq_combine_kernel
@@ -733,27 +691,6 @@ __global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restri
 // summed here in float64 (< 2^53) and normalised by finish_unmasked like every other kernel.
 // raw layout: [slab][template (list position)][oh][pitch] int32.
 // ---------------------------------------------------------------------------------------------
-// Append `rec` to the candidate list for every lane with `pred` - one atomic per wave (ballot + leader), so that
-// smooth score maps with millions of candidates do not serialise on the counter.  Call from wave-convergent or
-// divergent code alike (lanes that are not here count as pred = false).  Slots beyond `cap` are counted, not written.
-__device__ __forceinline__ void cand_append(bool pred, unsigned long long* counter, unsigned long long cap, mtm_hit* list,
-                                            const mtm_hit& rec) {
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(pred);
-    if (b == 0ull) return;                                      // uniform over the lanes that are here
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-    const int leader = (int)__builtin_ctzll(act);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    unsigned long long base = 0ull;
-    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(b));
-    const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader);
-    const uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
-    if (pred) {
-        const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + below;
-        if (slot < cap) list[slot] = rec;
-    }
-}
-
 struct SlabParams {
     mtm_hit* cand_hits;
     unsigned long long* cand_counter;

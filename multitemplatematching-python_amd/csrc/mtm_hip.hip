@@ -17,9 +17,9 @@
 #include <vector>
 
 #include "mtm_device.hip.h"
-#include "mtm_mfma.hip.h"
+#include "mtm_mfma_params.h"
 #include "mtm_templates.hip.h"
-#include "mtm_bf16.hip.h"
+#include "mtm_bf16_params.h"
 #include "mtm_internal.h"
 
 using namespace mtm;
@@ -982,6 +982,15 @@ int ensure_f32_plane(mtm_ctx* c) {
     return MTM_OK;
 }
 
+// raw-mode instantiations of ncc_mfma_kernel (biased int32 accumulators stored as they are)
+MfmaFn mfma_raw_fn(bool row_mux, bool packed_k) {
+    MfmaSel s;
+    s.method = kMfRaw;
+    s.rm = row_mux;
+    s.kp = packed_k;
+    return mfma_kernel(s);
+}
+
 // Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
 // `sb0`, `sb1`: range of kStatBand4-row output blocks to compute (banded image upload; fused single-channel
 // kernel only), sb1 < 0 = all.
@@ -1137,7 +1146,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
         for (int x = 0; x < 2; ++x) {
             p.img = c->sq_planes.as<uint8_t>() + (size_t)(1 + x) * plane_bytes;
             p.raw_out = c->raw16.as<int>() + (size_t)x * raw_map;
-            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false, true>), dim3(grid), dim3(256), lds, c->stream, p,
+            hipLaunchKernelGGL(mfma_raw_fn(true, false), dim3(grid), dim3(256), lds, c->stream, p,
                                c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>(),
                                c->sched.as<unsigned int>());
         }
@@ -1279,12 +1288,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const size_t lds = (size_t)p.st_off + (rmr ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);
             const int grid = ((p.n_work + 7) / 8) * 8;
             const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
-            if (rmr)
-                hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false, true>), dim3(grid), dim3(256), lds, c->stream, p, td,
-                                   c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
-            else
-                hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td,
-                                   c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+            hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, c->stream, p, td,
+                               c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
         }
         SlabParams q{};
         q.raw = c->slab_raw.as<int>();
@@ -1400,126 +1405,22 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.n_list = n_all - tg0 * tgsz;
         if (only_li >= 0) p.only_li = only_li - tg0 * tgsz;
         const int* tl_k = tl_class + tg0 * tgsz;
-        using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
-#define MTM_MF_ROW(MB, X, M) {ncc_mfma_kernel<MB, -1, X, false>, ncc_mfma_kernel<MB, 0, X, M>, ncc_mfma_kernel<MB, 1, X, M>, \
-                             ncc_mfma_kernel<MB, 2, X, M>, ncc_mfma_kernel<MB, 3, X, M>, ncc_mfma_kernel<MB, 4, X, false>,  \
-                             ncc_mfma_kernel<MB, 5, X, false>}
-        static const MfmaFn kMfmaFns[2][2][2][7] = {
-            {{MTM_MF_ROW(1, false, false), MTM_MF_ROW(2, false, false)}, {MTM_MF_ROW(1, true, false), MTM_MF_ROW(2, true, false)}},
-            {{MTM_MF_ROW(1, false, true), MTM_MF_ROW(2, false, true)}, {MTM_MF_ROW(1, true, true), MTM_MF_ROW(2, true, true)}}};
-#undef MTM_MF_ROW
-        // masked classes reach here only with methods 0..3 and one channel (mfma_class_ok)
-#define MTM_MF_RM(X, M) {ncc_mfma_kernel<2, 0, X, M, true>, ncc_mfma_kernel<2, 1, X, M, true>,                      \
-                        ncc_mfma_kernel<2, 2, X, M, true>, ncc_mfma_kernel<2, 3, X, M, true>,                      \
-                        ncc_mfma_kernel<2, 4, X, false, true>, ncc_mfma_kernel<2, 5, X, false, true>}
-        static const MfmaFn kMfmaRmFns[2][2][6] = {{MTM_MF_RM(false, false), MTM_MF_RM(true, false)},
-                                                   {MTM_MF_RM(false, true), MTM_MF_RM(true, true)}};
-#undef MTM_MF_RM
-#define MTM_MF_RMC3(X) {ncc_mfma_kernel<2, 0, X, false, true, 3>, ncc_mfma_kernel<2, 1, X, false, true, 3>,   \
-                       ncc_mfma_kernel<2, 2, X, false, true, 3>, ncc_mfma_kernel<2, 3, X, false, true, 3>,   \
-                       ncc_mfma_kernel<2, 4, X, false, true, 3>, ncc_mfma_kernel<2, 5, X, false, true, 3>}
-        static const MfmaFn kMfmaRmC3Fns[2][6] = {MTM_MF_RMC3(false), MTM_MF_RMC3(true)};
-#undef MTM_MF_RMC3
-        // 3-channel images: the same lean epilogue with per-channel window sums (methods fixed at compile time)
-#define MTM_MF_C3(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 3>, ncc_mfma_kernel<MB, 1, X, false, false, 3>,   \
-                         ncc_mfma_kernel<MB, 2, X, false, false, 3>, ncc_mfma_kernel<MB, 3, X, false, false, 3>,   \
-                         ncc_mfma_kernel<MB, 4, X, false, false, 3>, ncc_mfma_kernel<MB, 5, X, false, false, 3>}
-        static const MfmaFn kMfmaC3Fns[2][2][6] = {{MTM_MF_C3(1, false), MTM_MF_C3(2, false)},
-                                                   {MTM_MF_C3(1, true), MTM_MF_C3(2, true)}};
-#undef MTM_MF_C3
-        // fused global extremum: same kernels with the per-template running best as the threshold
-#define MTM_MF_EXT(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 1, true>, ncc_mfma_kernel<MB, 1, X, false, false, 1, true>,   \
-                          ncc_mfma_kernel<MB, 2, X, false, false, 1, true>, ncc_mfma_kernel<MB, 3, X, false, false, 1, true>,   \
-                          ncc_mfma_kernel<MB, 4, X, false, false, 1, true>, ncc_mfma_kernel<MB, 5, X, false, false, 1, true>}
-        static const MfmaFn kMfmaExtFns[2][2][6] = {{MTM_MF_EXT(1, false), MTM_MF_EXT(2, false)},
-                                                    {MTM_MF_EXT(1, true), MTM_MF_EXT(2, true)}};
-#undef MTM_MF_EXT
-#define MTM_MF_RMEXT(X) {ncc_mfma_kernel<2, 0, X, false, true, 1, true>, ncc_mfma_kernel<2, 1, X, false, true, 1, true>,   \
-                        ncc_mfma_kernel<2, 2, X, false, true, 1, true>, ncc_mfma_kernel<2, 3, X, false, true, 1, true>,   \
-                        ncc_mfma_kernel<2, 4, X, false, true, 1, true>, ncc_mfma_kernel<2, 5, X, false, true, 1, true>}
-        static const MfmaFn kMfmaRmExtFns[2][6] = {MTM_MF_RMEXT(false), MTM_MF_RMEXT(true)};
-#undef MTM_MF_RMEXT
-#define MTM_MF_EXTC3(MB, X) {ncc_mfma_kernel<MB, 0, X, false, false, 3, true>, ncc_mfma_kernel<MB, 1, X, false, false, 3, true>,   \
-                            ncc_mfma_kernel<MB, 2, X, false, false, 3, true>, ncc_mfma_kernel<MB, 3, X, false, false, 3, true>,   \
-                            ncc_mfma_kernel<MB, 4, X, false, false, 3, true>, ncc_mfma_kernel<MB, 5, X, false, false, 3, true>}
-        static const MfmaFn kMfmaExtC3Fns[2][2][6] = {{MTM_MF_EXTC3(1, false), MTM_MF_EXTC3(2, false)},
-                                                      {MTM_MF_EXTC3(1, true), MTM_MF_EXTC3(2, true)}};
-#undef MTM_MF_EXTC3
-#define MTM_MF_RMEXTC3(X) {ncc_mfma_kernel<2, 0, X, false, true, 3, true>, ncc_mfma_kernel<2, 1, X, false, true, 3, true>,   \
-                          ncc_mfma_kernel<2, 2, X, false, true, 3, true>, ncc_mfma_kernel<2, 3, X, false, true, 3, true>,   \
-                          ncc_mfma_kernel<2, 4, X, false, true, 3, true>, ncc_mfma_kernel<2, 5, X, false, true, 3, true>}
-        static const MfmaFn kMfmaRmExtC3Fns[2][6] = {MTM_MF_RMEXTC3(false), MTM_MF_RMEXTC3(true)};
-#undef MTM_MF_RMEXTC3
-        // fused global extremum of masked classes (binary uint8 mask, methods 0..3; reciprocal-normalisation builds only:
-        // MTM_OPT_EXACT_DIV calls keep the maps + extremum_kernel route)
-#define MTM_MF_EXTM(MB) {ncc_mfma_kernel<MB, 0, false, true, false, 1, true>, ncc_mfma_kernel<MB, 1, false, true, false, 1, true>,   \
-                        ncc_mfma_kernel<MB, 2, false, true, false, 1, true>, ncc_mfma_kernel<MB, 3, false, true, false, 1, true>}
-        static const MfmaFn kMfmaExtMaskedFns[2][4] = {MTM_MF_EXTM(1), MTM_MF_EXTM(2)};
-#undef MTM_MF_EXTM
-        static const MfmaFn kMfmaRmExtMaskedFns[4] = {ncc_mfma_kernel<2, 0, false, true, true, 1, true>,
-                                                      ncc_mfma_kernel<2, 1, false, true, true, 1, true>,
-                                                      ncc_mfma_kernel<2, 2, false, true, true, 1, true>,
-                                                      ncc_mfma_kernel<2, 3, false, true, true, 1, true>};
-        // two-row variant (methods 2..5), plain and with the fused global extremum
-#define MTM_MF_R2(X, E) {ncc_mfma_kernel<2, 2, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 3, X, false, false, 1, E, true>,   \
-                        ncc_mfma_kernel<2, 4, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 5, X, false, false, 1, E, true>}
-        static const MfmaFn kMfmaR2Fns[2][2][4] = {{MTM_MF_R2(false, false), MTM_MF_R2(true, false)},
-                                                   {MTM_MF_R2(false, true), MTM_MF_R2(true, true)}};
-#undef MTM_MF_R2
-        // packed-K variants (one channel, unmasked, the normalised methods 1 / 3 / 5): [extremum][exact division][..]
-#define MTM_MF_KP(MB, X, E) {ncc_mfma_kernel<MB, 1, X, false, false, 1, E, false, true>,                              \
-                            ncc_mfma_kernel<MB, 3, X, false, false, 1, E, false, true>,                              \
-                            ncc_mfma_kernel<MB, 5, X, false, false, 1, E, false, true>}
-#define MTM_MF_RMKP(X, E) {ncc_mfma_kernel<2, 1, X, false, true, 1, E, false, true>,                                  \
-                          ncc_mfma_kernel<2, 3, X, false, true, 1, E, false, true>,                                  \
-                          ncc_mfma_kernel<2, 5, X, false, true, 1, E, false, true>}
-        static const MfmaFn kMfmaKpFns[2][2][2][3] = {
-            {{MTM_MF_KP(1, false, false), MTM_MF_KP(2, false, false)}, {MTM_MF_KP(1, true, false), MTM_MF_KP(2, true, false)}},
-            {{MTM_MF_KP(1, false, true), MTM_MF_KP(2, false, true)}, {MTM_MF_KP(1, true, true), MTM_MF_KP(2, true, true)}}};
-        static const MfmaFn kMfmaRmKpFns[2][2][3] = {{MTM_MF_RMKP(false, false), MTM_MF_RMKP(true, false)},
-                                                     {MTM_MF_RMKP(false, true), MTM_MF_RMKP(true, true)}};
-        // masked packed-K variants (methods 1 / 3; the fused extremum only with the reciprocal normalisation)
-#define MTM_MF_KPM(MB, X, E) {ncc_mfma_kernel<MB, 1, X, true, false, 1, E, false, true>, ncc_mfma_kernel<MB, 3, X, true, false, 1, E, false, true>}
-#define MTM_MF_RMKPM(X, E) {ncc_mfma_kernel<2, 1, X, true, true, 1, E, false, true>, ncc_mfma_kernel<2, 3, X, true, true, 1, E, false, true>}
-        static const MfmaFn kMfmaKpMaskedFns[2][2][2] = {{MTM_MF_KPM(1, false, false), MTM_MF_KPM(2, false, false)},
-                                                         {MTM_MF_KPM(1, true, false), MTM_MF_KPM(2, true, false)}};
-        static const MfmaFn kMfmaKpMaskedExtFns[2][2] = {MTM_MF_KPM(1, false, true), MTM_MF_KPM(2, false, true)};
-        static const MfmaFn kMfmaRmKpMaskedFns[2][2] = {MTM_MF_RMKPM(false, false), MTM_MF_RMKPM(true, false)};
-        static const MfmaFn kMfmaRmKpMaskedExtFns[2] = MTM_MF_RMKPM(false, true);
-#undef MTM_MF_KPM
-#undef MTM_MF_RMKPM
-        // RGB packed-K variants
-#define MTM_MF_KP3(MB, X, E) {ncc_mfma_kernel<MB, 1, X, false, false, 3, E, false, true>,                             \
-                             ncc_mfma_kernel<MB, 3, X, false, false, 3, E, false, true>,                             \
-                             ncc_mfma_kernel<MB, 5, X, false, false, 3, E, false, true>}
-#define MTM_MF_RMKP3(X, E) {ncc_mfma_kernel<2, 1, X, false, true, 3, E, false, true>,                                 \
-                           ncc_mfma_kernel<2, 3, X, false, true, 3, E, false, true>,                                 \
-                           ncc_mfma_kernel<2, 5, X, false, true, 3, E, false, true>}
-        static const MfmaFn kMfmaKpC3Fns[2][2][2][3] = {
-            {{MTM_MF_KP3(1, false, false), MTM_MF_KP3(2, false, false)}, {MTM_MF_KP3(1, true, false), MTM_MF_KP3(2, true, false)}},
-            {{MTM_MF_KP3(1, false, true), MTM_MF_KP3(2, false, true)}, {MTM_MF_KP3(1, true, true), MTM_MF_KP3(2, true, true)}}};
-        static const MfmaFn kMfmaRmKpC3Fns[2][2][3] = {{MTM_MF_RMKP3(false, false), MTM_MF_RMKP3(true, false)},
-                                                       {MTM_MF_RMKP3(false, true), MTM_MF_RMKP3(true, true)}};
-#undef MTM_MF_KP3
-#undef MTM_MF_RMKP3
-#undef MTM_MF_KP
-#undef MTM_MF_RMKP
-        const bool c3 = c->chans == 3 && !sc.masked && !rm;
-        const int xd = c->exact_div ? 1 : 0;
-        const int m2 = (c->method - 1) / 2;               // methods 1 / 3 / 5 -> 0 / 1 / 2
-        const MfmaFn fn = (sc.kp_nseg && sc.masked) ? (ext ? (rm ? kMfmaRmKpMaskedExtFns[m2] : kMfmaKpMaskedExtFns[mb - 1][m2])
-                                                           : (rm ? kMfmaRmKpMaskedFns[xd][m2] : kMfmaKpMaskedFns[xd][mb - 1][m2]))
-                        : (sc.kp_nseg && c->chans == 3) ? (rm ? kMfmaRmKpC3Fns[ext ? 1 : 0][xd][m2]
-                                                              : kMfmaKpC3Fns[ext ? 1 : 0][xd][mb - 1][m2])
-                        : sc.kp_nseg ? (rm ? kMfmaRmKpFns[ext ? 1 : 0][xd][m2] : kMfmaKpFns[ext ? 1 : 0][xd][mb - 1][m2])
-                        : r2 ? kMfmaR2Fns[ext ? 1 : 0][xd][c->method - 2]
-                        : (ext && sc.masked) ? (rm ? kMfmaRmExtMaskedFns[c->method] : kMfmaExtMaskedFns[mb - 1][c->method])
-                        : (ext && rm) ? (c->chans == 3 ? kMfmaRmExtC3Fns[xd][c->method] : kMfmaRmExtFns[xd][c->method])
-                        : ext ? (c->chans == 3 ? kMfmaExtC3Fns[xd][mb - 1][c->method] : kMfmaExtFns[xd][mb - 1][c->method])
-                        : (rm && c->chans == 3) ? kMfmaRmC3Fns[c->exact_div ? 1 : 0][c->method]
-                        : c3 ? kMfmaC3Fns[c->exact_div ? 1 : 0][mb - 1][c->method]
-                        : rm ? kMfmaRmFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][c->method]
-                             : kMfmaFns[sc.masked ? 1 : 0][c->exact_div ? 1 : 0][mb - 1][c->chans == 1 ? 1 + c->method : 0];
+        // the instantiation of ncc_mfma_kernel for this class (the kernels live in the mtm_mfma_*.hip units)
+        MfmaSel sel;
+        sel.mb = mb;
+        sel.exact_div = c->exact_div != 0;
+        sel.masked = sc.masked;
+        sel.rm = rm;
+        sel.ch = (c->chans == 3 && !sc.masked) ? 3 : 1;
+        sel.method = (c->chans == 1 || sel.ch == 3) ? c->method : -1;     // other channel counts: the generic epilogue
+        sel.ext = ext;
+        sel.r2 = r2;
+        sel.kp = sc.kp_nseg > 0;
+        const MfmaFn fn = mfma_kernel(sel);
+        if (!fn) {
+            set_error("internal: no ncc_mfma_kernel instantiation for this class");
+            return MTM_E_STATE;
+        }
         // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
@@ -1614,12 +1515,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.img = planes;                                         // high bytes: raw accumulators
         p.kp_nseg = sc.kp_nseg;
         p.kp_blocks = sc.kp_nseg ? kp_blocks(h, sc.kp_nseg) : 0;
-        if (sc.kp_nseg)
-            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false, false, 1, false, false, true>), dim3(grid), dim3(256),
-                               lds, c->stream, p, td, tl_k, ap, st, maps, c->sched.as<unsigned int>());
-        else
-            hipLaunchKernelGGL((ncc_mfma_kernel<2, kMfRaw, false, false>), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k,
-                               ap, st, maps, c->sched.as<unsigned int>());
+        hipLaunchKernelGGL(mfma_raw_fn(false, sc.kp_nseg > 0), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
+                           c->sched.as<unsigned int>());
         p.img = planes + (size_t)img.u8_plane;                  // low bytes: finish
         p.n_list = n_all - tg0 * 16;                            // list positions inside the kernel are relative to tg0
         p.only_li = only_li >= 0 ? only_li - tg0 * 16 : -1;
@@ -1643,16 +1540,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.cand_on = 1;
             p.hits_only = 1;
         }
-        using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
-        static const MfmaFn kU16Fns[2][2][2] = {
-            {{ncc_mfma_kernel<2, kMfU16, false, false>, ncc_mfma_kernel<2, kMfU16, true, false>},
-             {ncc_mfma_kernel<2, kMfU16, false, false, false, 1, true>, ncc_mfma_kernel<2, kMfU16, true, false, false, 1, true>}},
-            {{ncc_mfma_kernel<2, kMfU16, false, false, false, 1, false, false, true>,
-              ncc_mfma_kernel<2, kMfU16, true, false, false, 1, false, false, true>},
-             {ncc_mfma_kernel<2, kMfU16, false, false, false, 1, true, false, true>,
-              ncc_mfma_kernel<2, kMfU16, true, false, false, 1, true, false, true>}}};             // [packed K][extremum][exact]
-        hipLaunchKernelGGL(kU16Fns[sc.kp_nseg ? 1 : 0][ext ? 1 : 0][c->exact_div ? 1 : 0], dim3(grid), dim3(256), lds2, c->stream,
-                           p, td, tl_k, ap, st, maps, c->sched.as<unsigned int>());
+        MfmaSel sel16;
+        sel16.method = kMfU16;
+        sel16.kp = sc.kp_nseg > 0;
+        sel16.ext = ext;
+        sel16.exact_div = c->exact_div != 0;
+        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds2, c->stream, p, td, tl_k, ap, st, maps,
+                           c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32) {
         const int n_all = (int)sc.members.size();
@@ -1704,10 +1598,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int grid = ((p.n_work + 7) / 8) * 8;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
         const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16 * mb;
-        if (mb == 2)
-            hipLaunchKernelGGL(ncc_bf16_kernel<2>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
-        else
-            hipLaunchKernelGGL(ncc_bf16_kernel<1>, dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        hipLaunchKernelGGL(bf16_kernel(mb), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
         c->timing.kernel_used = MTM_KERNEL_MFMA_F32;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;

@@ -8,10 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def code_object(so_path, arch="gfx950"):
+def code_objects(so_path, arch="gfx950"):
+    """Every gfx950 code object of the library: one offload bundle per translation unit."""
     blob = open(so_path, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     pos = blob.find(magic)
+    found = []
     while pos >= 0:
         n = struct.unpack_from("<Q", blob, pos + len(magic))[0]
         q = pos + len(magic) + 8
@@ -20,21 +22,28 @@ def code_object(so_path, arch="gfx950"):
             triple = blob[q + 24:q + 24 + tl].decode()
             q += 24 + tl
             if arch in triple and size > 0:
-                return blob[pos + off:pos + off + size]
+                found.append(blob[pos + off:pos + off + size])
         pos = blob.find(magic, pos + 1)
-    raise RuntimeError("no %s code object in %s" % (arch, so_path))
+    if not found:
+        raise RuntimeError("no %s code object in %s" % (arch, so_path))
+    return found
+
+
+def code_object(so_path, arch="gfx950"):
+    return code_objects(so_path, arch)[0]
 
 
 def kernels(so_path):
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code_object(so_path))
-        f.flush()
-        notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
     out = []
-    for blk in notes.split("- .agpr_count")[1:]:
-        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
-        out.append({"name": re.search(r"\.name:\s+(\S+)", blk).group(1), "vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"),
-                    "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size")})
+    for co in code_objects(so_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count")[1:]:
+            g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+            out.append({"name": re.search(r"\.name:\s+(\S+)", blk).group(1), "vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"),
+                        "scratch": g("private_segment_fixed_size"), "lds": g("group_segment_fixed_size")})
     return out
 
 
