@@ -81,6 +81,14 @@ extern "C" {
                                    the in-kernel candidate list, in global-extremum mode (unmasked 1- or
                                    3-channel templates) the per-template best is kept inside the score kernel;
                                    0: always materialise the maps.  Results are identical either way. */
+#define MTM_OPT_F32_MFMA 7      /* float32 images (every non-uint8, non-uint16 input: MTM/__init__.py:71-74), unmasked
+                                   templates, normalised methods.  1 (default): scores on the bf16 matrix cores (within
+                                   ~1e-5 of cv2's float64 result) as a SCREEN - everything that could be a peak, the
+                                   global extremum or a threshold case by that margin is re-scored with the float64
+                                   arithmetic of the exact kernel, so mtm_find_matches returns the exact kernel's hit
+                                   lists (score maps read back with mtm_score_map keep the ~1e-5 tolerance);
+                                   0: the float64 kernel for everything (10x slower, maps exact to rounding);
+                                   2: bf16 scores as they are, no re-scoring.  Environment: MTM_F32_MFMA. */
 
 /* error codes */
 #define MTM_OK            0
@@ -126,7 +134,9 @@ typedef struct mtm_timing {
                             s_memrealtime tick x 100 MHz) by one mid-grid work-group; 0 when not measured */
     float   ncc_sum_ms;  /* plain sum of the score-kernel launch durations (= ncc_kernel_ms unless launches of a
                             banded call overlapped; what a profiler's per-launch average times the count gives) */
-    float   pad_;
+    int32_t f32_route;   /* float32 images on the bf16 matrix cores (MTM_OPT_F32_MFMA = 1), how the exact decisions were
+                            reached: 0 not such a call, 1 kernel candidates re-scored, 2 map scan + neighbourhoods
+                            re-scored, 3 the float64 kernel after all (lists overflowed, or classes it has to run anyway) */
 } mtm_timing;
 
 /* ---- device / context ------------------------------------------------------------------- */

@@ -18,7 +18,7 @@ MTM_U8, MTM_F32, MTM_U16 = 0, 1, 2
 PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1
 BORDER_CONSTANT, BORDER_NEAREST = 0, 1
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
-OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY = 1, 2, 3, 4, 5, 6
+OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY, OPT_F32_MFMA = 1, 2, 3, 4, 5, 6, 7
 E_OVERFLOW = -5
 E_HIP = -2
 COMM_ID_BYTES = 128
@@ -42,7 +42,7 @@ class MtmTiming(ctypes.Structure):
                 ("peaks_ms", ctypes.c_float), ("ncc_kernel_ms", ctypes.c_float),
                 ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
                 ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("sclk_mhz", ctypes.c_float),
-                ("ncc_sum_ms", ctypes.c_float), ("pad_", ctypes.c_float)]
+                ("ncc_sum_ms", ctypes.c_float), ("f32_route", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),
@@ -209,6 +209,15 @@ def templ_records(templates):
     return rec, keep
 
 
+def _zero_copy(templates, keep):
+    """True if templ_records handed the caller's own buffers to the library (no array had to be copied)."""
+    it = iter(keep)
+    for t, m in templates:
+        if next(it) is not t or (m is not None and next(it) is not m):
+            return False
+    return True
+
+
 class _PinnedBlock:
     """Owner of one mtm_host_alloc block (freed with the last numpy view of it)."""
 
@@ -292,7 +301,10 @@ class Context:
         if key != self._rec_key:
             self._rec, keep = templ_records(templates)
             self._rec_keep = (keep, [t for t, _ in templates], [m for _, m in templates])
-            self._rec_key = key
+            # Only records that point at the caller's own buffers may be reused: a template that had to be copied
+            # (np.rot90(base), base[:, ::-1], base.T ...) would otherwise be matched from the copy of the FIRST call
+            # for ever, even after the caller edited the array in place - the reference re-reads it on every call.
+            self._rec_key = key if _zero_copy(templates, keep) else None
         return self._rec
 
     def set_templates(self, templates, method):

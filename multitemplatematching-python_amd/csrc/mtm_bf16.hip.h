@@ -26,6 +26,7 @@
 #pragma once
 #include "mtm_device_util.hip.h"
 #include "mtm_bf16_params.h"
+#include <type_traits>
 
 namespace mtm {
 
@@ -256,10 +257,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const int method = p.method;
     const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
     const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
-    if (lane_on) {
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (xq + 4 * half >= p.ow) break;
+    // (the two halves of a lane's eight pixels as a generic lambda over a compile-time constant: every accumulator index
+    // below must be one, or the accumulators leave the register file)
+    auto epilogue_half = [&](auto half_c) {
+        constexpr int half = decltype(half_c)::value;
         double ts[4][kMaxChans], s2[4], sq[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -287,6 +288,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     out[i] = bf_finish(method, corr, ts[i], s2[i], sq[i], T, p.chans);
                 }
                 const int xb = xq + 4 * half;
+                if (p.ext_on && p.ext_margin > 0.0f) {       // refined extremum mode: the outputs are looked at again below
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[mb][4 * half + i][e] = out[i];
+                }
                 if (p.ext_on) {
                     // cv2.minMaxLoc: the first index wins ties, NaN never wins
                     unsigned long long bestk = 0ull;
@@ -332,15 +337,75 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 }
             }
         }
-    }
+    };
+    if (lane_on) {
+        epilogue_half(std::integral_constant<int, 0>{});
+        if (xq + 4 < p.ow) epilogue_half(std::integral_constant<int, 1>{});
     }
     if (p.ext_on) {                 // one global atomic per template this wave improved
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const bool refined = p.ext_margin > 0.0f;
         if (lane < 16 * MB) {
             const unsigned long long key = ext_slot[lane];
             const int li = tg * MB * 16 + lane;
-            if (key && li < p.n_list) atomicMax(&p.ext_best[2 * tlist[li] + p.cand_min], key);
+            unsigned long long g = 0ull;
+            if (li < p.n_list) {
+                unsigned long long* addr = &p.ext_best[2 * tlist[li] + p.cand_min];
+                if (key) {
+                    const unsigned long long old = atomicMax(addr, key);
+                    g = old > key ? old : key;
+                } else if (refined) {
+                    g = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (refined) ext_slot[lane] = g;        // the best of this template published so far, this wave's included
+        }
+        if (refined) {
+            // Refined extremum mode (mtm_refine.hip.h): the scores above are within ~1e-5 of the exact ones, so the exact
+            // extremum of a template is among the outputs within the margin of the best approximate one.  Every output of
+            // this wave within the margin of the best published so far is appended to the candidate list; the exact
+            // extremum is then taken over the re-scored list.  (The list stays short: a wave lists something only while
+            // its outputs are within the margin of everything that finished before it.)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            auto list_half = [&](auto half_c) {
+                    constexpr int half = decltype(half_c)::value;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int lt = mb * 16 + 4 * q + e, li = tg * MB * 16 + lt;
+                            if (li >= p.n_list) continue;
+                            const unsigned long long gk = ext_slot[lt];
+                            float lo = -INFINITY;
+                            if (gk) {
+                                const uint32_t hiw = (uint32_t)(gk >> 32);
+                                const float sc = mf_order_float(p.cand_min ? ~hiw : hiw);
+                                const float ql = p.cand_min ? -sc : sc;
+                                lo = ql - p.ext_margin * fmaxf(1.0f, fabsf(ql));
+                            }
+                            const int xb = xq + 4 * half;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v = acc[mb][4 * half + i][e];
+                                const float ql = p.cand_min ? -v : v;
+                                mtm_hit hrec;
+                                hrec.templ_idx = tcl[lt].tglob;
+                                hrec.x = xb + i;
+                                hrec.y = y;
+                                hrec.w = p.w;
+                                hrec.h = p.h;
+                                hrec.score = v;
+                                cand_append(xb + i < p.ow && v == v && ql > lo, p.cand_counter, p.cand_cap, p.cand_hits, hrec);
+                            }
+                        }
+                    }
+            };
+            if (lane_on) {
+                list_half(std::integral_constant<int, 0>{});
+                if (xq + 4 < p.ow) list_half(std::integral_constant<int, 1>{});
+            }
         }
     }
 }

@@ -42,7 +42,8 @@ struct Bf16Params {
     int cand_min, cand_on, hits_only;
     // fused global extremum (mtm_find_matches, MTM_PEAKS_GLOBAL): nothing is stored, every wave keeps the best
     // (ordered score, ~index) key per template in LDS and merges it into ext_best[2 * template + cand_min]
-    int ext_on, ext_pad_;
+    int ext_on;
+    float ext_margin;        // > 0: refined extremum mode - outputs within this margin of the running best are listed (cand_hits)
     unsigned long long* ext_best;
 };
 

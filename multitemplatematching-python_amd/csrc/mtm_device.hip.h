@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(256) void verify_peaks_kernel(const float* __restri
                                                            unsigned long long cand_cap, mtm_hit* __restrict__ hits,
                                                            unsigned long long hit_cap,
                                                            unsigned long long* __restrict__ hit_count,
-                                                           int* __restrict__ tcount) {
+                                                           int* __restrict__ tcount, float thr_q) {
     const unsigned long long n = min(*cand_count, cand_cap);
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(256) void verify_peaks_kernel(const float* __restri
             }
             mx = fmaxf(mx, nv);
         }
-    if (v == mx) {
+    if (v == mx && v > thr_q) {       // (v > thr_q: always true for the integer kernels' lists; the float32 screen lists with a margin)
         const unsigned long long slot = atomicAdd(hit_count, 1ull);
         if (slot < hit_cap) hits[slot] = c;
         atomicAdd(&tcount[c.templ_idx], 1);
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(256) void verify_hash_kernel(const TemplDev* __rest
                                                           const int* __restrict__ vals, unsigned mask,
                                                           mtm_hit* __restrict__ hits, unsigned long long hit_cap,
                                                           unsigned long long* __restrict__ hit_count,
-                                                          int* __restrict__ tcount) {
+                                                          int* __restrict__ tcount, float thr_q) {
     const unsigned long long n = min(*cand_count, cand_cap);
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(256) void verify_hash_kernel(const TemplDev* __rest
                 }
             }
         }
-    if (v == mx) {
+    if (v == mx && v > thr_q) {       // (v > thr_q: always true for the integer kernels' lists; the float32 screen lists with a margin)
         const unsigned long long slot = atomicAdd(hit_count, 1ull);
         if (slot < hit_cap) hits[slot] = c;
         atomicAdd(&tcount[c.templ_idx], 1);

@@ -20,6 +20,7 @@
 #include "mtm_mfma_params.h"
 #include "mtm_templates.hip.h"
 #include "mtm_bf16_params.h"
+#include "mtm_refine.hip.h"
 #include "mtm_internal.h"
 
 using namespace mtm;
@@ -156,6 +157,8 @@ struct FmState {
     int mode = 0;
     float thr = 0.0f;
     bool mode_min = false, fused = false, prefetched = false;
+    bool pp_mode = false;       // float32 refinement by map scan: the candidate buffer holds potential peaks whose
+                                // neighbourhoods in the maps are exact - decisions by verify_peaks_kernel, never from the list alone
     int n = 0;
     int64_t cand_cap = 0;
     unsigned hash_mask = 0;
@@ -191,9 +194,16 @@ struct mtm_ctx {
                                             // between `stream` and this one, so the tail of one launch (its last
                                             // work-groups draining) is filled by the next launch instead of idling
     hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
+    int screen_l1 = 1;                      // MTM_SCREEN_L1: the hits-only screen starts with the per-lane bound (0: round 2's screen alone)
     int kpack = 1;                          // MTM_KPACK: packed K for template widths that are not multiples of 64
     int skip_f32 = 1;                       // MTM_SKIP_F32: banded uploads leave the float32 plane out (rebuilt on demand)
-    int f32_mfma = 1;                       // MTM_F32_MFMA: unmasked float32 classes on the bf16 matrix cores
+    int f32_mfma = 1;                       // MTM_F32_MFMA / MTM_OPT_F32_MFMA: unmasked float32 classes on the bf16 matrix cores:
+                                            // 0 = float64 kernel, 1 = bf16 screen + exact float64 re-scoring of everything
+                                            // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are
+    // float32 refinement (mtm_refine.hip.h), state of the current mtm_find_matches
+    bool refine_now = false;                // bf16 classes of this call are refined
+    bool refine_scan_now = false;           // ... by map scan + ring re-scoring (maps in memory) instead of kernel candidates
+    bool f32_exact_now = false;             // bf16 classes run the float64 kernel in this call (refinement lists overflowed)
     int mfma_r2 = 1;                        // MTM_MFMA_R2: two-row variant of the MFMA kernel where it applies
     int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
                                             // streams (their tails overlap; per-launch durations then overlap too)
@@ -437,7 +447,9 @@ bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
 // values far smaller than those sums (an exact copy: SQDIFF = 0), where no relative bound holds: float64 kernel.
 bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
     const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED || c->method == MTM_TM_CCOEFF_NORMED;
-    return c->f32_mfma && normed && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW;
+    // (1-D and 1x1 score maps go through scipy's find_peaks on the host, which has no refinement: float64 kernel)
+    return c->f32_mfma && normed && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW &&
+           c->rows > sc.h && c->cols > sc.w;
 }
 inline int bf16_nkb(int w) { return (w + 31) / 32; }
 long long bf16_group_bytes(int h, int w, int chans) { return (long long)chans * h * bf16_nkb(w) * 1024; }
@@ -725,7 +737,8 @@ int place_templates(mtm_ctx* c) {
     for (int i = 0; i < n; ++i) {
         const HostTempl& t = c->templs[i];
         const int kern = class_kernel[(size_t)t.cls];
-        const bool want_f64 = kern == MTM_KERNEL_AUTO || kern == MTM_KERNEL_NAIVE;
+        // float64 weights: the float64 / naive kernels, and the exact re-scoring behind the bf16 kernel
+        const bool want_f64 = kern == MTM_KERNEL_AUTO || kern == MTM_KERNEL_NAIVE || kern == MTM_KERNEL_MFMA_F32;
         if (t.chans != c->chans) {
             set_error("template " + std::to_string(i) + " has a different channel count than the image");
             return MTM_E_INVALID;
@@ -748,6 +761,7 @@ int place_templates(mtm_ctx* c) {
         }
         d.rows = t.rows;
         d.cols = t.cols;
+        d.cls = t.cls;
         d.oh = c->rows - t.rows + 1;
         d.ow = c->cols - t.cols + 1;
         d.map_pitch = (int)round_up((size_t)d.ow, 4);
@@ -1129,6 +1143,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
         p.cpr = p.lds_pitch / 16;
         p.cpr_rstep = 256 / p.cpr;
         p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = -(long long)16 * p.nb * 1024;
         p.only_li = -1;
         p.raw_map = raw_map;
@@ -1137,7 +1152,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
         const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
                                 ~(size_t)15;
         p.tc_off = (int)lds_main;
-        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
         const size_t lds = (size_t)p.st_off;
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
@@ -1258,6 +1273,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.cpr = p.lds_pitch / 16;
             p.cpr_rstep = 256 / p.cpr;
             p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
             p.only_li = -1;
             p.raw_map = raw_map;
             p.raw_pitch = map_pitch;
@@ -1284,7 +1300,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
                                     ~(size_t)15;
             p.tc_off = (int)lds_main;
-            p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+            p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
             const size_t lds = (size_t)p.st_off + (rmr ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);
             const int grid = ((p.n_work + 7) / 8) * 8;
             const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
@@ -1342,12 +1358,16 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cpr = p.lds_pitch / 16;
         p.cpr_rstep = 256 / p.cpr;
         p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = sc.group_bytes;
         p.only_li = only_li;
         p.dbg = c->mfma_dbg;
         p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
         p.cand_thr_lo = (double)c->cand_thr - 1e-6 * std::max(1.0, std::fabs((double)c->cand_thr));
+        p.screen_hi = std::min(p.cand_thr_lo, 0.999999) - 1e-6;
+        p.sq_floor = 0.99 / std::sqrt((double)w * (double)h);
+        p.screen_l1 = c->screen_l1;
         p.cand_min = c->cand_min ? 1 : 0;
         p.cand_thr = c->cand_thr;
         p.cand_cap = (unsigned long long)c->hit_cap;
@@ -1381,7 +1401,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch,
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
-        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
         // statistics prefetch region: (channels + 2) planes per wave (RM loads its statistics directly)
         size_t lds = (size_t)p.st_off + (rm ? 0 : r2 ? (size_t)kMfRows * 2 * 4 * 1024
                                                      : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
@@ -1489,6 +1509,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cpr = p.lds_pitch / 16;
         p.cpr_rstep = 256 / p.cpr;
         p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = sc.group_bytes;
         p.only_li = -1;
         p.raw_map = raw_map;
@@ -1504,7 +1525,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
                                                   (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
-        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + 16 + 15) & ~(size_t)15);
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
         const size_t lds = (size_t)p.st_off + (size_t)kMfRows * kMfStatBytesPerWave;
         const int grid = ((p.n_work + 7) / 8) * 8;
         constexpr int kSchedWords = 1 + 4096;
@@ -1548,7 +1569,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds2, c->stream, p, td, tl_k, ap, st, maps,
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
-    } else if (kernel == MTM_KERNEL_MFMA_F32) {
+    } else if (kernel == MTM_KERNEL_MFMA_F32 && !c->f32_exact_now) {
         const int n_all = (int)sc.members.size();
         const int mb = n_all > 16 ? 2 : 1;
         Bf16Params p{};
@@ -1593,6 +1614,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.ext_best = c->counters.as<unsigned long long>();
             p.cand_on = 1;
             p.hits_only = 1;
+            p.ext_margin = c->refine_now ? kRefineThrMargin : 0.0f;
         }
         const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
         const int grid = ((p.n_work + 7) / 8) * 8;
@@ -1661,12 +1683,65 @@ int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
 
 int ensure_maps(mtm_ctx* c) { return c->maps.ensure(sizeof(float) * std::max<size_t>(4, c->maps_floats)); }
 
+// float32 refinement (mtm_refine.hip.h): the records of the candidate buffer that belong to class `sc` get the scores
+// of the exact float64 kernel - `ring`: their whole 3x3 neighbourhoods, written into the maps.  Runs right behind the
+// class's score launch: the statistics planes are shared by all classes and only live until the next one starts.
+int launch_refine(mtm_ctx* c, const SizeClass& sc, const StatPlanes& st, bool ring, bool patch_maps) {
+    MTMC(ensure_f32_plane(c));
+    RefineParams p{};
+    p.img = image_dev(c);
+    p.td = c->td.as<TemplDev>();
+    p.weights = c->weights.as<double>();
+    p.st = st;
+    p.method = c->method;
+    p.cls = (int)(&sc - c->classes.data());
+    p.ring = ring ? 1 : 0;
+    p.list = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+    p.count = c->cands.as<unsigned long long>();
+    p.cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+    p.maps = patch_maps ? c->maps.as<float>() : nullptr;
+    const unsigned long long threads = p.cap * (ring ? 9ull : 1ull);
+    hipLaunchKernelGGL(refine_rescore_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, p);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
+// the map scan of the refined route: potential peaks of class `sc` (approximate maps in memory) -> candidate buffer
+int launch_refine_scan(mtm_ctx* c, const SizeClass& sc) {
+    const int oh = c->rows - sc.h + 1, ow = c->cols - sc.w + 1;
+    const dim3 grd((ow + kPkCols - 1) / kPkCols, (oh + 4 * kPkRows - 1) / (4 * kPkRows), (unsigned)sc.members.size());
+    hipLaunchKernelGGL(refine_scan_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(), c->td.as<TemplDev>(),
+                       c->tlist.as<int>() + sc.tlist_off, c->cand_min ? 1 : 0, c->cand_thr, kRefineNbrTol, c->opt_border,
+                       reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16),
+                       (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256), c->cands.as<unsigned long long>());
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
 int run_score_all(mtm_ctx* c) {
     if (!c->hits_only_now) MTMC(ensure_maps(c));
     for (const SizeClass& sc : c->classes) {
         StatPlanes st;
         MTMC(launch_stats(c, sc, &st));
         MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st));
+        if (c->refine_now && !c->f32_exact_now && resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32) {
+            if (c->refine_scan_now) {
+                MTMC(launch_refine_scan(c, sc));
+                MTMC(launch_refine(c, sc, st, true, true));
+            } else {
+                MTMC(launch_refine(c, sc, st, false, !c->hits_only_now));
+            }
+        }
+    }
+    if (c->refine_now && !c->f32_exact_now && c->ext_now) {
+        // global extremum: the keys the score kernel kept are approximate - rebuild them from the re-scored list
+        const size_t n = c->templs.size();
+        HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * n, c->stream));
+        const unsigned long long cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        hipLaunchKernelGGL(refine_extremum_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16), c->cands.as<unsigned long long>(), cap,
+                           c->td.as<TemplDev>(), c->cand_min ? 1 : 0, c->counters.as<unsigned long long>());
+        HIPC(hipGetLastError());
     }
     return MTM_OK;
 }
@@ -1779,6 +1854,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
@@ -1858,6 +1934,11 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
             c->hits_only = value ? 1 : 0;
             c->fuse_backoff = 0;
             c->backoff_len = 16;
+            return MTM_OK;
+        case MTM_OPT_F32_MFMA:
+            if (value < 0 || value > 2) break;
+            if ((c->f32_mfma != 0) != (value != 0)) c->placed = false;     // the packs follow the kernel
+            c->f32_mfma = (int)value;
             return MTM_OK;
         case MTM_OPT_DOT4_VARIANT:
             if (value < 0 || value >= kNumDotVariants || kDotVariants[value].wide) break;
@@ -2715,10 +2796,28 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     c->cand_on = false;
     c->hits_only_now = false;
     c->ext_now = false;
+    // float32 images on the bf16 matrix cores: the kernel's scores are a screen, the decisions are taken on exact
+    // float64 scores (mtm_refine.hip.h).  Calls that mix bf16 classes with float64-kernel ones (float masks) run
+    // everything on the float64 kernel.
+    c->refine_now = c->refine_scan_now = c->f32_exact_now = false;
+    {
+        bool any_bf16 = false, all_bf16 = n > 0;
+        for (const SizeClass& sc : c->classes) {
+            const bool b = resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32;
+            any_bf16 = any_bf16 || b;
+            all_bf16 = all_bf16 && b;
+        }
+        if (any_bf16 && c->f32_mfma == 1) {
+            if (all_bf16) c->refine_now = true;
+            else c->f32_exact_now = true;
+        }
+    }
+    if (c->f32_exact_now) fused = false;            // the float64 kernel writes maps and lists no candidates
     // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the 1- or 3-channel MFMA kernel
     // (plain, two-row or row-multiplexed; binary masks with the reciprocal normalisation), the uint16 byte-plane passes
     // or the float32 kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
-    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3)) {
+    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3) &&
+        !c->f32_exact_now) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
             ok = ok && ((resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() &&
@@ -2735,6 +2834,27 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         }
     }
     const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
+    if (mode == MTM_PEAKS_GLOBAL && c->refine_now && !c->ext_now) {
+        // no fused extremum in this configuration (maps requested, MTM_FUSE_PEAKS=0): the float64 kernel + extremum_kernel
+        c->refine_now = false;
+        c->f32_exact_now = true;
+    }
+    // the refined routes list their records in the candidate buffer: the outputs within the margin of the running best
+    // (global extremum), the potential peaks of the map scan (local extrema without kernel candidates)
+    const bool pp_mode = mode == MTM_PEAKS_LOCAL && c->refine_now && !fused && n > 0;
+    if ((c->refine_now && c->ext_now) || pp_mode) {
+        const size_t cands_cap = c->cands.cap;
+        MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
+        if (c->cands.cap != cands_cap) c->cands_zeroed = nullptr;
+        if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        c->cands_zeroed = nullptr;
+    }
+    if (pp_mode) {
+        c->refine_scan_now = true;
+        c->cand_min = mode_min;
+        const float tq = mode_min ? -thr : thr;
+        c->cand_thr = tq - kRefineThrMargin * std::max(1.0f, std::fabs(tq));
+    }
     if (fused) {
         const size_t cands_cap = c->cands.cap;
         MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
@@ -2745,6 +2865,8 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         c->cand_on = true;
         c->cand_min = mode_min;
         c->cand_thr = mode_min ? -thr : thr;
+        // (float32 refinement: everything within the margin of the threshold is listed and re-scored)
+        if (c->refine_now) c->cand_thr -= kRefineThrMargin * std::max(1.0f, std::fabs(c->cand_thr));
         // hits-only: single-channel MFMA classes, every map 2-D, no recent candidate overflow
         bool honly = c->hits_only && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n;
         c->hits_only_now = honly;
@@ -2785,6 +2907,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     S.cand_cap = cand_cap;
     S.hash_mask = hash_mask;
     S.prefetched = false;
+    S.pp_mode = pp_mode;
     if (mode == MTM_PEAKS_LOCAL && fused && !c->list2d.empty()) {
         // Few candidates (the usual case): they come back in one copy and the 3x3 test runs on the host
         // (fm_end).  Pinned landing buffer: the copy is a plain DMA instead of a staged one.
@@ -2815,21 +2938,38 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     std::vector<mtm_hit> hits;
 
     if (mode == MTM_PEAKS_GLOBAL) {
-        if (!c->ext_now) {
-            MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
-            HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
-        }
-        if (n > 0 && !c->ext_now) {
-            const int nb = 256;
-            hipLaunchKernelGGL(extremum_kernel, dim3(nb, n), dim3(256), 0, c->stream, c->maps.as<float>(),
-                               c->td.as<TemplDev>(), nb, c->counters.as<unsigned long long>());
-            HIPC(hipGetLastError());
-        }
-        HIPC(hipEventRecord(c->ev[2], c->stream));
         std::vector<unsigned long long> best(2 * (size_t)std::max(1, n));
-        HIPC(hipMemcpyAsync(best.data(), c->counters.p, sizeof(unsigned long long) * 2 * std::max(1, n),
-                            hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (!c->ext_now) {
+                MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
+                HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
+            }
+            if (n > 0 && !c->ext_now) {
+                const int nb = 256;
+                hipLaunchKernelGGL(extremum_kernel, dim3(nb, n), dim3(256), 0, c->stream, c->maps.as<float>(),
+                                   c->td.as<TemplDev>(), nb, c->counters.as<unsigned long long>());
+                HIPC(hipGetLastError());
+            }
+            HIPC(hipEventRecord(c->ev[2], c->stream));
+            HIPC(hipMemcpyAsync(best.data(), c->counters.p, sizeof(unsigned long long) * 2 * std::max(1, n),
+                                hipMemcpyDeviceToHost, c->stream));
+            unsigned long long nlisted = 0;
+            const bool refined = c->refine_now && c->ext_now;
+            if (refined)
+                HIPC(hipMemcpyAsync(&nlisted, c->cands.p, sizeof(nlisted), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            if (!refined || (int64_t)nlisted <= cand_cap) break;
+            // float32 refinement: more outputs within the margin of their template's best than the list holds (near-flat
+            // maps) - the float64 kernel decides, on maps in memory
+            c->refine_now = false;
+            c->f32_exact_now = true;
+            c->ext_now = false;
+            c->hits_only_now = false;
+            c->cand_on = false;
+            c->timing.ncc_launches = 0;
+            MTMC(run_score_all(c));
+            HIPC(hipEventRecord(c->ev[1], c->stream));
+        }
         for (int t = 0; t < n; ++t) {
             const unsigned long long key = best[2 * t + (mode_min ? 1 : 0)];
             const TemplDev& d = c->td_host[t];
@@ -2861,7 +3001,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         // Every pixel above the threshold is in the list (in both modes), so a neighbour that is not
         // is <= threshold < candidate: the list alone decides.  Saves two kernels, three fills and a copy.
         bool verified_on_host = false;
-        if (use_fused && n2d > 0) {
+        bool pp_mode = S.pp_mode;
+        const float thr_q = mode_min ? -thr : thr;      // a hit's quality (score, or -score for minima) exceeds this
+        if (use_fused && n2d > 0 && !pp_mode) {
             // the candidate list is already on its way into the pinned landing buffer (fm_begin)
             const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
             if (!S.prefetched) {
@@ -2918,7 +3060,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                             const size_t sidx = slot_of(key(h.templ_idx, yy, xx));
                             if (hk[sidx] != 0ull) mx = fmaxf(mx, mode_min ? -cd[hv[sidx]].score : cd[hv[sidx]].score);
                         }
-                    if (v == mx) {
+                    // (v > thr_q: every record the integer kernels list passes; the float32 screen lists with a margin)
+                    if (v == mx && v > thr_q) {
                         hits.push_back(h);
                         ++tflags[(size_t)h.templ_idx];
                     }
@@ -2929,7 +3072,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         }
         if (!verified_on_host && c->hits_only_now)
             HIPC(hipMemsetAsync(c->chash.p, 0, ((size_t)hash_mask + 1) * sizeof(unsigned long long), c->stream));
-        for (int attempt = 0; attempt < 3 && n2d > 0 && !verified_on_host; ++attempt) {
+        if (pp_mode) use_fused = true;          // the potential peaks are in the candidate buffer, their neighbourhoods in the maps
+        for (int attempt = 0; attempt < 5 && n2d > 0 && !verified_on_host; ++attempt) {
             MTMC(c->hits.ensure(hdr_bytes + sizeof(mtm_hit) * (size_t)c->hit_cap));
             uint8_t* dbase = c->hits.as<uint8_t>();
             HIPC(hipMemsetAsync(dbase, 0, hdr_bytes, c->stream));
@@ -2951,12 +3095,12 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                     hipLaunchKernelGGL(verify_hash_kernel, dim3(blocks), dim3(256), 0, c->stream, c->td.as<TemplDev>(),
                                        mode_min ? 1 : 0, c->opt_border, dcands, c->cands.as<unsigned long long>(),
                                        (unsigned long long)cand_cap, keys, vals, hash_mask, dhits,
-                                       (unsigned long long)c->hit_cap, counter, flags);
+                                       (unsigned long long)c->hit_cap, counter, flags, thr_q);
                 } else {
                     hipLaunchKernelGGL(verify_peaks_kernel, dim3(blocks), dim3(256), 0, c->stream,
                                        c->maps.as<float>(), c->td.as<TemplDev>(), mode_min ? 1 : 0, c->opt_border,
                                        dcands, c->cands.as<unsigned long long>(), (unsigned long long)cand_cap, dhits,
-                                       (unsigned long long)c->hit_cap, counter, flags);
+                                       (unsigned long long)c->hit_cap, counter, flags, thr_q);
                 }
             } else {
                 int max_oh = 0, max_ow = 0;
@@ -2979,6 +3123,28 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             std::memcpy(&count, host_buf.data(), sizeof(count));
             std::memcpy(&ncand, host_buf.data() + sizeof(count), sizeof(ncand));
             std::memcpy(tflags.data(), host_buf.data() + 2 * sizeof(count), sizeof(int) * n);
+            if (use_fused && (int64_t)ncand > cand_cap && c->refine_now) {
+                // float32 refinement, list overflowed.  Kernel candidates (everything above the threshold): take the
+                // potential peaks of a map scan instead - far fewer.  Those too (plateau-rich maps): the float64 kernel.
+                c->cand_on = false;
+                c->hits_only_now = false;
+                c->timing.ncc_launches = 0;
+                if (!pp_mode) {
+                    c->fuse_backoff = c->backoff_len;
+                    c->backoff_len = std::min(2 * c->backoff_len, 1024);
+                    pp_mode = true;
+                    c->refine_scan_now = true;
+                    HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+                } else {
+                    pp_mode = false;
+                    use_fused = false;
+                    c->refine_now = c->refine_scan_now = false;
+                    c->f32_exact_now = true;
+                }
+                MTMC(run_score_all(c));
+                HIPC(hipEventRecord(c->ev[1], c->stream));
+                continue;
+            }
             if (use_fused && (int64_t)ncand > cand_cap) {
                 use_fused = false;                  // dense maps: candidate list overflowed
                 // the next calls on this context go straight to map mode + full peak pass; the period doubles while
@@ -2995,7 +3161,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 }
                 continue;
             }
-            if (use_fused) c->backoff_len = 16;     // the candidates fitted
+            if (use_fused && !pp_mode) c->backoff_len = 16;     // the candidates fitted
             if ((int64_t)count <= c->hit_cap) {
                 hits.resize((size_t)count);
                 const size_t got = std::min<size_t>((size_t)count, first);
@@ -3065,7 +3231,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     MTMC(collect_ncc_time(c));
     c->timing.n_hits = (int64_t)hits.size();
     c->timing.hits_only = c->hits_only_now ? 1 : 0;
+    c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
     c->maps_valid = !c->hits_only_now && !c->ext_now;
+    c->refine_now = c->refine_scan_now = c->f32_exact_now = false;      // states of this call only
     *n_out = (int64_t)hits.size();
     c->last_hits.swap(hits);
     if ((int64_t)c->last_hits.size() > capacity) {

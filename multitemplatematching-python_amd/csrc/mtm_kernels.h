@@ -28,7 +28,7 @@ struct TemplDev {
     int rows, cols;         // h, w
     int map_pitch;          // floats per score-map row on the device (multiple of 4)
     int oh, ow;             // score-map size
-    int pad_;
+    int cls;                // index of the template's size class
 };
 
 // Window statistics planes of one size class (all double, pitch = stat_pitch elements).

@@ -221,8 +221,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     static_assert(!KP || (!R2 && METHOD >= 0 && (METHOD != kMfRaw || !RM)), "packed K");
     static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 15, q = lane >> 4;
 
     // ---- scheduling.  Persistent mode: the grid is the number of co-resident work-groups and
     // items are pulled from an atomic counter (sched[0]).  The MFMA main loop and the float64
@@ -247,11 +245,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     }
     // effective shader clock under this very load (the chip clocks to its power budget: MFMA-dense code runs well
     // below the 2.4 GHz the peak figures assume)
+    // (the two start values wait in LDS: kept in registers they were live across the whole kernel and the compiler
+    // spilled them - 16 bytes of scratch per lane and work-group, 25 MB of HBM writes per 4K launch)
     const bool clk_probe = p.clk_out != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
-    unsigned long long clk_t0 = 0, clk_r0 = 0;
     if (clk_probe) {
-        clk_t0 = __builtin_readcyclecounter();
-        clk_r0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* clk0 = reinterpret_cast<unsigned long long*>(s_item + 4);
+        clk0[0] = __builtin_readcyclecounter();
+        clk0[1] = __builtin_amdgcn_s_memrealtime();
     }
     const int per_xcd = (p.n_work + 7) >> 3;
     for (int iter = 0;; ++iter) {
@@ -278,6 +278,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
     const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : (R2 ? 2 * kMfRows : kMfRows));
+    // Lane coordinates of this work item, derived from an opaque copy of the thread index: whatever the prologue
+    // computes from them is then computed HERE, per item, instead of once ahead of the item loop - where it stayed
+    // live across the K loop (which owns every register) and was spilled to scratch memory.
+    int tid_i = threadIdx.x;
+    asm volatile("" : "+v"(tid_i));
+    const int wave = __builtin_amdgcn_readfirstlane(tid_i >> 6), lane = tid_i & 63;
+    const int j = lane & 15, q = lane >> 4;
     const int wave_rows = RM ? 2 * p.rm_R : (R2 ? 2 : 1);   // output rows per wave = tile-row stride between waves
     constexpr int kTG = R2 ? 16 : 16 * MB;              // templates per work item
 
@@ -290,8 +297,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
     MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
     constexpr int kTGc = METHOD == kMfU16 ? 16 : kTG;   // templates with constants (uint16: both groups are the same 16)
-    if (METHOD != kMfRaw && threadIdx.x < (RM ? p.rm_nt : kTGc)) {
-        const int li = tg * kTGc + threadIdx.x;
+    if (METHOD != kMfRaw && tid_i < (RM ? p.rm_nt : kTGc)) {
+        const int li = tg * kTGc + tid_i;
         if (li < p.n_list) {
             const TemplDev& T = td[tlist[li]];
             MfTemplConst k;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     k.ext_thr_lo = ql - 1e-6 * fmax(1.0, fabs(ql));
                 }
             }
-            tcl[threadIdx.x] = k;
+            tcl[tid_i] = k;
         }
     }
 
@@ -391,8 +398,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 typedef const __attribute__((address_space(1))) void* gptr_t;
                 typedef __attribute__((address_space(3))) void* lptr_t;
                 const int nchunk = (ch + (kMfRows - 1) * wave_rows) * p.cpr;
-                int ci = threadIdx.x;
-                int r = ci / p.cpr, d = ci - r * p.cpr;
+                int ci = tid_i;
+                int r = (ci * p.cpr_magic) >> 16, d = ci - r * p.cpr;     // ci / cpr for ci < 256 (cpr <= 33), without a division
                 const uint8_t* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
                 uint8_t* lbase_w = smem + wave * 1024;
 #ifdef MTM_PROBE_NO_STAGE      /* timing experiment: skip the image-tile staging loads (wrong results) */
@@ -1020,11 +1027,19 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     } else if constexpr (C1) {
         // ---- hits-only screen, straight from the accumulator registers (no LDS transposition): in this
         // mode nothing is stored, and almost no work item holds a candidate.  In the MFMA C/D layout lane
-        // (j, q) owns the 16 consecutive pixels 16 j + c and the templates 16 mb + 4 q + e.  Per template the
-        // lane keeps the running extremes of u = (acc + K + S1 (128 - mean)) / sqrt (reciprocal by
-        // v_rcp_f64, ~2^-26: this is a screen) and compares them ONCE with the threshold scaled by the
-        // template norm, lowered by 1e-6.  Only if some lane of the wave sees a possible candidate (or a
-        // saturated / constant-template output) does the wave run the full epilogue below, which
+        // (j, q) owns the 16 consecutive pixels 16 j + c and the templates 16 mb + 4 q + e.  Two levels:
+        //   1. a rigorous bound per lane and template.  A candidate needs num = acc + K + m S1 > thr * templ_norm * sqrt
+        //      at its pixel, so none of the lane's 16 pixels can be one unless
+        //         max(acc) + K + max(m S1_min, m S1_max)  >  thr * templ_norm * sqrt_min
+        //      - one integer v_max per accumulator register, the ranges of the 16 pixels' statistics shared by the four
+        //      lane groups of a column block, a handful of float64 operations per template.  (sqrt_min: a flat window has
+        //      sqrt = 0 and scores 0, never a candidate of a non-negative threshold; a window that is not flat has
+        //      sqrt >= 1 / sqrt(w h), the sums being integers - sq_floor.)
+        //   2. only if some lane's bound says "possible" (or a saturated / constant-template output is): the running
+        //      extremes of u = (acc + K + S1 (128 - mean)) / sqrt per pixel (reciprocal by v_rcp_f64, ~2^-26), compared
+        //      once with the threshold scaled by the template norm, lowered by 1e-6 - round 2's screen, 5 float64
+        //      operations per accumulator register.
+        // Only if level 2 still sees a possible candidate does the wave run the full epilogue below, which
         // repeats the exact test.  Results are therefore those of the full epilogue.
         bool wave_has_work = true;
         if constexpr (CH == 1 && !MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
@@ -1033,6 +1048,73 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             if (p.hits_only && (EXT || p.cand_thr_lo >= 0.0)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* sw0 = smem + p.st_off + wave * (R2 ? 2 * 4 * 1024 : mf_stat_bytes_per_wave(1));
+                bool pass1 = false;
+                if (p.screen_l1) {
+                    // v_min_f64 / v_max_f64 as they are (fmin / fmax on loaded values cost a canonicalising v_max each)
+                    auto min64 = [](double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+                    auto max64 = [](double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+                    // value of lane ^ off (ds_bpermute; the address from this scope's lane index - __shfl_xor takes it from a
+                    // lane id the compiler computes ahead of the item loop and spills across the K loop)
+                    auto xlane = [&](double v, int off) {
+                        const int addr = (lane ^ off) << 2;
+                        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+                        const int hi2 = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+                        return __hiloint2double(hi2, lo);
+                    };
+                    double s1lo[R2 ? 2 : 1], s1hi[R2 ? 2 : 1], sqlo[R2 ? 2 : 1];
+#pragma unroll
+                    for (int r = 0; r < (R2 ? 2 : 1); ++r) {
+                        // this lane's share of its column block: pixels 16 j + 4 q .. + 3; the block's other three lane
+                        // groups (lanes j + 16, + 32, + 48 around) hold the rest
+                        const uint8_t* sw = sw0 + r * 4 * 1024 + (4 * j + q) * 16;
+                        constexpr int kSqPlane = R2 ? 2 : 4;
+                        const double2 sa = *reinterpret_cast<const double2*>(sw + 0 * 1024);
+                        const double2 sb = *reinterpret_cast<const double2*>(sw + 1 * 1024);
+                        const double2 qa = *reinterpret_cast<const double2*>(sw + kSqPlane * 1024);
+                        const double2 qb = *reinterpret_cast<const double2*>(sw + (kSqPlane + 1) * 1024);
+                        s1lo[r] = min64(min64(sa.x, sa.y), min64(sb.x, sb.y));
+                        s1hi[r] = max64(max64(sa.x, sa.y), max64(sb.x, sb.y));
+                        sqlo[r] = min64(min64(qa.x, qa.y), min64(qb.x, qb.y));
+                    }
+#pragma unroll
+                    for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+                        for (int r = 0; r < (R2 ? 2 : 1); ++r) {
+                            s1lo[r] = min64(s1lo[r], xlane(s1lo[r], off));
+                            s1hi[r] = max64(s1hi[r], xlane(s1hi[r], off));
+                            sqlo[r] = min64(sqlo[r], xlane(sqlo[r], off));
+                        }
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        int amax[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            const v4i a = acc[mb][c];
+                            amax[0] = max(amax[0], a.x);
+                            amax[1] = max(amax[1], a.y);
+                            amax[2] = max(amax[2], a.z);
+                            amax[3] = max(amax[3], a.w);
+                        }
+                        const int r = R2 ? mb : 0;
+                        const double sq_eff = fmax(sqlo[r], p.sq_floor);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int lt = (R2 ? 0 : 16 * mb) + 4 * q + e;
+                            const bool live = tg * kTG + lt < p.n_list;     // beyond the list: zero-padded A rows
+                            const MfTemplConst& T = tcl[lt];
+                            const double m = METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0;
+                            const double thr_lo_e = EXT ? T.ext_thr_lo : p.cand_thr_lo;
+                            const double hi = EXT ? fmin(thr_lo_e, 0.999999) - 1e-6 : p.screen_hi;
+                            const double bound = ((double)amax[e] + T.mfma_k) + fmax(m * s1lo[r], m * s1hi[r]);
+                            pass1 = pass1 || (live && (T.all_ones != 0 || thr_lo_e < 0.0 || bound > hi * T.templ_norm * sq_eff));
+                        }
+                    }
+                } else {
+                    pass1 = true;
+                }
+                wave_has_work = __builtin_amdgcn_ballot_w64(pass1) != 0ull;
+                if (wave_has_work) {
                 bool pass = false;
                 // one MFMA group (4 templates of this lane) at a time: 4 x (K, 128 - mean, running extremes)
                 // stay in registers next to the 64 * MB accumulators
@@ -1081,11 +1163,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         // extremum mode: the template's own running best is the threshold (negative or none
                         // yet: no screen for this template)
                         const double thr_lo_e = EXT ? tcl[lt].ext_thr_lo : p.cand_thr_lo;
-                        const double hi = fmin(thr_lo_e, 0.999999) - 1e-6;
+                        const double hi = EXT ? fmin(thr_lo_e, 0.999999) - 1e-6 : p.screen_hi;
                         pass = pass || (live && (thr_lo_e < 0.0 || umax[e] > hi * tn));
                     }
                 }
                 wave_has_work = __builtin_amdgcn_ballot_w64(pass) != 0ull;
+                }   // level 2
             }
         }
         // ---- single channel, method fixed at compile time.  The statistics of the lane's pixels
@@ -1265,8 +1348,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     }
     }   // epilogue scope
     }   // work-item loop
-    if (clk_probe) {
-        const unsigned long long dt = __builtin_readcyclecounter() - clk_t0, dr = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    if (p.clk_out != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) {
+        const unsigned long long* clk0 = reinterpret_cast<const unsigned long long*>(s_item + 4);
+        const unsigned long long dt = __builtin_readcyclecounter() - clk0[0], dr = __builtin_amdgcn_s_memrealtime() - clk0[1];
         if (dr > 0) *p.clk_out = (float)((double)dt * 100.0 / (double)dr);
     }
 }

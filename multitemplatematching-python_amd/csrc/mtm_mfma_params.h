@@ -28,6 +28,9 @@ constexpr int kMfEpiBytesPerWave = 8 * kMfEpiPitch * 4;
 constexpr int kMfStatPlaneBytes = 2 * 1024;                // one statistics plane of a wave's 256 pixels
 constexpr int kMfStatBytesPerWave = 3 * kMfStatPlaneBytes;   // single channel: S1, S2, sqrt
 __host__ __device__ constexpr int mf_stat_bytes_per_wave(int ch) { return (ch + 2) * kMfStatPlaneBytes; }
+// Work-group scratch words behind the 32 per-template constants: [0] work item, [1] late start, [2] candidate list
+// full, [4..7] the start values of the shader-clock probe (two 64-bit counters)
+constexpr int kMfItemBytes = 32;
 // METHOD value of the raw mode: the biased int8 accumulators are stored as they are (uint16 images:
 // the first of two byte-plane passes, see kMfU16; sum I^2 M of masked classes; slabs).
 constexpr int kMfRaw = 6;
@@ -51,6 +54,7 @@ struct MfmaParams {
     int method;
     int lds_pitch;           // bytes per LDS tile row: (16 + 4*nb + 1) * 16
     int cpr, cpr_rstep, cpr_dstep;   // 16-byte chunks per tile row; 256 / cpr and 256 % cpr (tile DMA)
+    int cpr_magic, cpr_pad_;         // floor(65536 / cpr) + 1: i / cpr == (i * cpr_magic) >> 16 for i < 256
     long long group_bytes;   // bytes of one 16-template A pack: chans * h * nb * 1024
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
     int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
@@ -81,6 +85,9 @@ struct MfmaParams {
     long long raw_map;       //   (+ y * raw_pitch + x); kMfU16: the raw maps of the first pass (read)
     int raw_pitch;
     double cand_thr_lo;      // cand_thr minus 8 float32 ulps (hits-only pre-test in float64)
+    double screen_hi;        // hits-only screen: min(cand_thr_lo, 0.999999) - 1e-6 (extremum mode: per template, from its running best)
+    double sq_floor;         // hits-only screen: lower bound of the sqrt statistic of a window that is not flat, 0.99 / sqrt(w h)
+    int screen_l1, screen_pad_;   // 1: the screen starts with the per-lane bound (MTM_SCREEN_L1=0: round 2's screen alone)
     int hits_only;           // 1: candidates only, the score maps are not written (mtm_find_matches
                              // without map consumers); needs cand_on
     // fused global extremum (template parameter EXT; mtm_find_matches, MTM_PEAKS_GLOBAL, plain single-channel classes): nothing is

@@ -699,7 +699,6 @@ def test_float32_on_bf16_matrix_cores(mtm, ctx, coins, monkeypatch):
                 exp = O.compute_score_map(t, im, method)
                 worst = max(worst, map_close(got, exp, tol=5e-5))
     # many templates (two MFMA groups), RGB, raw methods, hit lists against the exact float64 kernel
-    # (well separated peaks: with thousands of near-ties a 1e-6 difference may move a local maximum by a pixel)
     im = variants["signed noise"] + variants["unit range"] * 20.0
     lt = [("t%d" % k, np.ascontiguousarray(im[7 * k:7 * k + 28, 11 * k:11 * k + 36])) for k in range(21)]
     rgbf = np.stack([im, np.roll(im, 5, axis=1), 300.0 - im], axis=2).astype(np.float32)
@@ -714,7 +713,7 @@ def test_float32_on_bf16_matrix_cores(mtm, ctx, coins, monkeypatch):
             assert exact.timing()["kernel_used"] == 0
             b = mtm._to_hit_list(raw, tl, 0, 0)
             assert len(a) == len(b) >= len(tl)
-            assert_hits_equal(hits_json(a), hits_json(b), tol=5e-5, ordered=False)      # (near-equal scores may swap places)
+            assert_hits_equal(hits_json(a), hits_json(b), tol=0.0, ordered=True)        # refined: the float64 kernel's list
         for method in (0, 2, 4):     # raw sums stay on the float64 kernel (they can cancel to ~0: no relative bound)
             got = mtm.computeScoreMap(lt[3][1], im, method)
             assert ctx.timing()["kernel_used"] == 0
@@ -723,6 +722,73 @@ def test_float32_on_bf16_matrix_cores(mtm, ctx, coins, monkeypatch):
     finally:
         exact.close()
     print("bf16-piece kernel: worst |score - oracle| = %.2e" % worst)
+
+
+@pytest.mark.gpu
+def test_float32_hit_lists_are_the_float64_kernels(coins):
+    """The default float32 route (bf16 matrix cores as a screen + exact float64 re-scoring, MTM_OPT_F32_MFMA = 1) returns
+    the hit records of the float64 kernel (MTM_OPT_F32_MFMA = 0) - same pixels, same order, same float32 scores bit for
+    bit - on images whose score maps are full of plateaus and near-ties, where a 1e-6 perturbation decides which pixel
+    "equals its 3x3 maximum": a smooth photograph-like image (TM_CCORR_NORMED of all-positive data is ~0.9 everywhere),
+    a three-row template, a piecewise-constant image (exact ties).  Every way the refinement can run is walked by
+    shrinking the hit capacity: kernel candidates (hits-only and with the maps in memory), the map scan after the
+    candidate list overflowed, the float64 kernel after the scan's list overflowed too; N_object == 1 likewise.
+    Reference: MTM/__init__.py:71-74 (float32 cast), :45 (peak_local_max), :226 (minMaxLoc)."""
+    from MTM import _lib
+    fast, exact = _lib.Context(0), _lib.Context(0)
+    exact.set_option(_lib.OPT_F32_MFMA, 0)
+    rng = np.random.default_rng(11)
+    smooth = synth.smooth_u8(3, (300, 420)).astype(np.float32) * 0.37 + 12.5
+    blocks = np.kron(rng.integers(0, 6, (38, 53)).astype(np.float32), np.ones((8, 8), np.float32)) * 17.25 + 3.0
+    cf = coins.astype(np.float32) * 0.5 + np.linspace(0, 40, coins.shape[1], dtype=np.float32)[None, :]
+    cases = []
+    for name, im in (("smooth", smooth), ("blocks", blocks), ("coins", cf)):
+        lt = [np.ascontiguousarray(im[20:52, 30:70]), np.ascontiguousarray(im[100:103, 200:260]),      # 3 rows: near-flat maps
+              np.ascontiguousarray(im[150:190, 40:64])] + \
+             [np.ascontiguousarray(im[10 * k:10 * k + 24, 16 * k:16 * k + 24]) for k in range(18)]   # a 21-template class
+        cases.append((name, im, lt))
+    routes = set()
+    try:
+        for name, im, lt in cases:
+            templs = [(t, None) for t in lt]
+            for method, thr in ((3, 0.5), (3, 0.98), (5, 0.3), (5, 0.8), (1, 0.1)):
+                ref = exact.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
+                assert exact.timing()["kernel_used"] == 0 and exact.timing()["f32_route"] == 0
+                for cap in (1 << 18, 20000, 1500):
+                    for honly in (1, 0):
+                        fast.set_option(_lib.OPT_HIT_CAPACITY, cap)
+                        fast.set_option(_lib.OPT_HITS_ONLY, honly)
+                        got = fast.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
+                        tm = fast.timing()
+                        routes.add(tm["f32_route"])
+                        assert tm["f32_route"] in (1, 2, 3), tm
+                        assert len(got) == len(ref), (name, method, thr, cap, honly, tm["f32_route"], len(got), len(ref))
+                        for f in ("templ_idx", "x", "y", "w", "h"):
+                            assert np.array_equal(got[f], ref[f]), (name, method, thr, cap, honly, tm["f32_route"], f)
+                        assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), \
+                            (name, method, thr, cap, honly, tm["f32_route"])
+            # N_object == 1: the global extremum per template (first occurrence on exact ties)
+            for method in (5, 3, 1):
+                ref = exact.search(templs, im, method, _lib.PEAKS_GLOBAL, 0.0)
+                for cap in (1 << 18, 64):
+                    fast.set_option(_lib.OPT_HIT_CAPACITY, cap)
+                    fast.set_option(_lib.OPT_HITS_ONLY, 1)
+                    got = fast.search(templs, im, method, _lib.PEAKS_GLOBAL, 0.0)
+                    routes.add(fast.timing()["f32_route"])
+                    assert len(got) == len(ref) == len(lt)
+                    for f in ("templ_idx", "x", "y"):
+                        assert np.array_equal(got[f], ref[f]), (name, method, cap, f, fast.timing()["f32_route"])
+                    assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (name, method, cap)
+        assert routes == {1, 2, 3}, routes          # every way of refining has been exercised
+        # MTM_OPT_F32_MFMA = 2: the bf16 scores as they are (no re-scoring), still within tolerance of the exact ones
+        fast.set_option(_lib.OPT_HIT_CAPACITY, 1 << 18)
+        fast.set_option(_lib.OPT_F32_MFMA, 2)
+        name, im, lt = cases[2]
+        got = fast.search([(t, None) for t in lt], im, 5, _lib.PEAKS_LOCAL, 0.8)
+        assert fast.timing()["f32_route"] == 0 and fast.timing()["kernel_used"] == 5 and len(got) >= len(lt)
+    finally:
+        fast.close()
+        exact.close()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1618,6 +1684,26 @@ def test_same_template_objects_call_after_call(mtm, coins):
     third = mtm.matchTemplates(lt, coins, score_threshold=0.5)
     assert third == hits_of(O.match_templates(lt, coins, score_threshold=0.5))
     assert all(h[1][2:] == (40, 60) for h in third if h[0] == "b")
+
+
+@pytest.mark.gpu
+def test_copied_template_views_are_reread(mtm, coins):
+    """A template the binding has to copy (np.rot90 view, reversed columns: rows without contiguous pixels) is marshalled
+    again in every call - the records of the first call would point at a private copy of the first call's pixels, and an
+    in-place edit of the caller's array would go unnoticed (the reference re-reads its templates on every call)."""
+    small, _ = coin_templates(coins)
+    base = np.ascontiguousarray(small)
+    for view in (np.rot90(base), base[:, ::-1], base.T):
+        assert not view.flags.c_contiguous
+        lt = [("v", view)]
+        first = mtm.matchTemplates(lt, coins, score_threshold=0.5)
+        assert first == hits_of(O.match_templates([("v", np.ascontiguousarray(view))], coins, score_threshold=0.5))
+        keep = base.copy()
+        base[...] = coins[150:150 + base.shape[0], 200:200 + base.shape[1]]     # same view object, other pixels
+        second = mtm.matchTemplates(lt, coins, score_threshold=0.5)
+        assert second == hits_of(O.match_templates([("v", np.ascontiguousarray(view))], coins, score_threshold=0.5))
+        assert second != first
+        base[...] = keep
 
 
 @pytest.mark.gpu

@@ -136,3 +136,30 @@ def test_template_matcher_refuses_reentry_while_streaming(mtm):
     gen.close()
     assert m.match(img) == []                 # released
     assert list(m.match_stream([img, img])) == [[], []]
+
+
+def test_template_records_memo_only_for_zero_copy_arrays():
+    """MTM._lib.Context._records reuses the marshalled template list of the previous call only when every record points
+    at the caller's own buffer; arrays that had to be copied (np.rot90 views ...) are marshalled - copied - again, so an
+    in-place edit between two calls is seen (round 2 advisor finding)."""
+    import numpy as np
+    from MTM import _lib
+    ctx = object.__new__(_lib.Context)          # no library / GPU needed for the marshalling
+    ctx._rec_key, ctx._rec, ctx._rec_keep = None, None, None
+    base = np.arange(12 * 9, dtype=np.uint8).reshape(12, 9)
+    mask = np.ones((12, 9), np.uint8)
+    lt = [(base, None), (base[2:8, 1:7], mask[2:8, 1:7])]       # contiguous pixels per row: zero copy
+    r1 = ctx._records(lt)
+    assert ctx._rec_key is not None and ctx._records(lt) is r1
+    assert int(r1["px"][0]) == base.ctypes.data and int(r1["px"][1]) == base[2:8, 1:7].ctypes.data
+    view = np.rot90(base)
+    lt2 = [(view, None)]
+    r2 = ctx._records(lt2)
+    assert ctx._rec_key is None                                   # copied: never reused
+    copy1 = ctx._rec_keep[0][0]
+    assert copy1 is not view and (copy1 == view).all()
+    base[...] = 255
+    r3 = ctx._records(lt2)
+    assert r3 is not r2
+    assert (ctx._rec_keep[0][0] == 255).all()
+    assert _lib._zero_copy(lt, [base, lt[1][0], lt[1][1]]) and not _lib._zero_copy(lt2, [copy1])
