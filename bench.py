@@ -4,6 +4,11 @@ bench.py - throughput of the MTM hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
 
+N > 1 runs either way: launched by ``torch.distributed.run --nproc-per-node N`` (WORLD_SIZE set) it is one process per
+GPU with an RCCL all-gather of the hit records; started plainly (``python bench.py --gpus N``) it is ONE process
+driving N GPUs through the library's device group (mtm_group: a context and a native worker thread per device,
+units sharded by cost, host merge - no collective needed).
+
 A "step" is ONE ``MTM.matchTemplates`` call as a user of the reference makes it: numpy
 arrays in, list of hits out - argument validation, template hand-over (unchanged templates stay resident on the
 GPU, as a loop over images leaves them), H2D of the image, window statistics, the sliding-window score kernel,
@@ -237,10 +242,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+    # --gpus N without a launcher: one process, N devices (mtm_group).  With WORLD_SIZE set: one process per GPU.
+    group_n = args.gpus if ("WORLD_SIZE" not in os.environ and args.gpus > 1) else 0
+    if not group_n and world != args.gpus:
         args.gpus = world
 
     # stdout is a protocol: exactly one JSON line, from rank 0.  Libraries print there too (gloo's
@@ -265,13 +269,28 @@ def main():
     if have_torch_gpu:
         torch.cuda.set_device(device)
 
-    img, units, plants, method, thr, desc = build_workload(args.config, world)
-    ctx = _lib.Context(device)
-    ctx.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
-    _lib._default_ctx = ctx                  # MTM.matchTemplates below runs on this context
-    exchange_kind = "rccl" if world > 1 else "none"
+    img, units, plants, method, thr, desc = build_workload(args.config, group_n or world)
+    group, group_devices = None, []
+    if group_n:
+        n_vis = _lib.load().mtm_device_count()
+        # BENCH_GROUP_ALIAS=1: more contexts than GPUs (control-flow test on a single-GPU box) - never set by the driver
+        if n_vis < group_n and not os.environ.get("BENCH_GROUP_ALIAS"):
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (group_n, n_vis))
+        group_devices = [i % max(n_vis, 1) for i in range(group_n)]
+        group = _lib.Group(group_devices)
+        group.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
+        _lib._engines[tuple(group_devices)] = group          # MTM.matchTemplates(devices=...) below runs on this group
+        ctx = None
+    else:
+        ctx = _lib.Context(device)
+        ctx.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
+        _lib._default_ctx = ctx                  # MTM.matchTemplates below runs on this context
+    exchange_kind = "rccl" if world > 1 else ("host merge (one process, mtm_group)" if group_n else "none")
+    comm_ranks = 1
     try:
-        exchange = HitExchange("rccl", rank, world, context=ctx)       # unique id through the package's TCP store
+        exchange = HitExchange("rccl", rank, world, context=ctx) if not group_n else None     # unique id through the package's TCP store
+        if world > 1:
+            comm_ranks = int(getattr(ctx, "n_ranks", 1))           # ranks of the RCCL communicator that was created
     except Exception as e:  # noqa: BLE001 - keep the job alive: same records over gloo instead of RCCL
         sys.stderr.write("[bench] RCCL hit exchange unavailable (%s); falling back to gloo\n" % e)
 
@@ -283,22 +302,27 @@ def main():
         exchange_kind = "gloo-fallback"
 
     costs = [unit_cost(u[1], img.shape, len(u) >= 3) for u in units]
-    mine = shard_units(costs, world)[rank]
+    mine = shard_units(costs, group_n or world)[0 if group_n else rank]     # group: device 0's shard (same LPT rule in the library)
     sub = [units[i] for i in mine]
     gidx = np.asarray(mine, dtype=np.int32)
     inf = float("inf")
 
     def sync():
         if have_torch_gpu:
-            torch.cuda.synchronize()
+            for d in (sorted(set(group_devices)) if group_n else [device]):
+                torch.cuda.synchronize(d)
         if dist is not None:
             dist.barrier()
 
     kernel_ms, total_ms, clocks, sum_ms, launches = [], [], [], [], 0
+    dev_kernel_ms = [[] for _ in range(group_n)]         # group: score-kernel time per device and step
 
     def note_timing():
         nonlocal launches
-        t = ctx.timing()
+        if group_n:
+            for i in range(group_n):
+                dev_kernel_ms[i].append(group.timing(i)["ncc_kernel_ms"])
+        t = group.timing(0) if group_n else ctx.timing()
         kernel_ms.append(t["ncc_kernel_ms"])
         sum_ms.append(t["ncc_sum_ms"])
         total_ms.append(t["total_ms"])
@@ -308,7 +332,10 @@ def main():
         return t
 
     # ---- the timed step: one matchTemplates call, numpy arrays in -> hit list out
-    if world == 1:
+    if group_n:
+        def call(lt=units):
+            return MTM.matchTemplates(lt, img, method=method, score_threshold=thr, maxOverlap=0.25, devices=group_devices)
+    elif world == 1:
         def call(lt=units):
             return MTM.matchTemplates(lt, img, method=method, score_threshold=thr, maxOverlap=0.25)
     else:
@@ -395,7 +422,7 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     sensors_after = gpu_sensors()
-    tinfo = ctx.timing()
+    tinfo = group.timing(0) if group_n else ctx.timing()
     k_ms, t_ms, clk, timed_launches = list(kernel_ms), list(total_ms), list(clocks), tinfo["ncc_launches"]
     s_ms = list(sum_ms)
     if dist is not None:
@@ -406,7 +433,7 @@ def main():
     px = img.shape[0] * img.shape[1]
     rate = lambda ms: round(px * len(units) / ms / 1e3, 1)        # noqa: E731  ms per call -> Mpx-corr/s
     extras = {}
-    if world == 1 and not args.skip_extras:
+    if world == 1 and not group_n and not args.skip_extras:
         gc.disable()
         # (a) fresh template bytes in every call: nothing derived from the previous call's templates is reused
         variants = []
@@ -531,7 +558,7 @@ def main():
         achieved = bytes_step / (k_step * 1e-3) / 1e9
         kname = {1: "ncc_naive_kernel", 2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(tinfo["kernel_used"], "ncc_f64_kernel")
         tmacs = macs / (k_step * 1e-3) / 1e12
-        traffic = pmc_traffic(tinfo["kernel_used"], args.config, world, hits_only)
+        traffic = pmc_traffic(tinfo["kernel_used"], args.config, group_n or world, hits_only)
         hbm = {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": round(achieved / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_step": int(bytes_step),
                "maps_materialised": not hits_only}
@@ -567,13 +594,16 @@ def main():
         med = float(np.median(per_call)) * 1e3
         out = {
             "metric": "Mpixel-correlations/s", "value": round(value, 1), "unit": "Mpx-corr/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": group_n or world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": desc, "image_hw": list(img.shape[:2]), "units": len(units),
                        "units_per_gpu": len(my_units), "method": method, "score_threshold": thr,
                        "max_overlap": 0.25, "prewarm_seconds": PREWARM_SECONDS, "prewarm_calls": n_pre + 1,
-                       "parallelism": "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
+                       "parallelism": ("units sharded over %d device(s) of one process (mtm_group), %s" % (group_n, exchange_kind))
+                                      if group_n else
+                                      "units sharded over %d rank(s), all-gather of hits: %s" % (world, exchange_kind),
+                       "processes": 1 if group_n else world,
                        "timed_region": "K x one MTM.matchTemplates call, numpy arrays in -> hit list out (SURVEY 8d): validation, "
                                        "template hand-over (unchanged templates stay resident), image H2D, window statistics, "
                                        "score kernel, peak extraction, D2H hits, all-gather (N > 1), NMS, hit list",
@@ -586,8 +616,16 @@ def main():
                       "before": sensors_before, "after": sensors_after},
             "hits": len(hits), "planted_found": bool(planted_ok),
         }
+        if group_n:
+            out["multi_gpu"] = {"mode": "one process, mtm_group", "devices": group_devices,
+                                "exchange": "none (hit lists merged on the host)",
+                                "kernel_ms_per_step_by_device": [round(float(np.mean(v)), 4) if v else None for v in dev_kernel_ms],
+                                "units_by_device": [int((group.shards([(u[1], u[2] if len(u) >= 3 else None) for u in units],
+                                                                      img.shape, method) == i).sum()) for i in range(group_n)]}
+        elif world > 1:
+            out["multi_gpu"] = {"mode": "one process per GPU", "exchange": exchange_kind, "communicator_ranks": comm_ranks}
         out.update(extras)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not group_n:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         sys.stdout.flush()

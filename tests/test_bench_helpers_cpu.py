@@ -68,3 +68,19 @@ def test_synthetic_smooth_image_and_crops():
         assert t.shape == (24, 24) and t.flags.c_contiguous and t.base is None
         pos = [(y, x) for y in range(120 - 24 + 1) for x in range(200 - 24 + 1) if a[y, x] == t[0, 0] and np.array_equal(a[y:y + 24, x:x + 24], t)]
         assert pos
+
+
+def test_gpus_flag_without_launcher_selects_the_device_group():
+    """`python bench.py --gpus N` (no torch.distributed.run, WORLD_SIZE unset) is the single-process device-group mode
+    (mtm_group) - round 2's bench refused to run that way.  Without a GPU it gets as far as counting the devices."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_GROUP_ALIAS")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    if r.returncode == 0:                       # a box with >= 2 GPUs: the line must say so
+        import json
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 2 and line["multi_gpu"]["mode"].startswith("one process")
+    else:
+        assert "torch.distributed.run" not in r.stderr
+        assert "GPU(s) visible" in r.stderr or "no HIP device" in r.stderr or "No HIP" in r.stderr or "hip" in r.stderr.lower(), r.stderr[-400:]

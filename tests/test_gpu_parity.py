@@ -2010,3 +2010,24 @@ def test_rgb_lean_path(mtm, ctx):
         set_kernel(ctx, "auto")
         set_exact(ctx, 0)
         ctx.set_option(6, 1)
+
+
+def test_bench_gpus_flag_runs_the_device_group_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: one process, two contexts behind mtm_group (both on this box's
+    one GPU: BENCH_GROUP_ALIAS), 64 units sharded 32 / 32, one JSON line with n_gpus 2, every planted template found."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["BENCH_GROUP_ALIAS"] = "1"
+    env["BENCH_PREWARM_S"] = "0.05"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["units"] == 64 and out["config"]["processes"] == 1
+    assert out["multi_gpu"]["units_by_device"] == [32, 32] and len(out["multi_gpu"]["kernel_ms_per_step_by_device"]) == 2
+    assert out["planted_found"] and out["hits"] >= 64 and out["value"] > 0

@@ -23,6 +23,8 @@ def make_case(seed):
     big = seed % 7 == 0                                       # >= 1 Mpx: banded uploads
     H, W = (int(rng.integers(900, 1200)), int(rng.integers(1150, 1400))) if big else (int(rng.integers(30, 420)), int(rng.integers(30, 640)))
     dtype = str(rng.choice(["uint8"] * 5 + ["uint16", "float32"]))
+    if os.environ.get("FUZZ_DTYPE"):                          # e.g. FUZZ_DTYPE=float32: every case of that dtype
+        dtype = os.environ["FUZZ_DTYPE"]
     chans = int(rng.choice([1, 1, 1, 3])) if dtype == "uint8" else 1
     kind = int(rng.integers(0, 3))
     if kind == 0:

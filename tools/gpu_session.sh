@@ -1,0 +1,49 @@
+#!/bin/bash
+# One gpurun call = one GPU box for a few minutes: run a list of stages back to back and leave everything under
+# gpurun_out/<tag>/ (merged back into the repo by gpurun).  Usage: tools/gpu_session.sh <tag> stage [stage ...]
+# Stages: tests | bench | screen_ab | f32 | fuzz_f32 | profile | alt_quick | group | probes
+set -u
+TAG=${1:-s}; shift
+R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+clean() { grep -vE "^RCCL|^HIP|^ROCm|^Host|^Librccl" ; }
+t0=$(date +%s)
+stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a $OUT/session.log; }
+for st in "$@"; do
+  stamp "stage $st"
+  case $st in
+    tests)
+      timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; stamp "pytest rc=$? $(tail -1 $OUT/pytest.log)" ;;
+    tests_all)      # no -x: every failure listed
+      timeout 1200 python -m pytest tests -m gpu -q > $OUT/pytest_all.log 2>&1; stamp "pytest rc=$? $(tail -1 $OUT/pytest_all.log)" ;;
+    bench)
+      python bench.py 2>$OUT/bench.err | clean | tail -1 > $OUT/bench.json; stamp "bench $(cut -c1-160 $OUT/bench.json)" ;;
+    bench_driver)   # the driver's command line
+      python bench.py --gpus 1 --steps 20 --warmup 5 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_driver.json; stamp "bench_driver $(cut -c1-160 $OUT/bench_driver.json)" ;;
+    screen_ab)      # the per-lane bound of the hits-only screen on / off, same box, alternating
+      for rep in 1 2; do for v in 1 0; do
+        MTM_SCREEN_L1=$v python bench.py --no-cpu-baseline --skip-extras --steps 200 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('L1=$v', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/screen_ab.txt
+      done; done ;;
+    f32)
+      for v in 1 2 0; do echo "== MTM_F32_MFMA=$v" >> $OUT/f32_probe.txt; MTM_F32_MFMA=$v timeout 300 python tools/probes/f32_probe.py >> $OUT/f32_probe.txt 2>&1; done
+      stamp "$(grep float32 $OUT/f32_probe.txt | tr '\n' '|')" ;;
+    fuzz_f32)
+      FUZZ_DTYPE=float32 timeout 420 python tools/fuzz_parity.py 0 ${FUZZ_N:-120} > $OUT/fuzz_f32.txt 2>&1; stamp "fuzz_f32: $(tail -2 $OUT/fuzz_f32.txt | tr '\n' ' ')" ;;
+    fuzz)
+      timeout 420 python tools/fuzz_parity.py 1000 ${FUZZ_N:-150} > $OUT/fuzz.txt 2>&1; stamp "fuzz: $(tail -2 $OUT/fuzz.txt | tr '\n' ' ')" ;;
+    profile)
+      bash tools/profile_round.sh $TAG/profile > $OUT/profile.log 2>&1; stamp "profile done" ;;
+    alt_quick)
+      ALT_K="not cfg and not full_size" bash tools/alt_modes.sh > $OUT/alt_modes.txt 2>&1; stamp "alt: $(grep -c passed $OUT/alt_modes.txt) modes" ;;
+    group)
+      BENCH_GROUP_ALIAS=1 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group2.json
+      BENCH_GROUP_ALIAS=1 python bench.py --gpus 8 --steps 10 --warmup 2 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group8.json
+      stamp "group: $(cut -c1-120 $OUT/bench_group2.json) | $(cut -c1-120 $OUT/bench_group8.json)" ;;
+    probes)
+      for pr in ${PROBES:-call_breakdown dense_probe coins_probe}; do timeout 300 python tools/probes/$pr.py > $OUT/$pr.txt 2>&1; stamp "$pr: $(tail -3 $OUT/$pr.txt | tr '\n' '|' | cut -c1-300)"; done ;;
+    *) stamp "unknown stage $st" ;;
+  esac
+done
+stamp "done"
+cat $OUT/session.log
