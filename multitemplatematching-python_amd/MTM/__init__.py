@@ -150,6 +150,7 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
     units = None
     if image.dtype == _U8 and image.ndim in (2, 3) and ichans <= 4:
         units = []
+        ignored_masks = 0           # warnings only once the list is known to take this path (the general loop below warns itself)
         for tempTuple in listTemplates:
             t = tempTuple[1]
             mask = None
@@ -160,12 +161,14 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
                         units = None
                         break
                 else:
-                    warnings.warn(_MSG_MASK_UNSUPPORTED)
+                    ignored_masks += 1
             if t.dtype != _U8 or t.ndim != image.ndim or (t.ndim == 3 and t.shape[2] != ichans):
                 units = None
                 break
             units.append((t, mask))
     if units is not None:
+        for _ in range(ignored_masks):      # one per template, as the reference's loop emits them (MTM/__init__.py:216-221)
+            warnings.warn(_MSG_MASK_UNSUPPORTED)
         engine = context or _lib.engine_for(devices)
         with engine.lock:
             return engine.search(units, image, method, mode, score_threshold)

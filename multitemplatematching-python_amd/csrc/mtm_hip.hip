@@ -1700,8 +1700,10 @@ int launch_refine(mtm_ctx* c, const SizeClass& sc, const StatPlanes& st, bool ri
     p.count = c->cands.as<unsigned long long>();
     p.cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
     p.maps = patch_maps ? c->maps.as<float>() : nullptr;
-    const unsigned long long threads = p.cap * (ring ? 9ull : 1ull);
-    hipLaunchKernelGGL(refine_rescore_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, p);
+    // one wave per record, records strided over a grid that fills the chip a few times (the list length is only known
+    // on the device; most calls list a few hundred records)
+    const unsigned grid = (unsigned)std::min<unsigned long long>(p.cap, 8192ull);
+    hipLaunchKernelGGL(refine_rescore_kernel, dim3(grid), dim3(64), 0, c->stream, p);
     HIPC(hipGetLastError());
     return MTM_OK;
 }

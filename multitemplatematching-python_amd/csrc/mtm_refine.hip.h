@@ -36,62 +36,103 @@ struct RefineParams {
 // The score ncc_f64_kernel<false> stores for (template T, output pixel x, y): per channel one float64 FMA chain over
 // the template in that kernel's order - 16-row x 32-column chunks, row-major inside a chunk - channel totals added in
 // channel order, then finish_unmasked.
-__device__ __forceinline__ float exact_score_f32(const RefineParams& p, const TemplDev& T, int x, int y) {
-    constexpr int kCh = 16, kCw = 32;           // kF64ChunkH, kF64ChunkW
-    const int h = T.rows, w = T.cols;
-    double tot = 0.0;
-    for (int c = 0; c < p.img.chans; ++c) {
-        const float* plane = p.img.f32 + c * p.img.f32_plane + (size_t)y * p.img.f32_pitch + x;
-        const double* k1 = p.weights + T.k1_off + (size_t)c * h * w;
-        double acc = 0.0;
-        for (int cy0 = 0; cy0 < h; cy0 += kCh) {
-            const int ch = min(kCh, h - cy0);
-            for (int cx0 = 0; cx0 < w; cx0 += kCw) {
-                const int cw = min(kCw, w - cx0);
+//
+// One wave per record.  A chain of w*h*C dependent FMAs cannot be split without changing its rounding, so what the wave
+// parallelises is everything around it: all 64 lanes fetch the next chunk of the image patch and of the weights
+// (coalesced, a register set in flight) while the chains run out of LDS on the chunk before - one chain in lane 0, or
+// (ring mode) the nine chains of a 3x3 neighbourhood in lanes 0..8, which share a patch with a one-pixel ring.
+// (A thread per window with loads straight from memory measured 0.35 ms for the 128 candidates of a 4K x 32 call -
+// every tap waited for its two loads; this form is bound by the FMA latency, ~25 us.)
+constexpr int kRfCh = 16, kRfCw = 32;                       // kF64ChunkH, kF64ChunkW
+constexpr int kRfPw = kRfCw + 2, kRfPh = kRfCh + 2;         // patch chunk with the ring
+constexpr int kRfPatch = kRfPw * kRfPh;                     // 612 floats
+constexpr int kRfPxPerLane = (kRfPatch + 63) / 64;          // 10
+constexpr int kRfKPerLane = kRfCh * kRfCw / 64;             // 8
+
+__global__ __launch_bounds__(64) void refine_rescore_kernel(RefineParams p) {
+    __shared__ float s_px[2][kRfPatch];
+    __shared__ double s_k[2][kRfCh * kRfCw];
+    const int lane = threadIdx.x;
+    const unsigned long long n = min(*p.count, p.cap);
+    const int R = p.ring ? 1 : 0;
+    for (unsigned long long i = blockIdx.x; i < n; i += gridDim.x) {
+        const mtm_hit rec = p.list[i];
+        const TemplDev T = p.td[rec.templ_idx];
+        if (T.cls != p.cls) continue;                                   // wave-uniform
+        const int h = T.rows, w = T.cols;
+        // this lane's window: the record itself (lane 0), or neighbour `lane` of its 3x3 ring (lanes 0..8)
+        const int ox = p.ring ? lane % 3 : 0, oy = p.ring ? lane / 3 : 0;      // offsets inside the ringed patch
+        const int wx = rec.x + ox - R, wy = rec.y + oy - R;
+        const bool mine = lane < (p.ring ? 9 : 1) && wx >= 0 && wx < T.ow && wy >= 0 && wy < T.oh;
+        const int ncy = (h + kRfCh - 1) / kRfCh, ncx = (w + kRfCw - 1) / kRfCw;
+        const int per_chan = ncy * ncx, n_chunks = per_chan * p.img.chans;
+        float fv[kRfPxPerLane];
+        double kv[kRfKPerLane];
+        auto fetch = [&](int k) {                       // chunk k -> registers (requests only)
+            const int c = k / per_chan, r = k - c * per_chan;
+            const int cy0 = (r / ncx) * kRfCh, cx0 = (r % ncx) * kRfCw;
+            const float* plane = p.img.f32 + c * p.img.f32_plane;
+            const double* k1 = p.weights + T.k1_off + (size_t)c * h * w;
+#pragma unroll
+            for (int u = 0; u < kRfPxPerLane; ++u) {
+                const int e = lane + 64 * u;
+                const int pr = e / kRfPw, pc = e - pr * kRfPw;
+                // rows / columns of the ring that fall outside the image are never used: clamp the address
+                const int yy = max(rec.y - R + cy0 + pr, 0), xx = max(rec.x - R + cx0 + pc, 0);
+                fv[u] = e < kRfPatch ? plane[(size_t)yy * p.img.f32_pitch + xx] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < kRfKPerLane; ++u) {
+                const int e = lane + 64 * u;
+                const int dy = e / kRfCw, dx = e - dy * kRfCw;
+                kv[u] = (cy0 + dy < h && cx0 + dx < w) ? k1[(size_t)(cy0 + dy) * w + cx0 + dx] : 0.0;
+            }
+        };
+        auto park = [&](int buf) {                      // registers -> LDS buffer
+#pragma unroll
+            for (int u = 0; u < kRfPxPerLane; ++u) {
+                const int e = lane + 64 * u;
+                if (e < kRfPatch) s_px[buf][e] = fv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < kRfKPerLane; ++u) s_k[buf][lane + 64 * u] = kv[u];
+        };
+        __syncthreads();                                // the previous record's chains are done with LDS
+        fetch(0);
+        park(0);
+        __syncthreads();
+        double tot = 0.0, acc = 0.0;
+        for (int k = 0; k < n_chunks; ++k) {
+            const int buf = k & 1;
+            if (k + 1 < n_chunks) fetch(k + 1);
+            if (mine) {
+                const int r = k % per_chan;
+                const int cy0 = (r / ncx) * kRfCh, cx0 = (r % ncx) * kRfCw;
+                const int ch = min(kRfCh, h - cy0), cw = min(kRfCw, w - cx0);
+                const float* px = &s_px[buf][oy * kRfPw + ox];
+                const double* kk = &s_k[buf][0];
                 for (int dy = 0; dy < ch; ++dy) {
-                    const float* r = plane + (size_t)(cy0 + dy) * p.img.f32_pitch + cx0;
-                    const double* k = k1 + (size_t)(cy0 + dy) * w + cx0;
                     int dx = 0;
-                    for (; dx + 8 <= cw; dx += 8) {             // loads of eight taps in flight, one chain
-                        float v[8];
-                        double kk[8];
+                    for (; dx + 4 <= cw; dx += 4) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            v[u] = r[dx + u];
-                            kk[u] = k[dx + u];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) acc = fma((double)v[u], kk[u], acc);
+                        for (int u = 0; u < 4; ++u) acc = fma((double)px[dy * kRfPw + dx + u], kk[dy * kRfCw + dx + u], acc);
                     }
-                    for (; dx < cw; ++dx) acc = fma((double)r[dx], k[dx], acc);
+                    for (; dx < cw; ++dx) acc = fma((double)px[dy * kRfPw + dx], kk[dy * kRfCw + dx], acc);
+                }
+                if (r == per_chan - 1) {                // channel done
+                    tot += acc;
+                    acc = 0.0;
                 }
             }
+            if (k + 1 < n_chunks) park(buf ^ 1);
+            __syncthreads();
         }
-        tot += acc;
+        if (mine) {
+            const float s = finish_unmasked(p.method, tot, p.st, (size_t)wy * p.st.pitch + wx, T, p.img.chans);
+            if (!p.ring || lane == 4) p.list[i].score = s;
+            if (p.maps) p.maps[T.map_off + (size_t)wy * T.map_pitch + wx] = s;
+        }
     }
-    return finish_unmasked(p.method, tot, p.st, (size_t)y * p.st.pitch + x, T, p.img.chans);
-}
-
-__global__ __launch_bounds__(256) void refine_rescore_kernel(RefineParams p) {
-    const unsigned long long n = min(*p.count, p.cap);
-    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long i = p.ring ? g / 9 : g;
-    if (i >= n) return;
-    const mtm_hit rec = p.list[i];
-    const TemplDev T = p.td[rec.templ_idx];
-    if (T.cls != p.cls) return;
-    int x = rec.x, y = rec.y;
-    bool centre = true;
-    if (p.ring) {
-        const int r = (int)(g - i * 9);
-        x += r % 3 - 1;
-        y += r / 3 - 1;
-        centre = r == 4;
-        if (x < 0 || x >= T.ow || y < 0 || y >= T.oh) return;
-    }
-    const float s = exact_score_f32(p, T, x, y);
-    if (centre) p.list[i].score = s;
-    if (p.maps) p.maps[T.map_off + (size_t)y * T.map_pitch + x] = s;
 }
 
 // Map scan of the refined route (peaks_kernel with tolerances): every pixel that COULD be a peak of the exact map - its

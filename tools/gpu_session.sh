@@ -42,6 +42,11 @@ for st in "$@"; do
       stamp "group: $(cut -c1-120 $OUT/bench_group2.json) | $(cut -c1-120 $OUT/bench_group8.json)" ;;
     probes)
       for pr in ${PROBES:-call_breakdown dense_probe coins_probe}; do timeout 300 python tools/probes/$pr.py > $OUT/$pr.txt 2>&1; stamp "$pr: $(tail -3 $OUT/$pr.txt | tr '\n' '|' | cut -c1-300)"; done ;;
+    bands_ab)       # upload-band layouts x one / two score streams, per-call metric
+      for d in 0 1; do for b in "0.25,1" "0.1,0.3,0.6,1" "0.08,0.22,0.46,0.9,1" "0.12,0.34,0.56,0.78,1"; do
+        MTM_DUAL_STREAM=$d MTM_UPLOAD_BANDS="$b" python bench.py --steps 150 --warmup 5 --skip-extras --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('dual=$d bands=$b', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['launches_per_step'], d['gpu_ms'])" | tee -a $OUT/bands_ab.txt
+      done; done ;;
     *) stamp "unknown stage $st" ;;
   esac
 done
