@@ -245,7 +245,27 @@ def pinned_empty(shape, dtype=np.uint8):
     return np.asarray(block)[:n].view(dtype).reshape(shape)       # the views keep `block` alive
 
 
-class Context:
+class _RecordMemo:
+    """Marshalled template lists, memoised (shared by Context and Group)."""
+    _rec_key = _rec = _rec_keep = None
+
+    def _records(self, templates):
+        """templ_records(templates), memoised on the identity (and shape) of the arrays: a caller that passes the same
+        template objects call after call - the usual loop over images - pays for the marshalling once.  The arrays are
+        kept referenced, so an id cannot be recycled; changed PIXELS are the library's business (it compares the bytes
+        with the copy it packed from in every mtm_set_templates)."""
+        key = [(id(t), t.shape, id(m)) for t, m in templates]
+        if key != self._rec_key:
+            self._rec, keep = templ_records(templates)
+            self._rec_keep = (keep, [t for t, _ in templates], [m for _, m in templates])
+            # Only records that point at the caller's own buffers may be reused: a template that had to be copied
+            # (np.rot90(base), base[:, ::-1], base.T ...) would otherwise be matched from the copy of the FIRST call
+            # for ever, even after the caller edited the array in place - the reference re-reads it on every call.
+            self._rec_key = key if _zero_copy(templates, keep) else None
+        return self._rec
+
+
+class Context(_RecordMemo):
     """One GPU context (single caller: guarded by a lock)."""
 
     def __init__(self, device=None):
@@ -292,20 +312,6 @@ class Context:
         check(self._lib.mtm_set_image_downscaled(self._h, ptr, a.shape[0], a.shape[1], chans, _dtype_code(a), stride,
                                                  int(downscale)), "mtm_set_image")
 
-    def _records(self, templates):
-        """templ_records(templates), memoised on the identity (and shape) of the arrays: a caller that passes the same
-        template objects call after call - the usual loop over images - pays for the marshalling once.  The arrays are
-        kept referenced, so an id cannot be recycled; changed PIXELS are the library's business (it compares the bytes
-        with the copy it packed from in every mtm_set_templates)."""
-        key = [(id(t), t.shape, id(m)) for t, m in templates]
-        if key != self._rec_key:
-            self._rec, keep = templ_records(templates)
-            self._rec_keep = (keep, [t for t, _ in templates], [m for _, m in templates])
-            # Only records that point at the caller's own buffers may be reused: a template that had to be copied
-            # (np.rot90(base), base[:, ::-1], base.T ...) would otherwise be matched from the copy of the FIRST call
-            # for ever, even after the caller edited the array in place - the reference re-reads it on every call.
-            self._rec_key = key if _zero_copy(templates, keep) else None
-        return self._rec
 
     def set_templates(self, templates, method):
         """templates: list of (array, mask_or_None) with identical dtype policy already applied."""
@@ -422,7 +428,7 @@ class Context:
         return out[:n.value], counts
 
 
-class Group:
+class Group(_RecordMemo):
     """Several GPUs in one process (mtm_group): units sharded over the devices (LPT on their MAC cost), the image
     uploaded and searched on every device concurrently by native worker threads, hit lists merged on the host in
     template order.  Same ``search`` interface and results as a single Context."""
@@ -474,7 +480,7 @@ class Group:
         return {f: getattr(t, f) for f, _ in MtmTiming._fields_}
 
     def search(self, templates, image, method, mode, score_threshold):
-        rec, keep = templ_records(templates)
+        rec = self._records(templates)
         a, ptr, stride = _pixel_rows(image)
         chans = 1 if a.ndim == 2 else a.shape[2]
         cap = 4096

@@ -101,6 +101,32 @@ def classify(got, exp, thr, tol):
     return "BENIGN %d unmatched" % len(only) if only else ""
 
 
+# FUZZ_VS_EXACT=1: float32 cases are ALSO run on a context with MTM_OPT_F32_MFMA = 0 (the float64 kernel) and the raw hit
+# records of the default route (bf16 screen + exact re-scoring) must equal its records byte for byte - the oracle's
+# float64 FFT is no judge of plateau ties (an exact-zero plateau of the FMA chain is 1e-10 noise there).
+exact_ctx = None
+vs_exact_cases = vs_exact_diffs = 0
+if os.environ.get("FUZZ_VS_EXACT"):
+    from MTM import _lib
+    exact_ctx = _lib.Context(0)
+    exact_ctx.set_option(_lib.OPT_F32_MFMA, 0)
+
+
+def vs_exact(lt, img, kw):
+    """'' or a description of the first difference between the default float32 route and the float64 kernel"""
+    image, _, _ = MTM._validate_search(lt, img, kw["N_object"], kw["searchBox"])
+    args = (lt, image, kw["method"], kw["N_object"], kw.get("score_threshold", 0.5))
+    a = MTM._raw_matches(*args).copy()
+    route = _lib.default_context().timing()["f32_route"]
+    b = MTM._raw_matches(*args, context=exact_ctx).copy()
+    if a.tobytes() == b.tobytes():
+        return ""
+    if len(a) != len(b):
+        return "route %d: %d records vs %d of the float64 kernel" % (route, len(a), len(b))
+    k = next(i for i in range(len(a)) if a[i].tobytes() != b[i].tobytes())
+    return "route %d: record %d %r vs %r" % (route, k, a[k], b[k])
+
+
 real = benign = 0
 t0 = time.time()
 for seed in range(first, first + count):
@@ -133,6 +159,15 @@ for seed in range(first, first + count):
             verdict = classify(g2, e2, None, 1e-5)
         else:
             verdict = classify(got, exp, thr, tol)
+    if exact_ctx is not None and img.dtype == np.float32 and not (verdict.startswith("REAL exception")):
+        try:
+            d = vs_exact(lt, img, kw)
+        except Exception as ex:                                # noqa: BLE001 - both routes refuse the same inputs
+            d = ""
+        vs_exact_cases += 1
+        if d:
+            vs_exact_diffs += 1
+            print("seed %d: DIFFERS FROM THE FLOAT64 KERNEL %s" % (seed, d), flush=True)
     if verdict.startswith("REAL"):
         real += 1
     elif verdict:
@@ -141,4 +176,6 @@ for seed in range(first, first + count):
         print("seed %d: %s | img %s %s, %d templates, method %d, thr %s, N_object %s, box %s" % (
             seed, verdict, img.shape, img.dtype, len(lt), method, thr, n_obj, box), flush=True)
 print("fuzz: %d cases from seed %d in %.0f s: %d REAL, %d BENIGN" % (count, first, time.time() - t0, real, benign))
-sys.exit(1 if real else 0)
+if exact_ctx is not None:
+    print("float32 default route vs float64 kernel: %d cases, %d with different records" % (vs_exact_cases, vs_exact_diffs))
+sys.exit(1 if real or vs_exact_diffs else 0)

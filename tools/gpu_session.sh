@@ -29,11 +29,11 @@ for st in "$@"; do
       for v in 1 2 0; do echo "== MTM_F32_MFMA=$v" >> $OUT/f32_probe.txt; MTM_F32_MFMA=$v timeout 300 python tools/probes/f32_probe.py >> $OUT/f32_probe.txt 2>&1; done
       stamp "$(grep float32 $OUT/f32_probe.txt | tr '\n' '|')" ;;
     fuzz_f32)
-      FUZZ_DTYPE=float32 timeout 420 python tools/fuzz_parity.py 0 ${FUZZ_N:-120} > $OUT/fuzz_f32.txt 2>&1; stamp "fuzz_f32: $(tail -2 $OUT/fuzz_f32.txt | tr '\n' ' ')" ;;
+      FUZZ_DTYPE=float32 FUZZ_VS_EXACT=1 timeout 600 python tools/fuzz_parity.py 0 ${FUZZ_N:-500} > $OUT/fuzz_f32.txt 2>&1; stamp "fuzz_f32: $(tail -2 $OUT/fuzz_f32.txt | tr '\n' ' ')" ;;
     fuzz)
       timeout 420 python tools/fuzz_parity.py 1000 ${FUZZ_N:-150} > $OUT/fuzz.txt 2>&1; stamp "fuzz: $(tail -2 $OUT/fuzz.txt | tr '\n' ' ')" ;;
     profile)
-      bash tools/profile_round.sh $TAG/profile > $OUT/profile.log 2>&1; stamp "profile done" ;;
+      bash tools/profile_round.sh ${PROFILE_TAG:-$TAG/profile} > $OUT/profile.log 2>&1; stamp "profile done" ;;
     alt_quick)
       ALT_K="not cfg and not full_size" bash tools/alt_modes.sh > $OUT/alt_modes.txt 2>&1; stamp "alt: $(grep -c passed $OUT/alt_modes.txt) modes" ;;
     group)
