@@ -21,10 +21,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["mtm_hip.hip", "mtm_mfma_plain.hip", "mtm_mfma_rm.hip", "mtm_mfma_ext.hip", "mtm_mfma_kp.hip", "mtm_bf16.hip",
+SOURCES = ["mtm_hip.hip", "mtm_mfma_plain.hip", "mtm_mfma_rm.hip", "mtm_mfma_ext.hip", "mtm_mfma_kp.hip", "mtm_mfma_rows.hip", "mtm_bf16.hip",
            "mtm_host.cpp", "mtm_group.cpp"]
 HEADERS = ["mtm_device.hip.h", "mtm_device_util.hip.h", "mtm_mfma.hip.h", "mtm_mfma_params.h", "mtm_templates.hip.h",
-           "mtm_bf16.hip.h", "mtm_bf16_params.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
+           "mtm_bf16.hip.h", "mtm_bf16_params.h", "mtm_refine.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
            os.path.join("..", "..", "include", "mtm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default"]

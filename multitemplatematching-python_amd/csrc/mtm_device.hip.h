@@ -294,15 +294,17 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
 constexpr int kStatBand4 = MTM_STAT_BAND4;    // stats_u8_kernel: output rows per work-group
 constexpr int kStatStrip = 1024;               // image columns per work-group (4 per thread)
 
-// output columns per work-group for a template width (multiple of 4: strips start dword-aligned)
-inline int stats_u8_owg(int w) { return (kStatStrip + 1 - w) & ~3; }
+// output columns per work-group for a template width (multiple of 16: strips start dword-aligned, and the 16-pixel
+// column blocks whose statistic ranges the kernel can write - `blk` - never straddle two strips)
+inline int stats_u8_owg(int w) { return (kStatStrip + 1 - w) & ~15; }
 
 __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict__ img, int pitch, int h, int w,
                                                        int oh, int ow, int owg, double inv_area, int num_type,
                                                        int want_sq, int want_t, int want_sum2, double* __restrict__ t0,
                                                        double* __restrict__ sum2, double* __restrict__ sq,
                                                        int st_pitch, double* __restrict__ rsq = nullptr,
-                                                       int yb_off = 0) {
+                                                       int yb_off = 0, double* __restrict__ blk = nullptr,
+                                                       int blk_pitch = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t E1[kStatStrip + 4], E2[kStatStrip + 4];   // exclusive prefixes
     __shared__ uint32_t wsum[2][4];
     const int x0 = blockIdx.x * owg, y0 = ((int)blockIdx.y + yb_off) * kStatBand4;   // yb_off: banded launches
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
             E2[kStatStrip] = ob + b;
         }
         __syncthreads();
+        double blk_s1[4] = {0.0, 0.0, 0.0, 0.0}, blk_sq[4] = {0.0, 0.0, 0.0, 0.0};
         if (out_on) {
             double tt[4], ws2[4], sqv[4], rs[4];
 #pragma unroll
@@ -388,6 +391,8 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
                 sqv[k] = small ? 0.0 : sqrt(diff2);
 #endif
                 rs[k] = sqv[k] > 0.0 ? 1.0 / sqv[k] : 0.0;
+                blk_s1[k] = tt[k];
+                blk_sq[k] = sqv[k];
             }
             const size_t o = (size_t)y * st_pitch + xg;
             if (want_t) {
@@ -405,6 +410,32 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
                     *reinterpret_cast<double2*>(rsq + o) = make_double2(rs[0], rs[1]);
                     *reinterpret_cast<double2*>(rsq + o + 2) = make_double2(rs[2], rs[3]);
                 }
+            }
+        }
+        if (blk != nullptr) {
+            // ranges over the 16-pixel column block this thread's quad of threads covers (the hits-only screen of the
+            // multi-row MFMA variants bounds a lane's 16 outputs with them): S1 min / max and the smallest sqrt over the
+            // block's output columns (x < ow); a block without any gets sqrt = +inf - no candidate can pass that
+            double lo = INFINITY, hi = 0.0, sm = INFINITY;
+            if (out_on) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (xg + k < ow) {
+                        lo = fmin(lo, blk_s1[k]);
+                        hi = fmax(hi, blk_s1[k]);
+                        sm = fmin(sm, blk_sq[k]);
+                    }
+            }
+#pragma unroll
+            for (int off = 1; off <= 2; off <<= 1) {
+                lo = fmin(lo, __shfl_xor(lo, off));
+                hi = fmax(hi, __shfl_xor(hi, off));
+                sm = fmin(sm, __shfl_xor(sm, off));
+            }
+            if ((t & 3) == 0 && 4 * t < owg && (xg >> 4) < blk_pitch) {
+                double* o = blk + ((size_t)y * blk_pitch + (xg >> 4)) * 4;
+                *reinterpret_cast<double2*>(o) = make_double2(lo == INFINITY ? 0.0 : lo, hi);
+                *reinterpret_cast<double2*>(o + 2) = make_double2(sm, 0.0);
             }
         }
         // slide the column sums one row down (zeros on the last row: nothing changes)

@@ -112,8 +112,9 @@ struct SizeClass {
     };
     std::vector<Slab> slabs;
     int slab_nt = 0, slab_R = 0;    // > 0: row-multiplexed raw launches (<= 16 templates); 0: plain raw launches
-    bool r2 = false;            // two-row MFMA variant (> 16 templates, w <= 64, one channel, methods 2..5): packs of
-                                // h + 1 rows per 16-template group (the last row zero)
+    int r2 = 0;                 // multi-row MFMA variant (> 16 templates, w <= 64, one channel, methods 2..5): 2 or 3 consecutive
+                                // output rows x 16 templates per wave; packs of h + r2 - 1 rows per 16-template group (the
+                                // extra rows zero); 0 = off
     long long mask_rm_off = -1; // masked class: row-multiplexed pack (1 "template" = the binary mask, R = 16) in apacks
     double mask_ones = 0.0;     // number of set mask pixels
     int n_pad = 0;              // members rounded up to a multiple of 16 (uint16 packs)
@@ -229,7 +230,7 @@ struct mtm_ctx {
     int slab_mfma = 1;                              // MTM_SLAB_MFMA: large templates as slabs on the MFMA kernel
     DevBuf slab_raw;                                // raw int32 maps of the slabs
     DevBuf tsrc, usrc_dev, tsums_dev, tgather;      // template source arena, unit views, source sums, gather scratch
-    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq;
+    DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq, stats_blk;
 
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
@@ -360,6 +361,15 @@ bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
     if (sc.masked) return c->chans == 1 && (long long)sc.w * sc.h <= 66051;
     return true;
 }
+// dynamic LDS of one ncc_mfma_kernel work-group: image tile (aliased by the epilogue buffers), per-template constants,
+// work-group scratch words, prefetched statistics
+size_t mfma_lds_bytes(int tile_rows, int nb, size_t stat_bytes) {
+    const size_t lds_pitch = (size_t)(16 + 4 * nb + 1) * 16;
+    const size_t lds_main = (std::max<size_t>((size_t)tile_rows * lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
+    const size_t st_off = (lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15;
+    return st_off + stat_bytes;
+}
+
 long long mfma_group_bytes(int h, int w, int chans) { return (long long)chans * h * ((w + 63) / 64) * 1024; }
 // packed K: MFMA steps (1 KiB of A operand each) of `rows` stream rows of nseg 16-tap segments
 inline int kp_blocks(int rows, int nseg) { return (rows * nseg + 3) / 4; }
@@ -528,7 +538,7 @@ void pack_class_mfma16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, doub
 
 void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
     const int h = sc.h, w = sc.w, nb = (w + 63) / 64, chans = c->chans, nseg = sc.kp_nseg;
-    // two-row variant: groups of h + 1 rows (one channel), the extra row stays zero; packed K: kp_blocks steps per channel
+    // multi-row variant: groups of h + r2 - 1 rows (one channel), the extra rows stay zero; packed K: kp_blocks steps per channel
     const long long gb = (sc.r2 || nseg) ? sc.group_bytes : mfma_group_bytes(h, w, chans);
     std::memset(out, 0, (size_t)gb * (sc.r2 ? ((int)sc.members.size() + 15) / 16 : mfma_groups_alloc((int)sc.members.size())));
     for (size_t li = 0; li < sc.members.size(); ++li) {
@@ -546,7 +556,7 @@ void pack_class_mfma(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
                         g[((((size_t)ch * kp_blocks(h, nseg) + sidx / 4) * 64) + (16 * (sidx % 4) + i)) * 16 + byte] = v ^ 0x80;
                         continue;
                     }
-                    g[((((size_t)ch * (sc.r2 ? h + 1 : h) + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                    g[((((size_t)ch * (sc.r2 ? h + sc.r2 - 1 : h) + dy) * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
                 }
     }
 }
@@ -640,7 +650,7 @@ int pack_class_on_device(mtm_ctx* c, const SizeClass& sc) {
     } else if (sc.r2) {
         p.mode = 0;
         p.chans = 1;
-        p.h = sc.h + 1;                      // rows per group in the pack; row h is zero (hv = valid template rows)
+        p.h = sc.h + sc.r2 - 1;              // rows per group in the pack; rows >= h are zero (hv = valid template rows)
         p.group_bytes = sc.group_bytes;
         p.n_chunks = p.group_bytes * ((p.n + 15) / 16) / 16;
     } else {
@@ -717,8 +727,15 @@ int place_templates(mtm_ctx* c) {
                 sc.slab_R = 16 / nt;
             }
         }
-        sc.r2 = c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
-                sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats;
+        sc.r2 = (c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
+                 sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats) ? 2 : 0;
+        // three rows per wave where they fit: one LDS tile for all h + 2 steps, and two work-groups per CU (<= 80 KB each,
+        // the fused extremum's keys included).  48 MFMAs then share the operand shifts of a step instead of
+        // 32 (tools/ubench/step3: +5 % on the K step alone).  MTM_MFMA_R2=2 keeps two rows.
+        if (sc.r2 && c->mfma_r2 != 2 && sc.h + 2 <= kMfChunkR2) {
+            const size_t lds3 = mfma_lds_bytes(sc.h + 2 + (kMfRows - 1) * 3, (sc.w + 63) / 64, (size_t)kMfRows * 2 * 1024 + 1024);
+            if (lds3 <= 80 * 1024) sc.r2 = 3;
+        }
         // packed K: uint8 classes (one channel, masked or not; RGB) on the plain or row-multiplexed tiling whose width
         // leaves part of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
         // this one whole MFMA steps).
@@ -857,7 +874,7 @@ int place_templates(mtm_ctx* c) {
             continue;
         }
         if (sc.r2) {
-            sc.group_bytes = mfma_group_bytes(sc.h + 1, sc.w, 1);        // h + 1 rows, the last one zero
+            sc.group_bytes = mfma_group_bytes(sc.h + sc.r2 - 1, sc.w, 1);        // h + r2 - 1 rows, the extra ones zero
             sc.apack_off = (long long)a_off;
             a_off += (size_t)sc.group_bytes * (((int)sc.members.size() + 15) / 16);
             continue;
@@ -1055,11 +1072,18 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0 = 0, 
             MTMC(c->stats_rsq.ensure(sizeof(double) * plane));
             rsq = c->stats_rsq.as<double>();
         }
+        double* blk = nullptr;
+        if (sc.r2 > 0 && normed) {             // multi-row MFMA variants: statistic ranges per 16-pixel column block
+            st.blk_pitch = (st.pitch + 15) / 16;
+            MTMC(c->stats_blk.ensure(sizeof(double) * 4 * (size_t)st.blk_pitch * oh));
+            blk = c->stats_blk.as<double>();
+            st.blk = blk;
+        }
         if (b1 > sb0) {
             const dim3 gs((ow + owg - 1) / owg, b1 - sb0);
             hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, img.u8,
                                img.u8_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, want_sum2, tp[0],
-                               sum2, sq, st.pitch, rsq, sb0);
+                               sum2, sq, st.pitch, rsq, sb0, blk, st.blk_pitch);
         }
     } else if (u8 && c->chans == 3 && w <= 768 && 3.0 * w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
         // RGB: the fused kernel with one scan per channel + one for the squares (sum2 always written:
@@ -1335,8 +1359,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         // request (mtm_score_map) computes its group and stores only that template
         const int n_all = (int)sc.members.size();
         const bool rm = sc.rm_R > 0;
-        const bool r2 = sc.r2;
-        const int mb = (n_all > 16 || rm) ? 2 : 1;
+        const bool r2 = sc.r2 > 0;
+        const int mb = r2 ? sc.r2 : (n_all > 16 || rm) ? 2 : 1;
         const int tgsz = r2 ? 16 : 16 * mb;          // templates per work item
         MfmaParams p{};
         p.img = c->slot[c->cur].u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
@@ -1352,7 +1376,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.nseg = (ow + kMfSeg - 1) / kMfSeg;
         p.nyb = (oh + kMfRows - 1) / kMfRows;
         p.ntg = (n_all + tgsz - 1) / tgsz;
-        if (r2) p.nyb = (oh + 2 * kMfRows - 1) / (2 * kMfRows);
+        if (r2) p.nyb = (oh + mb * kMfRows - 1) / (mb * kMfRows);
         p.method = c->method;
         p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
         p.cpr = p.lds_pitch / 16;
@@ -1380,7 +1404,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             tg0 = only_li / tgsz;
             p.ntg = 1;
         }
-        int tile_rows = r2 ? std::min(h + 1, kMfChunkR2) + (kMfRows - 1) * 2 : std::min(h, kMfChunkH) + kMfRows - 1;
+        int tile_rows = r2 ? std::min(h + mb - 1, kMfChunkR2) + (kMfRows - 1) * mb : std::min(h, kMfChunkH) + kMfRows - 1;
         if (rm) {
             p.rm_R = sc.rm_R;
             p.rm_nt = sc.rm_nt;
@@ -1403,7 +1427,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
         // statistics prefetch region: (channels + 2) planes per wave (RM loads its statistics directly)
-        size_t lds = (size_t)p.st_off + (rm ? 0 : r2 ? (size_t)kMfRows * 2 * 4 * 1024
+        size_t lds = (size_t)p.st_off + (rm ? 0 : r2 ? (size_t)kMfRows * ((mb + 1) / 2) * 1024
                                                      : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
         const bool ext = c->ext_now && only_li < 0;      // find_matches_impl checked the class
         if (ext) {
@@ -1889,7 +1913,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
     for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
-                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->sq_planes, &c->comm_send,
+                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->stats_blk, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})
         b->release();
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -2705,7 +2729,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         c->band_ev.push_back(e);
     }
     const int h = sc.h, oh = a.rows - h + 1;
-    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? 2 * kMfRows : kMfRows);   // output rows per score-kernel row block
+    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
     int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
     bool used2 = false;

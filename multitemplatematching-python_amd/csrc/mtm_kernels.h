@@ -37,6 +37,11 @@ struct StatPlanes {
     const double* sum2;           // sum over channels of window sum of squares
     const double* sq;             // sqrt(diff2), or 0 where the window is flat (normed only)
     int pitch;
+    // ranges of the statistics over every 16-pixel column block of an output row (stats_u8_kernel; the multi-row MFMA
+    // variants' hits-only screen): [S1 min, S1 max, sqrt min, -] per block, blk_pitch blocks per row; sqrt min = +inf
+    // for a block right of the last output column
+    int blk_pitch;
+    const double* blk;
 };
 
 struct ImageDev {

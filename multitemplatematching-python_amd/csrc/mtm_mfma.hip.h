@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // packed K is a compile-time variant (its own instantiations): two K loops in one kernel - a run-time choice -
     // push the register allocator of the 256-VGPR kernel into spilling accumulators
     static_assert(!KP || (!R2 && METHOD >= 0 && (METHOD != kMfRaw || !RM)), "packed K");
-    static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
+    static_assert(!R2 || ((MB == 2 || MB == 3) && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two- / three-row variant");
+    static_assert(MB <= 2 || R2, "three MFMA groups: the three-row variant only");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     // ---- scheduling.  Persistent mode: the grid is the number of co-resident work-groups and
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
     const int seg = rest % p.nseg, yb = rest / p.nseg;
-    const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : (R2 ? 2 * kMfRows : kMfRows));
+    const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : (R2 ? MB * kMfRows : kMfRows));
     // Lane coordinates of this work item, derived from an opaque copy of the thread index: whatever the prologue
     // computes from them is then computed HERE, per item, instead of once ahead of the item loop - where it stayed
     // live across the K loop (which owns every register) and was spilled to scratch memory.
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     asm volatile("" : "+v"(tid_i));
     const int wave = __builtin_amdgcn_readfirstlane(tid_i >> 6), lane = tid_i & 63;
     const int j = lane & 15, q = lane >> 4;
-    const int wave_rows = RM ? 2 * p.rm_R : (R2 ? 2 : 1);   // output rows per wave = tile-row stride between waves
+    const int wave_rows = RM ? 2 * p.rm_R : (R2 ? MB : 1);   // output rows per wave = tile-row stride between waves
     constexpr int kTG = R2 ? 16 : 16 * MB;              // templates per work item
 
     v4i acc[MB][16];
@@ -345,23 +346,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     constexpr bool kNormed = !MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                                          METHOD == MTM_TM_CCOEFF_NORMED);
     constexpr bool kMaskedNormed = MASKED && (METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED);
-    if constexpr (R2) {
-        // two rows per wave, S1 and sqrt only (methods 2..5 need no sum2): [row][S1, sqrt][half][lane][16 B]
+    if constexpr (R2 && kNormed) {
+        // MB rows per wave.  Only the hits-only screen's first level is on every item's path, and all it needs of the
+        // statistics are their ranges over each 16-pixel column block (StatPlanes::blk, written by stats_u8_kernel:
+        // [S1 min, S1 max, sqrt min, -] per block): 512 bytes per wave and row instead of 4 KiB - which is what lets
+        // three rows per wave fit two work-groups on a CU.  One LDS-DMA instruction fetches two rows (lanes 0..31 /
+        // 32..63: 16 blocks x 32 bytes each).  The per-pixel statistics of the rare paths behind the screen come
+        // straight from memory.
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
-        const int xc = min(x0 + 4 * lane, st.pitch - 4);
-        uint8_t* sbase = smem + p.st_off + wave * (2 * 4 * 1024);
+        uint8_t* sbase = smem + p.st_off + wave * (((MB + 1) / 2) * 1024);
+        const int bj = min((x0 >> 4) + ((lane & 31) >> 1), st.blk_pitch - 1);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const size_t sidx = (size_t)min(y0 + 2 * wave + r, p.oh - 1) * st.pitch + xc;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(st.t[0] + sidx + 2 * hh), (lptr_t)(sbase + (4 * r + hh) * 1024), 16, 0, 0);
-                if (kNormed)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(st.sq + sidx + 2 * hh), (lptr_t)(sbase + (4 * r + 2 + hh) * 1024), 16, 0, 0);
-            }
+        for (int r0 = 0; r0 < MB; r0 += 2) {
+            const int yr = min(y0 + MB * wave + min(r0 + (lane >> 5), MB - 1), p.oh - 1);
+            const double* src = st.blk + ((size_t)yr * st.blk_pitch + bj) * 4 + 2 * (lane & 1);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + (r0 / 2) * 1024), 16, 0, 0);
         }
-    } else if constexpr (C1 && METHOD != kMfRaw && METHOD != kMfU16 && !RM) {
+    } else if constexpr (C1 && METHOD != kMfRaw && METHOD != kMfU16 && !RM && !R2) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int yc = min(y0 + wave, p.oh - 1), xc = min(x0 + 4 * lane, st.pitch - 4);
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     for (int c = 0; c < p.chans; ++c) {
         const uint8_t* plane = p.img + c * p.plane;
-        const int krows = RM ? p.rm_steps : (R2 ? p.h + 1 : p.h);        // image rows a wave walks (K steps / nb)
+        const int krows = RM ? p.rm_steps : (R2 ? p.h + MB - 1 : p.h);        // image rows a wave walks (K steps / nb)
         constexpr int kChunk = R2 ? kMfChunkR2 : kMfChunkH;
         v4i r2_prev = v4i{0, 0, 0, 0};      // R2: the A operand of the previous step (the int8 zero before template row 0)
         for (int cy0 = 0; cy0 < krows; cy0 += kChunk) {
@@ -421,7 +423,47 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
-            if constexpr (R2) {
+            if constexpr (R2 && MB == 3) {
+                // ---- K loop of the three-row variant: MFMA group g is output row y + g, whose template row at image row
+                // r is r - y - g - the operand group 0 used g steps earlier.  A operands rotate through four register
+                // sets (this step's, the two before it, the one being loaded), B operands alternate between two: the body
+                // is unrolled four times.  One LDS tile holds all h + 2 steps (the launcher only picks this variant for
+                // h + 2 <= kMfChunkR2), so no operand has to be carried from one chunk to the next.
+                const uint8_t* aptr = apack_g + (size_t)cy0 * 1024;
+                const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
+                int loff = 0;
+                v4i qx, qy, qx2, qy2, a0, a1, a2 = v4i{0, 0, 0, 0}, a3 = v4i{0, 0, 0, 0};
+                if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+#define MTM_R3_LOAD(QA, QB, A)                                              \
+                QA = *reinterpret_cast<const v4i*>(lbase + loff);           \
+                QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);      \
+                A = *reinterpret_cast<const v4i*>(aptr);
+#define MTM_R3_STEP(QA, QB, ACUR, AP1, AP2, QA2, QB2, ANEXT)                \
+                {                                                           \
+                    aptr += 1024;                                           \
+                    loff += p.lds_pitch;                                    \
+                    MTM_R3_LOAD(QA2, QB2, ANEXT)                            \
+                    __builtin_amdgcn_sched_barrier(0);                      \
+                    const v4i ar_[3] = {ACUR, AP1, AP2};                    \
+                    mfma_step<3>(acc, QA, QB, ar_);                         \
+                    __builtin_amdgcn_sched_barrier(0);                      \
+                }
+                MTM_R3_LOAD(qx, qy, a0)           // step 0; a3 / a2 = the (zero) operands of the two steps before it
+                int ks = 0;
+                for (; ks + 4 <= ch; ks += 4) {
+                    MTM_R3_STEP(qx, qy, a0, a3, a2, qx2, qy2, a1)
+                    MTM_R3_STEP(qx2, qy2, a1, a0, a3, qx, qy, a2)
+                    MTM_R3_STEP(qx, qy, a2, a1, a0, qx2, qy2, a3)
+                    MTM_R3_STEP(qx2, qy2, a3, a2, a1, qx, qy, a0)
+                }
+                if (ks < ch) { MTM_R3_STEP(qx, qy, a0, a3, a2, qx2, qy2, a1) }
+                if (ks + 1 < ch) { MTM_R3_STEP(qx2, qy2, a1, a0, a3, qx, qy, a2) }
+                if (ks + 2 < ch) { MTM_R3_STEP(qx, qy, a2, a1, a0, qx2, qy2, a3) }
+#undef MTM_R3_LOAD
+#undef MTM_R3_STEP
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                __builtin_amdgcn_s_setprio(0);
+            } else if constexpr (R2) {
                 // ---- K loop of the two-row variant (nb == 1: one step per image row).  B operands alternate between
                 // two register sets, A operands rotate through three (this step's, the previous step's - the second
                 // row's operand - and the one being loaded), so the body is unrolled six times; every request runs
@@ -614,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     asm volatile("" : "+v"(tid_e));
     const int wave = tid_e >> 6, lane = tid_e & 63;
     const int j = lane & 15, q = lane >> 4;
-    const int y = y0 + (R2 ? 2 : 1) * wave;             // R2: the wave's first row; MFMA group mb is row y + mb
+    const int y = y0 + (R2 ? MB : 1) * wave;             // R2: the wave's first row; MFMA group mb is row y + mb
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
     if (p.dbg & 2) {            // probe: no epilogue (keep the accumulators observable)
         int sum = 0;
@@ -1047,7 +1089,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // such calls skip the screen instead of tracking the minima as well)
             if (p.hits_only && (EXT || p.cand_thr_lo >= 0.0)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const uint8_t* sw0 = smem + p.st_off + wave * (R2 ? 2 * 4 * 1024 : mf_stat_bytes_per_wave(1));
+                const uint8_t* sw0 = smem + p.st_off + wave * (R2 ? MB * 4 * 1024 : mf_stat_bytes_per_wave(1));
                 bool pass1 = false;
                 if (p.screen_l1) {
                     // v_min_f64 / v_max_f64 as they are (fmin / fmax on loaded values cost a canonicalising v_max each)
@@ -1061,13 +1103,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const int hi2 = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
                         return __hiloint2double(hi2, lo);
                     };
-                    double s1lo[R2 ? 2 : 1], s1hi[R2 ? 2 : 1], sqlo[R2 ? 2 : 1];
+                    double s1lo[R2 ? MB : 1], s1hi[R2 ? MB : 1], sqlo[R2 ? MB : 1];
+                    if constexpr (R2) {
+                        // the ranges of this lane's column block, one row at a time, as stats_u8_kernel wrote them
 #pragma unroll
-                    for (int r = 0; r < (R2 ? 2 : 1); ++r) {
+                        for (int r = 0; r < MB; ++r) {
+                            const uint8_t* sb = smem + p.st_off + wave * (((MB + 1) / 2) * 1024) + r * 512 + j * 32;
+                            const double2 lohi = *reinterpret_cast<const double2*>(sb);
+                            s1lo[r] = lohi.x;
+                            s1hi[r] = lohi.y;
+                            sqlo[r] = *reinterpret_cast<const double*>(sb + 16);
+                        }
+                    } else {
+#pragma unroll
+                    for (int r = 0; r < 1; ++r) {
                         // this lane's share of its column block: pixels 16 j + 4 q .. + 3; the block's other three lane
                         // groups (lanes j + 16, + 32, + 48 around) hold the rest
-                        const uint8_t* sw = sw0 + r * 4 * 1024 + (4 * j + q) * 16;
-                        constexpr int kSqPlane = R2 ? 2 : 4;
+                        const uint8_t* sw = sw0 + (4 * j + q) * 16;
+                        constexpr int kSqPlane = 4;
                         const double2 sa = *reinterpret_cast<const double2*>(sw + 0 * 1024);
                         const double2 sb = *reinterpret_cast<const double2*>(sw + 1 * 1024);
                         const double2 qa = *reinterpret_cast<const double2*>(sw + kSqPlane * 1024);
@@ -1078,12 +1131,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     }
 #pragma unroll
                     for (int off = 16; off <= 32; off <<= 1) {
-#pragma unroll
-                        for (int r = 0; r < (R2 ? 2 : 1); ++r) {
-                            s1lo[r] = min64(s1lo[r], xlane(s1lo[r], off));
-                            s1hi[r] = max64(s1hi[r], xlane(s1hi[r], off));
-                            sqlo[r] = min64(sqlo[r], xlane(sqlo[r], off));
-                        }
+                        s1lo[0] = min64(s1lo[0], xlane(s1lo[0], off));
+                        s1hi[0] = max64(s1hi[0], xlane(s1hi[0], off));
+                        sqlo[0] = min64(sqlo[0], xlane(sqlo[0], off));
+                    }
                     }
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
@@ -1120,8 +1171,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 // stay in registers next to the 64 * MB accumulators
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) {
-                    const uint8_t* sw = sw0 + (R2 ? mb * 4 * 1024 : 0);       // R2: group mb = the wave's row mb
-                    constexpr int kSqPlane = R2 ? 2 : 4;                     // 1 KiB planes: [S1 x 2][(S2 x 2)][sqrt x 2]
+                    const uint8_t* sw = sw0;                                 // (multi-row variants: group mb = the wave's row mb,
+                    constexpr int kSqPlane = 4;                              //  per-pixel statistics straight from memory)
+                    const size_t grow = (size_t)min(y + (R2 ? mb : 0), p.oh - 1) * st.pitch;
                     double kk[4], mm[4], umax[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1136,10 +1188,19 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int L = 4 * j + g;
-                        const double2 sa = *reinterpret_cast<const double2*>(sw + 0 * 1024 + L * 16);
-                        const double2 sb = *reinterpret_cast<const double2*>(sw + 1 * 1024 + L * 16);
-                        const double2 qa = *reinterpret_cast<const double2*>(sw + kSqPlane * 1024 + L * 16);
-                        const double2 qb = *reinterpret_cast<const double2*>(sw + (kSqPlane + 1) * 1024 + L * 16);
+                        double2 sa, sb, qa, qb;
+                        if constexpr (R2) {
+                            const size_t gi = grow + min(x0 + 4 * L, st.pitch - 4);
+                            sa = *reinterpret_cast<const double2*>(st.t[0] + gi);
+                            sb = *reinterpret_cast<const double2*>(st.t[0] + gi + 2);
+                            qa = *reinterpret_cast<const double2*>(st.sq + gi);
+                            qb = *reinterpret_cast<const double2*>(st.sq + gi + 2);
+                        } else {
+                            sa = *reinterpret_cast<const double2*>(sw + 0 * 1024 + L * 16);
+                            sb = *reinterpret_cast<const double2*>(sw + 1 * 1024 + L * 16);
+                            qa = *reinterpret_cast<const double2*>(sw + kSqPlane * 1024 + L * 16);
+                            qb = *reinterpret_cast<const double2*>(sw + (kSqPlane + 1) * 1024 + L * 16);
+                        }
                         const double s1g[4] = {sa.x, sa.y, sb.x, sb.y}, sqg[4] = {qa.x, qa.y, qb.x, qb.y};
 #pragma unroll
                         for (int c4 = 0; c4 < 4; ++c4) {
@@ -1178,20 +1239,23 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         double ps1[4][CH], pp1[4], psum2[4], psq[4], prsq[4];
         // statistics of the lane's four pixels: from the LDS prefetch into registers (R2: per row, inside the loop)
         auto load_stats = [&](int r2_row) {
-            const uint8_t* sl = smem + p.st_off + (R2 ? wave * (2 * 4 * 1024) + r2_row * (4 * 1024)
-                                                      : wave * mf_stat_bytes_per_wave(CH)) + lane * 16;
-            constexpr int kSq = R2 ? 2 : 2 * CH + 2;
+            const uint8_t* sl = smem + p.st_off + wave * mf_stat_bytes_per_wave(CH) + lane * 16;
+            constexpr int kSq = 2 * CH + 2;
+            // multi-row variants: this path is the rare one behind the screen - its statistics come from memory
+            const size_t gi = (size_t)min(y + r2_row, p.oh - 1) * st.pitch + min(xq, st.pitch - 4);
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
                 for (int cc = 0; cc < CH; ++cc) {
-                    const double2 a = *reinterpret_cast<const double2*>(sl + (2 * cc + hh) * 1024);
+                    const double2 a = R2 ? *reinterpret_cast<const double2*>(st.t[cc] + gi + 2 * hh)
+                                         : *reinterpret_cast<const double2*>(sl + (2 * cc + hh) * 1024);
                     ps1[2 * hh][cc] = a.x;
                     ps1[2 * hh + 1][cc] = a.y;
                 }
                 double2 b = make_double2(0.0, 0.0), d = make_double2(0.0, 0.0);
                 if (kNeedSum2) b = *reinterpret_cast<const double2*>(sl + (2 * CH + hh) * 1024);
-                if (kNormed) d = *reinterpret_cast<const double2*>(sl + (kSq + hh) * 1024);
+                if (kNormed) d = R2 ? *reinterpret_cast<const double2*>(st.sq + gi + 2 * hh)
+                                    : *reinterpret_cast<const double2*>(sl + (kSq + hh) * 1024);
                 psum2[2 * hh] = b.x;
                 psum2[2 * hh + 1] = b.y;
                 psq[2 * hh] = d.x;

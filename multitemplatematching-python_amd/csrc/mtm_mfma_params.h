@@ -141,15 +141,16 @@ struct MfmaSel {
     bool rm = false;        // row-multiplexed tiling (<= 16 templates)
     int ch = 1;             // channels handled by the lean epilogue: 1 or 3
     bool ext = false;       // fused global extremum (N_object == 1)
-    bool r2 = false;        // two-row tiling
+    bool r2 = false;        // multi-row tiling: mb (2 or 3) consecutive output rows x 16 templates per wave
     bool kp = false;        // packed K
 };
 // The instantiation for `s`, or nullptr if that combination is not built.
 MfmaFn mfma_kernel(const MfmaSel& s);
-// per translation unit (mtm_mfma_plain / _rm / _ext / _kp .hip); mfma_kernel() dispatches between them
+// per translation unit (mtm_mfma_plain / _rm / _ext / _kp / _rows .hip); mfma_kernel() dispatches between them
 MfmaFn mfma_kernel_plain(const MfmaSel& s);
 MfmaFn mfma_kernel_rm(const MfmaSel& s);
 MfmaFn mfma_kernel_ext(const MfmaSel& s);
 MfmaFn mfma_kernel_kp(const MfmaSel& s);
+MfmaFn mfma_kernel_rows(const MfmaSel& s);
 
 }  // namespace mtm

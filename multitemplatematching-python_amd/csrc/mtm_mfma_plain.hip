@@ -1,5 +1,5 @@
 // ncc_mfma_kernel instantiations, unit 1 of 4: plain tiling (one channel, compile-time method, masked or not; the generic
-// run-time-method epilogue), the two-row tiling, raw mode (slabs, sum I^2 M, the first uint16 byte-plane pass) and the
+// run-time-method epilogue), raw mode (slabs, sum I^2 M, the first uint16 byte-plane pass) and the
 // uint16 finishing pass.  Built as its own translation unit so that the ~300 instantiations compile in parallel.
 #include "mtm_mfma.hip.h"
 
@@ -24,14 +24,7 @@ MfmaFn mfma_kernel_plain(const MfmaSel& s) {
         return s.mb == 2 ? kU16Fns[s.kp ? 1 : 0][s.ext ? 1 : 0][xd] : nullptr;
     }
     if (s.method < -1 || s.method > 5) return nullptr;
-    if (s.r2) {                                                 // two-row tiling (methods 2..5): [extremum][exact][method - 2]
-#define MTM_MF_R2(X, E) {ncc_mfma_kernel<2, 2, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 3, X, false, false, 1, E, true>,   \
-                        ncc_mfma_kernel<2, 4, X, false, false, 1, E, true>, ncc_mfma_kernel<2, 5, X, false, false, 1, E, true>}
-        static const MfmaFn kMfmaR2Fns[2][2][4] = {{MTM_MF_R2(false, false), MTM_MF_R2(true, false)},
-                                                   {MTM_MF_R2(false, true), MTM_MF_R2(true, true)}};
-#undef MTM_MF_R2
-        return (s.method >= 2 && s.mb == 2) ? kMfmaR2Fns[s.ext ? 1 : 0][xd][s.method - 2] : nullptr;
-    }
+    if (s.r2) return mfma_kernel_rows(s);
     // [masked][exact][MB - 1][0: generic, 1 + method]; masked classes only reach here with methods 0..3 and one channel
 #define MTM_MF_ROW(MB, X, M) {ncc_mfma_kernel<MB, -1, X, false>, ncc_mfma_kernel<MB, 0, X, M>, ncc_mfma_kernel<MB, 1, X, M>, \
                              ncc_mfma_kernel<MB, 2, X, M>, ncc_mfma_kernel<MB, 3, X, M>, ncc_mfma_kernel<MB, 4, X, false>,  \

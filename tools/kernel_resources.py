@@ -47,6 +47,50 @@ def kernels(so_path):
     return out
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def loop_scratch_ops(so_path, name_filter="ncc_mfma_kernel"):
+    """{kernel: scratch instructions inside the innermost loops that contain MFMAs} - the K loops.  A loop is a backward
+    branch and everything between its target and itself.  A spill there means the register allocation tipped over (accumulators
+    moved around the inline-asm steps)."""
+    out = {}
+    for co in code_objects(so_path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        name, ins = None, []          # (address, opcode, first operand)
+
+        def flush():
+            if not (name and name_filter in name):
+                return
+            loops = []
+            for addr, op, arg in ins:
+                if not op.startswith("s_cbranch") and op != "s_branch":
+                    continue
+                off = int(arg)
+                if off < 32768:
+                    continue                        # forward
+                target = addr + 4 + (off - 65536) * 4
+                if any(o_.startswith("v_mfma") for a_, o_, _ in ins if target <= a_ <= addr):
+                    loops.append((target, addr))
+            # innermost MFMA loops only (the item / channel / chunk loops around them contain the whole kernel)
+            inner = [l for l in loops if not any(m != l and l[0] <= m[0] and m[1] <= l[1] for m in loops)]
+            out[name] = sum(1 for a_, o_, _ in ins if o_.startswith("scratch_") and any(lo <= a_ <= hi for lo, hi in inner))
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                flush()
+                name, ins = m.group(1), []
+                continue
+            m = re.match(r"\s+(\S+)\s*([^/]*)//\s*([0-9A-Fa-f]+):", line)
+            if m and name:
+                ins.append((int(m.group(3), 16), m.group(1), m.group(2).split(",")[0].strip()))
+        flush()
+    return out
+
+
 if __name__ == "__main__":
     so = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else os.path.join(ROOT, "multitemplatematching-python_amd", "MTM", "libmtm_hip.so")
     flt = sys.argv[-1] if len(sys.argv) > 1 and not os.path.exists(sys.argv[-1]) else ""
