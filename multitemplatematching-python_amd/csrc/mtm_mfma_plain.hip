@@ -24,7 +24,7 @@ MfmaFn mfma_kernel_plain(const MfmaSel& s) {
         return s.mb == 2 ? kU16Fns[s.kp ? 1 : 0][s.ext ? 1 : 0][xd] : nullptr;
     }
     if (s.method < -1 || s.method > 5) return nullptr;
-    if (s.r2) return mfma_kernel_rows(s);
+    if (s.r2) return nullptr;                                   // (mtm_mfma_rows.hip)
     // [masked][exact][MB - 1][0: generic, 1 + method]; masked classes only reach here with methods 0..3 and one channel
 #define MTM_MF_ROW(MB, X, M) {ncc_mfma_kernel<MB, -1, X, false>, ncc_mfma_kernel<MB, 0, X, M>, ncc_mfma_kernel<MB, 1, X, M>, \
                              ncc_mfma_kernel<MB, 2, X, M>, ncc_mfma_kernel<MB, 3, X, M>, ncc_mfma_kernel<MB, 4, X, false>,  \
@@ -41,7 +41,7 @@ MfmaFn mfma_kernel(const MfmaSel& s) {
     if (s.method == kMfRaw && s.rm) return mfma_kernel_rm(s);
     if (s.method == kMfRaw || s.method == kMfU16) return mfma_kernel_plain(s);
     if (s.kp) return s.rm ? mfma_kernel_rm(s) : mfma_kernel_kp(s);
-    if (s.r2) return mfma_kernel_plain(s);
+    if (s.r2) return mfma_kernel_rows(s);
     if (s.rm) return mfma_kernel_rm(s);
     if (s.ext || s.ch == 3) return mfma_kernel_ext(s);
     return mfma_kernel_plain(s);
