@@ -205,7 +205,7 @@ struct mtm_ctx {
     bool refine_now = false;                // bf16 classes of this call are refined
     bool refine_scan_now = false;           // ... by map scan + ring re-scoring (maps in memory) instead of kernel candidates
     bool f32_exact_now = false;             // bf16 classes run the float64 kernel in this call (refinement lists overflowed)
-    int mfma_r2 = 1;                        // MTM_MFMA_R2: two-row variant of the MFMA kernel where it applies
+    int mfma_r2 = 1;                        // MTM_MFMA_R2: 1 = two-row variant of the MFMA kernel where it applies, 3 = three rows, 0 = off
     int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
                                             // streams (their tails overlap; per-launch durations then overlap too)
     int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
@@ -729,10 +729,13 @@ int place_templates(mtm_ctx* c) {
         }
         sc.r2 = (c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
                  sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats) ? 2 : 0;
-        // three rows per wave where they fit: one LDS tile for all h + 2 steps, and two work-groups per CU (<= 80 KB each,
-        // the fused extremum's keys included).  48 MFMAs then share the operand shifts of a step instead of
-        // 32 (tools/ubench/step3: +5 % on the K step alone).  MTM_MFMA_R2=2 keeps two rows.
-        if (sc.r2 && c->mfma_r2 != 2 && sc.h + 2 <= kMfChunkR2) {
+        // MTM_MFMA_R2=3: three rows per wave where they fit - one LDS tile for all h + 2 steps, and two work-groups per CU
+        // (<= 80 KB each, the fused extremum's keys included).  48 MFMAs then share the operand shifts of a step instead of
+        // 32: +5 % on the K step in isolation (tools/ubench/step3), 3 % fewer cycles in the kernel - and 0.5 % less time,
+        // because the chip is at its power budget on random operands and answers with a 2.4 % lower clock
+        // (tools/ubench/power: the pure MFMA stream itself runs at 2.0 instead of 2.4 GHz on such data); its larger work
+        // items also quantise worse on the short launches of a banded upload.  Not the default.
+        if (sc.r2 && c->mfma_r2 == 3 && sc.h + 2 <= kMfChunkR2) {
             const size_t lds3 = mfma_lds_bytes(sc.h + 2 + (kMfRows - 1) * 3, (sc.w + 63) / 64, (size_t)kMfRows * 2 * 1024 + 1024);
             if (lds3 <= 80 * 1024) sc.r2 = 3;
         }
