@@ -48,7 +48,7 @@ for st in "$@"; do
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('dual=$d bands=$b', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['launches_per_step'], d['gpu_ms'])" | tee -a $OUT/bands_ab.txt
       done; done ;;
     rows_ab)        # three-row (default) against two-row MFMA variant, banded and single-launch, alternating
-      for rep in 1 2; do for v in 1 2; do for b in "0.25,1" "1"; do
+      for rep in 1 2; do for v in 1 3; do for b in "0.25,1" "1"; do
         MTM_MFMA_R2=$v MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps 200 2>>$OUT/bench.err | clean | tail -1 |
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('R2=$v bands=$b', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/rows_ab.txt
       done; done; done ;;
