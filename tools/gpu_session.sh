@@ -52,6 +52,8 @@ for st in "$@"; do
         MTM_MFMA_R2=$v MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps 200 2>>$OUT/bench.err | clean | tail -1 |
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('R2=$v bands=$b', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/rows_ab.txt
       done; done; done ;;
+    workloads)      # rocprofv3 summaries + PMC for the secondary workloads
+      bash tools/profile_workloads.sh ${PROFILE_TAG:-$TAG} ${WORKLOADS:-} > $OUT/workloads.log 2>&1; stamp "workloads done: $(grep -c '^==' $OUT/workloads.log)" ;;
     *) stamp "unknown stage $st" ;;
   esac
 done

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""One named workload, a few calls - the command rocprofv3 wraps in tools/profile_workloads.sh (GPU box).
+    workload.py <name> [calls]
+names: cfg2 cfg5 (BASELINE configs), u16_4k32 / f32_4k32 (4K x 32 templates 64x64 as uint16 / float32 pixels),
+f64_1080p8 (float32 pixels on the float64 kernel, MTM_OPT_F32_MFMA = 0), slab_414 (2048^2 x one 414x400 template: the
+reference's published benchmark shape, slabs on the MFMA kernel), dense_4k32 (photograph-like image: map mode + peak pass)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
+import numpy as np
+import synth
+from MTM import _lib
+
+name = sys.argv[1]
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+ctx = _lib.Context(0)
+method, thr = 5, 0.5
+if name in ("cfg2", "cfg5"):
+    img, units, _ = synth.make_config(name)
+    method, thr = (3, 0.9) if name == "cfg5" else (5, 0.5)
+    tl = [(u[1], u[2] if len(u) >= 3 else None) for u in units]
+elif name in ("u16_4k32", "f32_4k32"):
+    img, units, _ = synth.make_config("cfg3_32")
+    dt = np.uint16 if name.startswith("u16") else np.float32
+    img = img.astype(dt) * 257
+    tl = [(u[1].astype(dt) * 257, None) for u in units]
+elif name == "f64_1080p8":
+    img, units, _ = synth.make_config("cfg2")
+    img = img.astype(np.float32) * 0.5
+    tl = [(u[1].astype(np.float32) * 0.5, None) for u in units]
+    ctx.set_option(_lib.OPT_F32_MFMA, 0)
+elif name == "slab_414":
+    img = synth.smooth_u8(21, (2048, 2048))
+    tl = [(np.ascontiguousarray(img[300:700, 500:914]), None)]
+    thr = 0.9
+elif name == "dense_4k32":
+    img = synth.smooth_u8(11, (2160, 3840))
+    tl = [(u[1], None) for u in synth.cut_templates(5, img, 32, 64)]
+else:
+    sys.exit("unknown workload " + name)
+ctx.search(tl, img, method, _lib.PEAKS_LOCAL, thr)          # placement, allocation
+for _ in range(3):
+    ctx.search(tl, img, method, _lib.PEAKS_LOCAL, thr)
+st = []
+for _ in range(calls):
+    t0 = time.perf_counter()
+    h = ctx.search(tl, img, method, _lib.PEAKS_LOCAL, thr)
+    st.append(time.perf_counter() - t0)
+tm = ctx.timing()
+px = img.shape[0] * img.shape[1]
+macs = sum((img.shape[0] - t.shape[0] + 1) * (img.shape[1] - t.shape[1] + 1) * t.shape[0] * t.shape[1] * (1 if t.ndim == 2 else t.shape[2])
+           for t, _ in tl)
+algo = img.nbytes + sum(t.nbytes + (0 if m is None else m.nbytes) for t, m in tl)
+import json
+print(json.dumps({"workload": name, "image": list(img.shape), "dtype": str(img.dtype), "units": len(tl), "method": method,
+                  "median_ms_per_call": round(float(np.median(st)) * 1e3, 4), "hits": int(len(h)),
+                  "gpu_ms": round(float(tm["total_ms"]), 4), "ncc_kernel_ms": round(float(tm["ncc_kernel_ms"]), 4),
+                  "ncc_launches": int(tm["ncc_launches"]), "kernel_used": int(tm["kernel_used"]), "hits_only": int(tm["hits_only"]),
+                  "f32_route": int(tm["f32_route"]), "algorithmic_macs": int(macs), "input_bytes": int(algo),
+                  "tmacs_in_score_kernels": round(macs / max(tm["ncc_kernel_ms"], 1e-9) / 1e9, 2)}))
