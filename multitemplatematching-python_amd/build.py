@@ -5,8 +5,8 @@ tests and by hand:  python multitemplatematching-python_amd/build.py [--force]
 hipcc cross-compiles without a GPU.  The built .so is git-ignored but travels to the GPU box with
 the gpurun snapshot.
 
-The library is several translation units (the ~300 instantiations of the MFMA score kernel alone are four of
-them): every unit is compiled to an object of its own, in parallel, and only the units whose inputs changed
+The library is several translation units (context / placement / launches / search API / hit exchange, each with the
+kernels only it launches; the ~300 instantiations of the MFMA score kernel alone are five more): every unit is compiled to an object of its own, in parallel, and only the units whose inputs changed
 are recompiled (objects and their stamps live in csrc/build/, git-ignored).
 """
 import hashlib
@@ -21,9 +21,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["mtm_hip.hip", "mtm_mfma_plain.hip", "mtm_mfma_rm.hip", "mtm_mfma_ext.hip", "mtm_mfma_kp.hip", "mtm_mfma_rows.hip", "mtm_bf16.hip",
+SOURCES = ["mtm_context.hip", "mtm_placement.hip", "mtm_launch.hip", "mtm_api.hip", "mtm_comm.hip", "mtm_mfma_plain.hip", "mtm_mfma_rm.hip", "mtm_mfma_ext.hip", "mtm_mfma_kp.hip", "mtm_mfma_rows.hip", "mtm_bf16.hip",
            "mtm_host.cpp", "mtm_group.cpp"]
-HEADERS = ["mtm_device.hip.h", "mtm_device_util.hip.h", "mtm_mfma.hip.h", "mtm_mfma_params.h", "mtm_templates.hip.h",
+HEADERS = ["mtm_ctx.h", "mtm_k_image.hip.h", "mtm_k_stats.hip.h", "mtm_k_score.hip.h", "mtm_k_peaks.hip.h", "mtm_score_params.h",
+           "mtm_templates_params.h", "mtm_device_util.hip.h", "mtm_mfma.hip.h", "mtm_mfma_params.h", "mtm_templates.hip.h",
            "mtm_bf16.hip.h", "mtm_bf16_params.h", "mtm_refine.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
            os.path.join("..", "..", "include", "mtm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",

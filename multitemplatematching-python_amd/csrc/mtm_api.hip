@@ -1,0 +1,716 @@
+// libmtm_hip.so - the search entry points: mtm_find_matches and its variants (score pass, peak extraction or
+// verification of the kernels' candidates, float32 refinement routes, hit lists), score maps, timing.
+#include "mtm_ctx.h"
+
+using namespace mtm;
+using namespace mtmi;
+#include "mtm_k_peaks.hip.h"
+
+namespace {
+
+inline float decode_order(uint32_t o) {
+    const uint32_t b = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    float v;
+    std::memcpy(&v, &b, 4);
+    return v;
+}
+
+struct NextImage {
+    const void* px;
+    int rows, cols, chans, dtype;
+    int64_t stride;
+    bool staged;
+};
+
+// Enqueue the upload + plane conversion of the next image of a stream on the copy stream, into the
+// image slot the kernels are not reading.  Called by find_matches_impl after the kernels of the
+// current image are enqueued and before it waits for them: the PCIe transfer (and the host-side
+// staging the runtime does for pageable memory) runs under the kernels.
+int stage_next_image(mtm_ctx* c, NextImage* nx) {
+    if (!nx || nx->staged) return MTM_OK;
+    MTMC(ensure_copy_stream(c));
+    if (!c->next_ready) HIPC(hipEventCreateWithFlags(&c->next_ready, hipEventDisableTiming));
+    // The runtime batches stream commands and only submits them when somebody asks about the stream:
+    // push the kernels of the current image out first, then (below) the copy, so that they overlap.
+    (void)hipStreamQuery(c->stream);
+    // straight from the caller's (pageable) rows: the runtime stages them through its own pinned
+    // buffers, which measured 5x faster than a host copy into hipHostMalloc memory on this platform
+    MTMC(upload_image(c, c->slot[1 - c->cur], nx->px, nx->stride, nx->rows, nx->cols, nx->chans, nx->dtype,
+                      c->copy_stream));
+    HIPC(hipEventRecord(c->next_ready, c->copy_stream));
+    (void)hipStreamQuery(c->copy_stream);
+    nx->staged = true;
+    return MTM_OK;
+}
+
+int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                      int64_t* n_out, NextImage* next, const ImageArgs* up = nullptr);
+
+constexpr size_t kHitPrefetch = 1024;       // candidate / hit records fetched together with the counters
+
+int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmState& S, const ImageArgs* up = nullptr) {
+    HIPC(hipSetDevice(c->device));
+    bool banded = false;
+    if (up) {
+        // the geometry first (placement depends on it); the pixels follow in stream order
+        adopt_image(c, up->rows, up->cols, up->chans, up->dtype);
+        c->have_image = false;                       // until the upload is queued: an error below leaves no stale image
+        if (!c->have_templ) {
+            set_error("set the templates first");
+            return MTM_E_STATE;
+        }
+        c->have_image = true;
+    }
+    MTMC(place_templates(c));
+    if (up) {
+        banded = banded_ok(c, *up);
+        if (!banded) {
+            const int rc = upload_image(c, c->slot[c->cur], up->px, up->stride, up->rows, up->cols, up->chans, up->dtype,
+                                        c->stream);
+            if (rc != MTM_OK) {
+                c->have_image = false;
+                return rc;
+            }
+        }
+    }
+    const int n = (int)c->templs.size();
+    const bool mode_min = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_SQDIFF_NORMED;
+    // numpy compares the float32 map with the python-float threshold in float32
+    const float thr = (float)score_threshold;
+    c->timing = mtm_timing{};
+    c->maps_valid = false;
+
+    // fused peak candidates: only when every class runs the MFMA kernel - and not while the maps of this context are
+    // known to be dense (the last attempts overflowed the candidate list: smooth images at a low threshold), where the
+    // full peak pass over the maps is the cheaper route
+    bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
+    if (fused && c->fuse_backoff > 0) {
+        --c->fuse_backoff;
+        fused = false;
+    }
+    for (const SizeClass& sc : c->classes) {
+        const int rk = resolved_kernel(c, sc);
+        fused = fused && (rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16 || rk == MTM_KERNEL_MFMA_F32);
+    }
+    c->cand_on = false;
+    c->hits_only_now = false;
+    c->ext_now = false;
+    // float32 images on the bf16 matrix cores: the kernel's scores are a screen, the decisions are taken on exact
+    // float64 scores (mtm_refine.hip.h).  Calls that mix bf16 classes with float64-kernel ones (float masks) run
+    // everything on the float64 kernel.
+    c->refine_now = c->refine_scan_now = c->f32_exact_now = false;
+    {
+        bool any_bf16 = false, all_bf16 = n > 0;
+        for (const SizeClass& sc : c->classes) {
+            const bool b = resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32;
+            any_bf16 = any_bf16 || b;
+            all_bf16 = all_bf16 && b;
+        }
+        if (any_bf16 && c->f32_mfma == 1) {
+            if (all_bf16) c->refine_now = true;
+            else c->f32_exact_now = true;
+        }
+    }
+    if (c->f32_exact_now) fused = false;            // the float64 kernel writes maps and lists no candidates
+    // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the 1- or 3-channel MFMA kernel
+    // (plain, two-row or row-multiplexed; binary masks with the reciprocal normalisation), the uint16 byte-plane passes
+    // or the float32 kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
+    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3) &&
+        !c->f32_exact_now) {
+        bool ok = true;
+        for (const SizeClass& sc : c->classes)
+            ok = ok && ((resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() &&
+                         (!sc.masked || (!c->exact_div && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED))) ||
+                        resolved_kernel(c, sc) == MTM_KERNEL_MFMA16 || resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32);
+        if (ok) {
+            MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
+            HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * (size_t)n, c->stream));
+            c->ext_now = true;
+            c->cand_on = true;
+            c->hits_only_now = true;
+            c->cand_min = mode_min;
+            c->cand_thr = 0.0f;
+        }
+    }
+    const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
+    if (mode == MTM_PEAKS_GLOBAL && c->refine_now && !c->ext_now) {
+        // no fused extremum in this configuration (maps requested, MTM_FUSE_PEAKS=0): the float64 kernel + extremum_kernel
+        c->refine_now = false;
+        c->f32_exact_now = true;
+    }
+    // the refined routes list their records in the candidate buffer: the outputs within the margin of the running best
+    // (global extremum), the potential peaks of the map scan (local extrema without kernel candidates)
+    const bool pp_mode = mode == MTM_PEAKS_LOCAL && c->refine_now && !fused && n > 0;
+    if ((c->refine_now && c->ext_now) || pp_mode) {
+        const size_t cands_cap = c->cands.cap;
+        MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
+        if (c->cands.cap != cands_cap) c->cands_zeroed = nullptr;
+        if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        c->cands_zeroed = nullptr;
+    }
+    if (pp_mode) {
+        c->refine_scan_now = true;
+        c->cand_min = mode_min;
+        const float tq = mode_min ? -thr : thr;
+        c->cand_thr = tq - kRefineThrMargin * std::max(1.0f, std::fabs(tq));
+    }
+    if (fused) {
+        const size_t cands_cap = c->cands.cap;
+        MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
+        if (c->cands.cap != cands_cap) c->cands_zeroed = nullptr;      // reallocated (possibly at the same address)
+        // the counter is normally cleared right after the previous call fetched it (off the critical path)
+        if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        c->cands_zeroed = nullptr;
+        c->cand_on = true;
+        c->cand_min = mode_min;
+        c->cand_thr = mode_min ? -thr : thr;
+        // (float32 refinement: everything within the margin of the threshold is listed and re-scored)
+        if (c->refine_now) c->cand_thr -= kRefineThrMargin * std::max(1.0f, std::fabs(c->cand_thr));
+        // hits-only: single-channel MFMA classes, every map 2-D, no recent candidate overflow
+        bool honly = c->hits_only && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n;
+        c->hits_only_now = honly;
+    }
+    // hash table of the candidate positions (hits-only verification on the device: only when the
+    // candidates are too many to be checked on the host, see below)
+    unsigned hash_mask = 0;
+    if (c->hits_only_now && !c->ext_now) {
+        size_t hsz = 1024;
+        while (hsz < 2 * (size_t)cand_cap) hsz <<= 1;
+        hash_mask = (unsigned)(hsz - 1);
+        MTMC(c->chash.ensure(hsz * (sizeof(unsigned long long) + sizeof(int))));
+    }
+
+    HIPC(hipEventRecord(c->ev[0], c->stream));
+    if (banded) {
+        const int rc = run_score_banded(c, *up);
+        if (rc != MTM_OK) {
+            c->have_image = false;                   // possibly half an image on the device
+            (void)hipStreamSynchronize(c->copy_stream);
+            return rc;
+        }
+    } else {
+        MTMC(run_score_all(c));
+    }
+    HIPC(hipEventRecord(c->ev[1], c->stream));
+    c->cand_on = false;
+    // stream mode: the kernels of this image are on their way - start the upload of the next one now.
+    // (Not later: the device-to-host copy of the hit records below lands in pageable memory, which
+    // the runtime executes synchronously, i.e. after the kernels.)
+    MTMC(stage_next_image(c, next));
+
+    S.mode = mode;
+    S.thr = thr;
+    S.mode_min = mode_min;
+    S.fused = fused;
+    S.n = n;
+    S.cand_cap = cand_cap;
+    S.hash_mask = hash_mask;
+    S.prefetched = false;
+    S.pp_mode = pp_mode;
+    if (mode == MTM_PEAKS_LOCAL && fused && !c->list2d.empty()) {
+        // Few candidates (the usual case): they come back in one copy and the 3x3 test runs on the host
+        // (fm_end).  Pinned landing buffer: the copy is a plain DMA instead of a staged one.
+        const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
+        const size_t fetch_bytes = 16 + sizeof(mtm_hit) * nfetch;
+        if (c->pinned_cap < fetch_bytes) {
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->pinned_cap = 0;
+            HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
+            c->pinned_cap = fetch_bytes;
+        }
+        HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipEventRecord(c->ev[2], c->stream));
+        S.prefetched = true;
+    }
+    return MTM_OK;
+}
+
+// Synchronising half: waits for the stream, verifies / extracts the peaks, delivers the hits.
+int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    HIPC(hipSetDevice(c->device));
+    const int mode = S.mode, n = S.n;
+    const float thr = S.thr;
+    const bool mode_min = S.mode_min, fused = S.fused;
+    const int64_t cand_cap = S.cand_cap;
+    const unsigned hash_mask = S.hash_mask;
+    std::vector<mtm_hit> hits;
+
+    if (mode == MTM_PEAKS_GLOBAL) {
+        std::vector<unsigned long long> best(2 * (size_t)std::max(1, n));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (!c->ext_now) {
+                MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
+                HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
+            }
+            if (n > 0 && !c->ext_now) {
+                const int nb = 256;
+                hipLaunchKernelGGL(extremum_kernel, dim3(nb, n), dim3(256), 0, c->stream, c->maps.as<float>(),
+                                   c->td.as<TemplDev>(), nb, c->counters.as<unsigned long long>());
+                HIPC(hipGetLastError());
+            }
+            HIPC(hipEventRecord(c->ev[2], c->stream));
+            HIPC(hipMemcpyAsync(best.data(), c->counters.p, sizeof(unsigned long long) * 2 * std::max(1, n),
+                                hipMemcpyDeviceToHost, c->stream));
+            unsigned long long nlisted = 0;
+            const bool refined = c->refine_now && c->ext_now;
+            if (refined)
+                HIPC(hipMemcpyAsync(&nlisted, c->cands.p, sizeof(nlisted), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            if (!refined || (int64_t)nlisted <= cand_cap) break;
+            // float32 refinement: more outputs within the margin of their template's best than the list holds (near-flat
+            // maps) - the float64 kernel decides, on maps in memory
+            c->refine_now = false;
+            c->f32_exact_now = true;
+            c->ext_now = false;
+            c->hits_only_now = false;
+            c->cand_on = false;
+            c->timing.ncc_launches = 0;
+            MTMC(run_score_all(c));
+            HIPC(hipEventRecord(c->ev[1], c->stream));
+        }
+        for (int t = 0; t < n; ++t) {
+            const unsigned long long key = best[2 * t + (mode_min ? 1 : 0)];
+            const TemplDev& d = c->td_host[t];
+            uint32_t o = (uint32_t)(key >> 32);
+            if (mode_min) o = ~o;
+            const uint32_t idx = key ? (0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu)) : 0u;
+            mtm_hit hrec;
+            hrec.templ_idx = t;
+            hrec.x = (int)(idx % (uint32_t)d.ow);
+            hrec.y = (int)(idx / (uint32_t)d.ow);
+            hrec.w = d.cols;
+            hrec.h = d.rows;
+            hrec.score = key ? decode_order(o) : NAN;
+            hits.push_back(hrec);
+        }
+    } else {
+        // ---- 2-D maps.  One device buffer holds [64-bit counter | per-template ints | hit records];
+        // the header and the first kHitPrefetch records come back in ONE copy.
+        // Fused path: the score-map kernel already appended every pixel above the threshold to the
+        // candidate list; verify_peaks_kernel keeps the 3x3 local maxima.  If the candidate list
+        // overflowed (dense maps), or on any non-MFMA class, the full peaks_kernel pass runs instead.
+        const int n2d = (int)c->list2d.size();
+        const size_t hdr_bytes = round_up(2 * sizeof(unsigned long long) + sizeof(int) * (size_t)std::max(1, n), 16);
+        unsigned long long count = 0;
+        std::vector<int> tflags((size_t)std::max(1, n), 0);
+        std::vector<uint8_t> host_buf;
+        bool use_fused = fused;
+        // Few candidates (the usual case): they come back in one copy and the 3x3 test runs on the host.
+        // Every pixel above the threshold is in the list (in both modes), so a neighbour that is not
+        // is <= threshold < candidate: the list alone decides.  Saves two kernels, three fills and a copy.
+        bool verified_on_host = false;
+        bool pp_mode = S.pp_mode;
+        const float thr_q = mode_min ? -thr : thr;      // a hit's quality (score, or -score for minima) exceeds this
+        if (use_fused && n2d > 0 && !pp_mode) {
+            // the candidate list is already on its way into the pinned landing buffer (fm_begin)
+            const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
+            if (!S.prefetched) {
+                set_error("mtm_find_matches: internal state (candidate fetch not queued)");
+                return MTM_E_INVALID;
+            }
+            HIPC(hipStreamSynchronize(c->stream));
+            const uint8_t* land = static_cast<const uint8_t*>(c->pinned);
+            unsigned long long ncand = 0;
+            std::memcpy(&ncand, land, sizeof(ncand));
+            std::memcpy(&c->timing.sclk_mhz, land + 8, sizeof(float));
+            if (ncand <= nfetch) {
+                // everything needed is on the host: clear the counter for the next call while this one finishes
+                if (hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess) c->cands_zeroed = c->cands.p;
+                const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(land + 16);
+                // open-addressing table over the candidates (key -> index), kept in the context between calls
+                size_t tsize = 64;
+                while (tsize < 2 * (size_t)ncand + 8) tsize <<= 1;
+                std::vector<unsigned long long>& hk = c->vh_keys;
+                std::vector<int>& hv = c->vh_vals;
+                hk.assign(tsize, 0ull);
+                hv.resize(tsize);
+                const size_t tmask = tsize - 1;
+                auto key = [](int t, int y, int x) {
+                    return ((unsigned long long)(t + 1) << 42) | ((unsigned long long)y << 21) | (unsigned long long)x;
+                };
+                auto slot_of = [&](unsigned long long k) {
+                    size_t sidx = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & tmask;
+                    while (hk[sidx] != 0ull && hk[sidx] != k) sidx = (sidx + 1) & tmask;
+                    return sidx;
+                };
+                for (int i = 0; i < (int)ncand; ++i) {
+                    const unsigned long long k = key(cd[i].templ_idx, cd[i].y, cd[i].x);
+                    const size_t sidx = slot_of(k);
+                    if (hk[sidx] == 0ull) {         // (a pixel is listed once; keep the first if it ever were not)
+                        hk[sidx] = k;
+                        hv[sidx] = i;
+                    }
+                }
+                const float padv = (c->opt_border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+                for (int i = 0; i < (int)ncand; ++i) {
+                    const mtm_hit& h = cd[i];
+                    const TemplDev& d = c->td_host[h.templ_idx];
+                    const float v = mode_min ? -h.score : h.score;
+                    float mx = v;
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (!dy && !dx) continue;
+                            const int yy = h.y + dy, xx = h.x + dx;
+                            if (yy < 0 || yy >= d.oh || xx < 0 || xx >= d.ow) {
+                                mx = fmaxf(mx, padv);
+                                continue;
+                            }
+                            const size_t sidx = slot_of(key(h.templ_idx, yy, xx));
+                            if (hk[sidx] != 0ull) mx = fmaxf(mx, mode_min ? -cd[hv[sidx]].score : cd[hv[sidx]].score);
+                        }
+                    // (v > thr_q: every record the integer kernels list passes; the float32 screen lists with a margin)
+                    if (v == mx && v > thr_q) {
+                        hits.push_back(h);
+                        ++tflags[(size_t)h.templ_idx];
+                    }
+                }
+                count = hits.size();
+                verified_on_host = true;
+            }
+        }
+        if (!verified_on_host && c->hits_only_now)
+            HIPC(hipMemsetAsync(c->chash.p, 0, ((size_t)hash_mask + 1) * sizeof(unsigned long long), c->stream));
+        if (pp_mode) use_fused = true;          // the potential peaks are in the candidate buffer, their neighbourhoods in the maps
+        for (int attempt = 0; attempt < 5 && n2d > 0 && !verified_on_host; ++attempt) {
+            MTMC(c->hits.ensure(hdr_bytes + sizeof(mtm_hit) * (size_t)c->hit_cap));
+            uint8_t* dbase = c->hits.as<uint8_t>();
+            HIPC(hipMemsetAsync(dbase, 0, hdr_bytes, c->stream));
+            unsigned long long* counter = reinterpret_cast<unsigned long long*>(dbase);
+            int* flags = reinterpret_cast<int*>(counter + 2);
+            mtm_hit* dhits = reinterpret_cast<mtm_hit*>(dbase + hdr_bytes);
+            if (use_fused) {
+                // counter[1] <- candidate count (for the overflow check on the host)
+                HIPC(hipMemcpyAsync(counter + 1, c->cands.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                    c->stream));
+                const unsigned blocks = std::min((unsigned)((c->hit_cap + 255) / 256), 4096u);
+                const mtm_hit* dcands = reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16);
+                if (c->hits_only_now) {
+                    unsigned long long* keys = c->chash.as<unsigned long long>();
+                    int* vals = reinterpret_cast<int*>(keys + (size_t)hash_mask + 1);
+                    hipLaunchKernelGGL(cand_hash_insert_kernel, dim3(blocks), dim3(256), 0, c->stream, dcands,
+                                       c->cands.as<unsigned long long>(), (unsigned long long)cand_cap, keys, vals,
+                                       hash_mask);
+                    hipLaunchKernelGGL(verify_hash_kernel, dim3(blocks), dim3(256), 0, c->stream, c->td.as<TemplDev>(),
+                                       mode_min ? 1 : 0, c->opt_border, dcands, c->cands.as<unsigned long long>(),
+                                       (unsigned long long)cand_cap, keys, vals, hash_mask, dhits,
+                                       (unsigned long long)c->hit_cap, counter, flags, thr_q);
+                } else {
+                    hipLaunchKernelGGL(verify_peaks_kernel, dim3(blocks), dim3(256), 0, c->stream,
+                                       c->maps.as<float>(), c->td.as<TemplDev>(), mode_min ? 1 : 0, c->opt_border,
+                                       dcands, c->cands.as<unsigned long long>(), (unsigned long long)cand_cap, dhits,
+                                       (unsigned long long)c->hit_cap, counter, flags, thr_q);
+                }
+            } else {
+                int max_oh = 0, max_ow = 0;
+                for (int t : c->list2d) {
+                    max_oh = std::max(max_oh, c->td_host[t].oh);
+                    max_ow = std::max(max_ow, c->td_host[t].ow);
+                }
+                const dim3 grd((max_ow + kPkCols - 1) / kPkCols, (max_oh + 4 * kPkRows - 1) / (4 * kPkRows), n2d);
+                hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
+                                   c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
+                                   c->opt_border, dhits, (unsigned long long)c->hit_cap, counter, flags);
+            }
+            HIPC(hipGetLastError());
+            HIPC(hipEventRecord(c->ev[2], c->stream));
+            const size_t first = std::min<size_t>(kHitPrefetch, (size_t)c->hit_cap);
+            host_buf.resize(hdr_bytes + sizeof(mtm_hit) * first);
+            HIPC(hipMemcpyAsync(host_buf.data(), dbase, host_buf.size(), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            unsigned long long ncand = 0;
+            std::memcpy(&count, host_buf.data(), sizeof(count));
+            std::memcpy(&ncand, host_buf.data() + sizeof(count), sizeof(ncand));
+            std::memcpy(tflags.data(), host_buf.data() + 2 * sizeof(count), sizeof(int) * n);
+            if (use_fused && (int64_t)ncand > cand_cap && c->refine_now) {
+                // float32 refinement, list overflowed.  Kernel candidates (everything above the threshold): take the
+                // potential peaks of a map scan instead - far fewer.  Those too (plateau-rich maps): the float64 kernel.
+                c->cand_on = false;
+                c->hits_only_now = false;
+                c->timing.ncc_launches = 0;
+                if (!pp_mode) {
+                    c->fuse_backoff = c->backoff_len;
+                    c->backoff_len = std::min(2 * c->backoff_len, 1024);
+                    pp_mode = true;
+                    c->refine_scan_now = true;
+                    HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+                } else {
+                    pp_mode = false;
+                    use_fused = false;
+                    c->refine_now = c->refine_scan_now = false;
+                    c->f32_exact_now = true;
+                }
+                MTMC(run_score_all(c));
+                HIPC(hipEventRecord(c->ev[1], c->stream));
+                continue;
+            }
+            if (use_fused && (int64_t)ncand > cand_cap) {
+                use_fused = false;                  // dense maps: candidate list overflowed
+                // the next calls on this context go straight to map mode + full peak pass; the period doubles while
+                // the retries keep overflowing
+                c->fuse_backoff = c->backoff_len;
+                c->backoff_len = std::min(2 * c->backoff_len, 1024);
+                if (c->hits_only_now) {
+                    // no maps in memory: compute them (this call pays twice - the overflowed launch left early)
+                    c->hits_only_now = false;
+                    c->cand_on = false;
+                    c->timing.ncc_launches = 0;
+                    MTMC(run_score_all(c));
+                    HIPC(hipEventRecord(c->ev[1], c->stream));
+                }
+                continue;
+            }
+            if (use_fused && !pp_mode) c->backoff_len = 16;     // the candidates fitted
+            if ((int64_t)count <= c->hit_cap) {
+                hits.resize((size_t)count);
+                const size_t got = std::min<size_t>((size_t)count, first);
+                if (got) std::memcpy(hits.data(), host_buf.data() + hdr_bytes, sizeof(mtm_hit) * got);
+                if (count > got) {
+                    HIPC(hipMemcpyAsync(hits.data() + got, dhits + got, sizeof(mtm_hit) * ((size_t)count - got),
+                                        hipMemcpyDeviceToHost, c->stream));
+                    HIPC(hipStreamSynchronize(c->stream));
+                }
+                break;
+            }
+            c->hit_cap = (int64_t)count + 1024;     // grow and rerun the compaction pass
+            use_fused = false;
+        }
+        if (n2d == 0) {
+            HIPC(hipEventRecord(c->ev[2], c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+        }
+        if (!hits.empty()) {
+            // skimage: a map in which every pixel equals its local maximum has no peaks at all.
+            // peaks_kernel: tflags[t] = "some pixel differs from its local max";
+            // fused path:   tflags[t] = number of peaks of t (all pixels <=> trivial).
+            hits.erase(std::remove_if(hits.begin(), hits.end(),
+                                      [&](const mtm_hit& h) {
+                                          const TemplDev& d = c->td_host[h.templ_idx];
+                                          if (d.oh <= 1 || d.ow <= 1) return true;   // 1-D / 1x1 maps: host path below
+                                          if (use_fused) return (long long)tflags[h.templ_idx] == (long long)d.oh * d.ow;
+                                          return tflags[h.templ_idx] == 0;
+                                      }),
+                       hits.end());
+        }
+        // ---- 1x1 and 1-D maps (MTM/__init__.py:25-41) on the host
+        for (int t = 0; t < n; ++t) {
+            const TemplDev& d = c->td_host[t];
+            if (d.oh > 1 && d.ow > 1) continue;
+            const int len = std::max(d.oh, d.ow);
+            std::vector<float> line((size_t)len);
+            HIPC(hipMemcpy2DAsync(line.data(), sizeof(float) * (d.oh == 1 ? len : 1),
+                                  c->maps.as<float>() + d.map_off, sizeof(float) * d.map_pitch,
+                                  sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipStreamSynchronize(c->stream));
+            std::vector<int> pk;
+            if (len == 1) {
+                const float v = mode_min ? -line[0] : line[0];
+                if (v >= (mode_min ? -thr : thr)) pk.push_back(0);
+            } else {
+                pk = find_peaks_1d(line.data(), len, 1, mode_min ? -thr : thr, mode_min);
+            }
+            for (int i : pk) {
+                mtm_hit hrec;
+                hrec.templ_idx = t;
+                hrec.x = d.oh == 1 ? i : 0;
+                hrec.y = d.oh == 1 ? 0 : i;
+                hrec.w = d.cols;
+                hrec.h = d.rows;
+                hrec.score = line[(size_t)i];
+                hits.push_back(hrec);
+            }
+        }
+        // deterministic order: template, then descending quality, then row-major position
+        sort_hits(hits, mode_min);
+    }
+    HIPC(hipEventSynchronize(c->ev[2]));       // already complete: every path above synchronised the stream
+    HIPC(hipEventElapsedTime(&c->timing.score_ms, c->ev[0], c->ev[1]));
+    HIPC(hipEventElapsedTime(&c->timing.peaks_ms, c->ev[1], c->ev[2]));
+    HIPC(hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[2]));
+    MTMC(collect_ncc_time(c));
+    c->timing.n_hits = (int64_t)hits.size();
+    c->timing.hits_only = c->hits_only_now ? 1 : 0;
+    c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
+    c->maps_valid = !c->hits_only_now && !c->ext_now;
+    c->refine_now = c->refine_scan_now = c->f32_exact_now = false;      // states of this call only
+    *n_out = (int64_t)hits.size();
+    c->last_hits.swap(hits);
+    if ((int64_t)c->last_hits.size() > capacity) {
+        set_error("mtm_find_matches: output capacity too small (fetch the result with mtm_last_hits)");
+        return MTM_E_OVERFLOW;
+    }
+    if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
+    return MTM_OK;
+}
+
+int find_matches_impl(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                      int64_t* n_out, NextImage* next, const ImageArgs* up) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) ||
+        (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
+        set_error("mtm_find_matches: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (c->fm_in_flight) {
+        set_error("mtm_find_matches: a mtm_find_matches_async call is in flight (collect it with mtm_find_matches_wait)");
+        return MTM_E_INVALID;
+    }
+    FmState S;
+    MTMC(fm_begin(c, mode, score_threshold, next, S, up));
+    return fm_end(c, S, out, capacity, n_out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_bytes) {
+    if (!c || !out) {
+        set_error("mtm_score_map: bad arguments");
+        return MTM_E_INVALID;
+    }
+    MTM_NOT_IN_FLIGHT(c, "mtm_score_map");
+    HIPC(hipSetDevice(c->device));
+    MTMC(place_templates(c));
+    if (templ_idx < 0 || templ_idx >= (int)c->templs.size()) {
+        set_error("mtm_score_map: template index out of range");
+        return MTM_E_INVALID;
+    }
+    const TemplDev& d = c->td_host[templ_idx];
+    if (out_row_stride_bytes < (int64_t)(sizeof(float) * d.ow)) {
+        set_error("mtm_score_map: output row stride too small");
+        return MTM_E_INVALID;
+    }
+    const SizeClass& sc = c->classes[c->templs[templ_idx].cls];
+    // position of the template inside its class list
+    int pos = 0;
+    while (sc.members[pos] != templ_idx) ++pos;
+    c->timing = mtm_timing{};
+    StatPlanes st;
+    MTMC(ensure_maps(c));
+    MTMC(launch_stats(c, sc, &st));
+    MTMC(launch_ncc(c, sc, sc.tlist_off + pos, 1, st, pos));
+    HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off,
+                          sizeof(float) * d.map_pitch, sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost,
+                          c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    MTMC(collect_ncc_time(c));
+    return MTM_OK;
+}
+
+int mtm_find_matches(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                     int64_t* n_out) {
+    return find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr);
+}
+
+int mtm_find_matches_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                           int mode, double score_threshold, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    if (!c) {
+        set_error("mtm_find_matches_image: null context");
+        return MTM_E_INVALID;
+    }
+    MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image"));
+    const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
+    return find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr, &up);
+}
+
+int mtm_find_matches_next(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
+                          int64_t* n_out, const void* next_px, int rows, int cols, int chans, int dtype,
+                          int64_t row_stride_bytes) {
+    if (!c) {
+        set_error("mtm_find_matches_next: null context");
+        return MTM_E_INVALID;
+    }
+    MTMC(check_image_args(next_px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_next"));
+    NextImage nx{next_px, rows, cols, chans, dtype, row_stride_bytes, false};
+    const int rc = find_matches_impl(c, mode, score_threshold, out, capacity, n_out, &nx);
+    if (rc != MTM_OK && rc != MTM_E_OVERFLOW) {
+        if (nx.staged) (void)hipStreamSynchronize(c->copy_stream);   // drop the staged image
+        return rc;
+    }
+    // the results of the current image are final: make the staged image current
+    if (!nx.staged) MTMC(stage_next_image(c, &nx));
+    HIPC(hipEventSynchronize(c->next_ready));
+    c->cur = 1 - c->cur;
+    adopt_image(c, rows, cols, chans, dtype);
+    return rc;
+}
+
+int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        set_error("mtm_last_hits: bad arguments");
+        return MTM_E_INVALID;
+    }
+    *n_out = (int64_t)c->last_hits.size();
+    if ((int64_t)c->last_hits.size() > capacity) {
+        set_error("mtm_last_hits: output capacity too small");
+        return MTM_E_OVERFLOW;
+    }
+    if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
+    return MTM_OK;
+}
+
+int mtm_last_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_bytes) {
+    if (!c || !out) {
+        set_error("mtm_last_score_map: bad arguments");
+        return MTM_E_INVALID;
+    }
+    MTM_NOT_IN_FLIGHT(c, "mtm_last_score_map");
+    if (!c->placed || !c->maps_valid) {
+        set_error("mtm_last_score_map: the last mtm_find_matches did not materialise the score maps "
+                  "(MTM_OPT_HITS_ONLY = 0 makes it), or the inputs changed since");
+        return MTM_E_STATE;
+    }
+    if (templ_idx < 0 || templ_idx >= (int)c->templs.size()) {
+        set_error("mtm_last_score_map: template index out of range");
+        return MTM_E_INVALID;
+    }
+    const TemplDev& d = c->td_host[templ_idx];
+    if (out_row_stride_bytes < (int64_t)(sizeof(float) * d.ow)) {
+        set_error("mtm_last_score_map: output row stride too small");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off, sizeof(float) * d.map_pitch,
+                          sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return MTM_OK;
+}
+
+int mtm_find_matches_async(mtm_ctx* c, int mode, double score_threshold) {
+    if (!c || (mode != MTM_PEAKS_LOCAL && mode != MTM_PEAKS_GLOBAL)) {
+        set_error("mtm_find_matches_async: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (c->fm_in_flight) {
+        set_error("mtm_find_matches_async: a call is already in flight (collect it with mtm_find_matches_wait)");
+        return MTM_E_INVALID;
+    }
+    MTMC(fm_begin(c, mode, score_threshold, nullptr, c->fm));
+    c->fm_in_flight = true;
+    return MTM_OK;
+}
+
+int mtm_find_matches_wait(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        set_error("mtm_find_matches_wait: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (!c->fm_in_flight) {
+        set_error("mtm_find_matches_wait: no call in flight");
+        return MTM_E_INVALID;
+    }
+    c->fm_in_flight = false;
+    return fm_end(c, c->fm, out, capacity, n_out);
+}
+
+int mtm_get_timing(mtm_ctx* c, mtm_timing* out) {
+    if (!c || !out) return MTM_E_INVALID;
+    *out = c->timing;
+    return MTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RCCL hit exchange.  librccl is loaded lazily so that the library itself has no link-time
+// dependency on it (single-GPU users never touch it).
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"

@@ -1,0 +1,369 @@
+// libmtm_hip.so - the context: creation, options, the device copies of an image (upload, layout conversion).
+// gfx950 (MI355X / CDNA4) only; built by multitemplatematching-python_amd/build.py.
+#include "mtm_ctx.h"
+
+using namespace mtm;
+using namespace mtmi;
+#include "mtm_k_image.hip.h"
+
+namespace mtmi {
+
+// Allocates the raw + planar buffers of `sl` for an image and (re)writes their padding when the geometry is new.
+int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols, int chans, int dtype, hipStream_t stream,
+                 int factor, SlotGeom* g) {
+    (void)c;
+    const size_t esz = elem_size(dtype);
+    const size_t tight = (size_t)src_cols * chans * esz;
+    MTMC(sl.raw.ensure(tight * src_rows));
+    const int rows = src_rows / factor, cols = src_cols / factor;      // the planes hold the downscaled image
+    const int rows_alloc = rows + kPadRows;
+    const int pitch = (int)round_up((size_t)cols + kPadCols, 64);
+    const size_t f32_bytes = sizeof(float) * pitch * rows_alloc * chans;
+    const size_t u8_bytes = (size_t)pitch * rows_alloc * chans;
+    const long long geom = (((long long)rows * 65536 + cols) * 8 + chans) * 4 + dtype;
+    const size_t caps[3] = {sl.f32.cap, sl.u8.cap, sl.u8b.cap};
+    MTMC(sl.f32.ensure(f32_bytes));
+    // uint16, one channel: u8 = high-byte plane, u8b = [high ^ 0x80 plane][low ^ 0x80 plane]
+    const bool u16_planes = dtype == MTM_U16 && chans == 1;
+    const size_t u8b_bytes = u16_planes ? 2 * u8_bytes : u8_bytes;
+    if (dtype == MTM_U8 || u16_planes) {
+        MTMC(sl.u8.ensure(u8_bytes));
+        MTMC(sl.u8b.ensure(u8b_bytes));
+    }
+    // the padding (zeros; 0x80 in the int8 view) only needs writing when the planes are new
+    if (sl.geom != geom || caps[0] != sl.f32.cap || caps[1] != sl.u8.cap || caps[2] != sl.u8b.cap) {
+        HIPC(hipMemsetAsync(sl.f32.p, 0, f32_bytes, stream));
+        if (dtype == MTM_U8 || u16_planes) {
+            HIPC(hipMemsetAsync(sl.u8.p, 0, u8_bytes, stream));
+            HIPC(hipMemsetAsync(sl.u8b.p, 0x80, u8b_bytes, stream));
+        }
+        sl.geom = geom;
+    }
+    g->rows = rows;
+    g->cols = cols;
+    g->rows_alloc = rows_alloc;
+    g->pitch = pitch;
+    g->u8_bytes = u8_bytes;
+    return MTM_OK;
+}
+
+// Rows [r0, r1) of a single-channel uint8 image: copy into the raw buffer and convert into the planes of `sl`
+// (prepared by prepare_slot) on `stream`.  A pageable source makes the copy call block the host until the rows
+// are staged; work queued on OTHER streams before the call runs under it.
+int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
+                     hipStream_t stream, bool skip_f32) {
+    const int cols = g.cols, nrows = r1 - r0;
+    if (nrows <= 0) return MTM_OK;
+    uint8_t* raw = sl.raw.as<uint8_t>() + (size_t)r0 * cols;
+    HIPC(hipMemcpy2DAsync(raw, (size_t)cols, (const uint8_t*)src + (size_t)r0 * src_stride, (size_t)src_stride, (size_t)cols,
+                          nrows, hipMemcpyHostToDevice, stream));
+    uint8_t* u8 = sl.u8.as<uint8_t>() + (size_t)r0 * g.pitch;
+    uint8_t* u8b = sl.u8b.as<uint8_t>() + (size_t)r0 * g.pitch;
+    // no float32 plane here: nothing in a banded call reads it (33 of the 50 MB this conversion would write at 4K);
+    // ensure_f32_plane() makes it from the uint8 plane if a later call on this image needs it
+    float* f32 = skip_f32 ? nullptr : sl.f32.as<float>() + (size_t)r0 * g.pitch;
+    sl.f32_valid = !skip_f32;
+    int x_begin = 0;
+    if (cols >= 16) {        // 16 pixels per thread; the generic kernel takes the tail columns
+        const int cols16 = cols / 16;
+        hipLaunchKernelGGL(planarize_u8_c1_kernel, dim3((cols16 + 255) / 256, nrows), dim3(256), 0, stream, raw, nrows, cols,
+                           cols16, u8, u8b, g.pitch, f32, g.pitch);
+        x_begin = cols16 * 16;
+    }
+    if (x_begin < cols)
+        hipLaunchKernelGGL(planarize_u8_kernel, dim3((cols - x_begin + 255) / 256, nrows), dim3(256), 0, stream, raw, nrows,
+                           cols, 1, u8, u8b, g.pitch, (long long)g.pitch * g.rows_alloc, f32, g.pitch,
+                           (long long)g.pitch * g.rows_alloc, x_begin);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
+// Upload one image into `sl` and build its planar padded planes on `stream`.  `src` has tightly
+// packed rows when `src_stride` == cols * chans * elem size or any larger stride.
+int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
+                 int chans, int dtype, hipStream_t stream, int factor) {
+    SlotGeom g{};
+    MTMC(prepare_slot(c, sl, src_rows, src_cols, chans, dtype, stream, factor, &g));
+    sl.f32_valid = true;
+    const size_t tight = (size_t)src_cols * chans * elem_size(dtype);
+    HIPC(hipMemcpy2DAsync(sl.raw.p, tight, src, (size_t)src_stride, tight, src_rows, hipMemcpyHostToDevice, stream));
+    const int rows = g.rows, cols = g.cols, rows_alloc = g.rows_alloc, pitch = g.pitch;
+    const size_t u8_bytes = g.u8_bytes;
+    const bool u16_planes = dtype == MTM_U16 && chans == 1;
+    const dim3 grd((cols + 255) / 256, rows);
+    if (dtype == MTM_U16)
+        hipLaunchKernelGGL(planarize_u16_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint16_t>(), src_cols, chans, factor,
+                           rows, cols, u16_planes ? sl.u8.as<uint8_t>() : (uint8_t*)nullptr, sl.u8b.as<uint8_t>(),
+                           u16_planes ? sl.u8b.as<uint8_t>() + u8_bytes : (uint8_t*)nullptr, pitch, sl.f32.as<float>(),
+                           pitch, (long long)pitch * rows_alloc);
+    else if (factor > 1 && dtype == MTM_U8)
+        hipLaunchKernelGGL(planarize_u8_down_kernel, grd, dim3(256), 0, stream, sl.raw.as<uint8_t>(), src_cols, chans,
+                           factor, rows, cols, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
+                           (long long)pitch * rows_alloc, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    else if (factor > 1)
+        hipLaunchKernelGGL(planarize_f32_down_kernel, grd, dim3(256), 0, stream, sl.raw.as<float>(), src_cols, chans,
+                           factor, rows, cols, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    else if (dtype == MTM_U8) {
+        int x_begin = 0;
+        if (chans == 1 && cols >= 16) {        // 16 pixels per thread; the generic kernel takes the tail columns
+            const int cols16 = cols / 16;
+            hipLaunchKernelGGL(planarize_u8_c1_kernel, dim3((cols16 + 255) / 256, rows), dim3(256), 0, stream,
+                               sl.raw.as<uint8_t>(), rows, cols, cols16, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
+                               sl.f32.as<float>(), pitch);
+            x_begin = cols16 * 16;
+        }
+        if (x_begin < cols)
+            hipLaunchKernelGGL(planarize_u8_kernel, dim3((cols - x_begin + 255) / 256, rows), dim3(256), 0, stream,
+                               sl.raw.as<uint8_t>(), rows, cols, chans, sl.u8.as<uint8_t>(), sl.u8b.as<uint8_t>(), pitch,
+                               (long long)pitch * rows_alloc, sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc,
+                               x_begin);
+    }
+    else
+        hipLaunchKernelGGL(planarize_f32_kernel, grd, dim3(256), 0, stream, sl.raw.as<float>(), rows, cols, chans,
+                           sl.f32.as<float>(), pitch, (long long)pitch * rows_alloc);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
+void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype) {
+    c->sq_valid = false;
+    if (rows != c->rows || cols != c->cols || chans != c->chans || dtype != c->dtype) c->placed = false;
+    c->rows = rows;
+    c->cols = cols;
+    c->chans = chans;
+    c->dtype = dtype;
+    c->rows_alloc = rows + kPadRows;
+    c->u8_pitch = (int)round_up((size_t)cols + kPadCols, 64);
+    c->f32_pitch = c->u8_pitch;
+    c->have_image = true;
+}
+
+int check_image_args(const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                     const char* who) {
+    if (!px || rows <= 0 || cols <= 0 || chans < 1 || chans > kMaxChans ||
+        (dtype != MTM_U8 && dtype != MTM_F32 && dtype != MTM_U16)) {
+        set_error(std::string(who) + ": bad arguments (1..4 channels, uint8, uint16 or float32)");
+        return MTM_E_INVALID;
+    }
+    if (row_stride_bytes < (int64_t)((size_t)cols * chans * elem_size(dtype))) {
+        set_error(std::string(who) + ": row stride smaller than a row");
+        return MTM_E_INVALID;
+    }
+    return MTM_OK;
+}
+
+// The float32 plane of the current image, if the upload skipped it (banded uint8 uploads do: single channel).
+int ensure_f32_plane(mtm_ctx* c) {
+    mtm_ctx::ImageSlot& sl = c->slot[c->cur];
+    if (sl.f32_valid) return MTM_OK;
+    const size_t n4 = (size_t)c->u8_pitch * c->rows_alloc / 4;         // pitch is a multiple of 64
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, c->stream, sl.u8.as<uint8_t>(),
+                       sl.f32.as<float>(), n4);
+    HIPC(hipGetLastError());
+    sl.f32_valid = true;
+    return MTM_OK;
+}
+
+// The producer side of the upload pipelines (copies, layout conversion, window statistics of a band): its short
+// kernels must not queue behind the score kernel's work-groups for a free CU, hence the highest stream priority.
+int ensure_copy_stream(mtm_ctx* c) {
+    if (c->copy_stream) return MTM_OK;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIPC(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, c->copy_prio ? hi : 0));
+    return MTM_OK;
+}
+
+}  // namespace mtmi
+
+extern "C" {
+
+int mtm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void* mtm_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error(std::string("mtm_host_alloc: ") + hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+void mtm_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int mtm_ctx_create(mtm_ctx** out, int device_id) {
+    if (!out) {
+        set_error("mtm_ctx_create: null output");
+        return MTM_E_INVALID;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (libmtm_hip has no CPU fallback)");
+        return MTM_E_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        set_error("device id out of range");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(device_id));
+    mtm_ctx* c = new mtm_ctx();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        set_error(std::string("context creation: ") + hipGetErrorString(e));
+        delete c;
+        return MTM_E_HIP;
+    }
+    if (const char* v = std::getenv("MTM_AUTO_KERNEL")) {
+        if (!std::strcmp(v, "mfma")) c->auto_kernel = MTM_KERNEL_MFMA;
+        if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
+    }
+    if (const char* v = std::getenv("MTM_UPLOAD_BANDS")) {      // e.g. "0.2,0.6,1": cumulative row fractions; "1": one piece
+        std::vector<double> f;
+        for (const char* q = v; *q;) {
+            char* end = nullptr;
+            const double x = std::strtod(q, &end);
+            if (end == q) break;
+            if (x > 0.0 && x <= 1.0 && (f.empty() || x > f.back())) f.push_back(x);
+            q = *end == ',' ? end + 1 : end;
+        }
+        if (!f.empty()) {
+            f.back() = 1.0;
+            c->upload_bands = f;
+        }
+    }
+    if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
+    if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
+    if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
+    if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
+    if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
+    if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
+    if (const char* v = std::getenv("MTM_ROW_MUX")) c->row_mux = std::atoi(v);
+    if (const char* v = std::getenv("MTM_FUSE_STATS")) c->fuse_stats = std::atoi(v);
+    if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_STAGGER_MODE")) c->mfma_stagger_mode = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_PER_CU")) c->mfma_per_cu = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_STAGGER_NP")) c->mfma_stagger_np = std::atoi(v);
+    if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
+        const int k = std::atoi(v);
+        if (dot_variant_ok(k)) c->dot_variant = k;
+    }
+    *out = c;
+    return MTM_OK;
+}
+
+void mtm_ctx_destroy(mtm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    mtm_comm_destroy(c);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& sl : c->slot)
+        for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
+    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw}) b->release();
+    for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
+                      &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->stats_blk, &c->sq_planes, &c->comm_send,
+                      &c->comm_recv})
+        b->release();
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->comm_pin) (void)hipHostFree(c->comm_pin);
+    if (c->next_ready) (void)hipEventDestroy(c->next_ready);
+    for (hipEvent_t e : c->band_ev) (void)hipEventDestroy(e);
+    if (c->stream2_done) (void)hipEventDestroy(c->stream2_done);
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto& p : c->ncc_ev) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (int i = 0; i < 4; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
+    if (!c) return MTM_E_INVALID;
+    MTM_NOT_IN_FLIGHT(c, "mtm_set_option");
+    switch (option) {
+        case MTM_OPT_KERNEL:
+            if (value < MTM_KERNEL_AUTO || value > MTM_KERNEL_MFMA) break;
+            if (c->opt_kernel != (int)value) c->placed = false;     // the packs follow the kernel
+            c->opt_kernel = (int)value;
+            return MTM_OK;
+        case MTM_OPT_PEAK_BORDER:
+            if (value != MTM_BORDER_CONSTANT && value != MTM_BORDER_NEAREST) break;
+            c->opt_border = (int)value;
+            return MTM_OK;
+        case MTM_OPT_HIT_CAPACITY:
+            if (value < 1) break;
+            c->hit_cap = value;
+            return MTM_OK;
+        case MTM_OPT_EXACT_DIV:
+            c->exact_div = value ? 1 : 0;
+            return MTM_OK;
+        case MTM_OPT_HITS_ONLY:
+            c->hits_only = value ? 1 : 0;
+            c->fuse_backoff = 0;
+            c->backoff_len = 16;
+            return MTM_OK;
+        case MTM_OPT_F32_MFMA:
+            if (value < 0 || value > 2) break;
+            if ((c->f32_mfma != 0) != (value != 0)) c->placed = false;     // the packs follow the kernel
+            c->f32_mfma = (int)value;
+            return MTM_OK;
+        case MTM_OPT_DOT4_VARIANT:
+            if (!dot_variant_ok(value)) break;
+            c->dot_variant = (int)value;
+            return MTM_OK;
+        default: break;
+    }
+    set_error("mtm_set_option: bad option or value");
+    return MTM_E_INVALID;
+}
+
+int mtm_set_image_downscaled(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
+                             int64_t row_stride_bytes, int factor) {
+    if (!c) {
+        set_error("mtm_set_image: null context");
+        return MTM_E_INVALID;
+    }
+    MTM_NOT_IN_FLIGHT(c, "mtm_set_image");
+    MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_set_image"));
+    if (factor < 1 || factor > 64 || rows / factor < 1 || cols / factor < 1) {
+        set_error("mtm_set_image_downscaled: factor must be in 1..64 and leave at least one pixel");
+        return MTM_E_INVALID;
+    }
+    HIPC(hipSetDevice(c->device));
+    MTMC(upload_image(c, c->slot[c->cur], px, row_stride_bytes, rows, cols, chans, dtype, c->stream, factor));
+    HIPC(hipStreamSynchronize(c->stream));
+    adopt_image(c, rows / factor, cols / factor, chans, dtype);
+    return MTM_OK;
+}
+
+int mtm_set_image(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
+                  int64_t row_stride_bytes) {
+    return mtm_set_image_downscaled(c, px, rows, cols, chans, dtype, row_stride_bytes, 1);
+}
+
+}  // extern "C"

@@ -85,4 +85,42 @@ __device__ __forceinline__ float mf_order_float(uint32_t o) {
     return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
 }
 
+// rows of a score map for the 3x3 scans (peaks_kernel, refine_scan_kernel)
+constexpr int kPkCols = 256, kPkRows = 32;
+
+__device__ __forceinline__ void peaks_load_row(const float* __restrict__ m, int pitch, int oh, int ow, int y, int xb,
+                                               int lane, bool mode_min, float padv, float (&v)[4], float& hl,
+                                               float& hr) {
+    // v[k] = value of pixel (y, xb + k); hl / hr = pixels xb - 1 and xb + 4; everything outside the
+    // map is the pad value
+    if (y < 0 || y >= oh) {
+        v[0] = v[1] = v[2] = v[3] = hl = hr = padv;
+        return;
+    }
+    const float* r = m + (size_t)y * pitch;
+    if (xb + 3 < ow) {
+        const float4 q4 = *reinterpret_cast<const float4*>(r + xb);
+        v[0] = q4.x; v[1] = q4.y; v[2] = q4.z; v[3] = q4.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (xb + k < ow) ? r[xb + k] : padv;
+    }
+    if (mode_min) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (xb + k < ow) ? -v[k] : padv;
+    }
+    // neighbours across lanes
+    const float left = __shfl_up(v[3], 1), right = __shfl_down(v[0], 1);
+    hl = left;
+    hr = right;
+    if (lane == 0) {
+        const int x = xb - 1;
+        hl = (x >= 0) ? (mode_min ? -r[x] : r[x]) : padv;
+    }
+    if (lane == 63) {
+        const int x = xb + 4;
+        hr = (x < ow) ? (mode_min ? -r[x] : r[x]) : padv;
+    }
+}
+
 }  // namespace mtm

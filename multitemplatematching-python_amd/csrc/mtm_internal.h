@@ -1,5 +1,5 @@
 // Internal declarations shared by the host-only translation unit (mtm_host.cpp) and the HIP
-// translation unit (mtm_hip.hip).  Not part of the ABI.
+// translation units (mtm_context / _placement / _launch / _api / _comm .hip).  Not part of the ABI.
 #pragma once
 #include <cstdint>
 #include <string>

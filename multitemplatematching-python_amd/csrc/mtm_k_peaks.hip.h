@@ -1,0 +1,251 @@
+// Peak extraction kernels: full 3x3 scan, verification of kernel candidates (against maps / by hash), global extremum.  Launched by mtm_api.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#include "mtm_kernels.h"
+#include "../../include/mtm_hip.h"
+#include "mtm_device_util.hip.h"
+
+namespace mtm {
+
+// ---------------------------------------------------------------------------------------------
+// peak extraction: skimage.feature.peak_local_max(map, threshold_abs=thr, exclude_border=False)
+// on a 2-D map (reference MTM/__init__.py:45): pixel == max of its 3x3 neighbourhood and
+// pixel > thr.  mode_min evaluates it on the negated map (MTM/__init__.py:51-53).  Candidates are
+// appended to a global hit buffer; `nontrivial[t]` records that some pixel differs from its local
+// max (skimage returns no peak at all for a map where none does).
+// ---------------------------------------------------------------------------------------------
+// One wave owns a strip of 256 columns x kPkRows rows and walks it top to bottom: per row one
+// coalesced float4 load per lane (4 pixels), the horizontal neighbours come from the adjacent
+// lanes by shuffle (strip edges: two scalar loads), three rows of horizontal 3-maxima stay in
+// registers.  A work-group is 4 such strips stacked vertically.
+__global__ __launch_bounds__(256) void peaks_kernel(const float* __restrict__ maps,
+                                                    const TemplDev* __restrict__ td,
+                                                    const int* __restrict__ tlist, int mode_min,
+                                                    float thr, int border, mtm_hit* __restrict__ hits,
+                                                    unsigned long long cap,
+                                                    unsigned long long* __restrict__ counter,
+                                                    int* __restrict__ nontrivial) {
+    const int t = tlist[blockIdx.z];
+    const TemplDev T = td[t];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xs = blockIdx.x * kPkCols;
+    const int y0 = (blockIdx.y * 4 + wave) * kPkRows;
+    int nontriv = 0;
+    if (xs < T.ow && y0 < T.oh) {
+        const float* m = maps + T.map_off;
+        const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+        const float thr2 = mode_min ? -thr : thr;
+        const int xb = xs + 4 * lane;
+        // hm_*[k] = max over columns xb+k-1 .. xb+k+1 of one row; c_* = the row's own values
+        float va[4], vb[4], vc[4], hl, hr;
+        float hm_a[4], hm_b[4], hm_c[4];
+        auto hmax = [](const float (&v)[4], float hl, float hr, float (&h)[4]) {
+            h[0] = fmaxf(fmaxf(hl, v[0]), v[1]);
+            h[1] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+            h[2] = fmaxf(fmaxf(v[1], v[2]), v[3]);
+            h[3] = fmaxf(fmaxf(v[2], v[3]), hr);
+        };
+        peaks_load_row(m, T.map_pitch, T.oh, T.ow, y0 - 1, xb, lane, mode_min, padv, va, hl, hr);
+        hmax(va, hl, hr, hm_a);
+        peaks_load_row(m, T.map_pitch, T.oh, T.ow, y0, xb, lane, mode_min, padv, vb, hl, hr);
+        hmax(vb, hl, hr, hm_b);
+        const int y1 = min(y0 + kPkRows, T.oh);
+        for (int y = y0; y < y1; ++y) {
+            peaks_load_row(m, T.map_pitch, T.oh, T.ow, y + 1, xb, lane, mode_min, padv, vc, hl, hr);
+            hmax(vc, hl, hr, hm_c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = xb + k;
+                if (x < T.ow) {
+                    const float v = vb[k];
+                    const float mx = fmaxf(fmaxf(hm_a[k], hm_b[k]), hm_c[k]);
+                    if (!(v == mx)) {
+                        nontriv = 1;
+                    } else if (v > thr2) {
+                        const unsigned long long slot = atomicAdd(counter, 1ull);
+                        if (slot < cap) {
+                            mtm_hit hrec;
+                            hrec.templ_idx = t;
+                            hrec.x = x;
+                            hrec.y = y;
+                            hrec.w = T.cols;
+                            hrec.h = T.rows;
+                            hrec.score = mode_min ? -v : v;
+                            hits[slot] = hrec;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vb[k] = vc[k];
+                hm_a[k] = hm_b[k];
+                hm_b[k] = hm_c[k];
+            }
+        }
+    }
+    if (__syncthreads_or(nontriv) && threadIdx.x == 0) nontrivial[t] = 1;
+}
+
+// Second half of the fused peak extraction: the score-map kernel has appended every pixel above the
+// threshold to `cands`; a candidate is a peak iff it equals the maximum of its 3x3 neighbourhood
+// (same border rule and minima handling as peaks_kernel).  tcount[t] counts the peaks of template t:
+// tcount[t] == oh*ow means every pixel equals its local maximum, i.e. skimage's "trivial image".
+__global__ __launch_bounds__(256) void verify_peaks_kernel(const float* __restrict__ maps,
+                                                           const TemplDev* __restrict__ td, int mode_min,
+                                                           int border, const mtm_hit* __restrict__ cands,
+                                                           const unsigned long long* __restrict__ cand_count,
+                                                           unsigned long long cand_cap, mtm_hit* __restrict__ hits,
+                                                           unsigned long long hit_cap,
+                                                           unsigned long long* __restrict__ hit_count,
+                                                           int* __restrict__ tcount, float thr_q) {
+    const unsigned long long n = min(*cand_count, cand_cap);
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtm_hit c = cands[i];
+    const TemplDev T = td[c.templ_idx];
+    const float* m = maps + T.map_off;
+    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+    const float v = mode_min ? -c.score : c.score;
+    float mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = c.y + dy, xx = c.x + dx;
+            float nv = padv;
+            if (yy >= 0 && yy < T.oh && xx >= 0 && xx < T.ow) {
+                nv = m[(size_t)yy * T.map_pitch + xx];
+                if (mode_min) nv = -nv;
+            }
+            mx = fmaxf(mx, nv);
+        }
+    if (v == mx && v > thr_q) {       // (v > thr_q: always true for the integer kernels' lists; the float32 screen lists with a margin)
+        const unsigned long long slot = atomicAdd(hit_count, 1ull);
+        if (slot < hit_cap) hits[slot] = c;
+        atomicAdd(&tcount[c.templ_idx], 1);
+    }
+}
+
+// Hits-only mode (no score maps in memory): the same test on the candidate list alone.  Every pixel
+// above the threshold IS a candidate, so a neighbour that is not in the list is <= threshold < v and
+// cannot beat the candidate; neighbours that are in the list are found through an open-addressing
+// hash table keyed by (template, y, x) built by cand_hash_insert_kernel.
+__device__ __forceinline__ unsigned long long cand_key(int t, int y, int x) {
+    return ((unsigned long long)(t + 1) << 42) | ((unsigned long long)y << 21) | (unsigned long long)x;
+}
+__device__ __forceinline__ unsigned cand_slot(unsigned long long k, unsigned mask) {
+    return (unsigned)((k * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+
+__global__ __launch_bounds__(256) void cand_hash_insert_kernel(const mtm_hit* __restrict__ cands,
+                                                               const unsigned long long* __restrict__ cand_count,
+                                                               unsigned long long cand_cap,
+                                                               unsigned long long* __restrict__ keys,
+                                                               int* __restrict__ vals, unsigned mask) {
+    const unsigned long long n = min(*cand_count, cand_cap);
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtm_hit c = cands[i];
+    const unsigned long long k = cand_key(c.templ_idx, c.y, c.x);
+    for (unsigned s = cand_slot(k, mask);; s = (s + 1) & mask) {
+        const unsigned long long prev = atomicCAS(&keys[s], 0ull, k);
+        if (prev == 0ull || prev == k) {
+            vals[s] = (int)i;
+            return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void verify_hash_kernel(const TemplDev* __restrict__ td, int mode_min, int border,
+                                                          const mtm_hit* __restrict__ cands,
+                                                          const unsigned long long* __restrict__ cand_count,
+                                                          unsigned long long cand_cap,
+                                                          const unsigned long long* __restrict__ keys,
+                                                          const int* __restrict__ vals, unsigned mask,
+                                                          mtm_hit* __restrict__ hits, unsigned long long hit_cap,
+                                                          unsigned long long* __restrict__ hit_count,
+                                                          int* __restrict__ tcount, float thr_q) {
+    const unsigned long long n = min(*cand_count, cand_cap);
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mtm_hit c = cands[i];
+    const TemplDev T = td[c.templ_idx];
+    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+    const float v = mode_min ? -c.score : c.score;
+    float mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if (dy == 0 && dx == 0) continue;
+            const int yy = c.y + dy, xx = c.x + dx;
+            if (yy < 0 || yy >= T.oh || xx < 0 || xx >= T.ow) {
+                mx = fmaxf(mx, padv);
+                continue;
+            }
+            const unsigned long long k = cand_key(c.templ_idx, yy, xx);
+            for (unsigned s = cand_slot(k, mask);; s = (s + 1) & mask) {
+                const unsigned long long have = keys[s];
+                if (have == 0ull) break;                  // not a candidate: <= threshold < v
+                if (have == k) {
+                    const float nv = cands[vals[s]].score;
+                    mx = fmaxf(mx, mode_min ? -nv : nv);
+                    break;
+                }
+            }
+        }
+    if (v == mx && v > thr_q) {       // (v > thr_q: always true for the integer kernels' lists; the float32 screen lists with a margin)
+        const unsigned long long slot = atomicAdd(hit_count, 1ull);
+        if (slot < hit_cap) hits[slot] = c;
+        atomicAdd(&tcount[c.templ_idx], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// global extremum: cv2.minMaxLoc (reference MTM/__init__.py:226): first occurrence in row-major
+// order wins ties.  One packed 64-bit key per (template, min|max): high word = order-preserving
+// image of the float, low word = ~index, combined with atomicMax.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_order(float v) {
+    if (v == 0.0f) v = 0.0f;     // -0 -> +0
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void extremum_kernel(const float* __restrict__ maps,
+                                                       const TemplDev* __restrict__ td, int n_blocks_per_map,
+                                                       unsigned long long* __restrict__ best) {
+    const int t = blockIdx.y;
+    const TemplDev T = td[t];
+    const long long n = (long long)T.oh * T.ow;
+    const float* m = maps + T.map_off;
+    unsigned long long kmax = 0ull, kmin = 0ull;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)n_blocks_per_map * 256) {
+        const int y = (int)(i / T.ow), x = (int)(i - (long long)y * T.ow);
+        const float v = m[(size_t)y * T.map_pitch + x];
+        if (v != v) continue;   // NaN never wins
+        const uint32_t o = float_order(v);
+        const uint32_t ri = 0xFFFFFFFFu - (uint32_t)i;
+        const unsigned long long a = ((unsigned long long)o << 32) | ri;
+        const unsigned long long b = ((unsigned long long)(~o) << 32) | ri;
+        kmax = a > kmax ? a : kmax;
+        kmin = b > kmin ? b : kmin;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_down(kmax, off);
+        const unsigned long long b = __shfl_down(kmin, off);
+        kmax = a > kmax ? a : kmax;
+        kmin = b > kmin ? b : kmin;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (kmax) atomicMax(&best[2 * t], kmax);
+        if (kmin) atomicMax(&best[2 * t + 1], kmin);
+    }
+}
+
+
+}  // namespace mtm

@@ -1,10 +1,14 @@
-// Device-side data structures shared by the kernels and the launcher (mtm_hip.hip).
+// Device-side data structures shared by the kernels and the host-side units.
 #pragma once
 #include <cstdint>
 
 namespace mtm {
 
 constexpr int kMaxChans = 4;
+
+// float32 refinement (mtm_refine.hip.h): margins of the bf16 screen around the exact decisions
+constexpr float kRefineThrMargin = 1e-4f;   // candidates: approximate quality > threshold - margin * max(1, |threshold|)
+constexpr float kRefineNbrTol = 5e-5f;      // potential peaks of a map scan: approximate value >= 3x3 maximum - tolerance
 
 // Padding of the planar device image so that tile staging never needs bounds checks:
 // every kernel may read up to kPadCols bytes right of / kPadRows rows below the image.

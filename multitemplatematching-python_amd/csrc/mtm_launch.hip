@@ -1,0 +1,904 @@
+// libmtm_hip.so - launches: window statistics and score maps of a size class on whichever kernel runs it, the float32
+// refinement behind the bf16 kernel, the score pass of a whole call (plain and with a banded image upload).
+#include "mtm_ctx.h"
+
+using namespace mtm;
+using namespace mtmi;
+#include "mtm_k_stats.hip.h"
+#include "mtm_k_score.hip.h"
+#include "mtm_refine.hip.h"
+
+namespace {
+
+// dot4 kernel variants
+struct DotVariant {
+    int px, py, nt;
+    bool wide;
+    void (*fn)(DotParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*);
+};
+#define DOTV(PX, PY, NT, W) {PX, PY, NT, W, ncc_dot4_kernel<PX, PY, NT, W>}
+const DotVariant kDotVariants[] = {
+    DOTV(4, 4, 4, false),   // 0: default
+    DOTV(4, 4, 2, false),   // 1
+    DOTV(8, 2, 4, false),   // 2
+    DOTV(8, 4, 2, false),   // 3
+    DOTV(4, 2, 4, false),   // 4
+    DOTV(8, 2, 2, false),   // 5
+    DOTV(4, 2, 8, false),   // 6
+    DOTV(4, 2, 2, true),    // 7: uint64 totals for templates with C*w*h*255^2 >= 2^32
+};
+constexpr int kDotWideVariant = 7;
+constexpr int kNumDotVariants = sizeof(kDotVariants) / sizeof(kDotVariants[0]);
+
+// raw-mode instantiations of ncc_mfma_kernel (biased int32 accumulators stored as they are)
+MfmaFn mfma_raw_fn(bool row_mux, bool packed_k) {
+    MfmaSel s;
+    s.method = kMfRaw;
+    s.rm = row_mux;
+    s.kp = packed_k;
+    return mfma_kernel(s);
+}
+
+}  // namespace
+
+namespace mtmi {
+
+bool dot_variant_ok(int64_t v) { return v >= 0 && v < kNumDotVariants && !kDotVariants[v].wide; }
+
+// Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
+// `sb0`, `sb1`: range of kStatBand4-row output blocks to compute (banded image upload; fused single-channel
+// kernel only), sb1 < 0 = all.
+int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int sb1) {
+    const int h = sc.h, w = sc.w;
+    const int oh = c->rows - h + 1, ow = c->cols - w + 1;
+    const int method = c->method;
+    StatPlanes st{};
+    st.pitch = (int)round_up((size_t)ow, 4);
+    *out = st;
+    const int rk = resolved_kernel(c, sc);
+    const bool want_t_always = rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16 || rk == MTM_KERNEL_MFMA_F32;
+    const bool masked_mfma = sc.masked && rk == MTM_KERNEL_MFMA;
+    if ((sc.masked && !masked_mfma) || (method == MTM_TM_CCORR && !want_t_always)) return MTM_OK;   // none needed
+    const int num_type = masked_mfma ? 0
+                       : (method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    const bool normed = !masked_mfma && (method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED ||
+                                         method == MTM_TM_CCOEFF_NORMED);
+    const size_t plane = (size_t)st.pitch * oh;
+    MTMC(c->stats.ensure(sizeof(double) * plane * (kMaxChans + 2)));
+    double* base = c->stats.as<double>();
+    double* tp[kMaxChans];
+    for (int k = 0; k < kMaxChans; ++k) tp[k] = base + plane * k;
+    double* sum2 = base + plane * kMaxChans;
+    double* sq = base + plane * (kMaxChans + 1);
+    const int hs_pitch = st.pitch;
+    const long long hs_plane = (long long)hs_pitch * c->rows;
+    const bool u8 = c->dtype == MTM_U8;
+    const size_t esz = u8 ? sizeof(uint32_t) : sizeof(double);
+    MTMC(c->hs1.ensure(esz * hs_plane * c->chans));
+    MTMC(c->hs2.ensure(esz * hs_plane * c->chans));
+    const ImageDev img = image_dev(c);
+    const dim3 g1((ow + 256 * kHsumSeg - 1) / (256 * kHsumSeg), c->rows, c->chans);
+    const dim3 g2((ow + 255) / 256, (oh + kVsumBand - 1) / kVsumBand);
+    const int want_t = (num_type == 1 || want_t_always) ? 1 : 0;
+    const double inv_area = 1.0 / ((double)h * (double)w);
+    // fused single-kernel statistics for the common case
+    const bool fused_stats = u8 && c->chans == 1 && w <= 768 && (double)w * h * 65025.0 < 4294967296.0 &&
+                             c->fuse_stats;
+    if (fused_stats) {
+        const int want_sum2 = (num_type == 2 || (normed && num_type != 1) || !want_t_always || masked_mfma) ? 1 : 0;
+        const int owg = stats_u8_owg(w);
+        const int nsb = (oh + kStatBand4 - 1) / kStatBand4;
+        const int b1 = sb1 < 0 ? nsb : std::min(sb1, nsb);
+        double* rsq = nullptr;
+        if (sc.rm_R > 0 && normed) {
+            MTMC(c->stats_rsq.ensure(sizeof(double) * plane));
+            rsq = c->stats_rsq.as<double>();
+        }
+        double* blk = nullptr;
+        if (sc.r2 > 0 && normed) {             // multi-row MFMA variants: statistic ranges per 16-pixel column block
+            st.blk_pitch = (st.pitch + 15) / 16;
+            MTMC(c->stats_blk.ensure(sizeof(double) * 4 * (size_t)st.blk_pitch * oh));
+            blk = c->stats_blk.as<double>();
+            st.blk = blk;
+        }
+        if (b1 > sb0) {
+            const dim3 gs((ow + owg - 1) / owg, b1 - sb0);
+            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, img.u8,
+                               img.u8_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, want_sum2, tp[0],
+                               sum2, sq, st.pitch, rsq, sb0, blk, st.blk_pitch);
+        }
+    } else if (u8 && c->chans == 3 && w <= 768 && 3.0 * w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
+        // RGB: the fused kernel with one scan per channel + one for the squares (sum2 always written:
+        // vsum_stats_kernel does)
+        const int owg = stats_u8_owg(w);
+        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
+        hipLaunchKernelGGL(stats_u8_mc_kernel<3>, gs, dim3(256), 0, c->stream, img.u8, img.u8_pitch, img.u8_plane, h, w, oh,
+                           ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, 1, tp[0], (long long)plane, sum2, sq,
+                           st.pitch);
+    } else if (u8) {
+        if (c->cols <= 8191)
+            hipLaunchKernelGGL(hsum_u8_kernel, dim3(c->rows, c->chans), dim3(256), sizeof(uint32_t) * 2 * (c->cols + 1),
+                               c->stream, img.u8, img.u8_pitch, img.u8_plane, c->cols, w, ow, c->hs1.as<uint32_t>(),
+                               c->hs2.as<uint32_t>(), hs_pitch, hs_plane);
+        else {
+            MTMC(ensure_f32_plane(c));
+            hipLaunchKernelGGL(hsum_kernel<uint32_t>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
+                               img.f32_plane, c->rows, w, ow, c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(),
+                               hs_pitch, hs_plane);
+        }
+        hipLaunchKernelGGL((vsum_stats_kernel<uint32_t, unsigned long long>), g2, dim3(256), 0, c->stream,
+                           c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
+                           ow, inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq,
+                           st.pitch);
+    } else {
+        MTMC(ensure_f32_plane(c));
+        hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
+                           img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
+                           hs_plane);
+        hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream,
+                           c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
+                           inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
+    }
+    HIPC(hipGetLastError());
+    for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
+    st.sum2 = sum2;
+    st.sq = sq;
+    if (masked_mfma && sc.mask_rm_off >= 0 && fused_stats) {
+        // sum I^2 * M over every window on the matrix cores (see square_planes_kernel): two row-multiplexed
+        // raw correlations of the byte planes of I^2 with the mask, combined into the sum2 plane
+        const size_t plane_bytes = (size_t)img.u8_plane;
+        if (!c->sq_valid) {
+            MTMC(c->sq_planes.ensure(3 * plane_bytes));
+            const size_t n16 = plane_bytes / 16;
+            hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
+                               c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes,
+                               c->sq_planes.as<uint8_t>() + 2 * plane_bytes);
+            c->sq_valid = true;
+        }
+        MTMC(c->stats_hi.ensure(sizeof(double) * plane));
+        {
+            const int owg = stats_u8_owg(w);
+            const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
+            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, c->sq_planes.as<uint8_t>(), img.u8_pitch, h, w, oh,
+                               ow, owg, inv_area, 0, 0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr,
+                               st.pitch);
+        }
+        const int map_pitch = (int)round_up((size_t)ow, 4);
+        const long long raw_map = (long long)oh * map_pitch;
+        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(2 * raw_map)));
+        MfmaParams p{};
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = 1;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nb = (w + 63) / 64;
+        p.n_list = 1;
+        p.rm_R = 16;
+        p.rm_nt = 1;
+        p.rm_log2nt = 0;
+        p.rm_steps = h + 2 * 16 - 1;
+        p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+        p.nyb = (oh + 8 * 16 - 1) / (8 * 16);
+        p.ntg = 1;
+        p.n_work = p.nseg * p.nyb;
+        p.method = method;
+        p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.cpr = p.lds_pitch / 16;
+        p.cpr_rstep = 256 / p.cpr;
+        p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
+        p.group_bytes = -(long long)16 * p.nb * 1024;
+        p.only_li = -1;
+        p.raw_map = raw_map;
+        p.raw_pitch = map_pitch;
+        const int tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * 16;
+        const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
+                                ~(size_t)15;
+        p.tc_off = (int)lds_main;
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
+        const size_t lds = (size_t)p.st_off;
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.mask_rm_off + (long long)16 * p.nb * 1024;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        for (int x = 0; x < 2; ++x) {
+            p.img = c->sq_planes.as<uint8_t>() + (size_t)(1 + x) * plane_bytes;
+            p.raw_out = c->raw16.as<int>() + (size_t)x * raw_map;
+            hipLaunchKernelGGL(mfma_raw_fn(true, false), dim3(grid), dim3(256), lds, c->stream, p,
+                               c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>(),
+                               c->sched.as<unsigned int>());
+        }
+        const double km = 128.0 * sc.mask_ones - 16384.0 * (double)h * (double)w;
+        hipLaunchKernelGGL(masksq_combine_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, c->raw16.as<int>(),
+                           c->raw16.as<int>() + raw_map, map_pitch, c->stats_hi.as<double>(), sum2, st.pitch, km, oh, ow);
+        HIPC(hipGetLastError());
+    } else if (masked_mfma) {
+        // sum I^2 * M over every window: dot4 kernel with the mask bytes as the "template", into the
+        // sum2 plane (overwrites the unmasked window sum of squares, which the masked path never uses)
+        if (sc.mask_pack_off < 0) {
+            set_error("internal: masked class without a dot4 mask pack");
+            return MTM_E_STATE;
+        }
+        const DotVariant v = {4, 4, 1, false, ncc_dot4_kernel<4, 4, 1, false, true>};
+        DotParams p{};
+        p.img = img.u8;
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = 1;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        const int w4 = (w + 3) & ~3;
+        p.ncy = (h + kDotChunk - 1) / kDotChunk;
+        p.ncx = (w4 + kDotChunk - 1) / kDotChunk;
+        p.n_list = 1;
+        p.ntx = (ow + 32 * v.px - 1) / (32 * v.px);
+        p.nty = (oh + 8 * v.py - 1) / (8 * v.py);
+        p.nchunks = 1;
+        p.n_work = p.ntx * p.nty;
+        p.method = method;
+        p.sumsq_out = sum2;
+        // the kernel addresses its single template through td[tlist[0]].pack_off: point a scratch
+        // TemplDev at the class's mask pack (only pack_off is read on the MASKSQ path)
+        TemplDev mk = c->td_host[sc.members[0]];
+        mk.pack_off = sc.mask_pack_off;
+        MTMC(c->mask_td.ensure(sizeof(TemplDev) + sizeof(int)));
+        HIPC(hipMemcpyAsync(c->mask_td.p, &mk, sizeof(TemplDev), hipMemcpyHostToDevice, c->stream));
+        HIPC(hipMemsetAsync(c->mask_td.as<uint8_t>() + sizeof(TemplDev), 0, sizeof(int), c->stream));
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, c->stream, p, c->mask_td.as<TemplDev>(),
+                           reinterpret_cast<const int*>(c->mask_td.as<uint8_t>() + sizeof(TemplDev)),
+                           c->packs.as<uint8_t>(), st, c->maps.as<float>());
+        HIPC(hipGetLastError());
+    }
+    *out = st;
+    return MTM_OK;
+}
+
+// Score maps of `n_list` templates of class `sc` (device list at tlist + list_off).
+// `yb0`, `yb1`: range of output row blocks (MFMA kernel only; banded image upload), yb1 < 0 = all.
+int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const StatPlanes& st, int only_li, int yb0,
+               int yb1) {
+    const int h = sc.h, w = sc.w;
+    const int oh = c->rows - h + 1, ow = c->cols - w + 1;
+    const ImageDev img = image_dev(c);
+    const int* tl = c->tlist.as<int>() + list_off;
+    const TemplDev* td = c->td.as<TemplDev>();
+    float* maps = c->maps.as<float>();
+    const int kernel = resolved_kernel(c, sc);      // the same decision place_templates packed for
+
+    // timing events around the dominant kernel
+    if ((int)c->ncc_ev.size() <= c->timing.ncc_launches) {
+        hipEvent_t a, b;
+        HIPC(hipEventCreate(&a));
+        HIPC(hipEventCreate(&b));
+        c->ncc_ev.emplace_back(a, b);
+    }
+    auto& evp = c->ncc_ev[c->timing.ncc_launches];
+    hipStream_t ncc_s = (c->ncc_stream && kernel == MTM_KERNEL_MFMA) ? c->ncc_stream : c->stream;
+    HIPC(hipEventRecord(evp.first, ncc_s));
+
+    if (kernel == MTM_KERNEL_NAIVE) {
+        const dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4, n_list);
+        MTMC(ensure_f32_plane(c));
+        hipLaunchKernelGGL(ncc_naive_kernel, grd, blk, 0, c->stream, img, td, tl, c->weights.as<double>(), st,
+                           c->method, sc.masked ? 1 : 0, maps);
+        c->timing.kernel_used = MTM_KERNEL_NAIVE;
+    } else if (kernel == MTM_KERNEL_MFMA && !sc.slabs.empty()) {
+        // large templates: one RAW launch per slab (a template of its own against the image shifted by the slab's
+        // offset), then slab_combine_kernel adds the slabs up, restores the bias terms and normalises
+        const int n_all = (int)sc.members.size();
+        const int map_pitch = (int)round_up((size_t)ow, 4);
+        const long long raw_map = (long long)oh * map_pitch;
+        const int S = (int)sc.slabs.size();
+        MTMC(c->slab_raw.ensure(sizeof(int) * (size_t)S * n_all * (size_t)raw_map));
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        const bool rmr = sc.slab_R > 0;
+        for (int k = 0; k < S; ++k) {
+            const SizeClass::Slab& sl = sc.slabs[(size_t)k];
+            const int hs = sl.r1 - sl.r0, ws = sl.c1 - sl.c0;
+            MfmaParams p{};
+            p.img = c->slot[c->cur].u8b.as<uint8_t>() + (size_t)sl.ch * img.u8_plane + (size_t)sl.r0 * img.u8_pitch + sl.c0;
+            p.pitch = img.u8_pitch;
+            p.plane = img.u8_plane;
+            p.chans = 1;
+            p.h = hs;
+            p.w = ws;
+            p.oh = oh;
+            p.ow = ow;
+            p.nb = (ws + 63) / 64;
+            p.n_list = n_all;
+            p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+            p.method = c->method;
+            p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+            p.cpr = p.lds_pitch / 16;
+            p.cpr_rstep = 256 / p.cpr;
+            p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
+            p.only_li = -1;
+            p.raw_map = raw_map;
+            p.raw_pitch = map_pitch;
+            p.raw_out = c->slab_raw.as<int>() + (size_t)k * n_all * (size_t)raw_map;
+            int tile_rows;
+            if (rmr) {
+                const int R = sc.slab_R;
+                p.rm_R = R;
+                p.rm_nt = sc.slab_nt;
+                while ((1 << p.rm_log2nt) < sc.slab_nt) ++p.rm_log2nt;
+                p.rm_steps = hs + 2 * R - 1;
+                p.rm_cstride = rm_pack_bytes(hs, ws, R);
+                p.nyb = (oh + 8 * R - 1) / (8 * R);
+                p.ntg = 1;
+                p.group_bytes = -(long long)R * p.nb * 1024;
+                tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * R;
+            } else {
+                p.nyb = (oh + kMfRows - 1) / kMfRows;
+                p.ntg = (n_all + 31) / 32;
+                p.group_bytes = mfma_group_bytes(hs, ws, 1);
+                tile_rows = std::min(hs, kMfChunkH) + kMfRows - 1;
+            }
+            p.n_work = p.nseg * p.nyb * p.ntg;
+            const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
+                                    ~(size_t)15;
+            p.tc_off = (int)lds_main;
+            p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
+            const size_t lds = (size_t)p.st_off + (rmr ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);
+            const int grid = ((p.n_work + 7) / 8) * 8;
+            const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
+            hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, c->stream, p, td,
+                               c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+        }
+        SlabParams q{};
+        q.raw = c->slab_raw.as<int>();
+        q.raw_slab = (long long)n_all * raw_map;
+        q.raw_map = raw_map;
+        q.n_slabs = S;
+        q.oh = oh;
+        q.ow = ow;
+        q.pitch = map_pitch;
+        q.n_list = n_all;
+        q.method = c->method;
+        q.w = w;
+        q.h = h;
+        q.chans = c->chans;
+        q.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        q.cand_min = c->cand_min ? 1 : 0;
+        q.cand_thr = c->cand_thr;
+        q.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        q.cand_counter = c->cands.as<unsigned long long>();
+        q.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        q.hits_only = (q.cand_on && c->hits_only_now) ? 1 : 0;
+        hipLaunchKernelGGL(slab_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
+                           c->tlist.as<int>() + sc.tlist_off, st, maps, only_li);
+        c->timing.kernel_used = MTM_KERNEL_MFMA;
+    } else if (kernel == MTM_KERNEL_MFMA) {
+        // the MFMA kernel works on whole 16-template groups of the class list; a single-template
+        // request (mtm_score_map) computes its group and stores only that template
+        const int n_all = (int)sc.members.size();
+        const bool rm = sc.rm_R > 0;
+        const bool r2 = sc.r2 > 0;
+        const int mb = r2 ? sc.r2 : (n_all > 16 || rm) ? 2 : 1;
+        const int tgsz = r2 ? 16 : 16 * mb;          // templates per work item
+        MfmaParams p{};
+        p.img = c->slot[c->cur].u8b.as<uint8_t>();        // int8 view (bytes ^ 0x80), same geometry as img.u8
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = c->chans;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nb = (w + 63) / 64;
+        p.n_list = n_all;
+        p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+        p.nyb = (oh + kMfRows - 1) / kMfRows;
+        p.ntg = (n_all + tgsz - 1) / tgsz;
+        if (r2) p.nyb = (oh + mb * kMfRows - 1) / (mb * kMfRows);
+        p.method = c->method;
+        p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.cpr = p.lds_pitch / 16;
+        p.cpr_rstep = 256 / p.cpr;
+        p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
+        p.group_bytes = sc.group_bytes;
+        p.only_li = only_li;
+        p.dbg = c->mfma_dbg;
+        p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        p.cand_thr_lo = (double)c->cand_thr - 1e-6 * std::max(1.0, std::fabs((double)c->cand_thr));
+        p.screen_hi = std::min(p.cand_thr_lo, 0.999999) - 1e-6;
+        p.sq_floor = 0.99 / std::sqrt((double)w * (double)h);
+        p.screen_l1 = c->screen_l1;
+        p.cand_min = c->cand_min ? 1 : 0;
+        p.cand_thr = c->cand_thr;
+        p.cand_cap = (unsigned long long)c->hit_cap;
+        p.cand_counter = c->cands.as<unsigned long long>();
+        p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        // the 8 spare bytes of the candidate header carry the shader clock the kernel measured (fetched with it)
+        p.clk_out = (p.cand_on && c->cands.p) ? reinterpret_cast<float*>(c->cands.as<uint8_t>() + 8) : nullptr;
+        int tg0 = 0;
+        if (only_li >= 0 && !rm) {   // one template: just its group
+            tg0 = only_li / tgsz;
+            p.ntg = 1;
+        }
+        int tile_rows = r2 ? std::min(h + mb - 1, kMfChunkR2) + (kMfRows - 1) * mb : std::min(h, kMfChunkH) + kMfRows - 1;
+        if (rm) {
+            p.rm_R = sc.rm_R;
+            p.rm_nt = sc.rm_nt;
+            p.rm_log2nt = 0;
+            while ((1 << p.rm_log2nt) < sc.rm_nt) ++p.rm_log2nt;
+            p.rm_steps = h + 2 * sc.rm_R - 1;
+            p.rm_cstride = class_rm_pack_bytes(sc);
+            p.rm_rsq = c->stats_rsq.as<double>();
+            p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
+            p.ntg = 1;
+            tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * sc.rm_R;
+        }
+        if (yb1 >= 0) {                     // banded launch: row blocks yb0 .. yb1 - 1 (the caller keeps the range non-empty)
+            p.yb0 = yb0;
+            p.nyb = std::min(yb1, p.nyb) - yb0;
+        }
+        p.n_work = p.nseg * p.nyb * p.ntg;
+        const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch,
+                                                  (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
+        p.tc_off = (int)lds_main;
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
+        // statistics prefetch region: (channels + 2) planes per wave (RM loads its statistics directly)
+        size_t lds = (size_t)p.st_off + (rm ? 0 : r2 ? (size_t)kMfRows * ((mb + 1) / 2) * 1024
+                                                     : (size_t)kMfRows * mf_stat_bytes_per_wave(c->chans == 3 ? 3 : 1));
+        const bool ext = c->ext_now && only_li < 0;      // find_matches_impl checked the class
+        if (ext) {
+            p.ext_off = (int)lds;                         // 4 waves x 32 keys
+            lds += (size_t)kMfRows * 32 * sizeof(unsigned long long);
+            p.ext_best = c->counters.as<unsigned long long>();
+            p.cand_on = 1;
+            p.hits_only = 1;
+        }
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
+        p.kp_nseg = sc.kp_nseg;
+        p.kp_blocks = sc.kp_nseg ? kp_blocks(h, sc.kp_nseg) : 0;
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off +
+                            (rm ? (sc.kp_nseg ? 0LL : (long long)sc.rm_R * p.nb * 1024)
+                                : (long long)tg0 * (r2 ? 1 : mb) * sc.group_bytes);
+        // with a group offset the kernel's list positions must stay class-relative: shift the list
+        // pointer and the counts instead (positions inside the kernel are relative to tg0)
+        p.n_list = n_all - tg0 * tgsz;
+        if (only_li >= 0) p.only_li = only_li - tg0 * tgsz;
+        const int* tl_k = tl_class + tg0 * tgsz;
+        // the instantiation of ncc_mfma_kernel for this class (the kernels live in the mtm_mfma_*.hip units)
+        MfmaSel sel;
+        sel.mb = mb;
+        sel.exact_div = c->exact_div != 0;
+        sel.masked = sc.masked;
+        sel.rm = rm;
+        sel.ch = (c->chans == 3 && !sc.masked) ? 3 : 1;
+        sel.method = (c->chans == 1 || sel.ch == 3) ? c->method : -1;     // other channel counts: the generic epilogue
+        sel.ext = ext;
+        sel.r2 = r2;
+        sel.kp = sc.kp_nseg > 0;
+        const MfmaFn fn = mfma_kernel(sel);
+        if (!fn) {
+            set_error("internal: no ncc_mfma_kernel instantiation for this class");
+            return MTM_E_STATE;
+        }
+        // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        p.persistent = c->mfma_persistent;
+        int grid_launch = grid;
+        if (p.persistent) {
+            // residency query, cached per (kernel, LDS size): both calls are slow on the host
+            int per_cu = 0;
+            const auto key = std::make_pair(reinterpret_cast<const void*>(fn), lds);
+            auto it = c->occupancy_cache.find(key);
+            if (it == c->occupancy_cache.end()) {
+                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
+                it = c->occupancy_cache.emplace(key, per_cu).first;
+            }
+            per_cu = it->second;
+            if (c->n_cus == 0) {
+                hipDeviceProp_t prop;
+                HIPC(hipGetDeviceProperties(&prop, c->device));
+                c->n_cus = prop.multiProcessorCount;
+            }
+            per_cu = std::max(1, std::min(per_cu, c->mfma_per_cu));
+            p.stagger_mode = c->mfma_stagger_mode;
+            grid_launch = std::min(p.n_work, per_cu * c->n_cus);
+            // one main loop is chans*h*nb*16*MB MFMAs of 16 cycles; s_sleep(127) is ~8128 cycles
+            const double main_cycles = (double)c->chans * h * p.nb * 16.0 * mb * 16.0;
+            p.stagger_sleeps = c->mfma_stagger >= 0 ? c->mfma_stagger : (int)(0.75 * main_cycles / 8128.0 + 0.5);
+            HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
+        }
+        if (!p.persistent && c->mfma_stagger_np > 0) {
+            if (c->n_cus == 0) {
+                hipDeviceProp_t prop;
+                HIPC(hipGetDeviceProperties(&prop, c->device));
+                c->n_cus = prop.multiProcessorCount;
+            }
+            p.stagger_first = c->mfma_per_cu * c->n_cus;
+            p.stagger_mode = c->mfma_stagger_mode;
+            p.stagger_sleeps = c->mfma_stagger_np;
+            HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
+        }
+        hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps,
+                           c->sched.as<unsigned int>());
+        c->timing.kernel_used = MTM_KERNEL_MFMA;
+    } else if (kernel == MTM_KERNEL_MFMA16) {
+        // uint16: two launches over the image's byte planes x [T_hi | T_lo] of 16 templates per work item.  The first
+        // (high bytes) stores its raw accumulators, the second (low bytes) reads them back in its epilogue and
+        // finishes the exact 16-bit correlation + normalisation there (kMfU16).
+        const int n_all = (int)sc.members.size(), n_pad = sc.n_pad;
+        const int map_pitch = (int)round_up((size_t)ow, 4);
+        const long long raw_map = (long long)oh * map_pitch;
+        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(2LL * n_pad * raw_map)));
+        MfmaParams p{};
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = 1;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nb = (w + 63) / 64;
+        p.n_list = 2 * n_pad;
+        p.nseg = (ow + kMfSeg - 1) / kMfSeg;
+        p.nyb = (oh + kMfRows - 1) / kMfRows;
+        p.ntg = n_pad / 16;
+        p.method = c->method;
+        p.lds_pitch = (16 + 4 * p.nb + 1) * 16;
+        p.cpr = p.lds_pitch / 16;
+        p.cpr_rstep = 256 / p.cpr;
+        p.cpr_dstep = 256 % p.cpr;
+        p.cpr_magic = 65536 / p.cpr + 1;
+        p.group_bytes = sc.group_bytes;
+        p.only_li = -1;
+        p.raw_map = raw_map;
+        p.raw_pitch = map_pitch;
+        p.raw_out = c->raw16.as<int>();
+        int tg0 = 0;
+        if (only_li >= 0) {                 // one template: just its group of 16
+            tg0 = only_li / 16;
+            p.ntg = 1;
+            p.raw_out += (size_t)32 * tg0 * raw_map;
+        }
+        p.n_work = p.nseg * p.nyb * p.ntg;
+        const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
+                                                  (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
+        p.tc_off = (int)lds_main;
+        p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
+        const size_t lds = (size_t)p.st_off + (size_t)kMfRows * kMfStatBytesPerWave;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        constexpr int kSchedWords = 1 + 4096;
+        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
+        const uint8_t* planes = c->slot[c->cur].u8b.as<uint8_t>();
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * 2 * sc.group_bytes;
+        const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16;
+        p.img = planes;                                         // high bytes: raw accumulators
+        p.kp_nseg = sc.kp_nseg;
+        p.kp_blocks = sc.kp_nseg ? kp_blocks(h, sc.kp_nseg) : 0;
+        hipLaunchKernelGGL(mfma_raw_fn(false, sc.kp_nseg > 0), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
+                           c->sched.as<unsigned int>());
+        p.img = planes + (size_t)img.u8_plane;                  // low bytes: finish
+        p.n_list = n_all - tg0 * 16;                            // list positions inside the kernel are relative to tg0
+        p.only_li = only_li >= 0 ? only_li - tg0 * 16 : -1;
+        const double* ts = c->tsum.as<double>() + sc.tsum_off;
+        p.u16_tsum = ts + tg0 * 16;
+        p.u16_npad = n_pad;
+        p.u16_area = (double)h * (double)w;
+        p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        p.cand_min = c->cand_min ? 1 : 0;
+        p.cand_thr = c->cand_thr;
+        p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        p.cand_counter = c->cands.as<unsigned long long>();
+        p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        size_t lds2 = lds;
+        const bool ext = c->ext_now && only_li < 0;      // fused global extremum (find_matches_impl checked the classes)
+        if (ext) {
+            p.ext_off = (int)lds2;                        // 4 waves x 32 keys
+            lds2 += (size_t)kMfRows * 32 * sizeof(unsigned long long);
+            p.ext_best = c->counters.as<unsigned long long>();
+            p.cand_on = 1;
+            p.hits_only = 1;
+        }
+        MfmaSel sel16;
+        sel16.method = kMfU16;
+        sel16.kp = sc.kp_nseg > 0;
+        sel16.ext = ext;
+        sel16.exact_div = c->exact_div != 0;
+        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds2, c->stream, p, td, tl_k, ap, st, maps,
+                           c->sched.as<unsigned int>());
+        c->timing.kernel_used = MTM_KERNEL_MFMA16;
+    } else if (kernel == MTM_KERNEL_MFMA_F32 && !c->f32_exact_now) {
+        const int n_all = (int)sc.members.size();
+        const int mb = n_all > 16 ? 2 : 1;
+        Bf16Params p{};
+        p.img = img.f32;
+        p.pitch = img.f32_pitch;
+        p.plane = img.f32_plane;
+        p.chans = c->chans;
+        p.rows = c->rows;
+        p.cols = c->cols;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        p.nkb = bf16_nkb(w);
+        p.chunk_h = p.nkb <= 2 ? 64 : 32;
+        p.lds_cols = kBfSeg + 32 * p.nkb;
+        p.n_list = n_all;
+        p.nseg = (ow + kBfSeg - 1) / kBfSeg;
+        p.nyb = (oh + kBfRows - 1) / kBfRows;
+        p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
+        p.method = c->method;
+        p.group_bytes = sc.group_bytes;
+        p.piece_bytes = sc.group_bytes * mfma_groups_alloc(n_all);
+        p.only_li = only_li;
+        int tg0 = 0;
+        if (only_li >= 0) {
+            tg0 = only_li / (16 * mb);
+            p.ntg = 1;
+            p.n_list = n_all - tg0 * 16 * mb;
+            p.only_li = only_li - tg0 * 16 * mb;
+        }
+        p.n_work = p.nseg * p.nyb * p.ntg;
+        p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
+        p.cand_min = c->cand_min ? 1 : 0;
+        p.cand_thr = c->cand_thr;
+        p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        p.cand_counter = c->cands.as<unsigned long long>();
+        p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        if (c->ext_now && only_li < 0) {                  // fused global extremum (find_matches_impl checked the classes)
+            p.ext_on = 1;
+            p.ext_best = c->counters.as<unsigned long long>();
+            p.cand_on = 1;
+            p.hits_only = 1;
+            p.ext_margin = c->refine_now ? kRefineThrMargin : 0.0f;
+        }
+        const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
+        const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16 * mb;
+        hipLaunchKernelGGL(bf16_kernel(mb), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        c->timing.kernel_used = MTM_KERNEL_MFMA_F32;
+    } else if (kernel == MTM_KERNEL_DOT4) {
+        const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
+        const DotVariant& v = kDotVariants[wide ? kDotWideVariant : c->dot_variant];
+        DotParams p{};
+        p.img = img.u8;
+        p.pitch = img.u8_pitch;
+        p.plane = img.u8_plane;
+        p.chans = c->chans;
+        p.h = h;
+        p.w = w;
+        p.oh = oh;
+        p.ow = ow;
+        const int w4 = (w + 3) & ~3;
+        p.ncy = (h + kDotChunk - 1) / kDotChunk;
+        p.ncx = (w4 + kDotChunk - 1) / kDotChunk;
+        p.n_list = n_list;
+        p.ntx = (ow + 32 * v.px - 1) / (32 * v.px);
+        p.nty = (oh + 8 * v.py - 1) / (8 * v.py);
+        p.nchunks = (n_list + v.nt - 1) / v.nt;
+        p.n_work = p.ntx * p.nty * p.nchunks;
+        p.method = c->method;
+        const int grid = ((p.n_work + 7) / 8) * 8;
+        hipLaunchKernelGGL(v.fn, dim3(grid), dim3(256), 0, c->stream, p, td, tl, c->packs.as<uint8_t>(), st, maps);
+        c->timing.kernel_used = MTM_KERNEL_DOT4;
+    } else {
+        const int ntx = (ow + kF64BX - 1) / kF64BX, nty = (oh + kF64BY - 1) / kF64BY;
+        const dim3 grd(ntx * nty, n_list);
+        MTMC(ensure_f32_plane(c));
+        if (sc.masked)
+            hipLaunchKernelGGL(ncc_f64_kernel<true>, grd, dim3(256), 0, c->stream, img, td, tl,
+                               c->weights.as<double>(), st, c->method, maps, ntx);
+        else
+            hipLaunchKernelGGL(ncc_f64_kernel<false>, grd, dim3(256), 0, c->stream, img, td, tl,
+                               c->weights.as<double>(), st, c->method, maps, ntx);
+        if (c->timing.kernel_used == 0) c->timing.kernel_used = MTM_KERNEL_AUTO;
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(evp.second, ncc_s));
+    c->timing.ncc_launches++;
+    return MTM_OK;
+}
+
+int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
+    const bool dot_ok = c->dtype == MTM_U8 && sc.all_u8 && !sc.masked;
+    int kernel = c->opt_kernel;
+    if (c->dtype == MTM_F32) {
+        if ((kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) && sc.bf16_ok) return MTM_KERNEL_MFMA_F32;
+        return kernel == MTM_KERNEL_NAIVE ? MTM_KERNEL_NAIVE : MTM_KERNEL_AUTO;
+    }
+    if (c->dtype == MTM_U16) {
+        if ((kernel == MTM_KERNEL_AUTO || kernel == MTM_KERNEL_MFMA) && sc.mfma16_ok) return MTM_KERNEL_MFMA16;
+        return kernel == MTM_KERNEL_NAIVE ? MTM_KERNEL_NAIVE : MTM_KERNEL_AUTO;
+    }
+    if (kernel == MTM_KERNEL_AUTO) kernel = c->auto_kernel;
+    if (kernel == MTM_KERNEL_MFMA && (!sc.mfma_ok || (sc.masked && c->method > 3))) kernel = MTM_KERNEL_DOT4;
+    if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;
+    return kernel;
+}
+
+int ensure_maps(mtm_ctx* c) { return c->maps.ensure(sizeof(float) * std::max<size_t>(4, c->maps_floats)); }
+
+// float32 refinement (mtm_refine.hip.h): the records of the candidate buffer that belong to class `sc` get the scores
+// of the exact float64 kernel - `ring`: their whole 3x3 neighbourhoods, written into the maps.  Runs right behind the
+// class's score launch: the statistics planes are shared by all classes and only live until the next one starts.
+int launch_refine(mtm_ctx* c, const SizeClass& sc, const StatPlanes& st, bool ring, bool patch_maps) {
+    MTMC(ensure_f32_plane(c));
+    RefineParams p{};
+    p.img = image_dev(c);
+    p.td = c->td.as<TemplDev>();
+    p.weights = c->weights.as<double>();
+    p.st = st;
+    p.method = c->method;
+    p.cls = (int)(&sc - c->classes.data());
+    p.ring = ring ? 1 : 0;
+    p.list = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+    p.count = c->cands.as<unsigned long long>();
+    p.cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+    p.maps = patch_maps ? c->maps.as<float>() : nullptr;
+    // one wave per record, records strided over a grid that fills the chip a few times (the list length is only known
+    // on the device; most calls list a few hundred records)
+    const unsigned grid = (unsigned)std::min<unsigned long long>(p.cap, 8192ull);
+    hipLaunchKernelGGL(refine_rescore_kernel, dim3(grid), dim3(64), 0, c->stream, p);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
+// the map scan of the refined route: potential peaks of class `sc` (approximate maps in memory) -> candidate buffer
+int launch_refine_scan(mtm_ctx* c, const SizeClass& sc) {
+    const int oh = c->rows - sc.h + 1, ow = c->cols - sc.w + 1;
+    const dim3 grd((ow + kPkCols - 1) / kPkCols, (oh + 4 * kPkRows - 1) / (4 * kPkRows), (unsigned)sc.members.size());
+    hipLaunchKernelGGL(refine_scan_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(), c->td.as<TemplDev>(),
+                       c->tlist.as<int>() + sc.tlist_off, c->cand_min ? 1 : 0, c->cand_thr, kRefineNbrTol, c->opt_border,
+                       reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16),
+                       (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256), c->cands.as<unsigned long long>());
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
+int run_score_all(mtm_ctx* c) {
+    if (!c->hits_only_now) MTMC(ensure_maps(c));
+    for (const SizeClass& sc : c->classes) {
+        StatPlanes st;
+        MTMC(launch_stats(c, sc, &st));
+        MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st));
+        if (c->refine_now && !c->f32_exact_now && resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32) {
+            if (c->refine_scan_now) {
+                MTMC(launch_refine_scan(c, sc));
+                MTMC(launch_refine(c, sc, st, true, true));
+            } else {
+                MTMC(launch_refine(c, sc, st, false, !c->hits_only_now));
+            }
+        }
+    }
+    if (c->refine_now && !c->f32_exact_now && c->ext_now) {
+        // global extremum: the keys the score kernel kept are approximate - rebuild them from the re-scored list
+        const size_t n = c->templs.size();
+        HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * n, c->stream));
+        const unsigned long long cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+        hipLaunchKernelGGL(refine_extremum_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16), c->cands.as<unsigned long long>(), cap,
+                           c->td.as<TemplDev>(), c->cand_min ? 1 : 0, c->counters.as<unsigned long long>());
+        HIPC(hipGetLastError());
+    }
+    return MTM_OK;
+}
+
+// Time during which at least one score-kernel launch of the call was running: the launches of a banded call
+// overlap (two compute streams), so their intervals are laid on the timeline of the first one and united.
+int collect_ncc_time(mtm_ctx* c) {
+    const int n = c->timing.ncc_launches;
+    std::vector<std::pair<float, float>> iv;
+    for (int i = 0; i < n; ++i) {
+        float a = 0.f, d = 0.f;
+        if (i > 0) HIPC(hipEventElapsedTime(&a, c->ncc_ev[0].first, c->ncc_ev[i].first));
+        HIPC(hipEventElapsedTime(&d, c->ncc_ev[i].first, c->ncc_ev[i].second));
+        iv.emplace_back(a, a + d);
+    }
+    std::sort(iv.begin(), iv.end());
+    float total = 0.f, lo = 0.f, hi = -1.f, sum = 0.f;
+    for (const auto& x : iv) sum += x.second - x.first;
+    c->timing.ncc_sum_ms = sum;
+    for (const auto& x : iv) {
+        if (hi < lo || x.first > hi) {
+            if (hi >= lo) total += hi - lo;
+            lo = x.first;
+            hi = x.second;
+        } else {
+            hi = std::max(hi, x.second);
+        }
+    }
+    if (hi >= lo) total += hi - lo;
+    c->timing.ncc_kernel_ms = total;
+    return MTM_OK;
+}
+
+// Asynchronous half of mtm_find_matches: statistics, score kernels, the upload of the next image and (usual
+// case) the copy of the candidate list into pinned memory are queued; nothing waits for the GPU.
+// Can the image of a fused call arrive in row bands (copy / layout / statistics of band k+1 under the score
+// kernel of band k)?  One unmasked single-channel uint8 size class on the MFMA kernel with the fused
+// statistics kernel; anything else uploads the image in one piece (still without a round trip to the host).
+bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
+    if (c->upload_bands.size() < 2 || a.dtype != MTM_U8 || a.chans != 1 || c->classes.size() != 1) return false;
+    const SizeClass& sc = c->classes[0];
+    if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != MTM_KERNEL_MFMA) return false;
+    if (!(sc.w <= 768 && (double)sc.w * sc.h * 65025.0 < 4294967296.0)) return false;
+    return (size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256;
+}
+
+// The score pass of a fused call with a banded upload.  copy_stream: per band the rows' copy, their layout
+// conversion and the window statistics of the output rows that became computable; c->stream: the score kernel
+// over the row blocks whose statistics exist, behind the band's event.  With a pageable source every copy call
+// blocks the host while its rows are staged - the kernels queued before it run meanwhile.
+int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
+    const SizeClass& sc = c->classes[0];
+    if (!c->hits_only_now) MTMC(ensure_maps(c));
+    MTMC(ensure_copy_stream(c));
+    mtm_ctx::ImageSlot& sl = c->slot[c->cur];
+    SlotGeom g{};
+    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, MTM_U8, c->copy_stream, 1, &g));
+    const int nb = (int)c->upload_bands.size();
+    while ((int)c->band_ev.size() < nb) {
+        hipEvent_t e;
+        HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->band_ev.push_back(e);
+    }
+    const int h = sc.h, oh = a.rows - h + 1;
+    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
+    const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
+    int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
+    bool used2 = false;
+    if (!c->stream2) HIPC(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->stream2_done) HIPC(hipEventCreateWithFlags(&c->stream2_done, hipEventDisableTiming));
+    // stream2 starts behind whatever the call queued on c->stream so far (counter reset, statistics buffers ...)
+    HIPC(hipEventRecord(c->stream2_done, c->stream));
+    HIPC(hipStreamWaitEvent(c->stream2, c->stream2_done, 0));
+    for (int k = 0; k < nb; ++k) {
+        const bool last = k == nb - 1;
+        int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
+        if (r1 <= r_done) continue;
+        MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
+        r_done = r1;
+        const int avail = r1 - h + 1;                            // output rows whose windows are complete
+        const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);
+        StatPlanes st;
+        c->stats_stream = c->copy_stream;
+        const int rc = launch_stats(c, sc, &st, sb_done, sb1);
+        c->stats_stream = nullptr;
+        MTMC(rc);
+        sb_done = sb1;
+        HIPC(hipEventRecord(c->band_ev[(size_t)k], c->copy_stream));
+        (void)hipStreamQuery(c->copy_stream);                    // submit now (the runtime batches commands)
+        const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
+        if (yb1 > yb_done) {
+            hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
+            HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
+            c->ncc_stream = s;
+            const int rc2 = launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1);
+            c->ncc_stream = nullptr;
+            MTMC(rc2);
+            (void)hipStreamQuery(s);
+            used2 = used2 || s == c->stream2;
+            ++n_launch;
+            yb_done = yb1;
+        }
+    }
+    if (used2) {                                    // everything after the score pass is queued on c->stream
+        HIPC(hipEventRecord(c->stream2_done, c->stream2));
+        HIPC(hipStreamWaitEvent(c->stream, c->stream2_done, 0));
+    }
+    return MTM_OK;
+}
+
+}  // namespace mtmi

@@ -15,8 +15,6 @@
 
 namespace mtm {
 
-constexpr float kRefineThrMargin = 1e-4f;   // candidates: approximate quality > threshold - margin * max(1, |threshold|)
-constexpr float kRefineNbrTol = 5e-5f;      // potential peaks of a map scan: approximate value >= 3x3 maximum - tolerance
 
 struct RefineParams {
     ImageDev img;
@@ -113,9 +111,16 @@ __global__ __launch_bounds__(64) void refine_rescore_kernel(RefineParams p) {
                 const double* kk = &s_k[buf][0];
                 for (int dy = 0; dy < ch; ++dy) {
                     int dx = 0;
-                    for (; dx + 4 <= cw; dx += 4) {
+                    for (; dx + 16 <= cw; dx += 16) {           // 16 operand pairs out of LDS, then their 16 chained FMAs
+                        float v[16];
+                        double kw[16];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) acc = fma((double)px[dy * kRfPw + dx + u], kk[dy * kRfCw + dx + u], acc);
+                        for (int u = 0; u < 16; ++u) {
+                            v[u] = px[dy * kRfPw + dx + u];
+                            kw[u] = kk[dy * kRfCw + dx + u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = fma((double)v[u], kw[u], acc);
                     }
                     for (; dx < cw; ++dx) acc = fma((double)px[dy * kRfPw + dx], kk[dy * kRfCw + dx], acc);
                 }
