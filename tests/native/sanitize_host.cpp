@@ -1,0 +1,213 @@
+// Sanitizer driver for the host-only C++ of libmtm_hip.so (no GPU, no HIP): mtm_host.cpp (NMS, 1-D peaks, hit
+// sorting, template statistics) and mtm_group.cpp (worker threads, generation counter, LPT shards, host merge) are
+// compiled as they are, with -fsanitize=address,undefined and again with -fsanitize=thread; the per-device context
+// API the group drives (mtm_ctx_create, mtm_set_templates, mtm_find_matches_image, ...) is replaced by a fake that
+// returns deterministic hits - so the group's threading protocol runs thousands of jobs under the sanitizers.
+// Built and run by tests/test_native_sanitizers_cpu.py.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../multitemplatematching-python_amd/csrc/mtm_internal.h"
+
+using namespace mtm;
+
+// ---- fake per-device contexts (what mtm_context / _placement / _api .hip provide in the real library)
+struct mtm_ctx {
+    int device = 0;
+    std::vector<mtm_templ> templs;
+    int method = 0;
+    std::vector<mtm_hit> last;
+    int64_t opt = 0;
+};
+static std::atomic<int> g_live_ctx{0};
+
+extern "C" {
+int mtm_ctx_create(mtm_ctx** out, int device_id) {
+    if (device_id < 0) {
+        set_error("fake: no such device");
+        return MTM_E_NO_DEVICE;
+    }
+    *out = new mtm_ctx();
+    (*out)->device = device_id;
+    ++g_live_ctx;
+    return MTM_OK;
+}
+void mtm_ctx_destroy(mtm_ctx* c) {
+    if (c) --g_live_ctx;
+    delete c;
+}
+int mtm_set_option(mtm_ctx* c, int, int64_t v) {
+    c->opt = v;
+    return MTM_OK;
+}
+int mtm_set_templates(mtm_ctx* c, const mtm_templ* t, int n, int method) {
+    c->templs.assign(t, t + n);
+    c->method = method;
+    return MTM_OK;
+}
+// every template yields (rows % 7) hits whose coordinates encode (device-independent) facts about it; a template with
+// cols == 13 makes the call fail (error propagation through the worker)
+int mtm_find_matches_image(mtm_ctx* c, const void* px, int rows, int cols, int, int, int64_t, int, double thr, mtm_hit* out,
+                           int64_t cap, int64_t* n_out) {
+    c->last.clear();
+    for (size_t i = 0; i < c->templs.size(); ++i) {
+        const mtm_templ& t = c->templs[i];
+        if (t.cols == 13) {
+            set_error("fake: template refused");
+            return MTM_E_INVALID;
+        }
+        for (int k = 0; k < t.rows % 7; ++k) {
+            mtm_hit h;
+            h.templ_idx = (int)i;
+            h.x = t.cols * 100 + k;
+            h.y = rows - t.rows + (px ? 1 : 0);
+            h.w = t.cols;
+            h.h = t.rows;
+            h.score = (float)thr + (float)k * 0.001f + (float)cols * 1e-6f;
+            c->last.push_back(h);
+        }
+    }
+    *n_out = (int64_t)c->last.size();
+    if ((int64_t)c->last.size() > cap) {
+        set_error("fake: capacity");
+        return MTM_E_OVERFLOW;
+    }
+    if (!c->last.empty()) std::memcpy(out, c->last.data(), sizeof(mtm_hit) * c->last.size());
+    return MTM_OK;
+}
+int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t cap, int64_t* n_out) {
+    *n_out = (int64_t)c->last.size();
+    if ((int64_t)c->last.size() > cap) return MTM_E_OVERFLOW;
+    if (!c->last.empty()) std::memcpy(out, c->last.data(), sizeof(mtm_hit) * c->last.size());
+    return MTM_OK;
+}
+}
+
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #cond, __LINE__); \
+            std::exit(2);                                                        \
+        }                                                                        \
+    } while (0)
+
+static void test_group(std::mt19937& rng) {
+    for (int nd : {1, 2, 3, 8}) {
+        std::vector<int> devs(nd);
+        for (int i = 0; i < nd; ++i) devs[i] = i % 3;
+        mtm_group* g = nullptr;
+        CHECK(mtm_group_create(&g, devs.data(), nd) == MTM_OK);
+        CHECK(mtm_group_size(g) == nd && mtm_group_ctx(g, nd) == nullptr && mtm_group_ctx(g, 0) != nullptr);
+        CHECK(mtm_group_set_option(g, 3, 77) == MTM_OK);
+        static const uint8_t pixel = 0;
+        for (int job = 0; job < 400; ++job) {
+            const int n = (int)(rng() % 70);
+            std::vector<mtm_templ> t((size_t)n);
+            long long expect = 0;
+            bool refuse = false;
+            for (int i = 0; i < n; ++i) {
+                std::memset(&t[i], 0, sizeof(mtm_templ));
+                t[i].px = &pixel;
+                t[i].rows = 1 + (int)(rng() % 40);
+                t[i].cols = 1 + (int)(rng() % 40);
+                if (job % 50 == 49 && i == n / 2) t[i].cols = 13;
+                refuse = refuse || t[i].cols == 13;
+                t[i].chans = 1;
+                expect += t[i].rows % 7;
+            }
+            std::vector<int32_t> dev((size_t)std::max(n, 1));
+            CHECK(mtm_group_shards(g, t.data(), n, 5, 500, 600, dev.data()) == MTM_OK);
+            for (int i = 0; i < n; ++i) CHECK(dev[i] >= 0 && dev[i] < nd);
+            const int64_t cap = job % 7 == 0 ? 3 : 4096;            // small capacity: the overflow protocol
+            std::vector<mtm_hit> out((size_t)cap);
+            int64_t got = -1;
+            int rc = mtm_group_find_matches(g, t.data(), n, 5, &pixel, 500, 600, 1, MTM_U8, 600, 0, 0.5, out.data(), cap, &got);
+            if (refuse) {
+                CHECK(rc == MTM_E_INVALID && std::string(mtm_last_error()).find("template refused") != std::string::npos);
+                continue;
+            }
+            if (expect > cap) {
+                CHECK(rc == MTM_E_OVERFLOW && got == expect);
+                out.resize((size_t)got);
+                rc = mtm_group_last_hits(g, out.data(), got, &got);
+            }
+            CHECK(rc == MTM_OK && got == expect);
+            // merged in template order, global indices, each template's own hits in the order its device produced them
+            int prev = -1, k = 0;
+            for (int64_t i = 0; i < got; ++i) {
+                const mtm_hit& h = out[(size_t)i];
+                CHECK(h.templ_idx >= prev && h.templ_idx < n);
+                k = h.templ_idx == prev ? k + 1 : 0;
+                prev = h.templ_idx;
+                CHECK(h.w == t[(size_t)h.templ_idx].cols && h.h == t[(size_t)h.templ_idx].rows && h.x == h.w * 100 + k);
+            }
+        }
+        mtm_group_destroy(g);
+        CHECK(g_live_ctx.load() == 0);
+    }
+    mtm_group* bad = nullptr;
+    const int neg = -1;
+    CHECK(mtm_group_create(&bad, &neg, 1) == MTM_E_NO_DEVICE && bad == nullptr && g_live_ctx.load() == 0);
+}
+
+static void test_host(std::mt19937& rng) {
+    std::uniform_real_distribution<float> uf(0.f, 1.f);
+    for (int rep = 0; rep < 300; ++rep) {
+        const int n = (int)(rng() % 600);
+        std::vector<mtm_hit> hits((size_t)n);
+        for (auto& h : hits) {
+            h.templ_idx = (int)(rng() % 5);
+            h.x = (int)(rng() % 900);
+            h.y = (int)(rng() % 700);
+            h.w = 1 + (int)(rng() % 90);
+            h.h = 1 + (int)(rng() % 90);
+            h.score = rep % 11 == 0 ? 0.5f : uf(rng);               // all-equal scores: the stable-sort paths
+            if (rep % 17 == 0 && (rng() % 9) == 0) h.score = NAN;
+        }
+        std::vector<int32_t> keep((size_t)std::max(n, 1));
+        int64_t nk = -1;
+        CHECK(mtm_nms(hits.data(), n, uf(rng), rep & 1, rep % 5 == 0 ? 3 : -1, uf(rng), keep.data(), &nk) == MTM_OK);
+        CHECK(nk >= 0 && nk <= n);
+        for (int64_t i = 0; i < nk; ++i) CHECK(keep[(size_t)i] >= 0 && keep[(size_t)i] < n);
+        std::vector<mtm_hit> s = hits;
+        sort_hits(s, (rep & 1) != 0);
+        CHECK(s.size() == hits.size());
+        for (size_t i = 1; i < s.size(); ++i) CHECK(s[i - 1].templ_idx <= s[i].templ_idx);
+        // 1-D peaks on lines with plateaus and NaNs at the ends
+        const int len = 1 + (int)(rng() % 300);
+        std::vector<float> line((size_t)len);
+        for (auto& v : line) v = (float)(rng() % 7) * 0.1f;
+        const std::vector<int> pk = find_peaks_1d(line.data(), len, 1, 0.25f, (rep & 2) != 0);
+        for (int p : pk) CHECK(p > 0 && p < len - 1);
+        // template constants from pixels and from sums agree in size and do not read out of bounds
+        const int th = 1 + (int)(rng() % 20), tw = 1 + (int)(rng() % 20), tc = 1 + (int)(rng() % 3);
+        std::vector<double> px((size_t)th * tw * tc), mk((size_t)th * tw * tc);
+        for (auto& v : px) v = (double)(rng() % 256);
+        for (auto& v : mk) v = (double)(rng() % 2);
+        for (int method = 0; method < 6; ++method) {
+            const TemplStats a = compute_templ_stats(px.data(), nullptr, th, tw, tc, method, true);
+            const TemplStats b = compute_templ_stats(px.data(), mk.data(), th, tw, tc, method, true);
+            CHECK(a.inv_area > 0.0 && b.templ2_mask2_sum >= 0.0);
+        }
+    }
+    int64_t nk = 0;
+    CHECK(mtm_nms(nullptr, 5, 0.5, 0, -1, 0.5, nullptr, &nk) == MTM_E_INVALID && std::strlen(mtm_last_error()) > 0);
+}
+
+int main() {
+    std::mt19937 rng(12345);
+    test_host(rng);
+    test_group(rng);
+    // two groups driven from two caller threads at once (each group is single-caller; the library must not share state)
+    std::thread a([] { std::mt19937 r(1); test_group(r); }), b([] { std::mt19937 r(2); test_host(r); });
+    a.join();
+    b.join();
+    std::puts("sanitize_host: ok");
+    return 0;
+}
