@@ -1,6 +1,8 @@
 """Host-layer behaviour that needs no GPU: the reference's argument validation, messages and
 their order (MTM/__init__.py:129-167, :286-287, :67-68), checked against the messages captured
 from the unmodified reference (tests/golden/golden.json "errors")."""
+import os
+
 import numpy as np
 import pytest
 
@@ -83,6 +85,27 @@ def test_draw_boxes(mtm):
     assert tuple(rgb[30, 25]) == (image[30, 25],) * 3
     gray = mtm.drawBoxesOnGray(image, hits, boxThickness=1)
     assert gray.shape == image.shape and gray[20, 10] == 255 and gray[30, 25] == image[30, 25]
+
+
+def test_draw_fixture(mtm):
+    """drawBoxesOnRGB / drawBoxesOnGray against tests/golden/draw_fixture.json, which make_draw_fixture.py derives from
+    the definitions of cv2.rectangle (thickness 1), COLOR_GRAY2RGB and the fixed-point COLOR_RGB2GRAY with code of its
+    own (reference MTM/__init__.py:327-341, :375-389): outlines include both corners, boxes running off the canvas are
+    clipped, the input image is not modified."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "draw_fixture.json")) as f:
+        fx = json.load(f)
+    gray, rgb = np.array(fx["image_gray"], np.uint8), np.array(fx["image_rgb"], np.uint8)
+    hits = [(h[0], tuple(h[1]), h[2]) for h in fx["hits"]]
+    g0, r0 = gray.copy(), rgb.copy()
+    assert mtm.drawBoxesOnRGB(gray, hits, boxThickness=1).tolist() == fx["drawBoxesOnRGB(gray, thickness=1)"]
+    assert mtm.drawBoxesOnRGB(rgb, hits, boxThickness=1, boxColor=(10, 20, 30)).tolist() == \
+        fx["drawBoxesOnRGB(rgb, thickness=1, boxColor=(10,20,30))"]
+    assert mtm.drawBoxesOnGray(rgb, hits, boxThickness=1).tolist() == fx["drawBoxesOnGray(rgb, thickness=1)"]
+    assert mtm.drawBoxesOnGray(gray, hits, boxThickness=1, boxColor=99).tolist() == fx["drawBoxesOnGray(gray, thickness=1, boxColor=99)"]
+    assert (gray == g0).all() and (rgb == r0).all()
+    px16 = np.array([fx["rgb2gray_uint16"]["pixels"]], np.uint16)
+    assert mtm.drawBoxesOnGray(px16, []).tolist() == [fx["rgb2gray_uint16"]["gray"]]
 
 
 def test_draw_labels_and_gray_conversion(mtm):
