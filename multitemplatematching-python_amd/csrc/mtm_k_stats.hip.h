@@ -498,15 +498,15 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
 
 // ---------------------------------------------------------------------------------------------
 // Masked templates: sum I^2 * M over every window on the matrix cores.  I^2 is a 16-bit number; its two
-// bytes are image planes of their own (square_planes_kernel), the binary mask is the "template" of a
-// row-multiplexed raw correlation (one template, 16 output rows per MFMA), and masksq_combine_kernel
-// puts the two byte-plane results together:  c2 = 256 (a_h + 128 S1_h + K) + (a_l + 128 S1_l + K),
-// K = 128 sum(M) - 16384 A, S1_h / S1_l the window sums of the byte planes (S1_l = S2 - 256 S1_h with
-// S2 the plain window sum of squares).  All integers < 2^53: exact.
+// bytes are image planes of their own (square_planes_kernel, biased to int8 like every image plane), the binary
+// mask is the "template" of a row-multiplexed raw correlation (one template, 16 output rows per MFMA) - as the
+// int8 values 0 / 1 it already is, NOT biased: with a_x = sum (I_x - 128) * M the window sums drop out,
+//   sum I_x * M = a_x + 128 * sum(M),        c2 = 256 * sum I_h * M + sum I_l * M = 256 a_h + a_l + 257 * 128 * sum(M)
+// (round 2 biased the mask too and needed a window-sum pass over the high-byte plane per class to undo it).
+// All integers < 2^53: exact.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void square_planes_kernel(const uint8_t* __restrict__ u8, size_t n16,
-                                                            uint8_t* __restrict__ sh, uint8_t* __restrict__ shb,
-                                                            uint8_t* __restrict__ slb) {
+                                                            uint8_t* __restrict__ shb, uint8_t* __restrict__ slb) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= n16) return;
     const uint4 v = reinterpret_cast<const uint4*>(u8)[g];
@@ -522,7 +522,6 @@ __global__ __launch_bounds__(256) void square_planes_kernel(const uint8_t* __res
             lo[k] |= (sq & 255u) << (8 * b);
         }
     }
-    reinterpret_cast<uint4*>(sh)[g] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     reinterpret_cast<uint4*>(shb)[g] = make_uint4(hi[0] ^ 0x80808080u, hi[1] ^ 0x80808080u, hi[2] ^ 0x80808080u,
                                                   hi[3] ^ 0x80808080u);
     reinterpret_cast<uint4*>(slb)[g] = make_uint4(lo[0] ^ 0x80808080u, lo[1] ^ 0x80808080u, lo[2] ^ 0x80808080u,
@@ -530,16 +529,24 @@ __global__ __launch_bounds__(256) void square_planes_kernel(const uint8_t* __res
 }
 
 __global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restrict__ raw_h, const int* __restrict__ raw_l,
-                                                             int raw_pitch, const double* __restrict__ s1h,
-                                                             double* __restrict__ sum2, int st_pitch, double km,
-                                                             int oh, int ow) {
+                                                             int raw_pitch, double* __restrict__ sum2, int st_pitch,
+                                                             double km257, int oh, int ow, double* __restrict__ blk,
+                                                             int blk_pitch) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= ow || y >= oh) return;
-    const size_t o = (size_t)y * st_pitch + x, r = (size_t)y * raw_pitch + x;
-    const double h1 = s1h[o], l1 = sum2[o] - 256.0 * h1;     // sum2 holds the plain window sum of squares here
-    const double ch = (double)raw_h[r] + 128.0 * h1 + km, cl = (double)raw_l[r] + 128.0 * l1 + km;
-    sum2[o] = 256.0 * ch + cl;
+    double c2 = INFINITY;
+    if (x < ow && y < oh) {
+        const size_t o = (size_t)y * st_pitch + x, r = (size_t)y * raw_pitch + x;
+        c2 = fma(256.0, (double)raw_h[r], (double)raw_l[r]) + km257;
+        sum2[o] = c2;
+    }
+    if (blk != nullptr) {
+        // smallest c2 of every 16-pixel column block (third slot of the block record; the row-multiplexed tiling's
+        // hits-only screen bounds sqrt(tms c2) from below with it); +inf for a block right of the last output column
+#pragma unroll
+        for (int off = 1; off <= 8; off <<= 1) c2 = fmin(c2, __shfl_xor(c2, off));
+        if ((threadIdx.x & 15) == 0 && y < oh && (x >> 4) < blk_pitch) blk[((size_t)y * blk_pitch + (x >> 4)) * 4 + 2] = c2;
+    }
 }
 
 

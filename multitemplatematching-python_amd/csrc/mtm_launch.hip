@@ -96,7 +96,8 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
             rsq = c->stats_rsq.as<double>();
         }
         double* blk = nullptr;
-        if (sc.r2 > 0 && normed) {             // multi-row MFMA variants: statistic ranges per 16-pixel column block
+        // statistic ranges per 16-pixel column block: the hits-only screens of the multi-row and row-multiplexed tilings
+        if (c->chans == 1 && ((sc.r2 > 0 && normed) || (sc.rm_R > 0 && (normed || (masked_mfma && method == MTM_TM_CCORR_NORMED))))) {
             st.blk_pitch = (st.pitch + 15) / 16;
             MTMC(c->stats_blk.ensure(sizeof(double) * 4 * (size_t)st.blk_pitch * oh));
             blk = c->stats_blk.as<double>();
@@ -149,20 +150,11 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         // raw correlations of the byte planes of I^2 with the mask, combined into the sum2 plane
         const size_t plane_bytes = (size_t)img.u8_plane;
         if (!c->sq_valid) {
-            MTMC(c->sq_planes.ensure(3 * plane_bytes));
+            MTMC(c->sq_planes.ensure(2 * plane_bytes));
             const size_t n16 = plane_bytes / 16;
             hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
-                               c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes,
-                               c->sq_planes.as<uint8_t>() + 2 * plane_bytes);
+                               c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes);
             c->sq_valid = true;
-        }
-        MTMC(c->stats_hi.ensure(sizeof(double) * plane));
-        {
-            const int owg = stats_u8_owg(w);
-            const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
-            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stream, c->sq_planes.as<uint8_t>(), img.u8_pitch, h, w, oh,
-                               ow, owg, inv_area, 0, 0, 1, 0, c->stats_hi.as<double>(), (double*)nullptr, (double*)nullptr,
-                               st.pitch);
         }
         const int map_pitch = (int)round_up((size_t)ow, 4);
         const long long raw_map = (long long)oh * map_pitch;
@@ -206,15 +198,16 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.mask_rm_off + (long long)16 * p.nb * 1024;
         const int grid = ((p.n_work + 7) / 8) * 8;
         for (int x = 0; x < 2; ++x) {
-            p.img = c->sq_planes.as<uint8_t>() + (size_t)(1 + x) * plane_bytes;
+            p.img = c->sq_planes.as<uint8_t>() + (size_t)x * plane_bytes;
             p.raw_out = c->raw16.as<int>() + (size_t)x * raw_map;
             hipLaunchKernelGGL(mfma_raw_fn(true, false), dim3(grid), dim3(256), lds, c->stream, p,
                                c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>(),
                                c->sched.as<unsigned int>());
         }
-        const double km = 128.0 * sc.mask_ones - 16384.0 * (double)h * (double)w;
+        const double km257 = 257.0 * 128.0 * sc.mask_ones;      // the mask operand is not biased (masksq_combine_kernel)
         hipLaunchKernelGGL(masksq_combine_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, c->raw16.as<int>(),
-                           c->raw16.as<int>() + raw_map, map_pitch, c->stats_hi.as<double>(), sum2, st.pitch, km, oh, ow);
+                           c->raw16.as<int>() + raw_map, map_pitch, sum2, st.pitch, km257, oh, ow,
+                           const_cast<double*>(st.blk), st.blk_pitch);
         HIPC(hipGetLastError());
     } else if (masked_mfma) {
         // sum I^2 * M over every window: dot4 kernel with the mask bytes as the "template", into the

@@ -808,6 +808,57 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // pre-test, candidate emission and stores as the single-row path.
         __syncthreads();              // every wave is done reading the image tile: the buffers alias it
         const int R = p.rm_R, ntm = p.rm_nt - 1, lg = p.rm_log2nt;
+        // ---- hits-only screen of the row-multiplexed tiling (one channel; the normalised unmasked methods and masked
+        // TM_CCORR_NORMED): the per-lane bound of the single-row path's first level (see there), straight from the
+        // accumulator registers.  In the C/D layout lane (j, q) holds, per MFMA group and A row i = 4 q + e, the 16
+        // consecutive outputs 16 j + c of (template i % nt, output row mb R + i / nt); the ranges of the statistics over
+        // that 16-pixel block come from StatPlanes::blk (a 32-byte load per row, from memory: the item is long and
+        // this is once per item).  Masked: c1 = acc + 128 S1 + K against thr sqrt(tms c2), c2 = sum I^2 M >= its block
+        // minimum (third slot of the block record, written by masksq_combine_kernel).  A wave none of whose lanes can
+        // hold a candidate skips the transposition and the per-output normalisation below.
+        if constexpr (CH == 1 && ((!MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) ||
+                                  (MASKED && METHOD == MTM_TM_CCORR_NORMED))) {
+            if (p.hits_only && p.screen_l1 && st.blk != nullptr && (EXT || p.cand_thr_lo >= 0.0)) {
+                bool pass1 = false;
+                const int bj = min((x0 >> 4) + j, st.blk_pitch - 1);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    int amax[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const v4i a = acc[mb][c];
+                        amax[0] = max(amax[0], a.x);
+                        amax[1] = max(amax[1], a.y);
+                        amax[2] = max(amax[2], a.z);
+                        amax[3] = max(amax[3], a.w);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * q + e;
+                        const int t = i & ntm, rho = i >> lg;
+                        const int yy = y0 + wave * wave_rows + mb * R + rho;
+                        const bool live = t < p.n_list && yy < p.oh;
+                        const double* bp = st.blk + ((size_t)min(yy, p.oh - 1) * st.blk_pitch + bj) * 4;
+                        const double2 lohi = *reinterpret_cast<const double2*>(bp);
+                        const double third = bp[2];
+                        const MfTemplConst& T = tcl[t];
+                        const double thr_lo_e = EXT ? T.ext_thr_lo : p.cand_thr_lo;
+                        const double hi = EXT ? fmin(thr_lo_e, 0.999999) - 1e-6 : p.screen_hi;
+                        bool could;
+                        if constexpr (MASKED) {
+                            const double bound = ((double)amax[e] + T.mfma_k) + 128.0 * lohi.y;
+                            could = bound > hi * sqrt(T.tms * third);
+                        } else {
+                            const double m = METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0;
+                            const double bound = ((double)amax[e] + T.mfma_k) + fmax(m * lohi.x, m * lohi.y);
+                            could = T.all_ones != 0 || bound > hi * T.templ_norm * fmax(third, p.sq_floor);
+                        }
+                        pass1 = pass1 || (live && (thr_lo_e < 0.0 || could));
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(pass1) == 0ull) continue;      // wave-uniform; no work-group barrier below
+            }
+        }
         const bool col_on = xq < p.ow;
         const int xs = min(xq, st.pitch - 4);
         unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;

@@ -74,7 +74,7 @@ void pack_mask_rm(const mtm_ctx* c, const SizeClass& sc, uint8_t* out) {
             for (int dx = 0; dx < w; ++dx) {
                 const int b = dx / 64, q = (dx % 64) / 16, byte = dx % 16;
                 const uint8_t v = ht.mask[(size_t)dy * w + dx] > 0.0 ? 1 : 0;
-                out[(((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v ^ 0x80;
+                out[(((size_t)sp * nb + b) * 64 + (16 * q + i)) * 16 + byte] = v;           // int8 0 / 1: the mask is not biased
             }
         }
 }

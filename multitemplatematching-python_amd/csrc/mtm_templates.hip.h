@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void pack_units_kernel(PackParams p, const uin
                     v = unit_px(arena, u, ch, dy, dx);
                     if (p.masked) v *= unit_mask(arena, u, ch, dy, dx);
                 }
-                wds[byte >> 2] |= ((v ^ 0x80u) & 255u) << (8 * (byte & 3));
+                // (the mask of the sum I^2 M pass is its own int8 value, 0 or 1 - see masksq_combine_kernel; pixels are biased)
+                wds[byte >> 2] |= ((p.mode == 2 ? v : (v ^ 0x80u)) & 255u) << (8 * (byte & 3));
             }
         }
     }

@@ -37,7 +37,7 @@ constexpr int kSumsPerSource = 4 * kMaxChans + 2;
 //                    of template li = 16 g + i (bytes T ^ 0x80; taps beyond w / templates beyond n = 0)
 //   mode 1 (RM)    : [ch][sp = 0 .. h + 3R - 2][b][lane][16]; A row i = template i % nt, row offset i / nt:
 //                    template row dy = sp - R - i / nt (0 outside 0 .. h - 1)
-//   mode 2 (mask)  : mode 1 with nt = 1, R = 16 and the byte = (mask > 0) ^ 0x80, from unit tl[0]
+//   mode 2 (mask)  : mode 1 with nt = 1, R = 16 and the byte = (mask > 0) - 0 or 1, NOT biased - from unit tl[0]
 // `masked`: bytes are T * M (M binary).
 // ---------------------------------------------------------------------------------------------
 struct PackParams {
