@@ -204,6 +204,8 @@ struct mtm_ctx {
     hipEvent_t stream2_done = nullptr;
     std::vector<hipEvent_t> band_ev;
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
+    double band_min_fill = 2.0;                     // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work
+                                                    // items fill the resident work-group slots this many times (banded_ok)
 
     // templates
     bool have_templ = false;

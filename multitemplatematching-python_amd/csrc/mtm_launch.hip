@@ -827,7 +827,16 @@ bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
     const SizeClass& sc = c->classes[0];
     if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != MTM_KERNEL_MFMA) return false;
     if (!(sc.w <= 768 && (double)sc.w * sc.h * 65025.0 < 4294967296.0)) return false;
-    return (size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256;
+    if (!((size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256)) return false;
+    // A band's score launch must still fill the chip: two work-groups per CU are resident, and a launch of fewer than a
+    // couple of such generations runs at the latency of its last one.  1080p x 8 templates is 512 work items in all -
+    // banded 0.26 ms per call (two launches of 55 us for 62 us of work), in one piece 0.22 ms.
+    const int oh = a.rows - sc.h + 1, ow = a.cols - sc.w + 1, n = (int)sc.members.size();
+    const int rows_per_item = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);
+    const int tg = sc.rm_R > 0 ? 1 : (n + (sc.r2 ? 16 : 32) - 1) / (sc.r2 ? 16 : 32);
+    const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + rows_per_item - 1) / rows_per_item) * tg;
+    const int cus = c->n_cus > 0 ? c->n_cus : 256;
+    return (double)items * c->upload_bands[0] >= c->band_min_fill * (2.0 * cus);      // MTM_BAND_MIN_FILL (default 2; 0: always band)
 }
 
 // The score pass of a fused call with a banded upload.  copy_stream: per band the rows' copy, their layout

@@ -568,6 +568,7 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
     and the layouts that upload in one piece (several size classes, RGB, uint16, masks)."""
     from MTM import _lib
     monkeypatch.setenv("MTM_UPLOAD_BANDS", bands)
+    monkeypatch.setenv("MTM_BAND_MIN_FILL", "0")      # band even these small images (by default a band must fill the chip)
     fused, plain = _lib.Context(0), _lib.Context(0)
     try:
         img, units, plants = synth.make_workload(seed=21, image_hw=(1100, 1200), n_base=20, templ=32, noisy_per_unit=2)
