@@ -51,6 +51,10 @@ DOT4_PEAK_TMACS = 314.6        # 256 CU x 4 SIMD x 32 lanes x 4 MAC x 2.4 GHz (v
 # cycles per SIMD: 1024 SIMDs x 2.4 GHz x 2048 op/cycle = 5.03 POPS.  `peak` below is that figure.
 I8_MFMA_PEAK_TOPS = 5000.0
 I8_MFMA_UBENCH_TOPS = 3944.0
+# tools/ubench/power (round 3): NOTHING but v_mfma_i32_16x16x64_i8, two waves per SIMD, every CU - 4870 TOP/s at 2.39 GHz on
+# all-zero operands, 3960 TOP/s at 2.00 GHz on random operands that change with every instruction (what a correlation of
+# white-noise bytes feeds the multipliers): the chip's power budget, not the issue rate, caps random-data int8 work there.
+I8_MFMA_RANDOM_OPERANDS_TOPS = 3960.0
 I8_OPS_PER_CLK = 1024 * 2048   # whole chip, per shader cycle
 PREWARM_SECONDS = float(os.environ.get("BENCH_PREWARM_S", "0.6"))   # untimed load before the W warm-up calls (clock ramp)
 CONFIGS = ("north_star", "cfg2", "cfg3", "cfg4", "cfg5")
@@ -147,7 +151,12 @@ def pmc_traffic(kernel_used, config, world, hits_only=False):
             table = json.load(f)
         key = "%s/%s/n%d%s" % ({2: "ncc_dot4_kernel", 3: "ncc_mfma_kernel"}.get(kernel_used, "?"), config, world,
                                "/hits_only" if hits_only else "")
-        return table.get(key)
+        if key in table:
+            return table[key]
+        # the other BASELINE configs: the dominant kernel of the workload's own PMC passes (tools/profile_workloads.sh):
+        # bytes of ONE launch of that kernel (a config with several size classes has several such launches per step)
+        wl = table.get("workload/%s" % config)
+        return wl["hbm_bytes_per_launch"] if isinstance(wl, dict) and world == 1 else None
     except Exception:  # noqa: BLE001
         return None
 
@@ -571,7 +580,11 @@ def main():
                     "frac": round(2.0 * tmacs / I8_MFMA_PEAK_TOPS, 4), "traffic": traffic,
                     "traffic_note": "HBM bytes of one full-image launch from the committed PMC passes (profiles/), not of this run",
                     "ubench_ceiling": I8_MFMA_UBENCH_TOPS,
-                    "frac_of_ubench_ceiling": round(2.0 * tmacs / I8_MFMA_UBENCH_TOPS, 4), "hbm": hbm}
+                    "frac_of_ubench_ceiling": round(2.0 * tmacs / I8_MFMA_UBENCH_TOPS, 4),
+                    "power_limited_ceiling": I8_MFMA_RANDOM_OPERANDS_TOPS,
+                    "power_limited_ceiling_note": "pure MFMA stream on random operands (tools/ubench/power): 2.0 GHz under the "
+                                                  "power budget instead of 2.4 GHz",
+                    "frac_of_power_limited_ceiling": round(2.0 * tmacs / I8_MFMA_RANDOM_OPERANDS_TOPS, 4), "hbm": hbm}
             if sclk:
                 peak_at_clk = I8_OPS_PER_CLK * sclk * 1e6 / 1e12
                 roof.update({"sclk_mhz_in_kernel": round(sclk, 1),
