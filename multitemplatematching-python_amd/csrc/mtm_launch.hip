@@ -524,23 +524,19 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_MFMA16) {
-        // uint16: two launches over the image's byte planes x [T_hi | T_lo] of 16 templates per work item.  The first
-        // (high bytes) stores its raw accumulators, the second (low bytes) reads them back in its epilogue and
-        // finishes the exact 16-bit correlation + normalisation there (kMfU16).
+        // uint16: ONE launch over the image's two byte planes (the "channels" of the launch) x [T_hi | T_lo] of 16 templates
+        // per work item; the high-byte partial sums stay in registers while the low-byte plane is walked, and the epilogue
+        // finishes the exact 16-bit correlation + normalisation (kMfU16, mtm_mfma.hip.h).
         const int n_all = (int)sc.members.size(), n_pad = sc.n_pad;
-        const int map_pitch = (int)round_up((size_t)ow, 4);
-        const long long raw_map = (long long)oh * map_pitch;
-        MTMC(c->raw16.ensure(sizeof(int) * (size_t)(2LL * n_pad * raw_map)));
         MfmaParams p{};
         p.pitch = img.u8_pitch;
         p.plane = img.u8_plane;
-        p.chans = 1;
+        p.chans = 2;                                            // byte planes: high, low
         p.h = h;
         p.w = w;
         p.oh = oh;
         p.ow = ow;
         p.nb = (w + 63) / 64;
-        p.n_list = 2 * n_pad;
         p.nseg = (ow + kMfSeg - 1) / kMfSeg;
         p.nyb = (oh + kMfRows - 1) / kMfRows;
         p.ntg = n_pad / 16;
@@ -551,34 +547,25 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cpr_dstep = 256 % p.cpr;
         p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = sc.group_bytes;
-        p.only_li = -1;
-        p.raw_map = raw_map;
-        p.raw_pitch = map_pitch;
-        p.raw_out = c->raw16.as<int>();
         int tg0 = 0;
         if (only_li >= 0) {                 // one template: just its group of 16
             tg0 = only_li / 16;
             p.ntg = 1;
-            p.raw_out += (size_t)32 * tg0 * raw_map;
         }
         p.n_work = p.nseg * p.nyb * p.ntg;
         const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
-                                                  (size_t)kMfRows * kMfEpiBytesPerWave) + 15) & ~(size_t)15;
+                                                  (size_t)kMfRows * kMfU16EpiBytesPerWave) + 15) & ~(size_t)15;
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
-        const size_t lds = (size_t)p.st_off + (size_t)kMfRows * kMfStatBytesPerWave;
+        size_t lds = (size_t)p.st_off;                          // (no statistics prefetch: the epilogue reads them from memory)
         const int grid = ((p.n_work + 7) / 8) * 8;
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
-        const uint8_t* planes = c->slot[c->cur].u8b.as<uint8_t>();
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * 2 * sc.group_bytes;
         const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16;
-        p.img = planes;                                         // high bytes: raw accumulators
+        p.img = c->slot[c->cur].u8b.as<uint8_t>();             // plane 0: high bytes, plane 1: low bytes
         p.kp_nseg = sc.kp_nseg;
         p.kp_blocks = sc.kp_nseg ? kp_blocks(h, sc.kp_nseg) : 0;
-        hipLaunchKernelGGL(mfma_raw_fn(false, sc.kp_nseg > 0), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
-                           c->sched.as<unsigned int>());
-        p.img = planes + (size_t)img.u8_plane;                  // low bytes: finish
         p.n_list = n_all - tg0 * 16;                            // list positions inside the kernel are relative to tg0
         p.only_li = only_li >= 0 ? only_li - tg0 * 16 : -1;
         const double* ts = c->tsum.as<double>() + sc.tsum_off;
@@ -592,11 +579,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
-        size_t lds2 = lds;
         const bool ext = c->ext_now && only_li < 0;      // fused global extremum (find_matches_impl checked the classes)
         if (ext) {
-            p.ext_off = (int)lds2;                        // 4 waves x 32 keys
-            lds2 += (size_t)kMfRows * 32 * sizeof(unsigned long long);
+            p.ext_off = (int)lds;                         // 4 waves x 32 keys
+            lds += (size_t)kMfRows * 32 * sizeof(unsigned long long);
             p.ext_best = c->counters.as<unsigned long long>();
             p.cand_on = 1;
             p.hits_only = 1;
@@ -606,7 +592,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         sel16.kp = sc.kp_nseg > 0;
         sel16.ext = ext;
         sel16.exact_div = c->exact_div != 0;
-        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds2, c->stream, p, td, tl_k, ap, st, maps,
+        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32 && !c->f32_exact_now) {

@@ -195,7 +195,17 @@ __device__ __forceinline__ void mfma_step(v4i (&acc)[MB][16], const v4i qa, cons
 
 #ifndef MTM_MFMA_NO_ASM
 #include "mtm_mfma_step_asm.inc"
+#else
+__device__ __forceinline__ void mfma_step_one_set(v4i (&acc)[2][16], const v4i qa, const v4i qb, const v4i (&a)[2]) {
+    mfma_step<2>(acc, qa, qb, a);
+}
 #endif
+// the K step of an instantiation: the uint16 kernel (three accumulator sets) takes the one-scratch-set form
+template <int METHOD_, int MB>
+__device__ __forceinline__ void mfma_kstep(v4i (&acc)[MB][16], const v4i qa, const v4i qb, const v4i (&a)[MB]) {
+    if constexpr (METHOD_ == 7 && MB == 2) mfma_step_one_set(acc, qa, qb, a);       // kMfU16
+    else mfma_step<MB>(acc, qa, qb, a);
+}
 
 // METHOD >= 0: single-channel image, method fixed at compile time.  METHOD < 0: generic (any channel
 // count, runtime method).
@@ -294,6 +304,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[mb][c] = v4i{0, 0, 0, 0};
+    // uint16 (kMfU16): the image's two byte planes are the two "channels" of ONE launch.  After the high-byte plane the
+    // work item holds a_hh = acc[0] (I_hi x T_hi) and a_hl = acc[1] (I_hi x T_lo); a_hh moves to this third set, a_hl
+    // becomes the start value of acc[0], which then collects I_lo x T_hi on top of it (the two middle terms of the 16-bit
+    // product carry the same weight, 256), and acc[1] restarts at zero for I_lo x T_lo.  Round 2 wrote a_hh / a_hl to
+    // memory in a launch of their own and read them back in the second: 4.3 GB of traffic for 135 MB of input.
+    v4i u16_hh[METHOD == kMfU16 ? 16 : 1];
 
     // per-template constants -> LDS (read back in the epilogue; the staging barriers below order it)
     MfTemplConst* tcl = reinterpret_cast<MfTemplConst*>(smem + p.tc_off);
@@ -386,6 +402,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     for (int c = 0; c < p.chans; ++c) {
         const uint8_t* plane = p.img + c * p.plane;
+        const int cpk = METHOD == kMfU16 ? 0 : c;        // channel of the A pack (uint16: both byte planes meet the same [T_hi | T_lo])
+        if constexpr (METHOD == kMfU16) {
+            if (c == 1) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    u16_hh[k] = acc[0][k];
+                    acc[0][k] = acc[1][k];
+                    acc[1][k] = v4i{0, 0, 0, 0};
+                }
+            }
+        }
         const int krows = RM ? p.rm_steps : (R2 ? p.h + MB - 1 : p.h);        // image rows a wave walks (K steps / nb)
         constexpr int kChunk = R2 ? kMfChunkR2 : kMfChunkH;
         v4i r2_prev = v4i{0, 0, 0, 0};      // R2: the A operand of the previous step (the int8 zero before template row 0)
@@ -513,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // ---- K loop over the segment stream (packed K, see MfmaParams): as below, but every lane group q walks
             // its own (row, segment) position - five VALU instructions of bookkeeping per step instead of scalar ones
             const int nseg = p.kp_nseg;
-            const uint8_t* aptr = apack_g + (RM ? (size_t)c * p.rm_cstride : (size_t)c * p.kp_blocks * 1024) +
+            const uint8_t* aptr = apack_g + (RM ? (size_t)cpk * p.rm_cstride : (size_t)cpk * p.kp_blocks * 1024) +
                                   (size_t)((cy0 * nseg) >> 2) * 1024;           // cy0 is a multiple of 64
             const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + j * 16;
             const int nsteps = (ch * nseg + 3) >> 2;
@@ -542,16 +569,16 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 MTM_KP_ADVANCE()
                 MTM_KP_LOAD(qa1, qb1, a1)
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_step<MB>(acc, qa0, qb0, a0);
+                mfma_kstep<METHOD, MB>(acc, qa0, qb0, a0);
                 __builtin_amdgcn_sched_barrier(0);
                 MTM_KP_ADVANCE()
                 MTM_KP_LOAD(qa0, qb0, a0)
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_step<MB>(acc, qa1, qb1, a1);
+                mfma_kstep<METHOD, MB>(acc, qa1, qb1, a1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ks < nsteps) {
-                mfma_step<MB>(acc, qa0, qb0, a0);
+                mfma_kstep<METHOD, MB>(acc, qa0, qb0, a0);
             }
 #undef MTM_KP_ADVANCE
 #undef MTM_KP_LOAD
@@ -562,8 +589,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             // register sets: the operands of the next step (2 LDS chunks + MB packed template rows)
             // are requested before the 16*MB MFMAs of the current step issue.  sched_barrier keeps
             // the compiler from sinking the requests below the MFMAs.
-            const uint8_t* aptr = apack_g + (RM ? (size_t)c * p.rm_cstride + (size_t)cy0 * p.nb * 1024     // + ks * 1024
-                                               : ((size_t)(c * p.h + cy0) * p.nb) * 1024);
+            const uint8_t* aptr = apack_g + (RM ? (size_t)cpk * p.rm_cstride + (size_t)cy0 * p.nb * 1024     // + ks * 1024
+                                               : ((size_t)(cpk * p.h + cy0) * p.nb) * 1024);
             const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
             const int nsteps = ch * p.nb;
             int nb_i = 0;                       // 64-tap block of the step last requested
@@ -607,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #ifdef MTM_PROBE_NO_MFMA   /* timing experiment: the loop skeleton without MFMAs and operand shifts */
 #define MTM_MF_STEP(QA, QB, A, K) acc[0][K] += QA + QB + A[0] + A[MB - 1];
 #else
-#define MTM_MF_STEP(QA, QB, A, K) mfma_step<MB>(acc, QA, QB, A);
+#define MTM_MF_STEP(QA, QB, A, K) mfma_kstep<METHOD, MB>(acc, QA, QB, A);
 #endif
             // hits-only launches: the MFMA main loop outranks the (short) epilogue of the co-resident work-group
             // (-0.9 % kernel time; with the maps written the long epilogue is the one that must not starve: +1 %)
@@ -1003,16 +1030,15 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
         }
     } else if constexpr (METHOD == kMfU16) {
-        // ---- uint16 finishing pass.  This work item holds a_lh = acc[0] (I_lo x T_hi) and a_ll = acc[1] (I_lo x T_lo)
-        // of templates 16 tg .. 16 tg + 15; a_hh / a_hl of the same templates were stored by the raw pass over the
-        // high-byte plane at list positions 32 tg + t and 32 tg + 16 + t.  With R_xy = a_xy + 128 S1_x + K_y
+        // ---- uint16 epilogue.  The work item holds, for templates 16 tg .. 16 tg + 15: a_hh = u16_hh (I_hi x T_hi),
+        // a_mid = acc[0] (I_hi x T_lo + I_lo x T_hi) and a_ll = acc[1] (I_lo x T_lo).  With R_xy = a_xy + 128 S1_x + K_y
         // (K_y = 128 sum(T_y) - 16384 A, S1_x the window sum of byte plane x):
         //   sum I*T = 65536 R_hh + 256 (R_hl + R_lh) + R_ll
-        //           = 65536 a_hh + 256 (a_hl + a_lh) + a_ll  +  32896 S1  +  257 (256 K_hi + K_lo)
+        //           = 65536 a_hh + 256 a_mid + a_ll  +  32896 S1  +  257 (256 K_hi + K_lo)
         // because 256 S1_hi + S1_lo = S1, the window sum of the 16-bit image the statistics pass provides - the byte
         // planes need no sums of their own.  Every term is an integer < 2^53: exact in float64 in any order.  Then the
-        // common normalisation (run-time method).  Four stages of 4 templates: the lanes with q == stage put both
-        // accumulators of their 4 templates into the wave's buffer (rows 0-3 / 4-7).
+        // common normalisation (run-time method).  Four stages of 4 templates: the lanes with q == stage put the three
+        // sets of their 4 templates into the wave's buffer (rows 0-3 / 4-7 / 8-11).
         __syncthreads();              // every wave is done reading the image tile: the buffers alias it
         const bool lane_on = y < p.oh && xq < p.ow;
         const int method = p.method;
@@ -1042,30 +1068,31 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
         unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
         if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
-        // the raw accumulators of the first pass are requested one template ahead (they do not depend on the LDS staging)
-        const int* rbase = p.raw_out + (size_t)(32 * tg) * p.raw_map + (size_t)y * p.raw_pitch + xq;
         const int n_here = min(16, p.n_list - tg * 16);
-        v4i hhn = v4i{0, 0, 0, 0}, hln = v4i{0, 0, 0, 0};
-        if (lane_on && n_here > 0) {
-            hhn = *reinterpret_cast<const v4i*>(rbase);                 // raw_pitch is a multiple of 4
-            hln = *reinterpret_cast<const v4i*>(rbase + 16 * p.raw_map);
-        }
+        // (this kernel's transposition buffer has 12 rows per wave - kMfU16EpiBytesPerWave - so that the three sets of a
+        // stage's four templates go through it together)
+        int* epi3 = reinterpret_cast<int*>(smem + wave * kMfU16EpiBytesPerWave);
 #pragma unroll 1
         for (int stage = 0; stage < 4; ++stage) {
+            if (4 * stage >= n_here) break;                                   // wave-uniform
             if (q == stage) {
-                int* dst = &epi[16 * j];
+                int* dst = &epi3[16 * j];
                 const int rot = mf_epi_rot(j);
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const int col = (c + rot) & 15;
-                    dst[0 * kMfEpiPitch + col] = acc[0][c].x;
-                    dst[1 * kMfEpiPitch + col] = acc[0][c].y;
-                    dst[2 * kMfEpiPitch + col] = acc[0][c].z;
-                    dst[3 * kMfEpiPitch + col] = acc[0][c].w;
-                    dst[4 * kMfEpiPitch + col] = acc[MB - 1][c].x;
-                    dst[5 * kMfEpiPitch + col] = acc[MB - 1][c].y;
-                    dst[6 * kMfEpiPitch + col] = acc[MB - 1][c].z;
-                    dst[7 * kMfEpiPitch + col] = acc[MB - 1][c].w;
+                    dst[0 * kMfEpiPitch + col] = u16_hh[c].x;
+                    dst[1 * kMfEpiPitch + col] = u16_hh[c].y;
+                    dst[2 * kMfEpiPitch + col] = u16_hh[c].z;
+                    dst[3 * kMfEpiPitch + col] = u16_hh[c].w;
+                    dst[4 * kMfEpiPitch + col] = acc[0][c].x;
+                    dst[5 * kMfEpiPitch + col] = acc[0][c].y;
+                    dst[6 * kMfEpiPitch + col] = acc[0][c].z;
+                    dst[7 * kMfEpiPitch + col] = acc[0][c].w;
+                    dst[8 * kMfEpiPitch + col] = acc[MB - 1][c].x;
+                    dst[9 * kMfEpiPitch + col] = acc[MB - 1][c].y;
+                    dst[10 * kMfEpiPitch + col] = acc[MB - 1][c].z;
+                    dst[11 * kMfEpiPitch + col] = acc[MB - 1][c].w;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1075,22 +1102,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 for (int e = 0; e < 4; ++e) {
                     const int lt = 4 * stage + e, li = tg * 16 + lt;
                     if (lt >= n_here) break;                                     // wave-uniform
-                    const v4i hh4 = hhn, hl4 = hln;
-                    if (lt + 1 < n_here) {
-                        hhn = *reinterpret_cast<const v4i*>(rbase + (size_t)(lt + 1) * p.raw_map);
-                        hln = *reinterpret_cast<const v4i*>(rbase + (size_t)(lt + 17) * p.raw_map);
-                    }
                     if (p.only_li >= 0 && li != p.only_li) continue;
                     const MfTemplConst T = tcl[lt];
-                    const v4i lh4 = *reinterpret_cast<const v4i*>(&epi[e * kMfEpiPitch + rd_off]);
-                    const v4i ll4 = *reinterpret_cast<const v4i*>(&epi[(4 + e) * kMfEpiPitch + rd_off]);
-                    const int a_lh[4] = {lh4.x, lh4.y, lh4.z, lh4.w}, a_ll[4] = {ll4.x, ll4.y, ll4.z, ll4.w};
-                    const int a_hh[4] = {hh4.x, hh4.y, hh4.z, hh4.w}, a_hl[4] = {hl4.x, hl4.y, hl4.z, hl4.w};
+                    const v4i hh4 = *reinterpret_cast<const v4i*>(&epi3[e * kMfEpiPitch + rd_off]);
+                    const v4i md4 = *reinterpret_cast<const v4i*>(&epi3[(4 + e) * kMfEpiPitch + rd_off]);
+                    const v4i ll4 = *reinterpret_cast<const v4i*>(&epi3[(8 + e) * kMfEpiPitch + rd_off]);
+                    const int a_hh[4] = {hh4.x, hh4.y, hh4.z, hh4.w}, a_md[4] = {md4.x, md4.y, md4.z, md4.w};
+                    const int a_ll[4] = {ll4.x, ll4.y, ll4.z, ll4.w};
                     float out[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const double mid = (double)a_hl[i] + (double)a_lh[i];
-                        const double a = fma(65536.0, (double)a_hh[i], fma(256.0, mid, (double)a_ll[i]));
+                        const double a = fma(65536.0, (double)a_hh[i], fma(256.0, (double)a_md[i], (double)a_ll[i]));
                         const double corr = a + (up1[i] + T.mfma_k);
                         out[i] = finish_rt<EXACT_DIV>(method, corr, us1[i], usum2[i], usq[i], ursq[i], T);
                     }

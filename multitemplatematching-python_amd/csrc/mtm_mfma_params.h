@@ -23,6 +23,7 @@ constexpr int kMfChunkR2 = 72;       // K steps per LDS tile of the two-row vari
 // conflicting, which costs nothing for 4-byte LDS stores.  Pitch = 4 (mod 8) dwords.
 constexpr int kMfEpiPitch = 260;
 constexpr int kMfEpiBytesPerWave = 8 * kMfEpiPitch * 4;
+constexpr int kMfU16EpiBytesPerWave = 12 * kMfEpiPitch * 4;     // uint16 kernel: three accumulator sets of 4 templates per stage
 // Window statistics of a wave's 256 pixels, prefetched to LDS by LDS-DMA while the image tile is
 // staged: [3 planes: S1, S2, sqrt][2 halves][64 lanes][2 doubles]; lane L owns pixels 4L..4L+3.
 constexpr int kMfStatPlaneBytes = 2 * 1024;                // one statistics plane of a wave's 256 pixels

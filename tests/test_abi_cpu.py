@@ -112,7 +112,8 @@ def test_score_kernel_does_not_spill_accumulators():
     instantiation whose register allocation tips over starts spilling around those steps - slow, and (seen once,
     DESIGN 4.1 "packed K") wrong.  No instantiation may have a scratch instruction between its first and its last
     MFMA; the one- and two-row instantiations keep their total scratch small (a few prologue / epilogue values), the
-    two-row headline variants have none at all; the three-row ones spill only on the rare paths behind the screen."""
+    two-row headline variants have none at all; the three-row ones spill only on the rare paths behind the screen, the
+    uint16 kernel (three sets as well) only in its epilogue."""
     import importlib.util
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("llvm-readelf not available")
@@ -125,7 +126,8 @@ def test_score_kernel_does_not_spill_accumulators():
     assert len(ks) >= 100
     in_loop = kr.loop_scratch_ops(mtm_build.LIB)
     assert len(in_loop) == len(ks) and not any(in_loop.values()), {k: v for k, v in in_loop.items() if v}
-    three_row = lambda k: "ncc_mfma_kernelILi3E" in k["name"]      # noqa: E731
+    # 192 accumulator registers: the three-row variants and the uint16 kernel (three partial-sum sets, METHOD 7)
+    three_row = lambda k: re.search(r"ncc_mfma_kernelILi(3E|2ELi7E)", k["name"]) is not None      # noqa: E731
     worst = max((k for k in ks if not three_row(k)), key=lambda k: k["scratch"])
     assert worst["scratch"] <= 200, worst
     assert all(k["scratch"] <= 640 for k in ks if three_row(k))
