@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtm_hip.so")
+# MTM_LIB_PATH: a differently built libmtm_hip.so (kernel timing experiments, tools/probes); never a fallback
+LIB_PATH = os.environ.get("MTM_LIB_PATH") or os.path.join(_HERE, "libmtm_hip.so")
 
 MTM_U8, MTM_F32, MTM_U16 = 0, 1, 2
 PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1

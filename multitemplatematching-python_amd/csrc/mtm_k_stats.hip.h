@@ -292,6 +292,167 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
     }
 }
 
+// The same for single-channel uint16 images, read as the two biased byte planes the MFMA kernel takes (hib, lob:
+// byte ^ 0x80).  Window sums of I fit uint32 when w * h * 65535 < 2^32 (the launcher's condition; differences modulo
+// 2^32 as above); the squares need uint64 prefixes - one more wave scan on the high halves' carries is avoided by
+// scanning the 64-bit values with shuffles.  Operation order of the float64 statistics as in vsum_stats_kernel.
+__device__ __forceinline__ unsigned long long wave_inclusive_scan_u64(unsigned long long x, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void stats_u16_kernel(const uint8_t* __restrict__ hib, const uint8_t* __restrict__ lob,
+                                                        int pitch, int h, int w, int oh, int ow, int owg, double inv_area,
+                                                        int num_type, int want_sq, int want_t, int want_sum2,
+                                                        double* __restrict__ t0, double* __restrict__ sum2,
+                                                        double* __restrict__ sq, int st_pitch,
+                                                        double* __restrict__ blk = nullptr, int blk_pitch = 0) {
+    __shared__ __attribute__((aligned(16))) uint32_t E1[kStatStrip + 4];
+    __shared__ __attribute__((aligned(16))) unsigned long long E2[kStatStrip + 4];
+    __shared__ uint32_t wsum1[4];
+    __shared__ unsigned long long wsum2[4];
+    const int x0 = blockIdx.x * owg, y0 = (int)blockIdx.y * kStatBand4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int L = owg + w - 1;
+    const bool ld = 4 * t < L && x0 + 4 * t + 3 < pitch;
+    const size_t base = (size_t)y0 * pitch + x0 + 4 * t;
+    uint32_t c1[4] = {0, 0, 0, 0};
+    unsigned long long c2[4] = {0, 0, 0, 0};
+    auto px = [](uint32_t vh, uint32_t vl, uint32_t (&b)[4]) {      // four pixels from the two biased byte quads
+        vh ^= 0x80808080u;
+        vl ^= 0x80808080u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = (((vh >> (8 * k)) & 255u) << 8) | ((vl >> (8 * k)) & 255u);
+    };
+    const uint32_t zero = 0x80808080u;                              // biased zero
+    for (int r0 = 0; r0 < h; r0 += 4) {
+        uint32_t vh[4], vl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t o = base + (size_t)min(r0 + i, h - 1) * pitch;
+            vh[i] = ld ? *reinterpret_cast<const uint32_t*>(hib + o) : zero;
+            vl[i] = ld ? *reinterpret_cast<const uint32_t*>(lob + o) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (r0 + i < h) {
+                uint32_t b[4];
+                px(vh[i], vl[i], b);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    c1[k] += b[k];
+                    c2[k] += (unsigned long long)(b[k] * b[k]);
+                }
+            }
+    }
+    const int y1 = min(y0 + kStatBand4, oh);
+    const int xg = x0 + 4 * t;
+    const bool out_on = 4 * t < owg && xg < st_pitch;
+    for (int y = y0; y < y1; ++y) {
+        uint32_t nh = zero, nl = zero, oh_ = zero, ol = zero;
+        if (y + 1 < y1 && ld) {
+            const size_t on = base + (size_t)(y - y0 + h) * pitch, oo = base + (size_t)(y - y0) * pitch;
+            nh = *reinterpret_cast<const uint32_t*>(hib + on);
+            nl = *reinterpret_cast<const uint32_t*>(lob + on);
+            oh_ = *reinterpret_cast<const uint32_t*>(hib + oo);
+            ol = *reinterpret_cast<const uint32_t*>(lob + oo);
+        }
+        const uint32_t a = c1[0] + c1[1] + c1[2] + c1[3];
+        const unsigned long long b = c2[0] + c2[1] + c2[2] + c2[3];
+        const uint32_t sa = wave_inclusive_scan_u32(a);
+        const unsigned long long sb = wave_inclusive_scan_u64(b, lane);
+        if (lane == 63) {
+            wsum1[wave] = sa;
+            wsum2[wave] = sb;
+        }
+        __syncthreads();
+        uint32_t oa = sa - a;
+        unsigned long long ob = sb - b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < wave) {
+                oa += wsum1[k];
+                ob += wsum2[k];
+            }
+        const uint32_t e1[4] = {oa, oa + c1[0], oa + c1[0] + c1[1], oa + c1[0] + c1[1] + c1[2]};
+        const unsigned long long e2[4] = {ob, ob + c2[0], ob + c2[0] + c2[1], ob + c2[0] + c2[1] + c2[2]};
+        *reinterpret_cast<uint4*>(&E1[4 * t]) = make_uint4(e1[0], e1[1], e1[2], e1[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) E2[4 * t + k] = e2[k];
+        if (t == 255) {
+            E1[kStatStrip] = oa + a;
+            E2[kStatStrip] = ob + b;
+        }
+        __syncthreads();
+        double blk_s1[4] = {0.0, 0.0, 0.0, 0.0}, blk_sq[4] = {0.0, 0.0, 0.0, 0.0};
+        if (out_on) {
+            double tt[4], ws2[4], sqv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t s1 = E1[4 * t + k + w] - e1[k];
+                const unsigned long long s2 = E2[4 * t + k + w] - e2[k];
+                tt[k] = (double)s1;
+                ws2[k] = (double)s2;
+                double wnd_mean2 = 0.0;
+                if (num_type == 1) wnd_mean2 = (tt[k] * tt[k]) * inv_area;
+                const double diff2 = fmax(ws2[k] - wnd_mean2, 0.0);
+                const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * ws2[k]);
+                sqv[k] = small ? 0.0 : sqrt(diff2);
+                blk_s1[k] = tt[k];
+                blk_sq[k] = sqv[k];
+            }
+            const size_t o = (size_t)y * st_pitch + xg;
+            if (want_t) {
+                *reinterpret_cast<double2*>(t0 + o) = make_double2(tt[0], tt[1]);
+                *reinterpret_cast<double2*>(t0 + o + 2) = make_double2(tt[2], tt[3]);
+            }
+            if (want_sum2) {
+                *reinterpret_cast<double2*>(sum2 + o) = make_double2(ws2[0], ws2[1]);
+                *reinterpret_cast<double2*>(sum2 + o + 2) = make_double2(ws2[2], ws2[3]);
+            }
+            if (want_sq) {
+                *reinterpret_cast<double2*>(sq + o) = make_double2(sqv[0], sqv[1]);
+                *reinterpret_cast<double2*>(sq + o + 2) = make_double2(sqv[2], sqv[3]);
+            }
+        }
+        if (blk != nullptr) {            // ranges over 16-pixel column blocks, as stats_u8_kernel writes them
+            double lo = INFINITY, hi = 0.0, sm = INFINITY;
+            if (out_on) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (xg + k < ow) {
+                        lo = fmin(lo, blk_s1[k]);
+                        hi = fmax(hi, blk_s1[k]);
+                        sm = fmin(sm, blk_sq[k]);
+                    }
+            }
+#pragma unroll
+            for (int off = 1; off <= 2; off <<= 1) {
+                lo = fmin(lo, __shfl_xor(lo, off));
+                hi = fmax(hi, __shfl_xor(hi, off));
+                sm = fmin(sm, __shfl_xor(sm, off));
+            }
+            if ((t & 3) == 0 && 4 * t < owg && (xg >> 4) < blk_pitch) {
+                double* o = blk + ((size_t)y * blk_pitch + (xg >> 4)) * 4;
+                *reinterpret_cast<double2*>(o) = make_double2(lo == INFINITY ? 0.0 : lo, hi);
+                *reinterpret_cast<double2*>(o + 2) = make_double2(sm, 0.0);
+            }
+        }
+        uint32_t bn[4], bo[4];
+        px(nh, nl, bn);
+        px(oh_, ol, bo);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c1[k] += bn[k] - bo[k];
+            c2[k] += (unsigned long long)(bn[k] * bn[k]) - (unsigned long long)(bo[k] * bo[k]);
+        }
+    }
+}
+
 // The same for CH interleaved-to-planar channels (RGB): per-channel window sums S1_c, the sum of squares
 // over all channels and the guarded sqrt of  sum_c S2_c - (sum_c S1_c^2) / A  (operation order of
 // vsum_stats_kernel, so both routes round alike; the squares of the channels are added as integers

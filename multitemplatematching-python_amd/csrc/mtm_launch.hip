@@ -132,6 +132,20 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
                            c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
                            ow, inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq,
                            st.pitch);
+    } else if (c->dtype == MTM_U16 && c->chans == 1 && w <= 768 && (double)w * h * 65535.0 < 4294967296.0 && c->fuse_stats) {
+        // single-channel uint16: the fused kernel over the two byte planes (the ones the MFMA kernel reads)
+        const int owg = stats_u8_owg(w);
+        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
+        const uint8_t* hib = c->slot[c->cur].u8b.as<uint8_t>();
+        double* blk = nullptr;
+        if (normed && rk == MTM_KERNEL_MFMA16) {    // statistic ranges per 16-pixel column block: the kernel's hits-only screen
+            st.blk_pitch = (st.pitch + 15) / 16;
+            MTMC(c->stats_blk.ensure(sizeof(double) * 4 * (size_t)st.blk_pitch * oh));
+            blk = c->stats_blk.as<double>();
+            st.blk = blk;
+        }
+        hipLaunchKernelGGL(stats_u16_kernel, gs, dim3(256), 0, c->stream, hib, hib + img.u8_plane, img.u8_pitch, h, w, oh, ow,
+                           owg, inv_area, num_type, normed ? 1 : 0, want_t, 1, tp[0], sum2, sq, st.pitch, blk, st.blk_pitch);
     } else {
         MTMC(ensure_f32_plane(c));
         hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
@@ -579,6 +593,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        p.cand_thr_lo = (double)c->cand_thr - 1e-6 * std::max(1.0, std::fabs((double)c->cand_thr));
+        p.screen_hi = std::min(p.cand_thr_lo, 0.999999) - 1e-6;
+        p.sq_floor = 0.99 / std::sqrt((double)w * (double)h);
+        p.screen_l1 = c->screen_l1;
         const bool ext = c->ext_now && only_li < 0;      // fused global extremum (find_matches_impl checked the classes)
         if (ext) {
             p.ext_off = (int)lds;                         // 4 waves x 32 keys

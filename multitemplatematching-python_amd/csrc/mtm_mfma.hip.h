@@ -638,7 +638,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #endif
             // hits-only launches: the MFMA main loop outranks the (short) epilogue of the co-resident work-group
             // (-0.9 % kernel time; with the maps written the long epilogue is the one that must not starve: +1 %)
+#ifdef MTM_PROBE_U16_NO_PRIO
+            if (p.hits_only && METHOD != kMfU16) __builtin_amdgcn_s_setprio(3);
+#else
             if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+#endif
             MTM_MF_LOAD(qa0, qb0, a0)            // step 0
             int ks = 0;
             for (; ks + 2 <= nsteps; ks += 2) {
@@ -1066,12 +1070,54 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             up1[i] = 32896.0 * us1[i];
             ursq[i] = (normed && usq[i] > 0.0) ? 1.0 / usq[i] : 0.0;
         }
+        const int n_here = min(16, p.n_list - tg * 16);
+        // ---- hits-only screen (TM_CCORR_NORMED / TM_CCOEFF_NORMED): the per-lane bound of the 8-bit tilings (see the
+        // row-multiplexed epilogue) on the three partial sums.  Lane (j, q) holds templates 4 q + e at the 16 outputs
+        // 16 j + c of the wave's row; 65536 a_hh + 256 a_mid + a_ll is formed in float32 (three conversions, two fused
+        // multiply-adds: at most 4 x 2^-24 x 66049 x 16384 h w = 258.1 h w away from the integer, whatever the partial
+        // sums are), its maximum over c per template bounds the numerator over the block together with the range of S1
+        // over the block, and the smallest sqrt statistic of the block bounds the denominator (StatPlanes::blk, written
+        // by stats_u16_kernel).  A wave none of whose lanes can hold a candidate skips the float64 epilogue: 0.53 of
+        // this kernel's 3.2 ms at 4K x 32 templates.
+        if (p.hits_only && p.screen_l1 && st.blk != nullptr && (EXT || p.cand_thr_lo >= 0.0) &&
+            (method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED)) {
+            float vmax[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const v4i hh = u16_hh[c], md = acc[0][c], ll = acc[MB - 1][c];
+                vmax[0] = fmaxf(vmax[0], fmaf(65536.0f, (float)hh.x, fmaf(256.0f, (float)md.x, (float)ll.x)));
+                vmax[1] = fmaxf(vmax[1], fmaf(65536.0f, (float)hh.y, fmaf(256.0f, (float)md.y, (float)ll.y)));
+                vmax[2] = fmaxf(vmax[2], fmaf(65536.0f, (float)hh.z, fmaf(256.0f, (float)md.z, (float)ll.z)));
+                vmax[3] = fmaxf(vmax[3], fmaf(65536.0f, (float)hh.w, fmaf(256.0f, (float)md.w, (float)ll.w)));
+            }
+            const int bj = min((x0 >> 4) + j, st.blk_pitch - 1);
+            const double* bp = st.blk + ((size_t)min(y, p.oh - 1) * st.blk_pitch + bj) * 4;
+            const double2 lohi = *reinterpret_cast<const double2*>(bp);
+            const double third = bp[2];
+            const double slack = 258.1 * (double)p.h * (double)p.w;
+            bool pass1 = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lt = 4 * q + e;
+                const bool live = lt < n_here && y < p.oh;
+                const MfTemplConst& T = tcl[min(lt, 15)];
+                const double thr_lo_e = EXT ? T.ext_thr_lo : p.cand_thr_lo;
+                const double hi = EXT ? fmin(thr_lo_e, 0.999999) - 1e-6 : p.screen_hi;
+                const double m = method == MTM_TM_CCOEFF_NORMED ? 32896.0 - T.mean[0] : 32896.0;
+                const double bound = (((double)vmax[e] + slack) + T.mfma_k) + fmax(m * lohi.x, m * lohi.y);
+                const bool could = T.all_ones != 0 || bound > hi * T.templ_norm * fmax(third, p.sq_floor);
+                pass1 = pass1 || (live && (thr_lo_e < 0.0 || could));
+            }
+            if (__builtin_amdgcn_ballot_w64(pass1) == 0ull) continue;      // wave-uniform; no work-group barrier below
+        }
         unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
         if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
-        const int n_here = min(16, p.n_list - tg * 16);
         // (this kernel's transposition buffer has 12 rows per wave - kMfU16EpiBytesPerWave - so that the three sets of a
         // stage's four templates go through it together)
         int* epi3 = reinterpret_cast<int*>(smem + wave * kMfU16EpiBytesPerWave);
+#ifdef MTM_PROBE_U16_NO_EPI     /* timing experiment: the K loops alone (wrong results) */
+        if (p.oh < 0)
+#endif
 #pragma unroll 1
         for (int stage = 0; stage < 4; ++stage) {
             if (4 * stage >= n_here) break;                                   // wave-uniform

@@ -1353,6 +1353,77 @@ def test_uint16_exact_path(mtm, ctx, coins):
     assert_hits_equal(got, hits_json(exp), tol=1e-6)
 
 
+def test_uint16_fused_window_statistics_bit_for_bit(mtm, monkeypatch):
+    """stats_u16_kernel (window sums from the two byte planes, uint32 / uint64 prefix scans in LDS) against the two-pass
+    float64 statistics it replaces: every method's score map bit for bit, on random pixels, on a saturated image (the
+    largest window sums: 255 x 255 windows of 65535, one below the uint32 limit of the kernel) and on strips wider than
+    one work-group."""
+    from MTM import _lib
+    rng = np.random.default_rng(4242)
+    wide = rng.integers(0, 65536, (70, 2300), dtype=np.uint16)
+    sat = np.full((300, 340), 65535, np.uint16)
+    sat[100:140, 50:90] = rng.integers(0, 65536, (40, 40), dtype=np.uint16)
+    cases = [(wide, [wide[5:37, 40:100].copy(), wide[20:52, 1500:1560].copy()]),
+             (sat, [np.ascontiguousarray(sat[20:275, 30:285])]),
+             (rng.integers(0, 65536, (130, 190), dtype=np.uint16), [rng.integers(0, 65536, (17, 23), dtype=np.uint16)])]
+    monkeypatch.setenv("MTM_FUSE_STATS", "0")
+    two_pass = _lib.Context()
+    monkeypatch.delenv("MTM_FUSE_STATS")
+    fused = _lib.Context()
+    try:
+        for img, ts in cases:
+            for method in range(6):
+                maps = []
+                for c_ in (fused, two_pass):
+                    c_.set_image(img)
+                    c_.set_templates([(t, None) for t in ts], method)
+                    shape = (img.shape[0] - ts[0].shape[0] + 1, img.shape[1] - ts[0].shape[1] + 1)
+                    maps.append([c_.score_map(i, shape) for i in range(len(ts))])
+                    assert c_.timing()["kernel_used"] == 4
+                for a, b in zip(*maps):
+                    assert np.array_equal(a, b, equal_nan=True), (img.shape, method)
+    finally:
+        fused.close()
+        two_pass.close()
+
+
+def test_uint16_hits_only_screen_changes_nothing(monkeypatch):
+    """The uint16 kernel's hits-only screen (float32 bound of the three partial sums per lane against the block ranges
+    of the statistics) only skips work: hit records with and without it are identical - bright and dim images, high and
+    low contrast (where the bound is too loose to skip anything), thresholds near the scores of planted copies, local
+    maxima and the fused global extremum."""
+    from MTM import _lib
+    monkeypatch.setenv("MTM_SCREEN_L1", "0")
+    plain = _lib.Context()
+    monkeypatch.delenv("MTM_SCREEN_L1")
+    screened = _lib.Context()
+    rng = np.random.default_rng(20260927)
+    try:
+        for c_ in (plain, screened):
+            c_.set_option(_lib.OPT_HITS_ONLY, 1)
+        n_rec = 0
+        for case, (mean, sigma) in enumerate([(32896, 9000), (1200, 300), (60000, 2500), (40000, 12), (500, 3)]):
+            base = rng.normal(mean, sigma, (150, 330))
+            base[40:80, 200:260] += sigma * np.linspace(-2, 2, 60)[None, :]          # structure
+            img = np.clip(np.rint(base), 0, 65535).astype(np.uint16)
+            ts = [img[10:34, 20:60].copy(), img[50:74, 210:250].copy(), img[100:124, 100:140].copy()]
+            noisy = np.clip(ts[0].astype(np.int64) + np.rint(rng.normal(0, sigma * 0.8, ts[0].shape)).astype(np.int64), 0, 65535)
+            ts.append(noisy.astype(np.uint16))
+            ts += [np.ascontiguousarray(t[::-1]) for t in ts[:2]]
+            tl = [(t, None) for t in ts]
+            for method in (3, 5):
+                for mode, thr in ((_lib.PEAKS_LOCAL, 0.5), (_lib.PEAKS_LOCAL, 0.9), (_lib.PEAKS_LOCAL, 0.05), (_lib.PEAKS_GLOBAL, 0.0)):
+                    a = screened.search(tl, img, method, mode, thr)
+                    b = plain.search(tl, img, method, mode, thr)
+                    assert screened.timing()["kernel_used"] == 4 and screened.timing()["hits_only"] == 1
+                    assert np.array_equal(a, b), (case, method, mode, thr, len(a), len(b))
+                    n_rec += len(a)
+        assert n_rec > 100
+    finally:
+        plain.close()
+        screened.close()
+
+
 def test_uint16_many_templates(mtm):
     """uint16 classes of more than 16 templates: several work-item groups ([T_hi | T_lo] of 16 templates each), a
     partly filled last group, two size classes; every map (one-template launches and last_score_map of a whole-set
