@@ -78,6 +78,23 @@ int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src,
     return MTM_OK;
 }
 
+// The same for rows r0 .. r1 - 1 of a single-channel uint16 image: the three byte planes and the float32 plane.
+int upload_rows_u16c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
+                      hipStream_t stream) {
+    const int cols = g.cols, nrows = r1 - r0;
+    if (nrows <= 0) return MTM_OK;
+    uint16_t* raw = sl.raw.as<uint16_t>() + (size_t)r0 * cols;
+    HIPC(hipMemcpy2DAsync(raw, (size_t)cols * 2, (const uint8_t*)src + (size_t)r0 * src_stride, (size_t)src_stride,
+                          (size_t)cols * 2, nrows, hipMemcpyHostToDevice, stream));
+    const size_t o = (size_t)r0 * g.pitch;
+    sl.f32_valid = true;
+    hipLaunchKernelGGL(planarize_u16_kernel, dim3((cols + 255) / 256, nrows), dim3(256), 0, stream, raw, cols, 1, 1, nrows, cols,
+                       sl.u8.as<uint8_t>() + o, sl.u8b.as<uint8_t>() + o, sl.u8b.as<uint8_t>() + g.u8_bytes + o, g.pitch,
+                       sl.f32.as<float>() + o, g.pitch, (long long)g.pitch * g.rows_alloc);
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
 // Upload one image into `sl` and build its planar padded planes on `stream`.  `src` has tightly
 // packed rows when `src_stride` == cols * chans * elem size or any larger stride.
 int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,

@@ -340,6 +340,8 @@ int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols,
                  int factor, SlotGeom* out);
 int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
                      hipStream_t stream, bool skip_f32);
+int upload_rows_u16c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
+                      hipStream_t stream);
 int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
                  int chans, int dtype, hipStream_t stream, int factor = 1);
 void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype);

@@ -310,12 +310,12 @@ __global__ __launch_bounds__(256) void stats_u16_kernel(const uint8_t* __restric
                                                         int num_type, int want_sq, int want_t, int want_sum2,
                                                         double* __restrict__ t0, double* __restrict__ sum2,
                                                         double* __restrict__ sq, int st_pitch,
-                                                        double* __restrict__ blk = nullptr, int blk_pitch = 0) {
+                                                        double* __restrict__ blk = nullptr, int blk_pitch = 0, int yb_off = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t E1[kStatStrip + 4];
     __shared__ __attribute__((aligned(16))) unsigned long long E2[kStatStrip + 4];
     __shared__ uint32_t wsum1[4];
     __shared__ unsigned long long wsum2[4];
-    const int x0 = blockIdx.x * owg, y0 = (int)blockIdx.y * kStatBand4;
+    const int x0 = blockIdx.x * owg, y0 = ((int)blockIdx.y + yb_off) * kStatBand4;   // yb_off: banded launches
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int L = owg + w - 1;
     const bool ld = 4 * t < L && x0 + 4 * t + 3 < pitch;

@@ -135,7 +135,8 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
     } else if (c->dtype == MTM_U16 && c->chans == 1 && w <= 768 && (double)w * h * 65535.0 < 4294967296.0 && c->fuse_stats) {
         // single-channel uint16: the fused kernel over the two byte planes (the ones the MFMA kernel reads)
         const int owg = stats_u8_owg(w);
-        const dim3 gs((ow + owg - 1) / owg, (oh + kStatBand4 - 1) / kStatBand4);
+        const int nsb = (oh + kStatBand4 - 1) / kStatBand4;
+        const int b1 = sb1 < 0 ? nsb : std::min(sb1, nsb);
         const uint8_t* hib = c->slot[c->cur].u8b.as<uint8_t>();
         double* blk = nullptr;
         if (normed && rk == MTM_KERNEL_MFMA16) {    // statistic ranges per 16-pixel column block: the kernel's hits-only screen
@@ -144,8 +145,12 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
             blk = c->stats_blk.as<double>();
             st.blk = blk;
         }
-        hipLaunchKernelGGL(stats_u16_kernel, gs, dim3(256), 0, c->stream, hib, hib + img.u8_plane, img.u8_pitch, h, w, oh, ow,
-                           owg, inv_area, num_type, normed ? 1 : 0, want_t, 1, tp[0], sum2, sq, st.pitch, blk, st.blk_pitch);
+        if (b1 > sb0) {
+            const dim3 gs((ow + owg - 1) / owg, b1 - sb0);
+            hipLaunchKernelGGL(stats_u16_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, hib,
+                               hib + img.u8_plane, img.u8_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, 1,
+                               tp[0], sum2, sq, st.pitch, blk, st.blk_pitch, sb0);
+        }
     } else {
         MTMC(ensure_f32_plane(c));
         hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
@@ -287,7 +292,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         c->ncc_ev.emplace_back(a, b);
     }
     auto& evp = c->ncc_ev[c->timing.ncc_launches];
-    hipStream_t ncc_s = (c->ncc_stream && kernel == MTM_KERNEL_MFMA) ? c->ncc_stream : c->stream;
+    hipStream_t ncc_s = (c->ncc_stream && (kernel == MTM_KERNEL_MFMA || kernel == MTM_KERNEL_MFMA16)) ? c->ncc_stream : c->stream;
     HIPC(hipEventRecord(evp.first, ncc_s));
 
     if (kernel == MTM_KERNEL_NAIVE) {
@@ -566,6 +571,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             tg0 = only_li / 16;
             p.ntg = 1;
         }
+        if (yb1 >= 0) {                     // banded launch: row blocks yb0 .. yb1 - 1
+            p.yb0 = yb0;
+            p.nyb = std::min(yb1, p.nyb) - yb0;
+        }
         p.n_work = p.nseg * p.nyb * p.ntg;
         const size_t lds_main = (std::max<size_t>((size_t)(std::min(h, kMfChunkH) + kMfRows - 1) * p.lds_pitch,
                                                   (size_t)kMfRows * kMfU16EpiBytesPerWave) + 15) & ~(size_t)15;
@@ -610,7 +619,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         sel16.kp = sc.kp_nseg > 0;
         sel16.ext = ext;
         sel16.exact_div = c->exact_div != 0;
-        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps,
+        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps,
                            c->sched.as<unsigned int>());
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32 && !c->f32_exact_now) {
@@ -827,17 +836,19 @@ int collect_ncc_time(mtm_ctx* c) {
 // kernel of band k)?  One unmasked single-channel uint8 size class on the MFMA kernel with the fused
 // statistics kernel; anything else uploads the image in one piece (still without a round trip to the host).
 bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
-    if (c->upload_bands.size() < 2 || a.dtype != MTM_U8 || a.chans != 1 || c->classes.size() != 1) return false;
+    const bool u16 = a.dtype == MTM_U16;
+    if (c->upload_bands.size() < 2 || (a.dtype != MTM_U8 && !u16) || a.chans != 1 || c->classes.size() != 1) return false;
     const SizeClass& sc = c->classes[0];
-    if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != MTM_KERNEL_MFMA) return false;
-    if (!(sc.w <= 768 && (double)sc.w * sc.h * 65025.0 < 4294967296.0)) return false;
+    if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != (u16 ? MTM_KERNEL_MFMA16 : MTM_KERNEL_MFMA))
+        return false;
+    if (!(sc.w <= 768 && (double)sc.w * sc.h * (u16 ? 65535.0 : 65025.0) < 4294967296.0)) return false;   // the fused statistics
     if (!((size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256)) return false;
     // A band's score launch must still fill the chip: two work-groups per CU are resident, and a launch of fewer than a
     // couple of such generations runs at the latency of its last one.  1080p x 8 templates is 512 work items in all -
     // banded 0.26 ms per call (two launches of 55 us for 62 us of work), in one piece 0.22 ms.
     const int oh = a.rows - sc.h + 1, ow = a.cols - sc.w + 1, n = (int)sc.members.size();
-    const int rows_per_item = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);
-    const int tg = sc.rm_R > 0 ? 1 : (n + (sc.r2 ? 16 : 32) - 1) / (sc.r2 ? 16 : 32);
+    const int rows_per_item = u16 ? kMfRows : sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);
+    const int tg = u16 ? (n + 15) / 16 : sc.rm_R > 0 ? 1 : (n + (sc.r2 ? 16 : 32) - 1) / (sc.r2 ? 16 : 32);
     const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + rows_per_item - 1) / rows_per_item) * tg;
     const int cus = c->n_cus > 0 ? c->n_cus : 256;
     return (double)items * c->upload_bands[0] >= c->band_min_fill * (2.0 * cus);      // MTM_BAND_MIN_FILL (default 2; 0: always band)
@@ -853,7 +864,8 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     MTMC(ensure_copy_stream(c));
     mtm_ctx::ImageSlot& sl = c->slot[c->cur];
     SlotGeom g{};
-    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, MTM_U8, c->copy_stream, 1, &g));
+    const bool u16 = a.dtype == MTM_U16;
+    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, c->copy_stream, 1, &g));
     const int nb = (int)c->upload_bands.size();
     while ((int)c->band_ev.size() < nb) {
         hipEvent_t e;
@@ -861,7 +873,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         c->band_ev.push_back(e);
     }
     const int h = sc.h, oh = a.rows - h + 1;
-    const int RB = sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
+    const int RB = u16 ? kMfRows : sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
     int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
     bool used2 = false;
@@ -874,7 +886,10 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         const bool last = k == nb - 1;
         int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
         if (r1 <= r_done) continue;
-        MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
+        if (u16)
+            MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream));
+        else
+            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
         r_done = r1;
         const int avail = r1 - h + 1;                            // output rows whose windows are complete
         const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);

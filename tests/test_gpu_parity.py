@@ -565,7 +565,8 @@ def test_cfg4_full_list_and_eight_way_shards(mtm):
 def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
     """mtm_find_matches_image == mtm_set_image + mtm_find_matches, whatever the band layout: plain and
     row-multiplexed classes (band boundaries fall inside 8R-row blocks), hits-only and map mode, both peak modes,
-    and the layouts that upload in one piece (several size classes, RGB, uint16, masks)."""
+    single-channel uint16 (byte-plane kernel), and the layouts that upload in one piece (several size classes, RGB,
+    masks)."""
     from MTM import _lib
     monkeypatch.setenv("MTM_UPLOAD_BANDS", bands)
     monkeypatch.setenv("MTM_BAND_MIN_FILL", "0")      # band even these small images (by default a band must fill the chip)
@@ -582,7 +583,8 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
             (img, [(u[1], None) for u in units[:3]] + [(np.ascontiguousarray(units[4][1][:20, :28]), None)], 1, 0.3),   # two classes
             (rgb_img, [(u[1], None) for u in rgb_units], 5, 0.5),
             (msk_img, [(u[1], u[2]) for u in msk_units], 3, 0.9),
-            (img16, [(u[1].astype(np.uint16) * 200 + 7, None) for u in units[:4]], 5, 0.5),
+            (img16, [(u[1].astype(np.uint16) * 200 + 7, None) for u in units[:4]], 5, 0.5),   # uint16 kernel, banded as well
+            (img16, [(u[1].astype(np.uint16) * 200 + 7, None) for u in units], 3, 0.8),       # two groups of 16 templates
         ]
         for honly in (1, 0):
             fused.set_option(_lib.OPT_HITS_ONLY, honly)
