@@ -61,7 +61,9 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         }
         c->have_image = true;
     }
+    host_trace(c, 1);
     MTMC(place_templates(c));
+    host_trace(c, 2);
     if (up) {
         banded = banded_ok(c, *up);
         if (!banded) {
@@ -180,6 +182,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         MTMC(c->chash.ensure(hsz * (sizeof(unsigned long long) + sizeof(int))));
     }
 
+    host_trace(c, 3);
     HIPC(hipEventRecord(c->ev[0], c->stream));
     if (banded) {
         const int rc = run_score_banded(c, *up);
@@ -192,6 +195,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         MTMC(run_score_all(c));
     }
     HIPC(hipEventRecord(c->ev[1], c->stream));
+    host_trace(c, 9);
     c->cand_on = false;
     // stream mode: the kernels of this image are on their way - start the upload of the next one now.
     // (Not later: the device-to-host copy of the hit records below lands in pageable memory, which
@@ -310,6 +314,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 return MTM_E_INVALID;
             }
             HIPC(hipStreamSynchronize(c->stream));
+            host_trace(c, 10);
             const uint8_t* land = static_cast<const uint8_t*>(c->pinned);
             unsigned long long ncand = 0;
             std::memcpy(&ncand, land, sizeof(ncand));
@@ -521,7 +526,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
         }
         // deterministic order: template, then descending quality, then row-major position
+        host_trace(c, 11);
         sort_hits(hits, mode_min);
+        host_trace(c, 12);
     }
     HIPC(hipEventSynchronize(c->ev[2]));       // already complete: every path above synchronised the stream
     HIPC(hipEventElapsedTime(&c->timing.score_ms, c->ev[0], c->ev[1]));
@@ -608,9 +615,12 @@ int mtm_find_matches_image(mtm_ctx* c, const void* px, int rows, int cols, int c
         set_error("mtm_find_matches_image: null context");
         return MTM_E_INVALID;
     }
+    host_trace(c, 0);
     MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image"));
     const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
-    return find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr, &up);
+    const int rc = find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr, &up);
+    host_trace(c, 15);
+    return rc;
 }
 
 int mtm_find_matches_next(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,

@@ -1,5 +1,6 @@
 // libmtm_hip.so - the context: creation, options, the device copies of an image (upload, layout conversion).
 // gfx950 (MI355X / CDNA4) only; built by multitemplatematching-python_amd/build.py.
+#include <cstdio>
 #include "mtm_ctx.h"
 
 using namespace mtm;
@@ -265,6 +266,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
@@ -293,6 +295,16 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
 
 void mtm_ctx_destroy(mtm_ctx* c) {
     if (!c) return;
+    if (c->host_trace) {
+        static const char* kPhase[16] = {"entry", "args checked", "templates placed", "call set up", "band 0 copy queued",
+                                         "band 0 layout + statistics queued", "band 0 score queued", "last band copy queued",
+                                         "last band score queued", "score pass queued", "stream synchronised", "hits verified",
+                                         "hits sorted", "", "", "return"};
+        for (int k = 0; k < 16; ++k)
+            if (c->trace_n[k] > 0)
+                std::fprintf(stderr, "[mtm host trace] %-36s %9.1f us after entry (mean of %lld)\n", kPhase[k],
+                             c->trace_acc[k] / (double)c->trace_n[k], c->trace_n[k]);
+    }
     (void)hipSetDevice(c->device);
     mtm_comm_destroy(c);
     (void)hipStreamSynchronize(c->stream);

@@ -204,6 +204,11 @@ struct mtm_ctx {
     hipEvent_t stream2_done = nullptr;
     std::vector<hipEvent_t> band_ev;
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
+    // MTM_HOST_TRACE=1: host time stamps at the phases of a fused call, averaged and printed when the context is destroyed
+    bool host_trace = false;
+    double trace_acc[16] = {0};
+    long long trace_n[16] = {0};
+    double trace_t0 = 0.0;
     double band_min_fill = 2.0;                     // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work
                                                     // items fill the resident work-group slots this many times (banded_ok)
 
@@ -281,6 +286,18 @@ struct mtm_ctx {
 };
 
 namespace mtmi {
+
+inline double host_now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// phase `k` of the current call reached (k = 0: the call starts)
+inline void host_trace(mtm_ctx* c, int k) {
+    if (!c->host_trace) return;
+    const double t = host_now_us();
+    if (k == 0) c->trace_t0 = t;
+    c->trace_acc[k] += t - c->trace_t0;
+    ++c->trace_n[k];
+}
 
 inline ImageDev image_dev(const mtm_ctx* c) {
     ImageDev d;

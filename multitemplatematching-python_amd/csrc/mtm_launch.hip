@@ -891,6 +891,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         else
             MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
         r_done = r1;
+        host_trace(c, k == 0 ? 4 : 7);                           // the band's copy call returned
         const int avail = r1 - h + 1;                            // output rows whose windows are complete
         const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);
         StatPlanes st;
@@ -901,6 +902,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         sb_done = sb1;
         HIPC(hipEventRecord(c->band_ev[(size_t)k], c->copy_stream));
         (void)hipStreamQuery(c->copy_stream);                    // submit now (the runtime batches commands)
+        if (k == 0) host_trace(c, 5);                            // layout conversion + statistics of band 0 submitted
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
         if (yb1 > yb_done) {
             hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
@@ -910,6 +912,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
             c->ncc_stream = nullptr;
             MTMC(rc2);
             (void)hipStreamQuery(s);
+            host_trace(c, k == 0 ? 6 : 8);                       // the band's score launch is submitted
             used2 = used2 || s == c->stream2;
             ++n_launch;
             yb_done = yb1;
