@@ -41,13 +41,15 @@ def NMS(listHit: Sequence[Hit], scoreThreshold: float = 0.5, sortAscending: bool
     winning ties (:61-69); difference scores are suppressed on ``1 - score`` against ``1 - scoreThreshold``
     computed on the caller's scalar types (:73-75).
     """
+    if len(listHit) <= 1:
+        return listHit[:]               # a copy of whatever sequence type came in (MTM/NMS.py:53-55)
     hits = list(listHit)
-    if len(hits) <= 1:
-        return hits
     scores = [h[2] for h in hits]
     if N_object == 1:
-        s = np.asarray(scores, dtype=np.float64)        # exact for float32 and python floats alike
-        return [hits[int(np.argmin(s) if sortAscending else np.argmax(s))]]
+        # python's min() / max() as in the reference (:61-69): the first of equal scores, and a NaN score is only ever
+        # selected when it comes first (every comparison with it is False)
+        pick = min if sortAscending else max
+        return [pick(hits, key=lambda hit: hit[2])]
     if sortAscending:
         quality, threshold = [1 - s for s in scores], 1 - scoreThreshold
     else:

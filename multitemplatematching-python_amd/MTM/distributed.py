@@ -70,6 +70,9 @@ def _send(sock, payload: bytes):
     sock.sendall(struct.pack("<q", len(payload)) + payload)
 
 
+_MAX_MESSAGE = 1 << 30          # bytes; a hit list of 2^25 records - anything longer is not one of ours
+
+
 def _recv(sock) -> bytes:
     def exactly(n):
         buf = bytearray()
@@ -80,6 +83,8 @@ def _recv(sock) -> bytes:
             buf += part
         return bytes(buf)
     (n,) = struct.unpack("<q", exactly(8))
+    if not 0 <= n <= _MAX_MESSAGE:
+        raise ConnectionError("MTM TcpStore: implausible message length %d" % n)
     return exactly(n)
 
 
@@ -89,8 +94,13 @@ class TcpStore:
     Address and port default to MASTER_ADDR / MTM_STORE_PORT (else MASTER_PORT + 1), the variables every
     launcher (torch.distributed.run, mpirun wrappers, srun) already exports."""
 
-    def __init__(self, rank, world_size, addr=None, port=None, timeout=120.0):
+    def __init__(self, rank, world_size, addr=None, port=None, timeout=120.0, collective_timeout=None):
+        """timeout: the rendezvous (listen / connect / announce).  collective_timeout: how long a later broadcast or
+        allgather may wait for the slowest rank - None (default, also MTM_STORE_TIMEOUT unset) waits for ever, as a rank
+        that is behind (warm-up, disk) is not an error; MTM_STORE_TIMEOUT=<seconds> or the argument bounds it."""
         self.rank, self.world_size = int(rank), int(world_size)
+        if collective_timeout is None and os.environ.get("MTM_STORE_TIMEOUT"):
+            collective_timeout = float(os.environ["MTM_STORE_TIMEOUT"])
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         if port is None:
             port = int(os.environ.get("MTM_STORE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
@@ -110,9 +120,15 @@ class TcpStore:
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     conn.settimeout(timeout)
                     (r,) = struct.unpack("<i", _recv(conn))
+                    if not 1 <= r < self.world_size or r in self.peers:
+                        conn.close()
+                        raise ConnectionError("MTM TcpStore: a peer announced rank %d (world size %d, ranks seen %s)"
+                                              % (r, self.world_size, sorted(self.peers)))
                     self.peers[r] = conn
             finally:
                 srv.close()
+            for conn in self.peers.values():
+                conn.settimeout(collective_timeout)
         else:
             deadline = time.time() + timeout
             while True:
@@ -125,6 +141,7 @@ class TcpStore:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             _send(s, struct.pack("<i", self.rank))
+            s.settimeout(collective_timeout)
             self.sock = s
 
     def broadcast(self, payload=None) -> bytes:

@@ -115,13 +115,14 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     }
     if (c->f32_exact_now) fused = false;            // the float64 kernel writes maps and lists no candidates
     // fused global extremum (cv2.minMaxLoc inside the score kernel): every class on the 1- or 3-channel MFMA kernel
-    // (plain, two-row or row-multiplexed; binary masks with the reciprocal normalisation), the uint16 byte-plane passes
+    // (plain, two-row, row-multiplexed or in slabs - there in slab_combine_kernel; binary masks with the reciprocal
+    // normalisation), the uint16 byte-plane kernel
     // or the float32 kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
     if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3) &&
         !c->f32_exact_now) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
-            ok = ok && ((resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() &&
+            ok = ok && ((resolved_kernel(c, sc) == MTM_KERNEL_MFMA &&
                          (!sc.masked || (!c->exact_div && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED))) ||
                         resolved_kernel(c, sc) == MTM_KERNEL_MFMA16 || resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32);
         if (ok) {

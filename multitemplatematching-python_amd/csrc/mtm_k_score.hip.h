@@ -41,16 +41,36 @@ __global__ __launch_bounds__(256) void slab_combine_kernel(SlabParams p, const T
     if (only_li >= 0 && li != only_li) return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= p.ow || y >= p.oh) return;
+    const bool on = x < p.ow && y < p.oh;
+    if (!on && !p.ext_on) return;
     const TemplDev T = td[tlist[li]];
-    const size_t o = (size_t)li * p.raw_map + (size_t)y * p.pitch + x;
-    long long a = 0;
-    for (int k = 0; k < p.n_slabs; ++k) a += (long long)p.raw[(size_t)k * p.raw_slab + o];
-    const size_t sidx = (size_t)y * st.pitch + x;
-    double s1 = 0.0;
-    for (int c = 0; c < p.chans; ++c) s1 += st.t[c][sidx];
-    const double corr = ((double)a + 128.0 * s1) + T.mfma_k;
-    const float out = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
+    float out = NAN;
+    if (on) {
+        const size_t o = (size_t)li * p.raw_map + (size_t)y * p.pitch + x;
+        long long a = 0;
+        for (int k = 0; k < p.n_slabs; ++k) a += (long long)p.raw[(size_t)k * p.raw_slab + o];
+        const size_t sidx = (size_t)y * st.pitch + x;
+        double s1 = 0.0;
+        for (int c = 0; c < p.chans; ++c) s1 += st.t[c][sidx];
+        const double corr = ((double)a + 128.0 * s1) + T.mfma_k;
+        out = finish_unmasked(p.method, corr, st, sidx, T, p.chans);
+    }
+    if (p.ext_on) {
+        // cv2.minMaxLoc inside the combine pass: the key of extremum_kernel (NaN never wins, first occurrence in row-major
+        // order wins ties), one atomic per wave
+        unsigned long long key = 0ull;
+        if (on && out == out) {
+            const uint32_t ord = mf_float_order(out);
+            key = ((unsigned long long)(p.cand_min ? ~ord : ord) << 32) | (0xFFFFFFFFu - (uint32_t)(y * p.ow + x));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long other = __shfl_down(key, off);
+            key = other > key ? other : key;
+        }
+        if ((threadIdx.x & 63) == 0 && key) atomicMax(&p.ext_best[2 * tlist[li] + p.cand_min], key);
+        return;
+    }
     if (p.cand_on) {
         mtm_hit hrec;
         hrec.templ_idx = tlist[li];

@@ -386,6 +386,12 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         q.cand_counter = c->cands.as<unsigned long long>();
         q.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         q.hits_only = (q.cand_on && c->hits_only_now) ? 1 : 0;
+        if (c->ext_now && only_li < 0) {              // fused global extremum: keys instead of maps / candidates
+            q.ext_on = 1;
+            q.ext_best = c->counters.as<unsigned long long>();
+            q.cand_on = 0;
+            q.hits_only = 1;
+        }
         hipLaunchKernelGGL(slab_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q, td,
                            c->tlist.as<int>() + sc.tlist_off, st, maps, only_li);
         c->timing.kernel_used = MTM_KERNEL_MFMA;

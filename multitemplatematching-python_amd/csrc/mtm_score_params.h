@@ -49,6 +49,8 @@ struct SlabParams {
     int oh, ow, pitch;
     int n_list;
     int method;
+    int ext_on, ext_pad_;            // fused global extremum (N_object == 1): keys to ext_best, no maps, no candidates
+    unsigned long long* ext_best;    // [2 * template + cand_min], as the score kernels' EXT epilogues
 };
 
 }  // namespace mtm

@@ -140,3 +140,36 @@ def test_tcp_store_three_ranks():
     for rank, uid, lens, heads, parts2 in res:
         assert uid == b"id-from-rank-0" * 9 and lens == [3, 1003, 2003] and heads == [b"\x00", b"\x01", b"\x02"]
         assert parts2 == [b"", b"", b""]
+
+
+def _bad_rank_worker(port):
+    sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
+    from MTM.distributed import TcpStore
+    try:
+        TcpStore(5, 2, addr="127.0.0.1", port=port, timeout=20)     # announces rank 5 in a world of 2
+    except Exception:
+        pass
+
+
+def test_tcp_store_rejects_a_rank_out_of_range():
+    """A peer announcing a rank outside 1 .. world_size - 1 (or one already seen) fails the rendezvous on rank 0 at
+    accept time, not with a KeyError in a later collective; an implausible length prefix is refused as well."""
+    import multiprocessing as mp
+    import socket
+    import struct
+    from MTM.distributed import TcpStore, _recv
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    p = ctx.Process(target=_bad_rank_worker, args=(port,))
+    p.start()
+    with pytest.raises(ConnectionError, match="announced rank 5"):
+        TcpStore(0, 2, addr="127.0.0.1", port=port, timeout=30)
+    p.join(timeout=60)
+    a, b = socket.socketpair()
+    try:
+        a.sendall(struct.pack("<q", 1 << 40))
+        with pytest.raises(ConnectionError, match="implausible message length"):
+            _recv(b)
+    finally:
+        a.close()
+        b.close()

@@ -963,6 +963,22 @@ def test_large_templates_as_slabs_on_mfma(mtm, ctx):
         exp = O.match_templates(lt, im, method=5, score_threshold=0.5)
         assert_hits_equal(canon(mtm.matchTemplates(lt, im, method=5, score_threshold=0.5)), canon(exp), tol=1e-5)
         assert mtm.findMatches(lt, im, N_object=1) == [h for h in mtm.findMatches(lt, im, N_object=1, devices=[0, 0])]
+        # N_object == 1: the extremum comes out of slab_combine_kernel (no maps, no extremum_kernel) - the record of the
+        # maps + extremum_kernel route and the oracle's, maxima and minima
+        for method in (5, 1, 2):
+            fused = mtm.findMatches(lt, im, method=method, N_object=1)
+            tm = ctx.timing()
+            assert tm["hits_only"] == 1 and tm["kernel_used"] == 3, tm
+            ctx.set_option(_lib.OPT_HITS_ONLY, 0)
+            try:
+                via_maps = mtm.findMatches(lt, im, method=method, N_object=1)
+                assert ctx.timing()["hits_only"] == 0
+            finally:
+                ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+            assert fused == via_maps and len(fused) == len(lt), method
+            if method != 2:
+                exp1 = O.find_matches(lt, im, method=method, N_object=1)
+                assert_hits_equal(hits_json(fused), hits_json(exp1), tol=1e-5, ordered=False)
     # maps materialised == hits only
     ctx.set_option(_lib.OPT_HITS_ONLY, 0)
     try:

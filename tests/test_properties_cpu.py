@@ -34,6 +34,22 @@ def test_nms_equals_oracle(MTM, items, thr, overlap, ascending, n_object):
     assert [(h[0], tuple(h[1]), float(h[2])) for h in got] == [(h[0], tuple(h[1]), float(h[2])) for h in exp]
 
 
+def test_nms_trivial_cases_follow_the_reference(MTM):
+    """MTM/NMS.py:53-55,61-69: a list of at most one hit comes back as a copy OF ITS TYPE (listHit[:]); N_object == 1
+    picks with python's min() / max() - first of equal scores, and a NaN only when it comes first."""
+    one = (("a", (1, 2, 3, 4), np.float32(0.1)),)
+    got = MTM.NMS(one, 0.5)
+    assert type(got) is tuple and got == one                      # unthresholded copy, same sequence type
+    assert MTM.NMS([], 0.5) == [] and MTM.NMS((), 0.5) == ()
+    nan = float("nan")
+    hits = [("a", (0, 0, 5, 5), 0.3), ("b", (9, 9, 5, 5), nan), ("c", (20, 20, 5, 5), 0.8), ("d", (40, 40, 5, 5), 0.8)]
+    assert MTM.NMS(hits, 0.5, N_object=1) == [hits[2]] == O.NMS(hits, 0.5, N_object=1)
+    assert MTM.NMS(hits, 0.5, sortAscending=True, N_object=1) == [hits[0]]
+    first_nan = [hits[1]] + hits[2:]
+    got = MTM.NMS(first_nan, 0.5, N_object=1)
+    assert len(got) == 1 and got[0][0] == "b"                     # max() never replaces a leading NaN
+
+
 @settings(max_examples=40, **COMMON)
 @given(st.integers(0, 2 ** 31), st.integers(64, 3000))
 def test_nms_dense_grid_path(MTM, seed, n):
