@@ -202,6 +202,12 @@ struct mtm_ctx {
     int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
     int copy_prio = 1;                      // MTM_COPY_PRIO: 1 = the copy stream gets the highest stream priority
     hipEvent_t stream2_done = nullptr;
+    // side streams of a slab class: its raw launches are independent and (few templates, small images) far too small to
+    // fill the chip one at a time
+    std::vector<hipStream_t> slab_streams;
+    std::vector<hipEvent_t> slab_done;
+    hipEvent_t slab_fork = nullptr;
+    int slab_concurrency = 4;               // MTM_SLAB_STREAMS (1: one after another on the main stream)
     std::vector<hipEvent_t> band_ev;
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
     // MTM_HOST_TRACE=1: host time stamps at the phases of a fused call, averaged and printed when the context is destroyed

@@ -312,9 +312,35 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         constexpr int kSchedWords = 1 + 4096;
         MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
         const bool rmr = sc.slab_R > 0;
+        // The slabs' launches are independent.  One of them is (output rows / 8R) x (columns / 256) work items - 91 for the
+        // reference's own benchmark shape (2048^2 image, one 414 x 400 template: four slabs), against 512 resident
+        // work-group slots: launches that do not fill the chip twice over run side by side on up to slab_concurrency
+        // streams, forked from and joined into the score stream.
+        int n_side = 1;
+        {
+            const int rows_per_item = rmr ? 8 * sc.slab_R : kMfRows;
+            const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + rows_per_item - 1) / rows_per_item) *
+                                    (rmr ? 1 : (n_all + 31) / 32);
+            const int cus = c->n_cus > 0 ? c->n_cus : 256;
+            if (items < 4LL * cus) n_side = (int)std::min<long long>(std::min(S, c->slab_concurrency), (4LL * cus + items - 1) / items);
+        }
+        if (n_side > 1) {
+            while ((int)c->slab_streams.size() < n_side) {
+                hipStream_t s2;
+                hipEvent_t e2;
+                HIPC(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+                HIPC(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+                c->slab_streams.push_back(s2);
+                c->slab_done.push_back(e2);
+            }
+            if (!c->slab_fork) HIPC(hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
+            HIPC(hipEventRecord(c->slab_fork, ncc_s));
+            for (int i = 0; i < n_side; ++i) HIPC(hipStreamWaitEvent(c->slab_streams[(size_t)i], c->slab_fork, 0));
+        }
         for (int k = 0; k < S; ++k) {
             const SizeClass::Slab& sl = sc.slabs[(size_t)k];
             const int hs = sl.r1 - sl.r0, ws = sl.c1 - sl.c0;
+            hipStream_t slab_s = n_side > 1 ? c->slab_streams[(size_t)(k % n_side)] : ncc_s;
             MfmaParams p{};
             p.img = c->slot[c->cur].u8b.as<uint8_t>() + (size_t)sl.ch * img.u8_plane + (size_t)sl.r0 * img.u8_pitch + sl.c0;
             p.pitch = img.u8_pitch;
@@ -363,8 +389,12 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const size_t lds = (size_t)p.st_off + (rmr ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);
             const int grid = ((p.n_work + 7) / 8) * 8;
             const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
-            hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, c->stream, p, td,
+            hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, slab_s, p, td,
                                c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+        }
+        for (int i = 0; i < n_side && n_side > 1; ++i) {
+            HIPC(hipEventRecord(c->slab_done[(size_t)i], c->slab_streams[(size_t)i]));
+            HIPC(hipStreamWaitEvent(ncc_s, c->slab_done[(size_t)i], 0));
         }
         SlabParams q{};
         q.raw = c->slab_raw.as<int>();
