@@ -267,6 +267,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
+    if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));
     if (const char* v = std::getenv("MTM_SLAB_STREAMS")) c->slab_concurrency = std::max(1, std::min(8, std::atoi(v)));
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
@@ -322,6 +323,15 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
     for (hipEvent_t e : c->band_ev) (void)hipEventDestroy(e);
     if (c->stream2_done) (void)hipEventDestroy(c->stream2_done);
+    if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
+    for (auto& L : c->lanes) {
+        if (L.stream) {
+            (void)hipStreamSynchronize(L.stream);
+            (void)hipStreamDestroy(L.stream);
+        }
+        if (L.done) (void)hipEventDestroy(L.done);
+        for (DevBuf* b : {&L.stats, &L.stats_rsq, &L.stats_blk, &L.hs1, &L.hs2, &L.raw16, &L.slab_raw, &L.stats_hi}) b->release();
+    }
     if (c->slab_fork) (void)hipEventDestroy(c->slab_fork);
     for (hipEvent_t e : c->slab_done) (void)hipEventDestroy(e);
     for (hipStream_t s2 : c->slab_streams) {

@@ -202,6 +202,18 @@ struct mtm_ctx {
     int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
     int copy_prio = 1;                      // MTM_COPY_PRIO: 1 = the copy stream gets the highest stream priority
     hipEvent_t stream2_done = nullptr;
+    // lanes of a multi-class call: size classes are independent (their own statistics, launches, scratch); consecutive
+    // classes go to alternating lanes - a stream plus the per-class scratch buffers - so that the statistics / combine
+    // kernels and the tail of one class run under the score kernel of the next.  Lane 0 is the context's own stream and
+    // buffers.
+    struct Lane {
+        DevBuf stats, stats_rsq, stats_blk, hs1, hs2, raw16, slab_raw, stats_hi;
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<Lane> lanes;                // lanes 1 .. n - 1
+    hipEvent_t lane_fork = nullptr;
+    int class_lanes = 2;                    // MTM_CLASS_LANES (1: classes one after another on the main stream)
     // side streams of a slab class: its raw launches are independent and (few templates, small images) far too small to
     // fill the chip one at a time
     std::vector<hipStream_t> slab_streams;

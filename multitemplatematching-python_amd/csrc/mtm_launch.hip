@@ -45,6 +45,25 @@ namespace mtmi {
 
 bool dot_variant_ok(int64_t v) { return v >= 0 && v < kNumDotVariants && !kDotVariants[v].wide; }
 
+// The byte planes of I^2 (masked classes: sum I^2 M on the matrix cores), once per image; a no-op for everything but
+// single-channel uint8 images with a masked class on the MFMA kernel.
+int ensure_square_planes(mtm_ctx* c) {
+    if (c->sq_valid || c->dtype != MTM_U8 || c->chans != 1) return MTM_OK;
+    bool any = false;
+    for (const SizeClass& sc : c->classes)
+        any = any || (sc.masked && sc.mask_rm_off >= 0 && resolved_kernel(c, sc) == MTM_KERNEL_MFMA);
+    if (!any) return MTM_OK;
+    const ImageDev img = image_dev(c);
+    const size_t plane_bytes = (size_t)img.u8_plane;
+    MTMC(c->sq_planes.ensure(2 * plane_bytes));
+    const size_t n16 = plane_bytes / 16;
+    hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
+                       c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes);
+    HIPC(hipGetLastError());
+    c->sq_valid = true;
+    return MTM_OK;
+}
+
 // Window statistics of one size class (two kernels), into c->stats.  Returns the plane table.
 // `sb0`, `sb1`: range of kStatBand4-row output blocks to compute (banded image upload; fused single-channel
 // kernel only), sb1 < 0 = all.
@@ -168,13 +187,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         // sum I^2 * M over every window on the matrix cores (see square_planes_kernel): two row-multiplexed
         // raw correlations of the byte planes of I^2 with the mask, combined into the sum2 plane
         const size_t plane_bytes = (size_t)img.u8_plane;
-        if (!c->sq_valid) {
-            MTMC(c->sq_planes.ensure(2 * plane_bytes));
-            const size_t n16 = plane_bytes / 16;
-            hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
-                               c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes);
-            c->sq_valid = true;
-        }
+        MTMC(ensure_square_planes(c));
         const int map_pitch = (int)round_up((size_t)ow, 4);
         const long long raw_map = (long long)oh * map_pitch;
         MTMC(c->raw16.ensure(sizeof(int) * (size_t)(2 * raw_map)));
@@ -809,9 +822,54 @@ int launch_refine_scan(mtm_ctx* c, const SizeClass& sc) {
     return MTM_OK;
 }
 
+namespace {
+// The context's stream and per-class scratch exchanged with a lane's for the time a class is queued (everything below
+// launch_stats / launch_ncc keeps using c->stream, c->stats ...); swapped back on every path out.
+struct LaneScope {
+    mtm_ctx* c;
+    mtm_ctx::Lane* L;
+    void swap_all() {
+        std::swap(c->stream, L->stream);
+        std::swap(c->stats, L->stats);
+        std::swap(c->stats_rsq, L->stats_rsq);
+        std::swap(c->stats_blk, L->stats_blk);
+        std::swap(c->hs1, L->hs1);
+        std::swap(c->hs2, L->hs2);
+        std::swap(c->raw16, L->raw16);
+        std::swap(c->slab_raw, L->slab_raw);
+        std::swap(c->stats_hi, L->stats_hi);
+    }
+    LaneScope(mtm_ctx* c_, mtm_ctx::Lane* L_) : c(c_), L(L_) { if (L) swap_all(); }
+    ~LaneScope() { if (L) swap_all(); }
+    LaneScope(const LaneScope&) = delete;
+    LaneScope& operator=(const LaneScope&) = delete;
+};
+}  // namespace
+
 int run_score_all(mtm_ctx* c) {
     if (!c->hits_only_now) MTMC(ensure_maps(c));
+    // several size classes: alternate them over lanes (see mtm_ctx::Lane).  Not while the float32 refinement is on: its
+    // re-scoring kernels walk the candidate list of the class that just ran.
+    int n_lanes = 1;
+    if (c->classes.size() > 1 && c->class_lanes > 1 && !c->refine_now && !c->refine_scan_now && !c->f32_exact_now)
+        n_lanes = (int)std::min<size_t>(c->classes.size(), (size_t)c->class_lanes);
+    if (n_lanes > 1) {
+        while ((int)c->lanes.size() < n_lanes - 1) {
+            mtm_ctx::Lane L;
+            HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            HIPC(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+            c->lanes.push_back(L);
+        }
+        if (!c->lane_fork) HIPC(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+        MTMC(ensure_square_planes(c));                  // shared by the masked classes of every lane: before the fork
+        HIPC(hipEventRecord(c->lane_fork, c->stream));
+        for (int i = 0; i + 1 < n_lanes; ++i) HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, c->lane_fork, 0));
+    }
+    int k_cls = 0;
     for (const SizeClass& sc : c->classes) {
+        const int lane = n_lanes > 1 ? k_cls % n_lanes : 0;
+        ++k_cls;
+        LaneScope scope(c, lane > 0 ? &c->lanes[(size_t)(lane - 1)] : nullptr);
         StatPlanes st;
         MTMC(launch_stats(c, sc, &st));
         MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st));
@@ -823,6 +881,10 @@ int run_score_all(mtm_ctx* c) {
                 MTMC(launch_refine(c, sc, st, false, !c->hits_only_now));
             }
         }
+    }
+    for (int i = 0; i + 1 < n_lanes; ++i) {             // join: everything after the score pass is queued on c->stream
+        HIPC(hipEventRecord(c->lanes[(size_t)i].done, c->lanes[(size_t)i].stream));
+        HIPC(hipStreamWaitEvent(c->stream, c->lanes[(size_t)i].done, 0));
     }
     if (c->refine_now && !c->f32_exact_now && c->ext_now) {
         // global extremum: the keys the score kernel kept are approximate - rebuild them from the re-scored list
