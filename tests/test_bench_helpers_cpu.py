@@ -48,8 +48,13 @@ def test_masked_mac_accounting():
 def test_pmc_traffic_table():
     t = bench.pmc_traffic(3, "north_star", 1, hits_only=True)
     m = bench.pmc_traffic(3, "north_star", 1, hits_only=False)
-    assert t and m and 1.0 <= t / 135151376 < 1.3 and 1.0 <= m / 1022232704 < 1.3   # no wasted re-reads
-    assert bench.pmc_traffic(3, "cfg5", 1) is None
+    # no wasted re-reads: at most 1.3 x the algorithmic bytes (hits-only launches read the 16-pixel block ranges of the
+    # window statistics instead of the per-pixel planes the algorithmic figure counts - they stay well below it)
+    assert t and m and 0.1 <= t / 135151376 < 1.3 and 1.0 <= m / 1022232704 < 1.3
+    # the other BASELINE configs: one launch of the dominant kernel of the workload's own PMC passes; nothing for N > 1
+    c5 = bench.pmc_traffic(3, "cfg5", 1)
+    assert c5 is not None and c5 > 34e6 and bench.pmc_traffic(3, "cfg5", 8) is None     # (an 8K image alone is 33 MB)
+    assert bench.pmc_traffic(3, "no_such_config", 1) is None
 
 
 def test_synthetic_smooth_image_and_crops():
