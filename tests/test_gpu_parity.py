@@ -483,6 +483,50 @@ def test_cfg3_full_size_maps_against_oracle(mtm, ctx):
         sorted((h[0], h[1], float(h[2])) for h in hits)
 
 
+def test_cfg3_every_map_matrix_cores_equal_valu_kernel():
+    """BASELINE configs[2] at full size, ALL 128 score maps (1.06 G outputs) of the batched production launch on the int8
+    matrix cores against the same batched call on the independent VALU kernel (v_dot4_u32_u8, north_star's kernel):
+    exact-division mode bit for bit; default mode (correctly rounded reciprocals) at most one float32 ulp apart on a
+    vanishing share of the pixels.  The oracle checks three of these maps pixel by pixel (the test above); this one
+    leaves no map of the launch unchecked."""
+    from MTM import _lib
+    img, units, _ = synth.make_config("cfg3")
+    tl = [(u[1], None) for u in units]
+    shape = (img.shape[0] - 64 + 1, img.shape[1] - 64 + 1)
+    mf, d4 = _lib.Context(0), _lib.Context(0)
+    try:
+        d4.set_option(_lib.OPT_KERNEL, 2)
+        for c_ in (mf, d4):
+            c_.set_option(_lib.OPT_HITS_ONLY, 0)
+            c_.set_image(img)
+        d4.set_option(_lib.OPT_EXACT_DIV, 1)
+        d4.set_templates(tl, 5)
+        ref_hits = d4.find_matches(_lib.PEAKS_LOCAL, 0.5).copy()
+        assert d4.timing()["kernel_used"] == 2
+        for exact in (1, 0):
+            mf.set_option(_lib.OPT_EXACT_DIV, exact)
+            mf.set_templates(tl, 5)
+            hits = mf.find_matches(_lib.PEAKS_LOCAL, 0.5).copy()
+            assert mf.timing()["kernel_used"] == 3 and mf.timing()["hits_only"] == 0
+            assert np.array_equal(hits, ref_hits) or (exact == 0 and len(hits) == len(ref_hits))
+            n_diff = 0
+            for i in range(len(tl)):
+                a, b = mf.last_score_map(i, shape), d4.last_score_map(i, shape)
+                if exact:
+                    assert np.array_equal(a, b), i
+                else:
+                    ne = a != b
+                    if ne.any():
+                        n_diff += int(ne.sum())
+                        ulp = np.abs(a[ne].view(np.int32).astype(np.int64) - b[ne].view(np.int32).astype(np.int64))
+                        assert ulp.max() <= 1, (i, int(ulp.max()))
+            if not exact:
+                assert n_diff <= 1e-6 * len(tl) * shape[0] * shape[1], n_diff
+    finally:
+        mf.close()
+        d4.close()
+
+
 def test_cfg5_full_size_maps_against_oracle(mtm, ctx):
     """BASELINE configs[4] at full size (7680x4320, 80 masked units at 5 scales, TM_CCORR_NORMED): two complete
     score maps per size class - 32, 56, 80, 104 and 128 pixels, disc masks - out of the batched launch against
