@@ -330,7 +330,8 @@ void mtm_ctx_destroy(mtm_ctx* c) {
             (void)hipStreamDestroy(L.stream);
         }
         if (L.done) (void)hipEventDestroy(L.done);
-        for (DevBuf* b : {&L.stats, &L.stats_rsq, &L.stats_blk, &L.hs1, &L.hs2, &L.raw16, &L.slab_raw, &L.stats_hi}) b->release();
+        for (DevBuf* b : {&L.stats, &L.stats_rsq, &L.stats_blk, &L.hs1, &L.hs2, &L.raw16, &L.slab_raw, &L.stats_hi, &L.mask_td, &L.sched})
+            b->release();
     }
     if (c->slab_fork) (void)hipEventDestroy(c->slab_fork);
     for (hipEvent_t e : c->slab_done) (void)hipEventDestroy(e);

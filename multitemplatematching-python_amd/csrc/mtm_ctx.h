@@ -207,7 +207,7 @@ struct mtm_ctx {
     // kernels and the tail of one class run under the score kernel of the next.  Lane 0 is the context's own stream and
     // buffers.
     struct Lane {
-        DevBuf stats, stats_rsq, stats_blk, hs1, hs2, raw16, slab_raw, stats_hi;
+        DevBuf stats, stats_rsq, stats_blk, hs1, hs2, raw16, slab_raw, stats_hi, mask_td, sched;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
     };

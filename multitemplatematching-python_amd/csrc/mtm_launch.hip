@@ -838,6 +838,8 @@ struct LaneScope {
         std::swap(c->raw16, L->raw16);
         std::swap(c->slab_raw, L->slab_raw);
         std::swap(c->stats_hi, L->stats_hi);
+        std::swap(c->mask_td, L->mask_td);          // (the scratch template record of the dot4 sum I^2 M pass)
+        std::swap(c->sched, L->sched);              // (item counters of persistent / staggered launches)
     }
     LaneScope(mtm_ctx* c_, mtm_ctx::Lane* L_) : c(c_), L(L_) { if (L) swap_all(); }
     ~LaneScope() { if (L) swap_all(); }

@@ -82,6 +82,13 @@ def otsu_mask(small):
     return ((small > G["otsu_threshold"]) * 255).astype(np.uint8)
 
 
+def default_routes():
+    """False while tools/alt_modes.sh runs the suite with an environment switch that moves work to another kernel or
+    mode: assertions about WHICH route a call took only hold for the default routes (results are asserted always)."""
+    return not any(os.environ.get(k) for k in ("MTM_KERNEL", "MTM_HITS_ONLY", "MTM_FUSE_PEAKS", "MTM_F32_MFMA", "MTM_TEMPL_ON_DEVICE",
+                                               "MTM_SLAB_MFMA", "MTM_ROW_MUX", "MTM_FUSE_STATS"))
+
+
 # ------------------------------------------------------------------------------------------------
 # score maps
 # ------------------------------------------------------------------------------------------------
@@ -490,6 +497,8 @@ def test_cfg3_every_map_matrix_cores_equal_valu_kernel():
     vanishing share of the pixels.  The oracle checks three of these maps pixel by pixel (the test above); this one
     leaves no map of the launch unchecked."""
     from MTM import _lib
+    if not default_routes():
+        pytest.skip("compares the default matrix-core route with the VALU kernel")
     img, units, _ = synth.make_config("cfg3")
     tl = [(u[1], None) for u in units]
     shape = (img.shape[0] - 64 + 1, img.shape[1] - 64 + 1)
@@ -724,6 +733,8 @@ def test_float32_on_bf16_matrix_cores(mtm, ctx, coins, monkeypatch):
     bf16 matrix cores; the maps must stay within 5e-5 of the float64 oracle (north_star allows 1e-4) whatever the
     brightness offset, scale or gradient of the image - the centring of both operands is what makes 16 significant
     bits enough - and the hit lists must be those of the exact float64 kernel (MTM_F32_MFMA=0)."""
+    if os.environ.get("MTM_F32_MFMA"):
+        pytest.skip("the float32 route is forced by the environment")
     from MTM import _lib
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:303, 0:384]
@@ -781,6 +792,8 @@ def test_float32_hit_lists_are_the_float64_kernels(coins):
     shrinking the hit capacity: kernel candidates (hits-only and with the maps in memory), the map scan after the
     candidate list overflowed, the float64 kernel after the scan's list overflowed too; N_object == 1 likewise.
     Reference: MTM/__init__.py:71-74 (float32 cast), :45 (peak_local_max), :226 (minMaxLoc)."""
+    if not default_routes():
+        pytest.skip("asserts the default float32 routes (bf16 screen + exact re-scoring)")
     from MTM import _lib
     fast, exact = _lib.Context(0), _lib.Context(0)
     exact.set_option(_lib.OPT_F32_MFMA, 0)
@@ -1012,7 +1025,7 @@ def test_large_templates_as_slabs_on_mfma(mtm, ctx):
         for method in (5, 1, 2):
             fused = mtm.findMatches(lt, im, method=method, N_object=1)
             tm = ctx.timing()
-            assert tm["hits_only"] == 1 and tm["kernel_used"] == 3, tm
+            assert (tm["hits_only"] == 1 and tm["kernel_used"] == 3) or not default_routes(), tm
             ctx.set_option(_lib.OPT_HITS_ONLY, 0)
             try:
                 via_maps = mtm.findMatches(lt, im, method=method, N_object=1)
@@ -1441,7 +1454,7 @@ def test_uint16_fused_window_statistics_bit_for_bit(mtm, monkeypatch):
                     c_.set_templates([(t, None) for t in ts], method)
                     shape = (img.shape[0] - ts[0].shape[0] + 1, img.shape[1] - ts[0].shape[1] + 1)
                     maps.append([c_.score_map(i, shape) for i in range(len(ts))])
-                    assert c_.timing()["kernel_used"] == 4
+                    assert c_.timing()["kernel_used"] == 4 or not default_routes()
                 for a, b in zip(*maps):
                     assert np.array_equal(a, b, equal_nan=True), (img.shape, method)
     finally:
@@ -1477,7 +1490,7 @@ def test_uint16_hits_only_screen_changes_nothing(monkeypatch):
                 for mode, thr in ((_lib.PEAKS_LOCAL, 0.5), (_lib.PEAKS_LOCAL, 0.9), (_lib.PEAKS_LOCAL, 0.05), (_lib.PEAKS_GLOBAL, 0.0)):
                     a = screened.search(tl, img, method, mode, thr)
                     b = plain.search(tl, img, method, mode, thr)
-                    assert screened.timing()["kernel_used"] == 4 and screened.timing()["hits_only"] == 1
+                    assert (screened.timing()["kernel_used"] == 4 and screened.timing()["hits_only"] == 1) or not default_routes()
                     assert np.array_equal(a, b), (case, method, mode, thr, len(a), len(b))
                     n_rec += len(a)
         assert n_rec > 100
