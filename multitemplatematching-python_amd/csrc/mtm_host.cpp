@@ -286,25 +286,63 @@ void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_
         return;
     }
     // Lists are kept in insertion order (head = the cell's best box): a candidate of a dense cluster is almost always
-    // suppressed by the cluster's top, which is then the first box it meets; the own cell is visited first.
-    std::vector<int32_t> head((size_t)(gw * gh), -1), tail((size_t)(gw * gh), -1), next((size_t)n, -1);
+    // suppressed by the cluster's top, which is then the first box it meets; the own cell is visited first.  The kept
+    // boxes live in one compact array in the order they were kept (the lists link into it).
+    //
+    // The decision "overlap <= nms_threshold" is OpenCV's float expression 1.f - (float)(1.0 - inter / union), a
+    // non-decreasing step function of r = inter / union: there is one r* with  overlap <= threshold  <=>  r <= r*.  It is
+    // found by bisection on the expression itself; a pair is then decided by inter vs r* x union - no division - unless it
+    // falls within 1e-12 (relative) of the step, where the original expression decides.
+    auto overlap_of = [](double r) { return 1.0f - (float)(1.0 - r); };
+    double r_star = 2.0;                                  // threshold >= 1: nothing is ever suppressed
+    if (overlap_of(1.0) > nms_threshold) {
+        double lo = 0.0, hi = 1.0;                        // overlap_of(lo) <= threshold < overlap_of(hi)
+        for (int it = 0; it < 100 && hi - lo > 0.0; ++it) {
+            const double mid = lo + 0.5 * (hi - lo);
+            if (mid <= lo || mid >= hi) break;
+            if (overlap_of(mid) <= nms_threshold) lo = mid;
+            else hi = mid;
+        }
+        r_star = lo;
+    }
+    const double r_lo = r_star * (1.0 - 1e-12), r_hi = r_star * (1.0 + 1e-12);
+    struct Kept { int x, y, x2, y2; double area; int32_t next; };
+    std::vector<Kept> kb;
+    kb.reserve(cand.size());
+    std::vector<int32_t> head((size_t)(gw * gh), -1), tail((size_t)(gw * gh), -1);
     static const int kOrder[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+    const bool cell_pow2 = (cell & (cell - 1)) == 0;
+    int cell_shift = 0;
+    while ((1ll << cell_shift) < cell) ++cell_shift;
     for (int32_t idx : cand) {
         const mtm_hit& b = hits[idx];
-        const long long cx = fdiv(b.x, cell) - cx0 + 1, cy = fdiv(b.y, cell) - cy0 + 1;
+        const long long cx = (cell_pow2 && b.x >= 0 ? (long long)(b.x >> cell_shift) : fdiv(b.x, cell)) - cx0 + 1;
+        const long long cy = (cell_pow2 && b.y >= 0 ? (long long)(b.y >> cell_shift) : fdiv(b.y, cell)) - cy0 + 1;
+        const int bx2 = b.x + b.w, by2 = b.y + b.h;
+        const double barea = (double)((long long)b.w * b.h);
         bool ok = true;
         for (int o = 0; o < 9 && ok; ++o)
-            for (int32_t k = head[(size_t)((cy + kOrder[o][0]) * gw + cx + kOrder[o][1])]; k >= 0; k = next[k])
-                if (!(rect_overlap(b, hits[k]) <= nms_threshold)) {
+            for (int32_t k = head[(size_t)((cy + kOrder[o][0]) * gw + cx + kOrder[o][1])]; k >= 0; k = kb[(size_t)k].next) {
+                const Kept& q = kb[(size_t)k];
+                const int iw = std::min(bx2, q.x2) - std::max(b.x, q.x);
+                if (iw <= 0) continue;
+                const int ih = std::min(by2, q.y2) - std::max(b.y, q.y);
+                if (ih <= 0) continue;                               // disjoint: overlap 0 <= threshold
+                const double inter = (double)((long long)iw * ih), uni = barea + q.area - inter;
+                if (inter <= r_lo * uni) continue;
+                if (inter >= r_hi * uni || !(rect_overlap(b, hits[keep[(size_t)k]]) <= nms_threshold)) {
                     ok = false;
                     break;
                 }
+            }
         if (ok) {
+            const int32_t slot = (int32_t)kb.size();              // == keep.size(): kb[i] is the box of keep[i]
             keep.push_back(idx);
+            kb.push_back(Kept{b.x, b.y, bx2, by2, barea, -1});
             const size_t cellidx = (size_t)(cy * gw + cx);
-            if (tail[cellidx] >= 0) next[tail[cellidx]] = idx;
-            else head[cellidx] = idx;
-            tail[cellidx] = idx;
+            if (tail[cellidx] >= 0) kb[(size_t)tail[cellidx]].next = slot;
+            else head[cellidx] = slot;
+            tail[cellidx] = slot;
         }
     }
 }
