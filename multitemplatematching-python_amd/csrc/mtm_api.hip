@@ -184,7 +184,9 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     }
 
     host_trace(c, 3);
-    HIPC(hipEventRecord(c->ev[0], c->stream));
+    // start of the GPU time of the call (timing.total_ms).  Banded: recorded by run_score_banded once the first band's
+    // copy is on its way - nothing is queued ahead of that copy that does not have to be (every API call is 5-10 us)
+    if (!banded) HIPC(hipEventRecord(c->ev[0], c->stream));
     if (banded) {
         const int rc = run_score_banded(c, *up);
         if (rc != MTM_OK) {
@@ -224,7 +226,14 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
             HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
             c->pinned_cap = fetch_bytes;
         }
-        HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
+        static const bool kFetchByCopy = std::getenv("MTM_FETCH_COPY") != nullptr;        // (A/B: the copy command of round 2)
+        if (kFetchByCopy) {
+            HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
+        } else {
+            hipLaunchKernelGGL(fetch_cands_kernel, dim3(1), dim3(256), 0, c->stream, c->cands.as<uint4>(),
+                               static_cast<uint4*>(c->pinned), (unsigned long long)nfetch);
+            HIPC(hipGetLastError());
+        }
         HIPC(hipEventRecord(c->ev[2], c->stream));
         S.prefetched = true;
     }

@@ -248,4 +248,17 @@ __global__ __launch_bounds__(256) void extremum_kernel(const float* __restrict__
 }
 
 
+// The candidate list of a hits-only call goes to the host's page-locked landing buffer from a kernel (one small
+// work-group behind the score launch) instead of a device-to-host copy command: a queued kernel starts the moment its
+// predecessor retires, a copy command 15 us later (rocprofv3 timelines, profiles/r03_tl2) - and only the records that
+// exist cross PCIe.  src: [count (8 B), clock (8 B)][records]; dst: mapped host memory, same layout.
+__global__ __launch_bounds__(256) void fetch_cands_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                          unsigned long long max_records) {
+    const unsigned long long count = *reinterpret_cast<const unsigned long long*>(src);
+    const unsigned long long nrec = count < max_records ? count : max_records;
+    const unsigned n16 = (unsigned)((16ull + sizeof(mtm_hit) * nrec + 15ull) / 16ull);
+    for (unsigned i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+    __threadfence_system();
+}
+
 }  // namespace mtm

@@ -977,11 +977,13 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
     int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
     bool used2 = false;
-    if (!c->stream2) HIPC(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    if (!c->stream2_done) HIPC(hipEventCreateWithFlags(&c->stream2_done, hipEventDisableTiming));
-    // stream2 starts behind whatever the call queued on c->stream so far (counter reset, statistics buffers ...)
-    HIPC(hipEventRecord(c->stream2_done, c->stream));
-    HIPC(hipStreamWaitEvent(c->stream2, c->stream2_done, 0));
+    if (c->dual_stream) {               // (MTM_DUAL_STREAM=1: the score launches of consecutive bands alternate between two streams)
+        if (!c->stream2) HIPC(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        if (!c->stream2_done) HIPC(hipEventCreateWithFlags(&c->stream2_done, hipEventDisableTiming));
+        // stream2 starts behind whatever the call queued on c->stream so far (counter reset, statistics buffers ...)
+        HIPC(hipEventRecord(c->stream2_done, c->stream));
+        HIPC(hipStreamWaitEvent(c->stream2, c->stream2_done, 0));
+    }
     for (int k = 0; k < nb; ++k) {
         const bool last = k == nb - 1;
         int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
@@ -990,6 +992,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
             MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream));
         else
             MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
+        if (r_done == 0) HIPC(hipEventRecord(c->ev[0], c->stream));     // (see fm_begin)
         r_done = r1;
         host_trace(c, k == 0 ? 4 : 7);                           // the band's copy call returned
         const int avail = r1 - h + 1;                            // output rows whose windows are complete
