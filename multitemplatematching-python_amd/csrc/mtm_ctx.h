@@ -221,6 +221,7 @@ struct mtm_ctx {
     hipEvent_t slab_fork = nullptr;
     int slab_concurrency = 4;               // MTM_SLAB_STREAMS (1: one after another on the main stream)
     std::vector<hipEvent_t> band_ev;
+    int banded_cls = -1;                    // the size class a banded call runs under the upload (banded_ok)
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
     // MTM_HOST_TRACE=1: host time stamps at the phases of a fused call, averaged and printed when the context is destroyed
     bool host_trace = false;
@@ -393,7 +394,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                int yb0 = 0, int yb1 = -1);
 int ensure_maps(mtm_ctx* c);
 int run_score_all(mtm_ctx* c);
-bool banded_ok(const mtm_ctx* c, const ImageArgs& a);
+bool banded_ok(mtm_ctx* c, const ImageArgs& a);
 int run_score_banded(mtm_ctx* c, const ImageArgs& a);
 int collect_ncc_time(mtm_ctx* c);
 

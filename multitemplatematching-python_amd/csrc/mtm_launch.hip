@@ -848,13 +848,17 @@ struct LaneScope {
 };
 }  // namespace
 
-int run_score_all(mtm_ctx* c) {
+// Statistics + score launches of every size class but `skip` (the class a banded call has already queued; -1: none).
+// `fork`: the event the lanes start behind instead of the present end of c->stream (banded calls: the last band's event -
+// the image is complete - so that the next class runs under the banded class's last launch).
+static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
     if (!c->hits_only_now) MTMC(ensure_maps(c));
     // several size classes: alternate them over lanes (see mtm_ctx::Lane).  Not while the float32 refinement is on: its
     // re-scoring kernels walk the candidate list of the class that just ran.
     int n_lanes = 1;
-    if (c->classes.size() > 1 && c->class_lanes > 1 && !c->refine_now && !c->refine_scan_now && !c->f32_exact_now)
-        n_lanes = (int)std::min<size_t>(c->classes.size(), (size_t)c->class_lanes);
+    const size_t n_todo = c->classes.size() - (skip >= 0 ? 1 : 0);
+    if (c->classes.size() > 1 && n_todo > 0 && c->class_lanes > 1 && !c->refine_now && !c->refine_scan_now && !c->f32_exact_now)
+        n_lanes = (int)std::min<size_t>(skip >= 0 ? n_todo + 1 : n_todo, (size_t)c->class_lanes);
     if (n_lanes > 1) {
         while ((int)c->lanes.size() < n_lanes - 1) {
             mtm_ctx::Lane L;
@@ -864,11 +868,19 @@ int run_score_all(mtm_ctx* c) {
         }
         if (!c->lane_fork) HIPC(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
         MTMC(ensure_square_planes(c));                  // shared by the masked classes of every lane: before the fork
-        HIPC(hipEventRecord(c->lane_fork, c->stream));
-        for (int i = 0; i + 1 < n_lanes; ++i) HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, c->lane_fork, 0));
+        if (fork == nullptr || c->sq_valid) {           // (the planes of I^2 were just queued on c->stream: fork behind them)
+            HIPC(hipEventRecord(c->lane_fork, c->stream));
+            fork = c->lane_fork;
+        } else {                                        // banded call: behind its set-up (lane_fork, recorded by
+            for (int i = 0; i + 1 < n_lanes; ++i)       // run_score_banded) and behind the last band (fork)
+                HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, c->lane_fork, 0));
+        }
+        for (int i = 0; i + 1 < n_lanes; ++i) HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, fork, 0));
     }
-    int k_cls = 0;
+    int k_cls = skip >= 0 ? 1 : 0;                      // the banded class went to lane 0 (c->stream)
+    int idx = -1;
     for (const SizeClass& sc : c->classes) {
+        if (++idx == skip) continue;
         const int lane = n_lanes > 1 ? k_cls % n_lanes : 0;
         ++k_cls;
         LaneScope scope(c, lane > 0 ? &c->lanes[(size_t)(lane - 1)] : nullptr);
@@ -900,6 +912,8 @@ int run_score_all(mtm_ctx* c) {
     }
     return MTM_OK;
 }
+
+int run_score_all(mtm_ctx* c) { return run_score_classes(c, -1, nullptr); }
 
 // Time during which at least one score-kernel launch of the call was running: the launches of a banded call
 // overlap (two compute streams), so their intervals are laid on the timeline of the first one and united.
@@ -935,10 +949,26 @@ int collect_ncc_time(mtm_ctx* c) {
 // Can the image of a fused call arrive in row bands (copy / layout / statistics of band k+1 under the score
 // kernel of band k)?  One unmasked single-channel uint8 size class on the MFMA kernel with the fused
 // statistics kernel; anything else uploads the image in one piece (still without a round trip to the host).
-bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
+static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work);
+
+// Several size classes: the class with the most multiply-accumulates among those that qualify is the one that runs under
+// the upload (c->banded_cls); the others follow on the complete image (run_score_banded).
+bool banded_ok(mtm_ctx* c, const ImageArgs& a) {
+    c->banded_cls = -1;
+    double best = 0.0;
+    for (size_t i = 0; i < c->classes.size(); ++i) {
+        double work = 0.0;
+        if (class_bandable(c, a, c->classes[i], &work) && work > best) {
+            best = work;
+            c->banded_cls = (int)i;
+        }
+    }
+    return c->banded_cls >= 0;
+}
+
+static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work) {
     const bool u16 = a.dtype == MTM_U16;
-    if (c->upload_bands.size() < 2 || (a.dtype != MTM_U8 && !u16) || a.chans != 1 || c->classes.size() != 1) return false;
-    const SizeClass& sc = c->classes[0];
+    if (c->upload_bands.size() < 2 || (a.dtype != MTM_U8 && !u16) || a.chans != 1) return false;
     if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != (u16 ? MTM_KERNEL_MFMA16 : MTM_KERNEL_MFMA))
         return false;
     if (!(sc.w <= 768 && (double)sc.w * sc.h * (u16 ? 65535.0 : 65025.0) < 4294967296.0)) return false;   // the fused statistics
@@ -951,6 +981,7 @@ bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
     const int tg = u16 ? (n + 15) / 16 : sc.rm_R > 0 ? 1 : (n + (sc.r2 ? 16 : 32) - 1) / (sc.r2 ? 16 : 32);
     const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + rows_per_item - 1) / rows_per_item) * tg;
     const int cus = c->n_cus > 0 ? c->n_cus : 256;
+    *work = (double)oh * ow * sc.h * sc.w * n;
     return (double)items * c->upload_bands[0] >= c->band_min_fill * (2.0 * cus);      // MTM_BAND_MIN_FILL (default 2; 0: always band)
 }
 
@@ -959,7 +990,7 @@ bool banded_ok(const mtm_ctx* c, const ImageArgs& a) {
 // over the row blocks whose statistics exist, behind the band's event.  With a pageable source every copy call
 // blocks the host while its rows are staged - the kernels queued before it run meanwhile.
 int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
-    const SizeClass& sc = c->classes[0];
+    const SizeClass& sc = c->classes[(size_t)c->banded_cls];
     if (!c->hits_only_now) MTMC(ensure_maps(c));
     MTMC(ensure_copy_stream(c));
     mtm_ctx::ImageSlot& sl = c->slot[c->cur];
@@ -992,7 +1023,13 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
             MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream));
         else
             MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
-        if (r_done == 0) HIPC(hipEventRecord(c->ev[0], c->stream));     // (see fm_begin)
+        if (r_done == 0) {
+            HIPC(hipEventRecord(c->ev[0], c->stream));           // (see fm_begin)
+            if (c->classes.size() > 1) {                         // the lanes of the other classes start behind the call's set-up too
+                if (!c->lane_fork) HIPC(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
+                HIPC(hipEventRecord(c->lane_fork, c->stream));
+            }
+        }
         r_done = r1;
         host_trace(c, k == 0 ? 4 : 7);                           // the band's copy call returned
         const int avail = r1 - h + 1;                            // output rows whose windows are complete
@@ -1025,6 +1062,9 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         HIPC(hipEventRecord(c->stream2_done, c->stream2));
         HIPC(hipStreamWaitEvent(c->stream, c->stream2_done, 0));
     }
+    // the other size classes, on the complete image: the first of them on a lane behind the last band's event - under
+    // the banded class's last launch - the rest alternating as in run_score_all
+    if (c->classes.size() > 1) MTMC(run_score_classes(c, c->banded_cls, c->band_ev[(size_t)nb - 1]));
     return MTM_OK;
 }
 

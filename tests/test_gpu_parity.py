@@ -638,6 +638,9 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
             (msk_img, [(u[1], u[2]) for u in msk_units], 3, 0.9),
             (img16, [(u[1].astype(np.uint16) * 200 + 7, None) for u in units[:4]], 5, 0.5),   # uint16 kernel, banded as well
             (img16, [(u[1].astype(np.uint16) * 200 + 7, None) for u in units], 3, 0.8),       # two groups of 16 templates
+            # several classes, the heaviest of them banded, the others (a masked one among them) on the complete image
+            (img, [(u[1], None) for u in units[:6]] + [(np.ascontiguousarray(units[8][1][:24, :28]), None)] +
+                  [(np.ascontiguousarray(units[7][1][:28, :30]), (units[7][1][:28, :30] > 90).astype(np.uint8))], 3, 0.8),
         ]
         for honly in (1, 0):
             fused.set_option(_lib.OPT_HITS_ONLY, honly)
