@@ -228,7 +228,7 @@ struct mtm_ctx {
     double trace_acc[16] = {0};
     long long trace_n[16] = {0};
     double trace_t0 = 0.0;
-    double band_min_fill = 2.0;                     // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work
+    double band_min_fill = 1.0;                     // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work
                                                     // items fill the resident work-group slots this many times (banded_ok)
 
     // templates

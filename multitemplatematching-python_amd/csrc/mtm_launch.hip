@@ -982,7 +982,10 @@ static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass
     const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + rows_per_item - 1) / rows_per_item) * tg;
     const int cus = c->n_cus > 0 ? c->n_cus : 256;
     *work = (double)oh * ow * sc.h * sc.w * n;
-    return (double)items * c->upload_bands[0] >= c->band_min_fill * (2.0 * cus);      // MTM_BAND_MIN_FILL (default 2; 0: always band)
+    // MTM_BAND_MIN_FILL (default 1: the first band's launch is at least one full generation of resident work-groups; 0:
+    // always band).  Measured at 4K (tools/probes/two_class_probe.py): 2 x 16 templates 48x64 (first band = 0.97
+    // generations) 0.819 ms unbanded, 0.795 banded; 2 x 8 templates (0.49) 0.591 / 0.582; 1080p x 8 (0.125) 0.22 / 0.26.
+    return (double)items * c->upload_bands[0] >= 0.97 * c->band_min_fill * (2.0 * cus);
 }
 
 // The score pass of a fused call with a banded upload.  copy_stream: per band the rows' copy, their layout
