@@ -212,8 +212,14 @@ def _nms_raw(raw, scoreThreshold, sortAscending, N_object, maxOverlap):
     same float32 scores, but Python tuples are only built for the hits that survive."""
     if len(raw) <= 1:
         return raw
-    if N_object == 1:       # python max()/min(): the first best hit wins ties
-        i = int(np.argmin(raw["score"])) if sortAscending else int(np.argmax(raw["score"]))
+    if N_object == 1:
+        # python max() / min() as in the reference (MTM/NMS.py:61-69): the first best hit wins ties, and a NaN score
+        # (masked TM_CCORR_NORMED is 0/0 over a window that is zero under the mask, as in OpenCV) is only ever selected
+        # when it comes FIRST - every comparison with it is False.  numpy's argmax / argmin would return the first NaN.
+        sc = raw["score"]
+        if sc[0] != sc[0]:
+            return raw[0:1]
+        i = int(np.nanargmin(sc)) if sortAscending else int(np.nanargmax(sc))
         return raw[i:i + 1]
     # the 1 - score transform of sortAscending (float32 scores, python-float threshold) is done by mtm_nms
     idx = _lib.nms_hits(raw, scoreThreshold, maxOverlap, ascending=sortAscending)

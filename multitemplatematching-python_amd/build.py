@@ -18,8 +18,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "MTM", "libmtm_hip.so")
+# MTM_BUILD_TAG: an experiment build next to the product one (own objects, libmtm_hip_<tag>.so; run it with MTM_LIB_PATH)
+_TAG = os.environ.get("MTM_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "MTM", "libmtm_hip%s.so" % ("_" + _TAG if _TAG else ""))
 STAMP = LIB + ".stamp"
 SOURCES = ["mtm_context.hip", "mtm_placement.hip", "mtm_launch.hip", "mtm_api.hip", "mtm_comm.hip", "mtm_mfma_plain.hip", "mtm_mfma_rm.hip", "mtm_mfma_ext.hip", "mtm_mfma_kp.hip", "mtm_mfma_rows.hip", "mtm_bf16.hip",
            "mtm_host.cpp", "mtm_group.cpp"]

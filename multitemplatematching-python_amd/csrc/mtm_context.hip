@@ -324,12 +324,19 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     for (hipEvent_t e : c->band_ev) (void)hipEventDestroy(e);
     if (c->stream2_done) (void)hipEventDestroy(c->stream2_done);
     if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
+    if (c->f32_built) (void)hipEventDestroy(c->f32_built);
     for (auto& L : c->lanes) {
         if (L.stream) {
             (void)hipStreamSynchronize(L.stream);
             (void)hipStreamDestroy(L.stream);
         }
         if (L.done) (void)hipEventDestroy(L.done);
+        if (L.slab_fork) (void)hipEventDestroy(L.slab_fork);
+        for (hipEvent_t e : L.slab_done) (void)hipEventDestroy(e);
+        for (hipStream_t s2 : L.slab_streams) {
+            (void)hipStreamSynchronize(s2);
+            (void)hipStreamDestroy(s2);
+        }
         for (DevBuf* b : {&L.stats, &L.stats_rsq, &L.stats_blk, &L.hs1, &L.hs2, &L.raw16, &L.slab_raw, &L.stats_hi, &L.mask_td, &L.sched})
             b->release();
     }

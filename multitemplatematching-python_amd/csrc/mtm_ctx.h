@@ -175,7 +175,7 @@ struct mtm_ctx {
         bool f32_valid = true;      // false after a banded uint8 upload: the float32 plane was skipped (ensure_f32_plane)
     } slot[2];
     int cur = 0;
-    DevBuf sq_planes;           // [high byte of I^2][the same ^ 0x80][low byte ^ 0x80] of the current uint8 image
+    DevBuf sq_planes;           // two planes: [high byte of I^2 ^ 0x80][low byte ^ 0x80] of the current uint8 image
     bool sq_valid = false;
     hipStream_t copy_stream = nullptr;
     hipEvent_t next_ready = nullptr;
@@ -210,9 +210,15 @@ struct mtm_ctx {
         DevBuf stats, stats_rsq, stats_blk, hs1, hs2, raw16, slab_raw, stats_hi, mask_td, sched;
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        // the lane's own side streams for a slab class (two slab classes on two lanes must neither share fork / join
+        // events nor serialise on one set of side streams)
+        std::vector<hipStream_t> slab_streams;
+        std::vector<hipEvent_t> slab_done;
+        hipEvent_t slab_fork = nullptr;
     };
     std::vector<Lane> lanes;                // lanes 1 .. n - 1
     hipEvent_t lane_fork = nullptr;
+    hipEvent_t f32_built = nullptr;         // multi-lane calls: the float32 plane rebuilt after a banded upload (run_score_classes)
     int class_lanes = 2;                    // MTM_CLASS_LANES (1: classes one after another on the main stream)
     // side streams of a slab class: its raw launches are independent and (few templates, small images) far too small to
     // fill the chip one at a time

@@ -840,6 +840,9 @@ struct LaneScope {
         std::swap(c->stats_hi, L->stats_hi);
         std::swap(c->mask_td, L->mask_td);          // (the scratch template record of the dot4 sum I^2 M pass)
         std::swap(c->sched, L->sched);              // (item counters of persistent / staggered launches)
+        std::swap(c->slab_streams, L->slab_streams);    // (side streams + fork / join events of a slab class)
+        std::swap(c->slab_done, L->slab_done);
+        std::swap(c->slab_fork, L->slab_fork);
     }
     LaneScope(mtm_ctx* c_, mtm_ctx::Lane* L_) : c(c_), L(L_) { if (L) swap_all(); }
     ~LaneScope() { if (L) swap_all(); }
@@ -847,6 +850,19 @@ struct LaneScope {
     LaneScope& operator=(const LaneScope&) = delete;
 };
 }  // namespace
+
+// Does anything class `sc` launches read the float32 plane of the image (the float64 / naive score kernels, the two-pass
+// statistics)?  A banded uint8 upload leaves that plane out (ensure_f32_plane rebuilds it on demand).
+static bool class_reads_f32(const mtm_ctx* c, const SizeClass& sc) {
+    const int rk = resolved_kernel(c, sc);
+    if (rk == MTM_KERNEL_NAIVE || rk == MTM_KERNEL_AUTO) return true;               // ncc_naive_kernel / ncc_f64_kernel
+    if (c->dtype == MTM_U8) {
+        const bool fused1 = c->chans == 1 && sc.w <= 768 && (double)sc.w * sc.h * 65025.0 < 4294967296.0 && c->fuse_stats;
+        const bool fused3 = c->chans == 3 && sc.w <= 768 && 3.0 * sc.w * sc.h * 65025.0 < 4294967296.0 && c->fuse_stats;
+        return !fused1 && !fused3 && c->cols > 8191;                                 // hsum_kernel on the float32 plane
+    }
+    return false;       // uint16 / float32 images are uploaded with their float32 plane
+}
 
 // Statistics + score launches of every size class but `skip` (the class a banded call has already queued; -1: none).
 // `fork`: the event the lanes start behind instead of the present end of c->stream (banded calls: the last band's event -
@@ -876,6 +892,27 @@ static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
                 HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, c->lane_fork, 0));
         }
         for (int i = 0; i + 1 < n_lanes; ++i) HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, fork, 0));
+        // The float32 plane a banded upload left out is built ONCE, ahead of every lane that may read it: built lazily it
+        // would be queued on whichever lane asks first while the host already marks it valid, and a class on another
+        // lane could read it before it is written.  On the first lane's stream (behind the complete image, not behind
+        // the banded class's last score launch on c->stream); every other stream of the call waits for it.
+        if (!c->slot[c->cur].f32_valid) {
+            bool any = false;
+            int k = -1;
+            for (const SizeClass& sc : c->classes)
+                if (++k != skip) any = any || class_reads_f32(c, sc);
+            if (any) {
+                mtm_ctx::Lane& L0 = c->lanes[0];
+                if (!c->f32_built) HIPC(hipEventCreateWithFlags(&c->f32_built, hipEventDisableTiming));
+                std::swap(c->stream, L0.stream);
+                const int rc = ensure_f32_plane(c);
+                std::swap(c->stream, L0.stream);
+                MTMC(rc);
+                HIPC(hipEventRecord(c->f32_built, L0.stream));
+                HIPC(hipStreamWaitEvent(c->stream, c->f32_built, 0));
+                for (int i = 1; i + 1 < n_lanes; ++i) HIPC(hipStreamWaitEvent(c->lanes[(size_t)i].stream, c->f32_built, 0));
+            }
+        }
     }
     int k_cls = skip >= 0 ? 1 : 0;                      // the banded class went to lane 0 (c->stream)
     int idx = -1;

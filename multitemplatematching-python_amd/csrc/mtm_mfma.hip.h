@@ -200,10 +200,25 @@ __device__ __forceinline__ void mfma_step_one_set(v4i (&acc)[2][16], const v4i q
     mfma_step<2>(acc, qa, qb, a);
 }
 #endif
+// The K step of two MFMA groups.  MTM_STEP_VARIANT (build-time experiment switch): 1 = the whole step as ONE asm
+// statement (default), 2 = that with the odd-offset windows computed from the operand, 0 = round 2's four statements.
+#ifndef MTM_STEP_VARIANT
+#define MTM_STEP_VARIANT 1
+#endif
+__device__ __forceinline__ void mfma_step2(v4i (&acc)[2][16], const v4i qa, const v4i qb, const v4i (&a)[2]) {
+#if defined(MTM_MFMA_NO_ASM) || MTM_STEP_VARIANT == 0
+    mfma_step<2>(acc, qa, qb, a);
+#elif MTM_STEP_VARIANT == 2
+    mfma_step2_fused_b(acc, qa, qb, a);
+#else
+    mfma_step2_fused(acc, qa, qb, a);
+#endif
+}
 // the K step of an instantiation: the uint16 kernel (three accumulator sets) takes the one-scratch-set form
 template <int METHOD_, int MB>
 __device__ __forceinline__ void mfma_kstep(v4i (&acc)[MB][16], const v4i qa, const v4i qb, const v4i (&a)[MB]) {
     if constexpr (METHOD_ == 7 && MB == 2) mfma_step_one_set(acc, qa, qb, a);       // kMfU16
+    else if constexpr (MB == 2) mfma_step2(acc, qa, qb, a);
     else mfma_step<MB>(acc, qa, qb, a);
 }
 
@@ -512,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     MTM_R2_LOAD(QA2, QB2, ANEXT)                            \
                     __builtin_amdgcn_sched_barrier(0);                      \
                     const v4i ar_[2] = {ACUR, APREV};                       \
-                    mfma_step<2>(acc, QA, QB, ar_);                         \
+                    mfma_step2(acc, QA, QB, ar_);                           \
                     __builtin_amdgcn_sched_barrier(0);                      \
                 }
                 MTM_R2_LOAD(qx, qy, aA)           // step 0 of the chunk; aC = the step before it

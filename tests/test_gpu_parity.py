@@ -693,6 +693,38 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
         plain.close()
 
 
+def test_banded_call_with_float64_classes_on_two_lanes(mtm, monkeypatch):
+    """A banded upload leaves the float32 plane out; two more classes of the call run the float64 kernel (masked
+    templates wider than the matrix-core tiling takes), which reads that plane, on two different lanes.  The plane is
+    built once ahead of both lanes (round 3 built it lazily on whichever lane asked first - the other lane could read
+    it before it was written).  Fused call == set_image + find_matches, repeatedly."""
+    from MTM import _lib
+    monkeypatch.setenv("MTM_BAND_MIN_FILL", "0")
+    monkeypatch.setenv("MTM_UPLOAD_BANDS", "0.3,1")
+    fused, plain = _lib.Context(0), _lib.Context(0)
+    try:
+        img, units, _ = synth.make_workload(seed=77, image_hw=(1100, 1200), n_base=6, templ=32, noisy_per_unit=2)
+        wide1 = np.ascontiguousarray(img[300:308, 100:360])
+        wide2 = np.ascontiguousarray(img[700:710, 400:664])
+        tl = [(u[1], None) for u in units] + [(wide1, (wide1 > 60).astype(np.uint8)), (wide2, (wide2 > 90).astype(np.uint8))]
+        plain.set_image(img)
+        plain.set_templates(tl, 3)
+        exp = plain.find_matches(_lib.PEAKS_LOCAL, 0.9)
+        assert len(exp) >= len(tl)
+        for rep in range(6):
+            im = img if rep % 2 == 0 else np.ascontiguousarray(img[::-1])
+            got = fused.search(tl, im, 3, _lib.PEAKS_LOCAL, 0.9)
+            if rep % 2 == 0:
+                assert np.array_equal(got, exp), rep
+            else:
+                plain.set_image(im)
+                assert np.array_equal(got, plain.find_matches(_lib.PEAKS_LOCAL, 0.9)), rep
+                plain.set_image(img)
+    finally:
+        fused.close()
+        plain.close()
+
+
 def test_device_group_equals_single_context(mtm, coins, monkeypatch):
     """Several contexts in one process (mtm_group; here all on the one GPU of the box): LPT shards, concurrent
     upload + search per context, host merge - the hit list of the single-context call, for every shard count."""

@@ -170,3 +170,27 @@ def test_raw_array_pipeline_equals_list_pipeline(MTM, items, thr, overlap, ascen
     # offsets of a searchBox are added to x and y only
     moved = _to_hit_list(raw, lt, 7, 11)
     assert all(m[1] == (a[1][0] + 7, a[1][1] + 11, a[1][2], a[1][3]) for m, a in zip(moved, as_list))
+
+
+@pytest.mark.parametrize("ascending", [False, True])
+@pytest.mark.parametrize("scores", [[0.2, float("nan"), 0.9, 0.9, float("nan"), 0.1],
+                                    [float("nan"), 0.5, 0.9],
+                                    [0.4, float("nan"), float("nan")],
+                                    [float("nan"), float("nan")]])
+def test_single_object_pick_with_nan_scores(MTM, scores, ascending):
+    """N_object == 1 on raw arrays: python max() / min() (reference MTM/NMS.py:61-69) never select a NaN score unless it
+    comes first (masked TM_CCORR_NORMED yields 0/0 = NaN, as OpenCV does); the array fast path must agree with the
+    reference's list semantics, which MTM.NMS.NMS reproduces literally."""
+    import math
+    from MTM import _lib, _nms_raw, _to_hit_list
+    lt = [("t%d" % i, None) for i in range(3)]
+    raw = np.zeros(len(scores), dtype=_lib.HIT_DTYPE)
+    for k, s in enumerate(scores):
+        raw[k] = (k % 3, 10 * k, 5 * k, 8, 8, np.float32(s))
+    got = _to_hit_list(_nms_raw(raw, 0.5, ascending, 1, 0.3), lt, 0, 0)
+    as_list = _to_hit_list(raw, lt, 0, 0)
+    exp = [(min if ascending else max)(as_list, key=lambda h: h[2])]          # the reference's own expression
+    assert len(got) == 1 and got[0][:2] == exp[0][:2]
+    assert (math.isnan(got[0][2]) and math.isnan(exp[0][2])) or got[0][2] == exp[0][2]
+    lib = MTM.NMS(as_list, 0.5, ascending, 1, 0.3)
+    assert lib[0][:2] == exp[0][:2]

@@ -52,6 +52,18 @@ for st in "$@"; do
         MTM_MFMA_R2=$v MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps 200 2>>$OUT/bench.err | clean | tail -1 |
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('R2=$v bands=$b', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/rows_ab.txt
       done; done; done ;;
+    lib_ab)         # experiment builds (MTM_BUILD_TAG=<tag> -> libmtm_hip_<tag>.so) against the product library, same box, alternating
+      L=multitemplatematching-python_amd/MTM
+      for rep in 1 2 3; do for v in ${LIB_TAGS:-v0 v2} ""; do
+        lib=$R/$L/libmtm_hip${v:+_$v}.so; [ -f $lib ] || continue
+        for b in ${LIB_BANDS:-"0.25,1" "1"}; do
+        MTM_LIB_PATH=$lib MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps ${LIB_STEPS:-200} 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('lib=${v:-product} bands=$b', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/lib_ab.txt
+        done
+      done; done ;;
+    ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
+      for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
+      stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
     workloads)      # rocprofv3 summaries + PMC for the secondary workloads
       bash tools/profile_workloads.sh ${PROFILE_TAG:-$TAG} ${WORKLOADS:-} > $OUT/workloads.log 2>&1; stamp "workloads done: $(grep -c '^==' $OUT/workloads.log)" ;;
     *) stamp "unknown stage $st" ;;
