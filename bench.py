@@ -324,10 +324,11 @@ def main():
             dist.barrier()
 
     kernel_ms, total_ms, clocks, sum_ms, launches = [], [], [], [], 0
+    masked_ms, masked_launches = [], 0                   # sum I^2 M passes of masked classes (their own event pairs)
     dev_kernel_ms = [[] for _ in range(group_n)]         # group: score-kernel time per device and step
 
     def note_timing():
-        nonlocal launches
+        nonlocal launches, masked_launches
         if group_n:
             for i in range(group_n):
                 dev_kernel_ms[i].append(group.timing(i)["ncc_kernel_ms"])
@@ -338,6 +339,8 @@ def main():
         if t["sclk_mhz"] > 0:
             clocks.append(t["sclk_mhz"])
         launches = t["ncc_launches"]
+        masked_ms.append(t.get("masked_stat_ms", 0.0))
+        masked_launches = t.get("sq_launches", 0)
         return t
 
     # ---- the timed step: one matchTemplates call, numpy arrays in -> hit list out
@@ -603,7 +606,15 @@ def main():
                                     and len({u[1].shape[:2] for u in my_units}) == 1 else "one launch per size class"})
         msm = masked_stat_macs(img, my_units)
         if msm:
-            roof["masked_stat_macs_per_step"] = int(msm)      # sum I^2*M launches: outside the kernel timer, not in `achieved`
+            # sum I^2*M passes of the masked classes: outside the score kernel's timer and `achieved`, bracketed by event pairs
+            # of their own (mtm_timing.masked_stat_ms) and priced against the same int8 MFMA peak
+            roof["masked_stat_macs_per_step"] = int(msm)
+            ms_ms = float(np.mean(masked_ms[-args.steps:])) if masked_ms else 0.0
+            if ms_ms > 0:
+                ms_tops = 2.0 * msm / (ms_ms * 1e-3) / 1e12
+                roof["masked_stat"] = {"ms": round(ms_ms, 4), "launches_per_step": masked_launches,
+                                       "achieved": round(ms_tops, 1), "frac": round(ms_tops / I8_MFMA_PEAK_TOPS, 4)}
+                roof["frac_with_masked_stat"] = round(2.0 * (macs + msm) / ((k_step + ms_ms) * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS, 4)
         med = float(np.median(per_call)) * 1e3
         out = {
             "metric": "Mpixel-correlations/s", "value": round(value, 1), "unit": "Mpx-corr/s",

@@ -137,6 +137,8 @@ typedef struct mtm_timing {
     int32_t f32_route;   /* float32 images on the bf16 matrix cores (MTM_OPT_F32_MFMA = 1), how the exact decisions were
                             reached: 0 not such a call, 1 kernel candidates re-scored, 2 map scan + neighbourhoods
                             re-scored, 3 the float64 kernel after all (lists overflowed, or classes it has to run anyway) */
+    int32_t sq_launches; /* masked classes on the matrix cores: launches of the sum I^2 M pass (one per masked class) ... */
+    float   masked_stat_ms; /* ... and the time they took (sum of the passes' own event pairs; 0 without masked classes) */
 } mtm_timing;
 
 /* ---- device / context ------------------------------------------------------------------- */

@@ -43,7 +43,8 @@ class MtmTiming(ctypes.Structure):
                 ("peaks_ms", ctypes.c_float), ("ncc_kernel_ms", ctypes.c_float),
                 ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
                 ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("sclk_mhz", ctypes.c_float),
-                ("ncc_sum_ms", ctypes.c_float), ("f32_route", ctypes.c_int32)]
+                ("ncc_sum_ms", ctypes.c_float), ("f32_route", ctypes.c_int32),
+                ("sq_launches", ctypes.c_int32), ("masked_stat_ms", ctypes.c_float)]
 
 
 HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),

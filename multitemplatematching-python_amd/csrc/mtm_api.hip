@@ -280,6 +280,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             c->hits_only_now = false;
             c->cand_on = false;
             c->timing.ncc_launches = 0;
+            c->timing.sq_launches = 0;
             MTMC(run_score_all(c));
             HIPC(hipEventRecord(c->ev[1], c->stream));
         }
@@ -443,6 +444,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 c->cand_on = false;
                 c->hits_only_now = false;
                 c->timing.ncc_launches = 0;
+            c->timing.sq_launches = 0;
                 if (!pp_mode) {
                     c->fuse_backoff = c->backoff_len;
                     c->backoff_len = std::min(2 * c->backoff_len, 1024);
@@ -470,6 +472,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                     c->hits_only_now = false;
                     c->cand_on = false;
                     c->timing.ncc_launches = 0;
+            c->timing.sq_launches = 0;
                     MTMC(run_score_all(c));
                     HIPC(hipEventRecord(c->ev[1], c->stream));
                 }

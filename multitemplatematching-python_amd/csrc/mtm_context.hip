@@ -265,6 +265,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));
@@ -351,10 +352,11 @@ void mtm_ctx_destroy(mtm_ctx* c) {
         (void)hipStreamDestroy(c->stream2);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    for (auto& p : c->ncc_ev) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
-    }
+    for (auto* evs : {&c->ncc_ev, &c->sq_ev})
+        for (auto& p : *evs) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
     for (int i = 0; i < 4; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -161,6 +161,9 @@ struct mtm_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> sq_ev;       // event pairs of the sum I^2 M passes (timing.masked_stat_ms)
+    int masksq_fused = 1;       // MTM_MASKSQ_FUSED: sum I^2 M of a masked class as ONE launch over both byte planes of I^2 that
+                                // writes the sum2 plane itself (0: round 3's two raw launches + masksq_combine_kernel)
 
     // image
     bool have_image = false;

@@ -200,10 +200,14 @@ __device__ __forceinline__ void mfma_step_one_set(v4i (&acc)[2][16], const v4i q
     mfma_step<2>(acc, qa, qb, a);
 }
 #endif
-// The K step of two MFMA groups.  MTM_STEP_VARIANT (build-time experiment switch): 1 = the whole step as ONE asm
-// statement (default), 2 = that with the odd-offset windows computed from the operand, 0 = round 2's four statements.
+// The K step of two MFMA groups.  MTM_STEP_VARIANT (build-time experiment switch): 2 = the whole step as ONE asm
+// statement with the odd-offset windows computed from the operand (default; 44 VALU), 1 = one statement with the odd-offset
+// windows copied from the even ones (47 VALU), 0 = round 2's four statements.  Measured on one box, 4K x 32 templates,
+// kernel per step banded / single launch (profiles/r04a/lib_ab.txt): 0: 0.6636 / 0.6262 ms at 1943 / 2036 MHz,
+// 1: 0.6499 / 0.6131 at 1893 / 1982, 2: 0.6490 / 0.6116 at 1873 / 1967 - 6 % fewer cycles, 2.3 % less time (the chip
+// clocks to its power budget); register-only step: 17.4 -> 16.2 cycles per MFMA (tools/ubench/step).
 #ifndef MTM_STEP_VARIANT
-#define MTM_STEP_VARIANT 1
+#define MTM_STEP_VARIANT 2
 #endif
 __device__ __forceinline__ void mfma_step2(v4i (&acc)[2][16], const v4i qa, const v4i qb, const v4i (&a)[2]) {
 #if defined(MTM_MFMA_NO_ASM) || MTM_STEP_VARIANT == 0
@@ -280,9 +284,37 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         clk0[1] = __builtin_amdgcn_s_memrealtime();
     }
     const int per_xcd = (p.n_work + 7) >> 3;
+    // persistent == 2: items are drawn per XCD (one counter per XCD, a cache line apart, behind the per-CU arrival
+    // counters): XCD x works through the contiguous item range [x per_xcd, (x + 1) per_xcd) - the order the
+    // non-persistent launch gives it through its block index, which keeps the rows of the image an XCD reads in its own
+    // L2 - and takes from the other XCDs' ranges once its own is used up.  The draw for the NEXT item is issued when the
+    // K loop ends, so that its round trip runs under the epilogue.
+    auto xcd_counter = [&](unsigned x) { return &sched[1 + 4096 + 32 * x]; };
+    auto xcd_count = [&](unsigned x) { return min(per_xcd, max(0, p.n_work - (int)x * per_xcd)); };
+    unsigned next_draw = 0xFFFFFFFFu;           // thread 0: the own-XCD draw issued behind the previous item's K loop
     for (int iter = 0;; ++iter) {
     int wid;
-    if (p.persistent) {
+    if (p.persistent == 2) {
+        __syncthreads();                       // previous item fully done (s_item / LDS reuse)
+        if (threadIdx.x == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
+            unsigned k = next_draw != 0xFFFFFFFFu ? next_draw : atomicAdd(xcd_counter(xcc), 1u);
+            int w = p.n_work;
+            if ((int)k < xcd_count(xcc)) {
+                w = (int)xcc * per_xcd + (int)k;
+            } else {
+                for (unsigned d = 1; d < 8 && w == p.n_work; ++d) {
+                    const unsigned x2 = (xcc + d) & 7u;
+                    if (xcd_count(x2) == 0) continue;
+                    k = atomicAdd(xcd_counter(x2), 1u);
+                    if ((int)k < xcd_count(x2)) w = (int)x2 * per_xcd + (int)k;
+                }
+            }
+            s_item[0] = w;
+        }
+        __syncthreads();
+        wid = s_item[0];
+    } else if (p.persistent) {
         __syncthreads();                       // previous item fully done (s_item / LDS reuse)
         if (threadIdx.x == 0) s_item[0] = (int)atomicAdd(&sched[0], 1u);
         __syncthreads();
@@ -291,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if (iter > 0) break;
         wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     }
+    next_draw = 0xFFFFFFFFu;               // (a constant again until the K loop has ended: nothing lives across the loop)
     if (wid >= p.n_work) break;
     if (!EXT && METHOD != kMfRaw && p.hits_only) {
         // hits-only launch whose candidate list overflowed: the call will be repeated with the maps in memory
@@ -353,7 +386,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
-            k.ext_thr_lo = -INFINITY;
+            {   // (built behind an opaque asm: as a plain constant the compiler hoists it out of the item loop, where it
+                // lives across the K loop - which owns every register - in scratch memory)
+                int ninf_hi = (int)0xfff00000;
+                asm volatile("" : "+v"(ninf_hi));
+                k.ext_thr_lo = __hiloint2double(ninf_hi, 0);
+            }
             k.ext_hi = 0u;
             k.ext_pad_ = 0;
             if (EXT) {
@@ -417,7 +455,19 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 
     for (int c = 0; c < p.chans; ++c) {
         const uint8_t* plane = p.img + c * p.plane;
-        const int cpk = METHOD == kMfU16 ? 0 : c;        // channel of the A pack (uint16: both byte planes meet the same [T_hi | T_lo])
+        // channel of the A pack (uint16: both byte planes meet the same [T_hi | T_lo]; sum I^2 M: both planes meet the mask)
+        const int cpk = (METHOD == kMfU16 || (RM && METHOD == kMfRaw && p.sq_fused)) ? 0 : c;
+        if constexpr (RM && METHOD == kMfRaw && !KP) {
+            // sum I^2 M in ONE launch (round 4): the byte planes of I^2 are the two "channels".  The high-byte sums
+            // a_h = sum (J_h - 128) M are scaled by 256 in place and the low-byte plane accumulates on top of them:
+            // 256 a_h + a_l, |.| <= 256 * 128 * w h + 128 w h < 2^31 for w h <= 65025 (the launcher's bound).
+            if (p.sq_fused && c == 1) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[mb][k] = acc[mb][k] << 8;
+            }
+        }
         if constexpr (METHOD == kMfU16) {
             if (c == 1) {
 #pragma unroll
@@ -688,6 +738,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
 
+    if (p.persistent == 2 && threadIdx.x == 0)
+        next_draw = atomicAdd(xcd_counter(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u), 1u);
     // ---- epilogue: per wave, 8 templates at a time through LDS ([8 templates][pixel] int32).
     // A lane owns 4 consecutive pixels: their statistics are loaded ONCE into registers (they do
     // not depend on the template), per-template constants come from LDS, every (lane, template)
@@ -817,6 +869,60 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         __syncthreads();
         const int R = p.rm_R, ntm = p.rm_nt - 1, lg = p.rm_log2nt;
         const bool col_on = xq < p.ow;
+        if (p.sq_fused) {
+            // ---- sum I^2 M, finished here (round 4; round 3: two raw launches + masksq_combine_kernel): the accumulator
+            // holds 256 a_h + a_l, c2 = that + 257 * 128 * sum(M) (p.sq_k; the mask operand is not biased) goes to the
+            // class's sum2 plane as float64, and the smallest c2 of every 16-pixel column block - lanes 4 b .. 4 b + 3 of
+            // a row - to the third slot of the block record (the masked hits-only screen bounds sqrt(tms c2) with it;
+            // +inf right of the last output column).
+            double* sum2_out = const_cast<double*>(st.sum2);
+            double* blk_out = const_cast<double*>(st.blk);
+            const int bj = (x0 >> 4) + (lane >> 2);
+            auto xmin = [&](double v, int off) {
+                const int addr = (lane ^ off) << 2;
+                const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+                const int hi2 = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+                return fmin(v, __hiloint2double(hi2, lo));
+            };
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll 1
+                for (int round = 0; round < 2; ++round) {
+                    if ((q >> 1) == round) put(acc[mb]);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                    for (int s8 = 0; s8 < 8; ++s8) {
+                        const int i = 8 * round + s8;
+                        const int t = i & ntm, rho = i >> lg;
+                        const int yy = y0 + wave * wave_rows + mb * R + rho;
+                        if (t >= p.n_list || yy >= p.oh) continue;              // wave-uniform
+                        const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
+                        const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
+                        double c2v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) c2v[k] = xq + k < p.ow ? (double)a32[k] + p.sq_k : INFINITY;
+                        double* orow = sum2_out + (size_t)yy * st.pitch + xq;
+                        if (xq + 3 < p.ow) {
+                            *reinterpret_cast<double2*>(orow) = make_double2(c2v[0], c2v[1]);
+                            *reinterpret_cast<double2*>(orow + 2) = make_double2(c2v[2], c2v[3]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (xq + k < p.ow) orow[k] = c2v[k];
+                        }
+                        double bmin = fmin(fmin(c2v[0], c2v[1]), fmin(c2v[2], c2v[3]));
+                        bmin = xmin(bmin, 1);
+                        bmin = xmin(bmin, 2);
+                        if (blk_out != nullptr && (lane & 3) == 0 && bj < st.blk_pitch)
+                            blk_out[((size_t)yy * st.blk_pitch + bj) * 4 + 2] = bmin;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            continue;           // next work item (the loop's tail has no work-group barrier)
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll 1

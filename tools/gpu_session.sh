@@ -61,6 +61,18 @@ for st in "$@"; do
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('lib=${v:-product} bands=$b', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/lib_ab.txt
         done
       done; done ;;
+    persist_ab)     # item scheduling of the score kernel: launch per item / persistent (global or per-XCD draw), with and without the start stagger
+      for rep in 1 2; do for v in "0 -1 0" "2 -1 0" "2 0 0" "1 -1 0" "0 -1 3" "2 2 0" "2 6 0"; do set -- $v
+        for b in ${LIB_BANDS:-"0.25,1" "1"}; do
+        MTM_MFMA_PERSISTENT=$1 MTM_MFMA_STAGGER=$2 MTM_MFMA_STAGGER_NP=$3 MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps ${LIB_STEPS:-200} 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('persistent=$1 stagger=$2 stagger_np=$3 bands=$b', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/persist_ab.txt
+        done
+      done; done ;;
+    cfg5_ab)        # sum I^2 M of the masked classes: one fused launch per class against round 3's two raw launches + combine
+      for rep in 1 2; do for v in 1 0; do
+        MTM_MASKSQ_FUSED=$v python bench.py --config cfg5 --no-cpu-baseline --skip-extras --steps 10 --warmup 3 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('masksq_fused=$v', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], d.get('gpu_ms'), r.get('masked_stat'))" | tee -a $OUT/cfg5_ab.txt
+      done; done ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
