@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="north_star", choices=CONFIGS)
     ap.add_argument("--kernel", default=os.environ.get("MTM_KERNEL", "auto"))
+    ap.add_argument("--exchange", default=None, choices=["rccl", "host"],
+                    help="hit exchange of the one-process multi-GPU form (--gpus N without a launcher): rccl = ncclCommInitAll "
+                         "over the devices + one all-gather per device inside ncclGroupStart/End (default when N > 1), "
+                         "host = merge of the workers' host lists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-extras", action="store_true",
                     help="only the timed calls (profiling runs): no resident / fresh-template / map-mode / stream side measurements")
@@ -246,6 +250,19 @@ def cpu_baseline(img, units, method, thr, n_sample):
             "seconds": round(dt, 3)}
 
 
+def resolve_group_exchange(group, requested):
+    """The hit exchange of the one-process multi-GPU form.  Default (None) and "rccl": ncclCommInitAll over the group's
+    devices; if that fails (a device listed twice - BENCH_GROUP_ALIAS on a single-GPU box -, no librccl) the group keeps
+    the host merge and the line says why.  Returns (kind in use, ncclCommCount, note)."""
+    if requested == "host":
+        return "host", 0, "host merge requested"
+    try:
+        ranks = group.comm_init(strict=True)
+        return "rccl", ranks, "ncclCommInitAll over %d device(s)" % len(group)
+    except Exception as e:  # noqa: BLE001
+        return "host", 0, "rccl unavailable, host merge instead: %s" % e
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -290,11 +307,14 @@ def main():
         group.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
         _lib._engines[tuple(group_devices)] = group          # MTM.matchTemplates(devices=...) below runs on this group
         ctx = None
+        group_exchange, group_comm_ranks, group_exchange_note = resolve_group_exchange(group, args.exchange)
     else:
         ctx = _lib.Context(device)
         ctx.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
         _lib._default_ctx = ctx                  # MTM.matchTemplates below runs on this context
-    exchange_kind = "rccl" if world > 1 else ("host merge (one process, mtm_group)" if group_n else "none")
+    exchange_kind = "rccl" if world > 1 else ("none" if not group_n else
+                                              "rccl all-gather inside ncclGroupStart/End (one process, ncclCommInitAll)"
+                                              if group_exchange == "rccl" else "host merge (one process, mtm_group)")
     comm_ranks = 1
     try:
         exchange = HitExchange("rccl", rank, world, context=ctx) if not group_n else None     # unique id through the package's TCP store
@@ -642,7 +662,8 @@ def main():
         }
         if group_n:
             out["multi_gpu"] = {"mode": "one process, mtm_group", "devices": group_devices,
-                                "exchange": "none (hit lists merged on the host)",
+                                "exchange": group.exchange_used(), "exchange_requested": args.exchange or "rccl",
+                                "communicator_ranks": group_comm_ranks, "exchange_note": group_exchange_note,
                                 "kernel_ms_per_step_by_device": [round(float(np.mean(v)), 4) if v else None for v in dev_kernel_ms],
                                 "units_by_device": [int((group.shards([(u[1], u[2] if len(u) >= 3 else None) for u in units],
                                                                       img.shape, method) == i).sum()) for i in range(group_n)]}

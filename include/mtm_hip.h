@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 3
+#define MTM_ABI_VERSION 4
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -288,6 +288,19 @@ int      mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_tem
                                 const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
                                 int mode, double score_threshold, mtm_hit* out, int64_t capacity, int64_t* n_out);
 int      mtm_group_last_hits(mtm_group* g, mtm_hit* out, int64_t capacity, int64_t* n_out);
+/* The hit exchange of a group as north_star / SURVEY 8e name it: a single process, ncclCommInitAll over the group's
+ * devices, one stream per device, ONE all-gather of fixed-size slots of 24-byte hit records per device inside
+ * ncclGroupStart / ncclGroupEnd; rank 0's gathered list is merged and returned (the reference's fan-in,
+ * MTM/__init__.py:173-177, followed by the one global NMS of MTM/NMS.py:78).  mtm_group_comm_init() creates the
+ * communicators and selects that exchange; it fails with MTM_E_COMM - and the group keeps the host merge - when RCCL is
+ * missing or a device is listed twice (RCCL takes one rank per device).  mtm_group_comm_ranks(): ncclCommCount of rank 0
+ * (0 without communicators).  mtm_group_set_exchange() switches between the two; both deliver the same list. */
+#define MTM_GROUP_EXCHANGE_HOST 0
+#define MTM_GROUP_EXCHANGE_RCCL 1
+int      mtm_group_comm_init(mtm_group* g);
+int      mtm_group_comm_ranks(mtm_group* g);
+int      mtm_group_set_exchange(mtm_group* g, int kind);
+int      mtm_group_exchange_used(const mtm_group* g);            /* what the last mtm_group_find_matches used */
 
 /* ---- multi-GPU: one process per GPU, templates sharded across ranks (north_star) ------------ */
 /* RCCL all-gather of per-rank hit lists over xGMI.  The 128-byte unique id is created on rank 0
@@ -306,6 +319,14 @@ int mtm_comm_allgather_hits(mtm_ctx* ctx, const mtm_hit* local, int64_t n_local,
  * buffer was large enough has already left it. */
 int mtm_comm_last_gather(mtm_ctx* ctx, mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out);
 int mtm_comm_destroy(mtm_ctx* ctx);
+/* The same exchange for n contexts of ONE process (what mtm_group_comm_init / mtm_group_find_matches use): communicators
+ * by ncclCommInitAll over the contexts' devices (context i becomes rank i; MTM_E_COMM if two contexts share a device),
+ * and one call that queues every rank's all-gather inside ncclGroupStart / ncclGroupEnd, each on its context's stream, and
+ * returns rank 0's gathered list.  mtm_comm_count(): ncclCommCount of the context's communicator, 0 without one. */
+int mtm_comm_init_all(mtm_ctx* const* ctxs, int n);
+int mtm_comm_count(mtm_ctx* ctx);
+int mtm_comm_allgather_hits_all(mtm_ctx* const* ctxs, int n, const mtm_hit* const* local, const int64_t* n_local,
+                                mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MTM_LIB_PATH") or os.path.join(_HERE, "libmtm_hip.so")
 
 MTM_U8, MTM_F32, MTM_U16 = 0, 1, 2
+GROUP_EXCHANGE_HOST, GROUP_EXCHANGE_RCCL = 0, 1
 PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1
 BORDER_CONSTANT, BORDER_NEAREST = 0, 1
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
@@ -23,7 +24,7 @@ OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, 
 E_OVERFLOW = -5
 E_HIP = -2
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MtmTempl(ctypes.Structure):
@@ -102,6 +103,10 @@ SYMBOLS = {
                                               ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
                                               _P(ctypes.c_int64)]),
     "mtm_group_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_group_comm_init": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtm_group_comm_ranks": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtm_group_set_exchange": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "mtm_group_exchange_used": (ctypes.c_int, [ctypes.c_void_p]),
     "mtm_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
     "mtm_host_free": (None, [ctypes.c_void_p]),
     "mtm_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
@@ -112,6 +117,10 @@ SYMBOLS = {
     "mtm_comm_last_gather": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                             _P(ctypes.c_int64)]),
     "mtm_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtm_comm_init_all": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_int]),
+    "mtm_comm_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "mtm_comm_allgather_hits_all": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_int, _P(ctypes.c_void_p), _P(ctypes.c_int64),
+                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, _P(ctypes.c_int64)]),
 }
 
 _lib = None
@@ -467,6 +476,29 @@ class Group(_RecordMemo):
 
     def set_option(self, opt, value):
         check(self._lib.mtm_group_set_option(self._h, int(opt), int(value)), "mtm_group_set_option")
+
+    # ---- hit exchange: host merge (default) or the in-process RCCL all-gather ------
+    def comm_init(self, strict=True):
+        """ncclCommInitAll over the group's devices and the RCCL exchange for the searches that follow.  Returns the
+        number of ranks of the communicator (ncclCommCount); with strict=False a failure (RCCL missing, a device listed
+        twice) leaves the host merge in place and returns 0 instead of raising."""
+        rc = self._lib.mtm_group_comm_init(self._h)
+        if rc != 0:
+            if strict:
+                check(rc, "mtm_group_comm_init")
+            return 0
+        return self.comm_ranks()
+
+    def comm_ranks(self):
+        return int(self._lib.mtm_group_comm_ranks(self._h))
+
+    def set_exchange(self, kind):
+        """"host" | "rccl" """
+        check(self._lib.mtm_group_set_exchange(self._h, {"host": GROUP_EXCHANGE_HOST, "rccl": GROUP_EXCHANGE_RCCL}[kind]),
+              "mtm_group_set_exchange")
+
+    def exchange_used(self):
+        return {GROUP_EXCHANGE_HOST: "host", GROUP_EXCHANGE_RCCL: "rccl"}[int(self._lib.mtm_group_exchange_used(self._h))]
 
     def shards(self, templates, image_shape, method):
         """device index of every unit, as a search over an image of this shape would assign them"""

@@ -17,6 +17,11 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    // one process, several devices (mtm_comm_init_all / mtm_comm_allgather_hits_all)
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 Rccl g_rccl;
 
@@ -35,6 +40,10 @@ int load_rccl() {
     g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(lib, "ncclCommAbort"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    g_rccl.CommCount = reinterpret_cast<decltype(g_rccl.CommCount)>(dlsym(lib, "ncclCommCount"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
         set_error("librccl.so lacks an expected symbol");
         dlclose(lib);
@@ -200,6 +209,140 @@ int mtm_comm_last_gather(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* co
         o += cnt;
     }
     return MTM_OK;
+}
+
+// ---- one process, one communicator per device of a group (single process, ncclCommInitAll, one stream per
+// device, the all-gather of every device inside ncclGroupStart / ncclGroupEnd, issued by the calling thread)
+int mtm_comm_init_all(mtm_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1) {
+        set_error("mtm_comm_init_all: bad arguments");
+        return MTM_E_INVALID;
+    }
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) {
+            set_error("mtm_comm_init_all: null context");
+            return MTM_E_INVALID;
+        }
+        devs[(size_t)i] = ctxs[i]->device;
+        for (int k = 0; k < i; ++k)
+            if (devs[(size_t)k] == devs[(size_t)i]) {
+                // RCCL refuses two ranks of one communicator on one device; such a group (several contexts aliased
+                // onto one GPU) merges its hit lists on the host
+                set_error("mtm_comm_init_all: device " + std::to_string(devs[(size_t)i]) +
+                          " is listed twice - one RCCL rank per device (the group keeps the host merge)");
+                return MTM_E_COMM;
+            }
+    }
+    MTMC(load_rccl());
+    if (!g_rccl.CommInitAll || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
+        set_error("librccl.so lacks ncclCommInitAll / ncclGroupStart / ncclGroupEnd");
+        return MTM_E_COMM;
+    }
+    for (int i = 0; i < n; ++i) (void)mtm_comm_destroy(ctxs[i]);
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    NCCLC(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[(size_t)i];
+        ctxs[i]->n_ranks = n;
+        ctxs[i]->rank = i;
+        ctxs[i]->comm_slot_hits = 512;
+    }
+    return MTM_OK;
+}
+
+int mtm_comm_count(mtm_ctx* c) {
+    if (!c || !c->comm) return 0;
+    int n = c->n_ranks;
+    if (g_rccl.CommCount && g_rccl.CommCount(c->comm, &n) != ncclSuccess) return 0;
+    return n;
+}
+
+int mtm_comm_allgather_hits_all(mtm_ctx* const* ctxs, int n, const mtm_hit* const* local, const int64_t* n_local, mtm_hit* out,
+                                int64_t capacity, int64_t* counts_out, int64_t* n_out) {
+    if (!ctxs || n < 1 || !local || !n_local || !counts_out || !n_out || capacity < 0 || (capacity > 0 && !out)) {
+        set_error("mtm_comm_allgather_hits_all: bad arguments");
+        return MTM_E_INVALID;
+    }
+    long long mx = 1;
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->comm || ctxs[i]->n_ranks != n || ctxs[i]->rank != i || n_local[i] < 0 ||
+            (n_local[i] > 0 && !local[i])) {
+            set_error("mtm_comm_allgather_hits_all: contexts are not the ranks 0 .. n-1 of one mtm_comm_init_all");
+            return MTM_E_INVALID;
+        }
+        MTM_NOT_IN_FLIGHT(ctxs[i], "mtm_comm_allgather_hits_all");
+        mx = std::max<long long>(mx, n_local[i]);
+    }
+    // one process: every count is known before the exchange, so the slot is sized once ([count | records], 512 records
+    // or the next power of two that holds the longest list) and ONE all-gather per device does it
+    long long slot_hits = 512;
+    while (slot_hits < mx) slot_hits <<= 1;
+    const size_t slot = 16 + sizeof(mtm_hit) * (size_t)slot_hits;
+    for (int i = 0; i < n; ++i) {
+        mtm_ctx* c = ctxs[i];
+        HIPC(hipSetDevice(c->device));
+        MTMC(c->comm_send.ensure(slot));
+        MTMC(c->comm_recv.ensure(slot * n));
+        const size_t pin_bytes = slot * (size_t)(n + 1);
+        if (c->comm_pin_cap < pin_bytes) {
+            if (c->comm_pin) (void)hipHostFree(c->comm_pin);
+            c->comm_pin = nullptr;
+            c->comm_pin_cap = 0;
+            HIPC(hipHostMalloc(&c->comm_pin, pin_bytes, hipHostMallocDefault));
+            c->comm_pin_cap = pin_bytes;
+        }
+        uint8_t* mine = static_cast<uint8_t*>(c->comm_pin);
+        std::memset(mine, 0, 16);
+        const long long cnt = n_local[i];
+        std::memcpy(mine, &cnt, sizeof(cnt));
+        if (cnt > 0) std::memcpy(mine + 16, local[i], sizeof(mtm_hit) * (size_t)cnt);
+        HIPC(hipMemcpyAsync(c->comm_send.p, mine, 16 + sizeof(mtm_hit) * (size_t)cnt, hipMemcpyHostToDevice, c->stream));
+    }
+    NCCLC(g_rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        mtm_ctx* c = ctxs[i];
+        const ncclResult_t r = g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            set_error(std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error"));
+            return MTM_E_COMM;
+        }
+    }
+    NCCLC(g_rccl.GroupEnd());
+    // rank 0's gathered slots feed the caller (the global NMS runs once, MTM/NMS.py:78); the other devices only have to
+    // finish their part of the collective
+    mtm_ctx* c0 = ctxs[0];
+    HIPC(hipSetDevice(c0->device));
+    uint8_t* gathered = static_cast<uint8_t*>(c0->comm_pin) + slot;
+    HIPC(hipMemcpyAsync(gathered, c0->comm_recv.p, slot * n, hipMemcpyDeviceToHost, c0->stream));
+    const double limit = c0->comm_timeout_s;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < n; ++i) {
+        mtm_ctx* c = ctxs[i];
+        hipError_t qs;
+        int spins = 0;
+        while ((qs = hipStreamQuery(c->stream)) == hipErrorNotReady) {
+            if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (limit > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+                for (int k = 0; k < n; ++k) {
+                    if (g_rccl.CommAbort) (void)g_rccl.CommAbort(ctxs[k]->comm);
+                    ctxs[k]->comm = nullptr;
+                    ctxs[k]->n_ranks = 1;
+                    ctxs[k]->rank = 0;
+                }
+                set_error("mtm_comm_allgather_hits_all: the exchange did not finish within the deadline (MTM_COMM_TIMEOUT_S); "
+                          "communicators aborted");
+                return MTM_E_COMM;
+            }
+        }
+        HIPC(qs);
+    }
+    std::vector<long long> counts((size_t)n, 0);
+    for (int r = 0; r < n; ++r) std::memcpy(&counts[(size_t)r], gathered + slot * r, sizeof(long long));
+    c0->comm_last_counts = counts;
+    c0->comm_last_slot = slot;
+    return mtm_comm_last_gather(c0, out, capacity, counts_out, n_out);
 }
 
 int mtm_comm_destroy(mtm_ctx* c) {

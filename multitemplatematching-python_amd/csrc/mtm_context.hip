@@ -266,6 +266,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
+    if (const char* v = std::getenv("MTM_RM_EDGES")) c->rm_edges = std::atoi(v);
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));

@@ -162,6 +162,7 @@ struct mtm_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sq_ev;       // event pairs of the sum I^2 M passes (timing.masked_stat_ms)
+    int rm_edges = 1;           // MTM_RM_EDGES: one-group K steps where a row-multiplexed wave's other group has no template row (0: off)
     int masksq_fused = 1;       // MTM_MASKSQ_FUSED: sum I^2 M of a masked class as ONE launch over both byte planes of I^2 that
                                 // writes the sum2 plane itself (0: round 3's two raw launches + masksq_combine_kernel)
 

@@ -3,11 +3,21 @@
 // cost, every device uploads the image and searches its shard concurrently (mtm_set_templates +
 // mtm_find_matches_image on its own context and streams), and the per-device hit lists are merged on the host in
 // template order.  The reference's equivalent is its thread pool over templates (MTM/__init__.py:172-175); the
-// independence of the units is the same, the workers are GPUs.  No collective is needed in a single process:
-// every hit list is already in host memory when its worker finishes (the one-process-per-GPU form with the RCCL
-// all-gather is mtm_comm_*).  Host-only C++ on top of the C ABI.
+// independence of the units is the same, the workers are GPUs.
+//   * Hit exchange (round 4).  north_star / SURVEY 8e name the exchange: a single process, ncclCommInitAll, one stream
+//     per device, one all-gather of fixed-size slots of hit records inside ncclGroupStart / ncclGroupEnd.
+//     mtm_group_comm_init() builds those communicators; with MTM_GROUP_EXCHANGE_RCCL selected the per-device lists
+//     travel device-side through that all-gather and rank 0's gathered list is what gets merged - the list the host
+//     merge (every list is in host memory when its worker returns; the default without communicators, and the
+//     fallback when a device is listed twice) produces from the workers' buffers.
+//   * Image staging (round 4).  Every worker used to hand the caller's pageable image to its own upload (N staging
+//     copies of the same pixels through the runtime's bounce buffers).  Now the workers copy one slice each into ONE
+//     page-locked buffer, wait for each other, and every device's (banded) upload is a plain DMA from it.
+// Host-only C++ on top of the C ABI.
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -53,6 +63,17 @@ struct mtm_group {
     bool stop = false;
     Job job;
     std::vector<mtm_hit> last_hits;
+    // hit exchange
+    int exchange = MTM_GROUP_EXCHANGE_HOST;     // what the next search uses
+    int exchange_used = MTM_GROUP_EXCHANGE_HOST;   // what the last search used
+    bool comm_ready = false;
+    // shared page-locked staging of the image (MTM_GROUP_STAGE=0: every worker uploads the caller's buffer itself)
+    bool stage_on = true;
+    void* pin = nullptr;
+    size_t pin_cap = 0;
+    size_t row_bytes = 0;                       // bytes of one image row in the staging buffer (tight)
+    bool staged_job = false;                    // this job's image goes through the staging buffer
+    std::atomic<int> staged{0};                 // workers that have copied their slice of this job's image
 };
 
 namespace {
@@ -62,12 +83,32 @@ void run_job(mtm_group* g, Worker& w) {
     w.hits.clear();
     w.rc = MTM_OK;
     w.err.clear();
+    const void* px = j.px;
+    int64_t stride = j.stride;
+    if (g->staged_job) {
+        // my slice of the rows -> the shared page-locked buffer (every worker takes part, also one without units), then
+        // wait for the others: the searches below read all of it
+        const int nd = (int)g->workers.size(), wi = (int)(&w - g->workers.data());
+        const int r0 = (int)((long long)j.rows * wi / nd), r1 = (int)((long long)j.rows * (wi + 1) / nd);
+        uint8_t* dst = static_cast<uint8_t*>(g->pin);
+        const uint8_t* src = static_cast<const uint8_t*>(j.px);
+        if ((size_t)j.stride == g->row_bytes) {
+            std::memcpy(dst + (size_t)r0 * g->row_bytes, src + (size_t)r0 * g->row_bytes, (size_t)(r1 - r0) * g->row_bytes);
+        } else {
+            for (int r = r0; r < r1; ++r) std::memcpy(dst + (size_t)r * g->row_bytes, src + (long long)r * j.stride, g->row_bytes);
+        }
+        g->staged.fetch_add(1, std::memory_order_acq_rel);
+        for (int spins = 0; g->staged.load(std::memory_order_acquire) < nd; ++spins)
+            if (spins > 200) std::this_thread::yield();
+        px = g->pin;
+        stride = (int64_t)g->row_bytes;
+    }
     if (w.templs.empty()) return;                     // more devices than units
     int rc = mtm_set_templates(w.ctx, w.templs.data(), (int)w.templs.size(), j.method);
     if (rc == MTM_OK) {
         int64_t n = 0;
         w.hits.resize(4096);
-        rc = mtm_find_matches_image(w.ctx, j.px, j.rows, j.cols, j.chans, j.dtype, j.stride, j.mode, j.thr, w.hits.data(),
+        rc = mtm_find_matches_image(w.ctx, px, j.rows, j.cols, j.chans, j.dtype, stride, j.mode, j.thr, w.hits.data(),
                                     (int64_t)w.hits.size(), &n);
         if (rc == MTM_E_OVERFLOW) {
             w.hits.resize((size_t)n);
@@ -129,10 +170,49 @@ int mtm_group_create(mtm_group** out, const int* device_ids, int n_devices) {
             return rc;
         }
     }
+    if (const char* v = std::getenv("MTM_GROUP_STAGE")) g->stage_on = std::atoi(v) != 0;
     for (int i = 0; i < n_devices; ++i) g->workers[(size_t)i].th = std::thread(worker_main, g, i);
     *out = g;
     return MTM_OK;
 }
+
+int mtm_group_comm_init(mtm_group* g) {
+    if (!g) {
+        set_error("mtm_group_comm_init: null group");
+        return MTM_E_INVALID;
+    }
+    std::vector<mtm_ctx*> ctxs;
+    for (Worker& w : g->workers) ctxs.push_back(w.ctx);
+    g->comm_ready = false;
+    const int rc = mtm_comm_init_all(ctxs.data(), (int)ctxs.size());
+    if (rc != MTM_OK) {
+        g->exchange = MTM_GROUP_EXCHANGE_HOST;
+        return rc;
+    }
+    g->comm_ready = true;
+    g->exchange = MTM_GROUP_EXCHANGE_RCCL;
+    return MTM_OK;
+}
+
+int mtm_group_comm_ranks(mtm_group* g) {
+    if (!g || !g->comm_ready || g->workers.empty()) return 0;
+    return mtm_comm_count(g->workers[0].ctx);
+}
+
+int mtm_group_set_exchange(mtm_group* g, int kind) {
+    if (!g || (kind != MTM_GROUP_EXCHANGE_HOST && kind != MTM_GROUP_EXCHANGE_RCCL)) {
+        set_error("mtm_group_set_exchange: bad arguments");
+        return MTM_E_INVALID;
+    }
+    if (kind == MTM_GROUP_EXCHANGE_RCCL && !g->comm_ready) {
+        set_error("mtm_group_set_exchange: no communicators (mtm_group_comm_init first)");
+        return MTM_E_STATE;
+    }
+    g->exchange = kind;
+    return MTM_OK;
+}
+
+int mtm_group_exchange_used(const mtm_group* g) { return g ? g->exchange_used : MTM_GROUP_EXCHANGE_HOST; }
 
 void mtm_group_destroy(mtm_group* g) {
     if (!g) return;
@@ -143,7 +223,8 @@ void mtm_group_destroy(mtm_group* g) {
     g->cv_job.notify_all();
     for (Worker& w : g->workers)
         if (w.th.joinable()) w.th.join();
-    for (Worker& w : g->workers) mtm_ctx_destroy(w.ctx);
+    for (Worker& w : g->workers) mtm_ctx_destroy(w.ctx);        // (also destroys the context's communicator)
+    if (g->pin) mtm_host_free(g->pin);
     delete g;
 }
 
@@ -208,6 +289,20 @@ int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, i
         w.templs.push_back(templs[i]);
         w.global_idx.push_back(i);
     }
+    // the image through ONE page-locked buffer (groups of several devices, images of a megabyte and more)
+    {
+        const size_t esz = dtype == MTM_U8 ? 1 : dtype == MTM_U16 ? 2 : 4;
+        const size_t row_bytes = (size_t)cols * (size_t)chans * esz, need = row_bytes * (size_t)rows;
+        g->staged_job = g->stage_on && nd > 1 && need >= ((size_t)1 << 20) && row_stride_bytes >= (int64_t)row_bytes;
+        if (g->staged_job && g->pin_cap < need) {
+            if (g->pin) mtm_host_free(g->pin);
+            g->pin = mtm_host_alloc(need);
+            g->pin_cap = g->pin ? need : 0;
+            if (!g->pin) g->staged_job = false;       // (no page-locked memory: every worker uploads the caller's buffer)
+        }
+        g->row_bytes = row_bytes;
+        g->staged.store(0, std::memory_order_release);
+    }
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->job = Job{method, mode, score_threshold, px, rows, cols, chans, dtype, row_stride_bytes};
@@ -226,7 +321,30 @@ int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, i
         }
     // merge in the single-device order: template index, then each device's own order within a template
     std::vector<mtm_hit> all;
-    for (Worker& w : g->workers) all.insert(all.end(), w.hits.begin(), w.hits.end());
+    g->exchange_used = MTM_GROUP_EXCHANGE_HOST;
+    if (g->exchange == MTM_GROUP_EXCHANGE_RCCL && g->comm_ready) {
+        // device-side: one all-gather per device inside ncclGroupStart / End; rank 0's gathered list (rank order, each
+        // rank's own order inside) is the concatenation the host merge would build
+        std::vector<mtm_ctx*> ctxs;
+        std::vector<const mtm_hit*> local;
+        std::vector<int64_t> n_local, counts((size_t)nd, 0);
+        size_t total = 0;
+        for (Worker& w : g->workers) {
+            ctxs.push_back(w.ctx);
+            local.push_back(w.hits.data());
+            n_local.push_back((int64_t)w.hits.size());
+            total += w.hits.size();
+        }
+        all.resize(total);
+        int64_t n_all = 0;
+        const int rcx = mtm_comm_allgather_hits_all(ctxs.data(), nd, local.data(), n_local.data(), all.data(), (int64_t)all.size(),
+                                                    counts.data(), &n_all);
+        if (rcx != MTM_OK) return rcx;
+        all.resize((size_t)n_all);
+        g->exchange_used = MTM_GROUP_EXCHANGE_RCCL;
+    } else {
+        for (Worker& w : g->workers) all.insert(all.end(), w.hits.begin(), w.hits.end());
+    }
     std::stable_sort(all.begin(), all.end(), [](const mtm_hit& a, const mtm_hit& b) { return a.templ_idx < b.templ_idx; });
     *n_out = (int64_t)all.size();
     g->last_hits.swap(all);

@@ -218,6 +218,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         p.cpr_dstep = 256 % p.cpr;
         p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = -(long long)16 * p.nb * 1024;
+        p.rm_edges = c->rm_edges;
         p.only_li = -1;
         p.raw_map = raw_map;
         p.raw_pitch = map_pitch;
@@ -413,6 +414,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 p.nyb = (oh + 8 * R - 1) / (8 * R);
                 p.ntg = 1;
                 p.group_bytes = -(long long)R * p.nb * 1024;
+                p.rm_edges = c->rm_edges;
                 tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * R;
             } else {
                 p.nyb = (oh + kMfRows - 1) / kMfRows;
@@ -523,6 +525,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.rm_steps = h + 2 * sc.rm_R - 1;
             p.rm_cstride = class_rm_pack_bytes(sc);
             p.rm_rsq = c->stats_rsq.as<double>();
+            p.rm_edges = c->rm_edges;
             p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
             p.ntg = 1;
             tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * sc.rm_R;

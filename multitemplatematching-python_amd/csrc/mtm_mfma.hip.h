@@ -218,6 +218,21 @@ __device__ __forceinline__ void mfma_step2(v4i (&acc)[2][16], const v4i qa, cons
     mfma_step2_fused(acc, qa, qb, a);
 #endif
 }
+// The K step of the row-multiplexed tilings: both groups, or - edge steps, see the generic K loop - only one of them
+// (mode 1: group 0, 2: group 1).  One asm statement with three paths (tools/gen_mfma_step.py says why).
+__device__ __forceinline__ void mfma_step2_rm(v4i (&acc)[2][16], const v4i qa, const v4i qb, const v4i (&a)[2], const int mode) {
+#if defined(MTM_MFMA_NO_ASM) || MTM_STEP_VARIANT == 0
+    if (mode == 0) {
+        mfma_step<2>(acc, qa, qb, a);
+    } else {
+        v4i (&acc1)[1][16] = reinterpret_cast<v4i (&)[1][16]>(acc[mode - 1]);
+        const v4i a1[1] = {a[mode - 1]};
+        mfma_step<1>(acc1, qa, qb, a1);
+    }
+#else
+    mfma_step2_edges(acc, qa, qb, a, mode);
+#endif
+}
 // the K step of an instantiation: the uint16 kernel (three accumulator sets) takes the one-scratch-set form
 template <int METHOD_, int MB>
 __device__ __forceinline__ void mfma_kstep(v4i (&acc)[MB][16], const v4i qa, const v4i qb, const v4i (&a)[MB]) {
@@ -699,7 +714,24 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #ifdef MTM_PROBE_NO_MFMA   /* timing experiment: the loop skeleton without MFMAs and operand shifts */
 #define MTM_MF_STEP(QA, QB, A, K) acc[0][K] += QA + QB + A[0] + A[MB - 1];
 #else
-#define MTM_MF_STEP(QA, QB, A, K) mfma_kstep<METHOD, MB>(acc, QA, QB, A);
+            // Row-multiplexed tilings (round 4): a wave's two MFMA groups are output rows [0, R) and [R, 2 R) of the same
+            // templates, and image row s of the wave's h + 2 R - 1 holds template rows of group 0 only for s < h + R - 1 and
+            // of group 1 only for s >= R - outside, the group's A operand is all zero.  Those edge steps run the
+            // one-group step (16 MFMAs instead of 32): 2 R of the h + 2 R - 1 steps, i.e. for ONE template or mask
+            // (R = 16, h = 64) 79 step-equivalents instead of 95.
+            constexpr bool kRmEdges = RM && MB == 2 && METHOD != kMfU16;
+            int srow = cy0, sblk = 0;                       // image row / 64-tap block of the step being executed
+            const int edge_lo = RM ? p.rm_R : 0, edge_hi = RM ? p.h + p.rm_R - 1 : 0x7fffffff;
+#define MTM_MF_STEP(QA, QB, A, K)                                                       \
+            if constexpr (kRmEdges) {                                                   \
+                const int mode_ = !p.rm_edges ? 0 : srow < edge_lo ? 1 : srow >= edge_hi ? 2 : 0; \
+                mfma_step2_rm(acc, QA, QB, A, __builtin_amdgcn_readfirstlane(mode_));   \
+                const bool last_ = sblk + 1 == p.nb;                                    \
+                srow += last_ ? 1 : 0;                                                  \
+                sblk = last_ ? 0 : sblk + 1;                                            \
+            } else {                                                                    \
+                mfma_kstep<METHOD, MB>(acc, QA, QB, A);                                 \
+            }
 #endif
             // hits-only launches: the MFMA main loop outranks the (short) epilogue of the co-resident work-group
             // (-0.9 % kernel time; with the maps written the long epilogue is the one that must not starve: +1 %)

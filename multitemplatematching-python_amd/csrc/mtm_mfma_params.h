@@ -114,7 +114,8 @@ struct MfmaParams {
     // Row-multiplexed raw mode as the sum I^2 M pass of a masked class in one launch: the two byte planes of I^2 are the
     // launch's channels (chans = 2), the accumulators are scaled by 256 between them and the epilogue writes
     // c2 = acc + sq_k as float64 into st.sum2 plus its 16-pixel block minima into st.blk (no raw maps, no combine kernel).
-    int sq_fused, sq_pad_;
+    int sq_fused;
+    int rm_edges;            // row-multiplexed tilings: 1 = the edge steps (one group's A operand all zero) run the one-group step
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)

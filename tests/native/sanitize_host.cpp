@@ -81,6 +81,34 @@ int mtm_find_matches_image(mtm_ctx* c, const void* px, int rows, int cols, int, 
     if (!c->last.empty()) std::memcpy(out, c->last.data(), sizeof(mtm_hit) * c->last.size());
     return MTM_OK;
 }
+// page-locked memory of the group's shared image staging: plain heap here
+void* mtm_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void mtm_host_free(void* p) { std::free(p); }
+// the in-process communicator calls: rank i = context i; the "all-gather" concatenates the lists in rank order
+static std::atomic<int> g_comm_calls{0};
+int mtm_comm_init_all(mtm_ctx* const* ctxs, int n) {
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < i; ++k)
+            if (ctxs[i]->device == ctxs[k]->device) {
+                set_error("fake: device listed twice");
+                return MTM_E_COMM;
+            }
+    return MTM_OK;
+}
+int mtm_comm_count(mtm_ctx*) { return 1; }
+int mtm_comm_allgather_hits_all(mtm_ctx* const*, int n, const mtm_hit* const* local, const int64_t* n_local, mtm_hit* out,
+                                int64_t cap, int64_t* counts, int64_t* n_out) {
+    ++g_comm_calls;
+    int64_t o = 0;
+    for (int r = 0; r < n; ++r) {
+        counts[r] = n_local[r];
+        if (o + n_local[r] > cap) return MTM_E_OVERFLOW;
+        if (n_local[r]) std::memcpy(out + o, local[r], sizeof(mtm_hit) * (size_t)n_local[r]);
+        o += n_local[r];
+    }
+    *n_out = o;
+    return MTM_OK;
+}
 int mtm_last_hits(mtm_ctx* c, mtm_hit* out, int64_t cap, int64_t* n_out) {
     *n_out = (int64_t)c->last.size();
     if ((int64_t)c->last.size() > cap) return MTM_E_OVERFLOW;
@@ -105,6 +133,12 @@ static void test_group(std::mt19937& rng) {
         CHECK(mtm_group_create(&g, devs.data(), nd) == MTM_OK);
         CHECK(mtm_group_size(g) == nd && mtm_group_ctx(g, nd) == nullptr && mtm_group_ctx(g, 0) != nullptr);
         CHECK(mtm_group_set_option(g, 3, 77) == MTM_OK);
+        // in-process communicators: one rank per device - refused (host merge kept) when a device is listed twice
+        const bool unique_devs = nd <= 3;
+        CHECK(mtm_group_set_exchange(g, MTM_GROUP_EXCHANGE_RCCL) == MTM_E_STATE);
+        CHECK(mtm_group_comm_init(g) == (unique_devs ? MTM_OK : MTM_E_COMM));
+        CHECK(mtm_group_comm_ranks(g) == (unique_devs ? 1 : 0));
+        const int calls0 = g_comm_calls.load();
         static const uint8_t pixel = 0;
         for (int job = 0; job < 400; ++job) {
             const int n = (int)(rng() % 70);
@@ -125,6 +159,7 @@ static void test_group(std::mt19937& rng) {
             CHECK(mtm_group_shards(g, t.data(), n, 5, 500, 600, dev.data()) == MTM_OK);
             for (int i = 0; i < n; ++i) CHECK(dev[i] >= 0 && dev[i] < nd);
             const int64_t cap = job % 7 == 0 ? 3 : 4096;            // small capacity: the overflow protocol
+            if (unique_devs) CHECK(mtm_group_set_exchange(g, job % 3 != 2 ? MTM_GROUP_EXCHANGE_RCCL : MTM_GROUP_EXCHANGE_HOST) == MTM_OK);
             std::vector<mtm_hit> out((size_t)cap);
             int64_t got = -1;
             int rc = mtm_group_find_matches(g, t.data(), n, 5, &pixel, 500, 600, 1, MTM_U8, 600, 0, 0.5, out.data(), cap, &got);
@@ -138,6 +173,7 @@ static void test_group(std::mt19937& rng) {
                 rc = mtm_group_last_hits(g, out.data(), got, &got);
             }
             CHECK(rc == MTM_OK && got == expect);
+            CHECK(mtm_group_exchange_used(g) == (unique_devs && job % 3 != 2 ? MTM_GROUP_EXCHANGE_RCCL : MTM_GROUP_EXCHANGE_HOST));
             // merged in template order, global indices, each template's own hits in the order its device produced them
             int prev = -1, k = 0;
             for (int64_t i = 0; i < got; ++i) {
@@ -146,6 +182,31 @@ static void test_group(std::mt19937& rng) {
                 k = h.templ_idx == prev ? k + 1 : 0;
                 prev = h.templ_idx;
                 CHECK(h.w == t[(size_t)h.templ_idx].cols && h.h == t[(size_t)h.templ_idx].rows && h.x == h.w * 100 + k);
+            }
+        }
+        CHECK(unique_devs ? g_comm_calls.load() > calls0 : g_comm_calls.load() == calls0);
+        // an image of a megabyte and more goes through the group's shared page-locked staging buffer: every worker copies
+        // its slice of the rows (strided and contiguous sources), waits for the others, searches from the buffer
+        if (nd > 1) {
+            const int rows = 1030, cols = 1100;
+            for (int64_t stride : {(int64_t)cols, (int64_t)cols + 52}) {
+                std::vector<uint8_t> img((size_t)rows * (size_t)stride, 7);
+                for (int job = 0; job < 40; ++job) {
+                    const int n = 1 + (int)(rng() % 12);
+                    std::vector<mtm_templ> t((size_t)n);
+                    long long expect = 0;
+                    for (int i = 0; i < n; ++i) {
+                        std::memset(&t[i], 0, sizeof(mtm_templ));
+                        t[i].px = img.data();
+                        t[i].rows = 1 + (int)(rng() % 40);
+                        t[i].cols = 14 + (int)(rng() % 30);
+                        expect += t[i].rows % 7;
+                    }
+                    std::vector<mtm_hit> out(4096);
+                    int64_t got = -1;
+                    CHECK(mtm_group_find_matches(g, t.data(), n, 5, img.data(), rows, cols, 1, MTM_U8, stride, 0, 0.5, out.data(), 4096,
+                                                 &got) == MTM_OK && got == expect);
+                }
             }
         }
         mtm_group_destroy(g);

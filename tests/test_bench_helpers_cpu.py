@@ -89,3 +89,33 @@ def test_gpus_flag_without_launcher_selects_the_device_group():
     else:
         assert "torch.distributed.run" not in r.stderr
         assert "GPU(s) visible" in r.stderr or "no HIP device" in r.stderr or "No HIP" in r.stderr or "hip" in r.stderr.lower(), r.stderr[-400:]
+
+
+def test_exchange_flag_and_fallback(monkeypatch):
+    """--exchange: rccl is the default of the one-process multi-GPU form, host can be asked for; when the communicators
+    cannot be created (a device listed twice, no librccl) the group keeps the host merge and the line says why."""
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    assert bench.parse().exchange is None                      # default: rccl when N > 1 (resolve_group_exchange)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--exchange", "host"])
+    assert bench.parse().exchange == "host"
+
+    class FakeGroup:
+        def __init__(self, ok):
+            self.ok, self.inits = ok, 0
+
+        def __len__(self):
+            return 8
+
+        def comm_init(self, strict=True):
+            self.inits += 1
+            if not self.ok:
+                raise RuntimeError("mtm_comm_init_all: device 0 is listed twice")
+            return 8
+
+    g = FakeGroup(True)
+    assert bench.resolve_group_exchange(g, None)[:2] == ("rccl", 8) and g.inits == 1
+    assert bench.resolve_group_exchange(g, "rccl")[:2] == ("rccl", 8)
+    g = FakeGroup(True)
+    assert bench.resolve_group_exchange(g, "host")[:2] == ("host", 0) and g.inits == 0
+    kind, ranks, note = bench.resolve_group_exchange(FakeGroup(False), None)
+    assert kind == "host" and ranks == 0 and "listed twice" in note

@@ -725,6 +725,42 @@ def test_banded_call_with_float64_classes_on_two_lanes(mtm, monkeypatch):
         plain.close()
 
 
+def test_group_rccl_exchange_in_process(mtm):
+    """The exchange north_star names for one process: ncclCommInitAll over the group's devices, one all-gather
+    per device inside ncclGroupStart / End, rank 0's gathered list merged.  On a one-GPU box that is a communicator of one
+    rank - the code path is the N-rank one.  A device listed twice cannot form an RCCL communicator: the group says so
+    and keeps the host merge.  Either exchange returns the single-context list."""
+    from MTM import _lib
+    img, units, plants = synth.make_workload(seed=33, image_hw=(900, 1300), n_base=9, templ=32, noisy_per_unit=2)
+    tl = [(u[1], None) for u in units]
+    ctx = _lib.Context(0)
+    g1, g2 = _lib.Group([0]), _lib.Group([0, 0])
+    try:
+        ref = ctx.search(tl, img, 5, _lib.PEAKS_LOCAL, 0.5)
+        assert len(ref) >= len(tl)
+        assert g1.comm_ranks() == 0 and g1.exchange_used() == "host"
+        with pytest.raises(_lib.MtmError):
+            g1.set_exchange("rccl")                          # no communicators yet
+        assert g1.comm_init() == 1 and g1.comm_ranks() == 1
+        for kind in ("rccl", "host", "rccl"):
+            g1.set_exchange(kind)
+            assert np.array_equal(g1.search(tl, img, 5, _lib.PEAKS_LOCAL, 0.5), ref), kind
+            assert g1.exchange_used() == kind
+        # more hits than one 512-record slot: the slot follows the longest list
+        many = g1.search(tl, img, 5, _lib.PEAKS_LOCAL, 0.05)
+        assert len(many) > 600 and np.array_equal(many, ctx.search(tl, img, 5, _lib.PEAKS_LOCAL, 0.05))
+        assert g1.exchange_used() == "rccl"
+        # one rank per device: an aliased group keeps the host merge
+        assert g2.comm_init(strict=False) == 0 and g2.comm_ranks() == 0
+        with pytest.raises(_lib.MtmError, match="listed twice"):
+            g2.comm_init()
+        assert np.array_equal(g2.search(tl, img, 5, _lib.PEAKS_LOCAL, 0.5), ref) and g2.exchange_used() == "host"
+    finally:
+        g1.close()
+        g2.close()
+        ctx.close()
+
+
 def test_device_group_equals_single_context(mtm, coins, monkeypatch):
     """Several contexts in one process (mtm_group; here all on the one GPU of the box): LPT shards, concurrent
     upload + search per context, host merge - the hit list of the single-context call, for every shard count."""
