@@ -73,6 +73,10 @@ for st in "$@"; do
         MTM_MASKSQ_FUSED=$v python bench.py --config cfg5 --no-cpu-baseline --skip-extras --steps 10 --warmup 3 2>>$OUT/bench.err | clean | tail -1 |
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('masksq_fused=$v', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], d.get('gpu_ms'), r.get('masked_stat'))" | tee -a $OUT/cfg5_ab.txt
       done; done ;;
+    rm_ab)          # row-multiplexed tilings: one-group edge steps on / off (few-template calls, slabs)
+      for v in 1 0 1 0; do MTM_RM_EDGES=$v timeout 300 python tools/probes/rm_probe.py 2>&1 | grep -E "x  ?[1248] templates" | sed "s/^/RM_EDGES=$v /" >> $OUT/rm_ab.txt; done
+      for v in 1 0; do MTM_RM_EDGES=$v timeout 120 python tools/probes/workload.py slab_414 30 2>&1 | tail -2 | sed "s/^/RM_EDGES=$v /" >> $OUT/rm_ab.txt; done
+      stamp "rm_ab: $(grep -c templates $OUT/rm_ab.txt) lines" ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
