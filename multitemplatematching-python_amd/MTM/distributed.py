@@ -125,6 +125,16 @@ class TcpStore:
                         raise ConnectionError("MTM TcpStore: a peer announced rank %d (world size %d, ranks seen %s)"
                                               % (r, self.world_size, sorted(self.peers)))
                     self.peers[r] = conn
+            except BaseException:
+                # a failed rendezvous (bad rank, time-out) must not leave the ranks that DID connect waiting in their
+                # first collective for ever (collective_timeout=None): they see their connection closed instead
+                for c in self.peers.values():
+                    try:
+                        c.close()
+                    except OSError:
+                        pass
+                self.peers.clear()
+                raise
             finally:
                 srv.close()
             for conn in self.peers.values():

@@ -173,3 +173,51 @@ def test_tcp_store_rejects_a_rank_out_of_range():
     finally:
         a.close()
         b.close()
+
+
+def test_tcp_store_failed_rendezvous_releases_the_ranks_that_connected():
+    """Rank 0's rendezvous fails on the second peer (it announces a rank that is out of range): the first peer, already
+    accepted and sitting in its first collective without a time-out, must see its connection closed - not wait for ever."""
+    import socket
+    import struct
+    import threading
+    import time
+    from MTM.distributed import TcpStore, _recv, _send
+    port = _free_port()
+    seen = {}
+
+    def good_peer():
+        for _ in range(200):
+            try:
+                s = socket.create_connection(("127.0.0.1", port), timeout=10)
+                break
+            except OSError:
+                time.sleep(0.05)
+        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        _send(s, struct.pack("<i", 1))
+        seen["connected"] = True
+        s.settimeout(30)                              # (the test's own guard; the store's collectives wait without limit)
+        try:
+            data = _recv(s)                           # the first broadcast that never comes
+            seen["got"] = data
+        except (ConnectionError, OSError) as e:
+            seen["closed"] = repr(e)
+        finally:
+            s.close()
+
+    def bad_peer():
+        while "connected" not in seen:
+            time.sleep(0.01)
+        s = socket.create_connection(("127.0.0.1", port), timeout=10)
+        _send(s, struct.pack("<i", 7))
+        time.sleep(0.5)
+        s.close()
+
+    ths = [threading.Thread(target=good_peer), threading.Thread(target=bad_peer)]
+    for t in ths:
+        t.start()
+    with pytest.raises(ConnectionError, match="announced rank 7"):
+        TcpStore(0, 3, addr="127.0.0.1", port=port, timeout=30)
+    for t in ths:
+        t.join(timeout=40)
+    assert "closed" in seen and "got" not in seen, seen

@@ -8,6 +8,7 @@ path is exact integer arithmetic with a float64 epilogue in the oracle's operati
 in fact held to 1e-6 here.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ import synth
 from helpers import (assert_hits_equal, canon, coin_templates, hits_json, load_coins, load_golden)
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 G = load_golden()
 REF = G["reference_run"]
@@ -723,6 +725,104 @@ def test_banded_call_with_float64_classes_on_two_lanes(mtm, monkeypatch):
     finally:
         fused.close()
         plain.close()
+
+
+@pytest.mark.parametrize("env", ["MTM_KERNEL=dot4", "MTM_ROW_MUX=0", "MTM_HITS_ONLY=0", "MTM_MASKSQ_FUSED=0", "MTM_RM_EDGES=0",
+                                 "MTM_MFMA_PERSISTENT=2", "MTM_MFMA_R2=0", "MTM_SCREEN_L1=0", "MTM_CLASS_LANES=1"])
+def test_production_reachable_routes_give_the_default_lists(mtm, env, monkeypatch):
+    """Every switch that selects a kernel or route a production call can also reach by itself (the VALU kernel for shapes
+    the matrix-core path does not take, plain instead of row-multiplexed tiling, maps in memory, the unfused sum I^2 M
+    pass, two-group edge steps, the persistent per-XCD draw, ...) returns the hit lists of the default route: same boxes
+    in the same order, scores to 1e-6 (tools/alt_modes.sh runs the whole suite under each; this is the driver's share)."""
+    from MTM import _lib
+    img, units, _ = synth.make_workload(seed=41, image_hw=(700, 1500), n_base=20, templ=32, noisy_per_unit=2)
+    msk_img, msk_units, _ = synth.make_workload(seed=43, image_hw=(640, 900), n_base=2, templ=32, scales=(24, 40), masked=True)
+    cases = [(img, [(u[1], None) for u in units], 5, 0.5),                        # > 16 templates: two-row tiling
+             (img, [(u[1], None) for u in units[:5]], 3, 0.7),                    # row-multiplexed, nt = 8
+             (img, [(units[0][1], None)], 5, 0.5),                                # one template: R = 16, the edge steps
+             (img, [(u[1], None) for u in units[:3]] + [(np.ascontiguousarray(units[4][1][:20, :28]), None)], 1, 0.3),
+             (msk_img, [(u[1], u[2]) for u in msk_units], 3, 0.9)]                # masked classes: the sum I^2 M pass
+    ref_ctx = _lib.Context(0)
+    k, v = env.split("=")
+    monkeypatch.setenv(k, v)
+    alt = _lib.Context(0)
+    try:
+        for mode in (_lib.PEAKS_LOCAL, _lib.PEAKS_GLOBAL):
+            for im, tl, method, thr in cases:
+                a = alt.search(tl, im, method, mode, thr)
+                b = ref_ctx.search(tl, im, method, mode, thr)
+                assert len(a) == len(b) >= len(tl), (env, method, mode, len(a), len(b))
+                for f in ("templ_idx", "x", "y", "w", "h"):
+                    assert np.array_equal(a[f], b[f]), (env, method, mode, f)
+                assert np.abs(a["score"] - b["score"]).max() <= 1e-6, (env, method, mode)
+    finally:
+        alt.close()
+        ref_ctx.close()
+
+
+@pytest.mark.parametrize("seed", [78, 180, 244])
+def test_float32_exact_zero_plateaus_name_the_exact_answer(mtm, seed, monkeypatch):
+    """The three float32 fuzz cases of round 3 where the library and the oracle disagreed (tools/fuzz_parity.py,
+    FUZZ_DTYPE=float32; profiles/r03_r03fz/fuzz_f32.txt), settled against exact arithmetic instead of asserted.  All three
+    are difference scores (TM_SQDIFF / TM_SQDIFF_NORMED) of templates cut from a flat region: wherever the window equals
+    the template value for value, sum (I - T)^2 is exactly 0, cv2's expression max(S2 - 2 corr + T2, 0) is 0 in exact
+    arithmetic and so is the normalised score - a plateau of exact zeros.  The float64 kernel's FMA chain returns exactly
+    0.0 there; the oracle's float64 summation order leaves ~1e-10 noise on it, so its peak finder sees fewer plateau
+    pixels and its first-minimum lands on whichever zero its noise favours.  Checked here: (a) every hit only one of the two
+    lists has sits on a window that IS an exact copy (or exact copy under the mask), and the library's score there is
+    exactly 0.0; (b) with N_object == 1 the library returns cv2.minMaxLoc's answer for the exact map - the FIRST exact copy
+    in row-major order (reference MTM/__init__.py:226-230)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    monkeypatch.setenv("FUZZ_DTYPE", "float32")
+    import fuzz_parity as F
+    img, lt, method, thr, n_obj, box = F.make_case(seed)
+    assert img.dtype == np.float32 and method in (0, 1)
+    oimg, olt = F.as_oracle(img, lt)
+    kw = dict(method=method, N_object=n_obj, searchBox=box)
+    if thr is not None:
+        kw["score_threshold"] = thr
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = mtm.findMatches(lt, img, **kw)
+        exp = O.find_matches(olt, oimg, **kw)
+    templ = {t[0]: t for t in lt}
+
+    def exact_copy(label, bx):
+        x, y, w, h = bx
+        t = templ[label]
+        win = img[y:y + h, x:x + w]
+        d = win.astype(np.float64) - t[1].astype(np.float64)          # float32 values: the difference is exact in float64
+        if len(t) >= 3 and method == 0:
+            d = d * (np.asarray(t[2], np.float64) != 0)
+        return not d.any()
+
+    g = {(h[0], tuple(h[1])): float(h[2]) for h in got}
+    e = {(h[0], tuple(h[1])): float(h[2]) for h in exp}
+    disputed = sorted(g.keys() ^ e.keys())
+    assert disputed, "the case no longer differs from the oracle: drop it from this test"
+    for k in disputed:
+        assert exact_copy(*k), (seed, k)
+        if k in g:
+            assert g[k] == 0.0, (seed, k, g[k])
+    for k, v in g.items():                       # and nowhere else does the library call something an exact zero
+        if v == 0.0:
+            assert exact_copy(*k), (seed, k)
+    if n_obj == 1:
+        x0, y0 = (box[0], box[1]) if box else (0, 0)
+        H, W = (box[3], box[2]) if box else img.shape[:2]
+        for label, bx, score in got:
+            if score != 0.0:
+                continue
+            x, y, w, h = bx
+            first = None                          # first exact copy in row-major order of the searched region
+            for yy in range(y0, y + 1):
+                xs = range(x0, (x if yy == y else x0 + W - w) + 1)
+                hit = next((xx for xx in xs if exact_copy(label, (xx, yy, w, h))), None)
+                if hit is not None:
+                    first = (hit, yy)
+                    break
+            assert first == (x, y), (seed, label, bx, first)
 
 
 def test_group_rccl_exchange_in_process(mtm):

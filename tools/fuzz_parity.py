@@ -13,9 +13,8 @@ import numpy as np
 import MTM, synth
 import mtm_oracle as O
 
-warnings.simplefilter("ignore")
-first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+first = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].lstrip("-").isdigit() else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 100
 
 
 def make_case(seed):
@@ -101,15 +100,17 @@ def classify(got, exp, thr, tol):
     return "BENIGN %d unmatched" % len(only) if only else ""
 
 
+def main():
+    global exact_ctx, vs_exact_cases, vs_exact_diffs
+    warnings.simplefilter("ignore")
+    run()
+
+
 # FUZZ_VS_EXACT=1: float32 cases are ALSO run on a context with MTM_OPT_F32_MFMA = 0 (the float64 kernel) and the raw hit
 # records of the default route (bf16 screen + exact re-scoring) must equal its records byte for byte - the oracle's
 # float64 FFT is no judge of plateau ties (an exact-zero plateau of the FMA chain is 1e-10 noise there).
 exact_ctx = None
 vs_exact_cases = vs_exact_diffs = 0
-if os.environ.get("FUZZ_VS_EXACT"):
-    from MTM import _lib
-    exact_ctx = _lib.Context(0)
-    exact_ctx.set_option(_lib.OPT_F32_MFMA, 0)
 
 
 def vs_exact(lt, img, kw):
@@ -117,6 +118,7 @@ def vs_exact(lt, img, kw):
     image, _, _ = MTM._validate_search(lt, img, kw["N_object"], kw["searchBox"])
     args = (lt, image, kw["method"], kw["N_object"], kw.get("score_threshold", 0.5))
     a = MTM._raw_matches(*args).copy()
+    from MTM import _lib
     route = _lib.default_context().timing()["f32_route"]
     b = MTM._raw_matches(*args, context=exact_ctx).copy()
     if a.tobytes() == b.tobytes():
@@ -127,55 +129,65 @@ def vs_exact(lt, img, kw):
     return "route %d: record %d %r vs %r" % (route, k, a[k], b[k])
 
 
-real = benign = 0
-t0 = time.time()
-for seed in range(first, first + count):
-    img, lt, method, thr, n_obj, box = make_case(seed)
-    if os.environ.get("FUZZ_DTYPES") and str(img.dtype) not in os.environ["FUZZ_DTYPES"].split(","):
-        continue
-    oimg, olt = as_oracle(img, lt)
-    kw = dict(method=method, N_object=n_obj, searchBox=box)
-    if thr is not None:
-        kw["score_threshold"] = thr
-    try:
-        got = MTM.findMatches(lt, img, **kw)
-        exp = O.find_matches(olt, oimg, **kw)
-    except Exception as ex:                                    # noqa: BLE001
+def run():
+    global exact_ctx, vs_exact_cases, vs_exact_diffs
+    if os.environ.get("FUZZ_VS_EXACT"):
+        from MTM import _lib
+        exact_ctx = _lib.Context(0)
+        exact_ctx.set_option(_lib.OPT_F32_MFMA, 0)
+    real = benign = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        img, lt, method, thr, n_obj, box = make_case(seed)
+        if os.environ.get("FUZZ_DTYPES") and str(img.dtype) not in os.environ["FUZZ_DTYPES"].split(","):
+            continue
+        oimg, olt = as_oracle(img, lt)
+        kw = dict(method=method, N_object=n_obj, searchBox=box)
+        if thr is not None:
+            kw["score_threshold"] = thr
         try:
-            O.find_matches(olt, oimg, **kw)
-            verdict = "REAL exception %r" % (ex,)
-        except Exception as ex2:                               # both refuse: same class of error?
-            verdict = "" if type(ex2).__name__ == type(ex).__name__ or isinstance(ex, ValueError) else "REAL exception %r vs %r" % (ex, ex2)
-        got = exp = []
-    else:
-        tol = 1e-4 if img.dtype == np.float32 else 2e-5
-        if method in (0, 2, 4):
-            # raw sums: relative to the magnitude of the sums they are differences of (the oracle's float64 FFT is itself
-            # only that accurate: an exact copy gives SQDIFF ~1e-3 there, 0 in the integer paths)
-            tpl = np.asarray(olt[0][1], np.float64)
-            scale = max([abs(float(h[2])) for h in exp] + [1.0, float((tpl * tpl).sum())])
-            g2 = [(h[0], h[1], float(h[2]) / scale) for h in got]
-            e2 = [(h[0], h[1], float(h[2]) / scale) for h in exp]
-            verdict = classify(g2, e2, None, 1e-5)
+            got = MTM.findMatches(lt, img, **kw)
+            exp = O.find_matches(olt, oimg, **kw)
+        except Exception as ex:                                    # noqa: BLE001
+            try:
+                O.find_matches(olt, oimg, **kw)
+                verdict = "REAL exception %r" % (ex,)
+            except Exception as ex2:                               # both refuse: same class of error?
+                verdict = "" if type(ex2).__name__ == type(ex).__name__ or isinstance(ex, ValueError) else "REAL exception %r vs %r" % (ex, ex2)
+            got = exp = []
         else:
-            verdict = classify(got, exp, thr, tol)
-    if exact_ctx is not None and img.dtype == np.float32 and not (verdict.startswith("REAL exception")):
-        try:
-            d = vs_exact(lt, img, kw)
-        except Exception as ex:                                # noqa: BLE001 - both routes refuse the same inputs
-            d = ""
-        vs_exact_cases += 1
-        if d:
-            vs_exact_diffs += 1
-            print("seed %d: DIFFERS FROM THE FLOAT64 KERNEL %s" % (seed, d), flush=True)
-    if verdict.startswith("REAL"):
-        real += 1
-    elif verdict:
-        benign += 1
-    if verdict:
-        print("seed %d: %s | img %s %s, %d templates, method %d, thr %s, N_object %s, box %s" % (
-            seed, verdict, img.shape, img.dtype, len(lt), method, thr, n_obj, box), flush=True)
-print("fuzz: %d cases from seed %d in %.0f s: %d REAL, %d BENIGN" % (count, first, time.time() - t0, real, benign))
-if exact_ctx is not None:
-    print("float32 default route vs float64 kernel: %d cases, %d with different records" % (vs_exact_cases, vs_exact_diffs))
-sys.exit(1 if real or vs_exact_diffs else 0)
+            tol = 1e-4 if img.dtype == np.float32 else 2e-5
+            if method in (0, 2, 4):
+                # raw sums: relative to the magnitude of the sums they are differences of (the oracle's float64 FFT is itself
+                # only that accurate: an exact copy gives SQDIFF ~1e-3 there, 0 in the integer paths)
+                tpl = np.asarray(olt[0][1], np.float64)
+                scale = max([abs(float(h[2])) for h in exp] + [1.0, float((tpl * tpl).sum())])
+                g2 = [(h[0], h[1], float(h[2]) / scale) for h in got]
+                e2 = [(h[0], h[1], float(h[2]) / scale) for h in exp]
+                verdict = classify(g2, e2, None, 1e-5)
+            else:
+                verdict = classify(got, exp, thr, tol)
+        if exact_ctx is not None and img.dtype == np.float32 and not (verdict.startswith("REAL exception")):
+            try:
+                d = vs_exact(lt, img, kw)
+            except Exception as ex:                                # noqa: BLE001 - both routes refuse the same inputs
+                d = ""
+            vs_exact_cases += 1
+            if d:
+                vs_exact_diffs += 1
+                print("seed %d: DIFFERS FROM THE FLOAT64 KERNEL %s" % (seed, d), flush=True)
+        if verdict.startswith("REAL"):
+            real += 1
+        elif verdict:
+            benign += 1
+        if verdict:
+            print("seed %d: %s | img %s %s, %d templates, method %d, thr %s, N_object %s, box %s" % (
+                seed, verdict, img.shape, img.dtype, len(lt), method, thr, n_obj, box), flush=True)
+    print("fuzz: %d cases from seed %d in %.0f s: %d REAL, %d BENIGN" % (count, first, time.time() - t0, real, benign))
+    if exact_ctx is not None:
+        print("float32 default route vs float64 kernel: %d cases, %d with different records" % (vs_exact_cases, vs_exact_diffs))
+    sys.exit(1 if real or vs_exact_diffs else 0)
+
+
+if __name__ == "__main__":
+    main()
