@@ -570,8 +570,9 @@ def main():
             extras["photograph_like_image"] = {"median_ms_per_call": round(sm, 4), "value": rate(sm), "hits": len(hs),
                                                "peaks_before_nms": int(tms["n_hits"]), "hits_only": int(tms["hits_only"]),
                                                "gpu_ms": round(float(tms["total_ms"]), 4),
-                                               "note": "smooth score maps: map mode + full peak pass after the candidate "
-                                                       "list overflowed; host sort + NMS of the raw peaks included"}
+                                               "note": "smooth score maps, thousands of raw peaks: hits_only = 1 -> the candidate list "
+                                                       "(2^20 records) held them, device-side hash verification; hits_only = 0 -> the list "
+                                                       "overflowed: map mode + full peak pass.  Host sort + NMS of the raw peaks included"}
             ctx.set_option(_lib.OPT_HITS_ONLY, 1)          # clears the back-off
         gc.enable()
 

@@ -86,8 +86,13 @@ extern "C" {
                                    ~1e-5 of cv2's float64 result) as a SCREEN - everything that could be a peak, the
                                    global extremum or a threshold case by that margin is re-scored with the float64
                                    arithmetic of the exact kernel, so mtm_find_matches returns the exact kernel's hit
-                                   lists (score maps read back with mtm_score_map keep the ~1e-5 tolerance);
-                                   0: the float64 kernel for everything (10x slower, maps exact to rounding);
+                                   lists as long as the bf16 scores stay inside the screen's margins (1e-4 around the
+                                   threshold / the running best, 5e-5 between 3x3 neighbours: empirical margins, not a
+                                   bound - the observed error is <= 1e-5 and 900 fuzz cases show no difference, but a
+                                   low-contrast window next to a much brighter region can in principle exceed them);
+                                   score maps read back with mtm_score_map keep the ~1e-5 tolerance;
+                                   0: the float64 kernel for everything (10x slower, maps exact to rounding) - the
+                                   setting that guarantees the exact lists;
                                    2: bf16 scores as they are, no re-scoring.  Environment: MTM_F32_MFMA. */
 
 /* error codes */

@@ -77,6 +77,10 @@ for st in "$@"; do
       for v in 1 0 1 0; do MTM_RM_EDGES=$v timeout 300 python tools/probes/rm_probe.py 2>&1 | grep -E "x  ?[1248] templates" | sed "s/^/RM_EDGES=$v /" >> $OUT/rm_ab.txt; done
       for v in 1 0; do MTM_RM_EDGES=$v timeout 120 python tools/probes/workload.py slab_414 30 2>&1 | tail -2 | sed "s/^/RM_EDGES=$v /" >> $OUT/rm_ab.txt; done
       stamp "rm_ab: $(grep -c templates $OUT/rm_ab.txt) lines" ;;
+    trace)          # host time stamps of the phases of a fused call (stderr of the context at exit) + per-call breakdown
+      MTM_HOST_TRACE=1 timeout 120 python tools/probes/loop_calls.py 0 200 > $OUT/host_trace.txt 2>&1
+      timeout 120 python tools/probes/call_breakdown.py >> $OUT/host_trace.txt 2>&1
+      stamp "trace: $(grep -c 'host trace' $OUT/host_trace.txt) phases" ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
