@@ -192,6 +192,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         if (rc != MTM_OK) {
             c->have_image = false;                   // possibly half an image on the device
             (void)hipStreamSynchronize(c->copy_stream);
+            if (c->copy_stream_b) (void)hipStreamSynchronize(c->copy_stream_b);
             return rc;
         }
     } else {

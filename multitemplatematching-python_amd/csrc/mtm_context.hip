@@ -51,13 +51,17 @@ int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols,
 // Rows [r0, r1) of a single-channel uint8 image: copy into the raw buffer and convert into the planes of `sl`
 // (prepared by prepare_slot) on `stream`.  A pageable source makes the copy call block the host until the rows
 // are staged; work queued on OTHER streams before the call runs under it.
+// `copy_done` (optional): recorded right behind the copy; `before_kernels` (optional): the conversion kernels wait for it
+// (banded uploads on two streams: the next band's copy starts behind this one's copy, not behind its kernels).
 int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                     hipStream_t stream, bool skip_f32) {
+                     hipStream_t stream, bool skip_f32, hipEvent_t copy_done, hipEvent_t before_kernels) {
     const int cols = g.cols, nrows = r1 - r0;
     if (nrows <= 0) return MTM_OK;
     uint8_t* raw = sl.raw.as<uint8_t>() + (size_t)r0 * cols;
     HIPC(hipMemcpy2DAsync(raw, (size_t)cols, (const uint8_t*)src + (size_t)r0 * src_stride, (size_t)src_stride, (size_t)cols,
                           nrows, hipMemcpyHostToDevice, stream));
+    if (copy_done) HIPC(hipEventRecord(copy_done, stream));
+    if (before_kernels) HIPC(hipStreamWaitEvent(stream, before_kernels, 0));
     uint8_t* u8 = sl.u8.as<uint8_t>() + (size_t)r0 * g.pitch;
     uint8_t* u8b = sl.u8b.as<uint8_t>() + (size_t)r0 * g.pitch;
     // no float32 plane here: nothing in a banded call reads it (33 of the 50 MB this conversion would write at 4K);
@@ -81,12 +85,14 @@ int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src,
 
 // The same for rows r0 .. r1 - 1 of a single-channel uint16 image: the three byte planes and the float32 plane.
 int upload_rows_u16c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                      hipStream_t stream) {
+                      hipStream_t stream, hipEvent_t copy_done, hipEvent_t before_kernels) {
     const int cols = g.cols, nrows = r1 - r0;
     if (nrows <= 0) return MTM_OK;
     uint16_t* raw = sl.raw.as<uint16_t>() + (size_t)r0 * cols;
     HIPC(hipMemcpy2DAsync(raw, (size_t)cols * 2, (const uint8_t*)src + (size_t)r0 * src_stride, (size_t)src_stride,
                           (size_t)cols * 2, nrows, hipMemcpyHostToDevice, stream));
+    if (copy_done) HIPC(hipEventRecord(copy_done, stream));
+    if (before_kernels) HIPC(hipStreamWaitEvent(stream, before_kernels, 0));
     const size_t o = (size_t)r0 * g.pitch;
     sl.f32_valid = true;
     hipLaunchKernelGGL(planarize_u16_kernel, dim3((cols + 255) / 256, nrows), dim3(256), 0, stream, raw, cols, 1, 1, nrows, cols,
@@ -189,6 +195,7 @@ int ensure_copy_stream(mtm_ctx* c) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     HIPC(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, c->copy_prio ? hi : 0));
+    HIPC(hipStreamCreateWithPriority(&c->copy_stream_b, hipStreamNonBlocking, c->copy_prio ? hi : 0));
     return MTM_OK;
 }
 
@@ -267,6 +274,8 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
     if (const char* v = std::getenv("MTM_RM_EDGES")) c->rm_edges = std::atoi(v);
+    if (const char* v = std::getenv("MTM_CAND_STAGE")) c->cand_stage = std::atoi(v);
+    if (const char* v = std::getenv("MTM_BAND_STREAMS")) c->band_streams = std::max(1, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));
@@ -353,6 +362,11 @@ void mtm_ctx_destroy(mtm_ctx* c) {
         (void)hipStreamDestroy(c->stream2);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream_b) {
+        (void)hipStreamSynchronize(c->copy_stream_b);
+        (void)hipStreamDestroy(c->copy_stream_b);
+    }
+    for (hipEvent_t e : c->band_copy_ev) (void)hipEventDestroy(e);
     for (auto* evs : {&c->ncc_ev, &c->sq_ev})
         for (auto& p : *evs) {
             (void)hipEventDestroy(p.first);

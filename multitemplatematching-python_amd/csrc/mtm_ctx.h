@@ -162,6 +162,7 @@ struct mtm_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sq_ev;       // event pairs of the sum I^2 M passes (timing.masked_stat_ms)
+    int cand_stage = 1;         // MTM_CAND_STAGE: peak candidates of a wave collected in LDS, one atomic per wave and work item (0: one per emission)
     int rm_edges = 1;           // MTM_RM_EDGES: one-group K steps where a row-multiplexed wave's other group has no template row (0: off)
     int masksq_fused = 1;       // MTM_MASKSQ_FUSED: sum I^2 M of a masked class as ONE launch over both byte planes of I^2 that
                                 // writes the sum2 plane itself (0: round 3's two raw launches + masksq_combine_kernel)
@@ -182,6 +183,12 @@ struct mtm_ctx {
     DevBuf sq_planes;           // two planes: [high byte of I^2 ^ 0x80][low byte ^ 0x80] of the current uint8 image
     bool sq_valid = false;
     hipStream_t copy_stream = nullptr;
+    // banded uploads (round 4): consecutive bands alternate between copy_stream and copy_stream_b, a band's COPY waits for
+    // the previous band's copy only (band_copy_ev), its conversion / statistics kernels for the previous band's kernels
+    // (band_ev) - the copy engine no longer idles while a band's kernels run (MTM_BAND_STREAMS=1: one stream, round 3)
+    hipStream_t copy_stream_b = nullptr;
+    std::vector<hipEvent_t> band_copy_ev;
+    int band_streams = 2;
     hipEvent_t next_ready = nullptr;
     // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
     // statistics of the rows that became computable); the score kernel of a band waits for its event
@@ -389,9 +396,9 @@ struct SlotGeom {
 int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols, int chans, int dtype, hipStream_t stream,
                  int factor, SlotGeom* out);
 int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                     hipStream_t stream, bool skip_f32);
+                     hipStream_t stream, bool skip_f32, hipEvent_t copy_done = nullptr, hipEvent_t before_kernels = nullptr);
 int upload_rows_u16c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                      hipStream_t stream);
+                      hipStream_t stream, hipEvent_t copy_done = nullptr, hipEvent_t before_kernels = nullptr);
 int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,
                  int chans, int dtype, hipStream_t stream, int factor = 1);
 void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype);

@@ -550,6 +550,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.cand_on = 1;
             p.hits_only = 1;
         }
+        if (p.cand_on && !ext && c->cand_stage) {             // wave-private candidate staging (see emit_at)
+            lds = (lds + 15) & ~(size_t)15;
+            p.cs_off = (int)lds;
+            lds += (size_t)kMfRows * kMfCandStageBytes;
+        }
         const int grid = ((p.n_work + 7) / 8) * 8;
         const int* tl_class = c->tlist.as<int>() + sc.tlist_off;
         p.kp_nseg = sc.kp_nseg;
@@ -691,6 +696,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.ext_best = c->counters.as<unsigned long long>();
             p.cand_on = 1;
             p.hits_only = 1;
+        }
+        if (p.cand_on && !ext && c->cand_stage) {
+            lds = (lds + 15) & ~(size_t)15;
+            p.cs_off = (int)lds;
+            lds += (size_t)kMfRows * kMfCandStageBytes;
         }
         MfmaSel sel16;
         sel16.method = kMfU16;
@@ -1079,6 +1089,13 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->band_ev.push_back(e);
     }
+    while ((int)c->band_copy_ev.size() < nb) {
+        hipEvent_t e;
+        HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->band_copy_ev.push_back(e);
+    }
+    const bool two_streams = c->band_streams > 1 && nb > 1;
+    int k_prev = -1;                        // the band queued before this one (bands without rows are skipped)
     const int h = sc.h, oh = a.rows - h + 1;
     const int RB = u16 ? kMfRows : sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
@@ -1095,10 +1112,16 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         const bool last = k == nb - 1;
         int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
         if (r1 <= r_done) continue;
+        // the band's stream: with two of them the copy waits for the previous band's COPY, the kernels for its kernels
+        hipStream_t bs = (two_streams && (k & 1)) ? c->copy_stream_b : c->copy_stream;
+        hipEvent_t cdone = two_streams ? c->band_copy_ev[(size_t)k] : nullptr;
+        hipEvent_t kwait = (two_streams && k_prev >= 0) ? c->band_ev[(size_t)k_prev] : nullptr;
+        if (two_streams && k_prev >= 0) HIPC(hipStreamWaitEvent(bs, c->band_copy_ev[(size_t)k_prev], 0));
         if (u16)
-            MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream));
+            MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, bs, cdone, kwait));
         else
-            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, c->copy_stream, c->skip_f32 != 0));
+            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, bs, c->skip_f32 != 0, cdone, kwait));
+        if (two_streams) (void)hipStreamQuery(bs);
         if (r_done == 0) {
             HIPC(hipEventRecord(c->ev[0], c->stream));           // (see fm_begin)
             if (c->classes.size() > 1) {                         // the lanes of the other classes start behind the call's set-up too
@@ -1111,13 +1134,14 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         const int avail = r1 - h + 1;                            // output rows whose windows are complete
         const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);
         StatPlanes st;
-        c->stats_stream = c->copy_stream;
+        c->stats_stream = bs;
         const int rc = launch_stats(c, sc, &st, sb_done, sb1);
         c->stats_stream = nullptr;
         MTMC(rc);
         sb_done = sb1;
-        HIPC(hipEventRecord(c->band_ev[(size_t)k], c->copy_stream));
-        (void)hipStreamQuery(c->copy_stream);                    // submit now (the runtime batches commands)
+        HIPC(hipEventRecord(c->band_ev[(size_t)k], bs));
+        (void)hipStreamQuery(bs);                                // submit now (the runtime batches commands)
+        k_prev = k;
         if (k == 0) host_trace(c, 5);                            // layout conversion + statistics of band 0 submitted
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
         if (yb1 > yb_done) {

@@ -32,6 +32,9 @@ __host__ __device__ constexpr int mf_stat_bytes_per_wave(int ch) { return (ch + 
 // Work-group scratch words behind the 32 per-template constants: [0] work item, [1] late start, [2] candidate list
 // full, [4..7] the start values of the shader-clock probe (two 64-bit counters)
 constexpr int kMfItemBytes = 32;
+// Wave-private staging of peak candidates in LDS (hits-only / candidate mode): [count, pad x 3][kMfCandStage records]
+constexpr int kMfCandStage = 96;
+constexpr int kMfCandStageBytes = 16 + kMfCandStage * 24;
 // METHOD value of the raw mode: the biased int8 accumulators are stored as they are (uint16 images:
 // the first of two byte-plane passes, see kMfU16; sum I^2 M of masked classes; slabs).
 constexpr int kMfRaw = 6;
@@ -114,8 +117,10 @@ struct MfmaParams {
     // Row-multiplexed raw mode as the sum I^2 M pass of a masked class in one launch: the two byte planes of I^2 are the
     // launch's channels (chans = 2), the accumulators are scaled by 256 between them and the epilogue writes
     // c2 = acc + sq_k as float64 into st.sum2 plus its 16-pixel block minima into st.blk (no raw maps, no combine kernel).
+    int cs_off;              // byte offset in LDS of the candidate staging buffers (4 waves x kMfCandStageBytes); 0 = none
     int sq_fused;
     int rm_edges;            // row-multiplexed tilings: 1 = the edge steps (one group's A operand all zero) run the one-group step
+    int cs_pad_;
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)

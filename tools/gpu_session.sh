@@ -81,6 +81,11 @@ for st in "$@"; do
       MTM_HOST_TRACE=1 timeout 120 python tools/probes/loop_calls.py 0 200 > $OUT/host_trace.txt 2>&1
       timeout 120 python tools/probes/call_breakdown.py >> $OUT/host_trace.txt 2>&1
       stamp "trace: $(grep -c 'host trace' $OUT/host_trace.txt) phases" ;;
+    env_ab)         # any environment switch against the default, per-call metric: ENV_AB="MTM_BAND_STREAMS=1 MTM_CAND_STAGE=0"
+      for rep in 1 2 3; do for e in "X=0" ${ENV_AB:-MTM_BAND_STREAMS=1}; do
+        env $e python bench.py --no-cpu-baseline --skip-extras --steps ${LIB_STEPS:-200} 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$e', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/env_ab.txt
+      done; done ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;

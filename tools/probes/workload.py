@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One named workload, a few calls - the command rocprofv3 wraps in tools/profile_workloads.sh (GPU box).
     workload.py <name> [calls]
-names: cfg2 cfg5 (BASELINE configs), u16_4k32 / f32_4k32 (4K x 32 templates 64x64 as uint16 / float32 pixels),
+names: cfg2 cfg3 cfg4 cfg5 (BASELINE configs; cfg4 = its 256 units on one GPU), u16_4k32 / f32_4k32 (4K x 32 templates 64x64 as uint16 / float32 pixels),
 f64_1080p8 (float32 pixels on the float64 kernel, MTM_OPT_F32_MFMA = 0), slab_414 (2048^2 x one 414x400 template: the
 reference's published benchmark shape, slabs on the MFMA kernel), dense_4k32 (photograph-like image: map mode + peak pass)."""
 import os, sys, time
@@ -15,7 +15,7 @@ name = sys.argv[1]
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ctx = _lib.Context(0)
 method, thr = 5, 0.5
-if name in ("cfg2", "cfg5"):
+if name in ("cfg2", "cfg3", "cfg4", "cfg5"):
     img, units, _ = synth.make_config(name)
     method, thr = (3, 0.9) if name == "cfg5" else (5, 0.5)
     tl = [(u[1], u[2] if len(u) >= 3 else None) for u in units]
