@@ -275,6 +275,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
     if (const char* v = std::getenv("MTM_RM_EDGES")) c->rm_edges = std::atoi(v);
     if (const char* v = std::getenv("MTM_CAND_STAGE")) c->cand_stage = std::atoi(v);
+    if (const char* v = std::getenv("MTM_DENSE_ROWMAX")) c->dense_rowmax = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_STREAMS")) c->band_streams = std::max(1, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;

@@ -162,6 +162,9 @@ struct mtm_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sq_ev;       // event pairs of the sum I^2 M passes (timing.masked_stat_ms)
+    int dense_rowmax = 1;       // MTM_DENSE_ROWMAX: while the back-off lasts (dense maps), map mode + row-local-maximum candidates
+                                // + verify_peaks_kernel instead of the full peak pass (0: round 3's peaks_kernel over every map)
+    bool cand_rowmax_now = false;   // this call takes that route
     int cand_stage = 1;         // MTM_CAND_STAGE: peak candidates of a wave collected in LDS, one atomic per wave and work item (0: one per emission)
     int rm_edges = 1;           // MTM_RM_EDGES: one-group K steps where a row-multiplexed wave's other group has no template row (0: off)
     int masksq_fused = 1;       // MTM_MASKSQ_FUSED: sum I^2 M of a masked class as ONE launch over both byte planes of I^2 that
@@ -183,12 +186,15 @@ struct mtm_ctx {
     DevBuf sq_planes;           // two planes: [high byte of I^2 ^ 0x80][low byte ^ 0x80] of the current uint8 image
     bool sq_valid = false;
     hipStream_t copy_stream = nullptr;
-    // banded uploads (round 4): consecutive bands alternate between copy_stream and copy_stream_b, a band's COPY waits for
-    // the previous band's copy only (band_copy_ev), its conversion / statistics kernels for the previous band's kernels
-    // (band_ev) - the copy engine no longer idles while a band's kernels run (MTM_BAND_STREAMS=1: one stream, round 3)
+    // banded uploads, experiment of round 4 (MTM_BAND_STREAMS=2; default 1 = one copy-side stream): consecutive bands
+    // alternate between copy_stream and copy_stream_b, a band's COPY waits for the previous band's copy only
+    // (band_copy_ev), its conversion / statistics kernels for the previous band's kernels (band_ev), so that the copy
+    // engine does not idle while a band's kernels run.  Measured at 4K x 32 templates, three alternating pairs on one box
+    // (profiles/r04e/env_ab.txt): 0.8755 / 0.8944 / 0.8907 ms per call against 0.8807 / 0.8802 / 0.8809 with one stream -
+    // no gain (the second band's copy now competes with the first band's kernels for the start of the first score launch).
     hipStream_t copy_stream_b = nullptr;
     std::vector<hipEvent_t> band_copy_ev;
-    int band_streams = 2;
+    int band_streams = 1;
     hipEvent_t next_ready = nullptr;
     // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
     // statistics of the rows that became computable); the score kernel of a band waits for its event
@@ -269,11 +275,12 @@ struct mtm_ctx {
     // options
     int opt_kernel = MTM_KERNEL_AUTO;
     int opt_border = MTM_BORDER_NEAREST;   // scikit-image >= 0.19 (maximum_filter mode='nearest'); MTM_PEAK_BORDER=constant: <= 0.18
-    // Capacity (records) of the candidate list and of the hit list.  Round 4: 2^20 (24 MB each) instead of 2^18 - a
-    // photograph-like 4K image x 32 templates at threshold 0.5 has 0.01-0.4 % of its outputs above the threshold
-    // (3e5-1e6 candidates): with the larger list such calls stay in hits-only mode (screens + device-side hash
-    // verification) instead of overflowing into map mode + the full peak pass (2.4 -> see DESIGN section 4.1).
-    int64_t hit_cap = 1 << 20;
+    // Capacity (records) of the candidate list and of the hit list.  2^18: measured in round 4 against 2^20 on a
+    // photograph-like 4K image x 32 templates at threshold 0.5 (~1e6 outputs above the threshold): a list that holds them
+    // all keeps the call in hits-only mode, but a million emissions cost the score kernel +0.64 ms (1.32 against 0.68 ms,
+    // one atomic per wave and item) - more than map mode + the candidate test of the dense route; up to ~2.6e5
+    // candidates the list is the cheaper way, and that is where it overflows.
+    int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
     int mfma_dbg = 0;
     int fuse_stats = 1;        // MTM_FUSE_STATS: single-kernel window statistics (uint8, one channel)

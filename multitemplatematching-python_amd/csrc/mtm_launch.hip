@@ -506,6 +506,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.screen_l1 = c->screen_l1;
         p.cand_min = c->cand_min ? 1 : 0;
         p.cand_thr = c->cand_thr;
+        p.cand_rowmax = (c->cand_rowmax_now && p.cand_on && !p.hits_only) ? 1 : 0;
         p.cand_cap = (unsigned long long)c->hit_cap;
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);

@@ -834,13 +834,14 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    auto emit_at = [&](const float (&out)[4], int li, int yrow) {
+    auto emit_at = [&](const float (&out)[4], int li, int yrow, unsigned allow = 15u) {
         unsigned m = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = p.cand_min ? -out[i] : out[i];
             if (xq + i < p.ow && v > p.cand_thr) m |= 1u << i;
         }
+        m &= allow;
         if (emit_full) m = 0;
         const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
         const unsigned long long b0 = __builtin_amdgcn_ballot_w64((m & 1u) != 0), b1 = __builtin_amdgcn_ballot_w64((m & 2u) != 0);
@@ -905,6 +906,25 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
     auto emit = [&](const float (&out)[4], int li) { emit_at(out, li, y); };
+    // Dense maps with the maps in memory (p.cand_rowmax; round 4): the candidate list is only a preselection there
+    // (verify_peaks_kernel tests every candidate against the map), so it may leave out whatever cannot be a 3x3 maximum:
+    // a pixel with a larger neighbour in its own row.  Bit i of the result: pixel i of this lane's four is not exceeded by its
+    // left / right neighbour (NaN neighbours never exceed; beyond the wave's 256 pixels or the map: unknown - kept).  All
+    // lanes of the wave that are in the epilogue call this together (the neighbours' values come from the adjacent lanes).
+    auto rowmax_mask = [&](const float (&out)[4]) -> unsigned {
+        const float sgn = p.cand_min ? -1.0f : 1.0f;
+        const float q0 = sgn * out[0], q1 = sgn * out[1], q2 = sgn * out[2], q3 = sgn * out[3];
+        float lf = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, __float_as_int(q3)));
+        float rt = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(q0)));
+        if (lane == 0) lf = -INFINITY;
+        if (lane == 63 || xq + 4 >= p.ow) rt = -INFINITY;
+        unsigned m = 0;
+        m |= (!(lf > q0) && !(q1 > q0)) ? 1u : 0u;
+        m |= (!(q0 > q1) && !(q2 > q1)) ? 2u : 0u;
+        m |= (!(q1 > q2) && !(q3 > q2)) ? 4u : 0u;
+        m |= (!(q2 > q3) && !(rt > q3)) ? 8u : 0u;
+        return m;
+    };
     // global extremum (EXT): the lane's best key not below the template's running best goes to the wave's
     // LDS slot (cv2.minMaxLoc: the first index wins ties, NaN never wins)
     auto ext_update = [&](const float (&out)[4], int yrow, uint32_t best_hi, unsigned long long* slot) {
@@ -1180,9 +1200,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         if constexpr (EXT) {
                             ext_update(out, yy, T.ext_hi, &ext_slot[t]);
                         } else if (p.cand_on) {
+                            const unsigned allow = p.cand_rowmax ? rowmax_mask(out) : 15u;
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy);
+                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy, allow);
                         }
                         if (!p.hits_only) store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, out);
                     }
@@ -1661,9 +1682,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             ext_update(out, yrow, T.ext_hi, &ext_slot[lt0 + s8]);
                         } else if (p.cand_on) {
                             // cheap any-of-4 test; emit_at() repeats the exact per-pixel test (rare)
+                            const unsigned allow = p.cand_rowmax ? rowmax_mask(out) : 15u;
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, yrow);
+                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, yrow, allow);
                         }
                         if (!p.hits_only) store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, out);
                     }

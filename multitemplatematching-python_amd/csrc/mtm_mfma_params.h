@@ -120,7 +120,7 @@ struct MfmaParams {
     int cs_off;              // byte offset in LDS of the candidate staging buffers (4 waves x kMfCandStageBytes); 0 = none
     int sq_fused;
     int rm_edges;            // row-multiplexed tilings: 1 = the edge steps (one group's A operand all zero) run the one-group step
-    int cs_pad_;
+    int cand_rowmax;         // 1 (maps in memory only): list only candidates no neighbour in their own row exceeds
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)

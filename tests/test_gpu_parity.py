@@ -2191,6 +2191,52 @@ def test_context_state_sequences(mtm, seed):
             assert_hits_equal(hits_json(names), hits_json(exp), tol=1e-5, ordered=False)
 
 
+def test_dense_route_row_maxima_candidates(mtm, monkeypatch):
+    """Dense maps, the route taken while the back-off lasts (round 4): maps in memory, the score kernel lists only the
+    pixels above the threshold that no neighbour in their own row exceeds, verify_peaks_kernel tests that list against
+    the maps - no full peak pass.  With a candidate capacity between the number of row maxima and the number of all
+    pixels above the threshold the first call overflows (hits-only), the following ones take the dense route and must
+    return the oracle's hits; so must the route switched off (MTM_DENSE_ROWMAX=0: the full peak pass) and a capacity
+    that even the row maxima overflow.  Maxima and minima (TM_SQDIFF_NORMED), plateaus included (flat patches)."""
+    from MTM import _lib
+    dense = synth.smooth_u8(7, (300, 520), scales=(3, 9, 27), noise=0.1)
+    dense[40:70, 100:180] = 90                               # flat patches: plateaus of equal scores
+    dense[200:240, 300:420] = 90
+    rng = np.random.default_rng(9)
+    lt = []
+    for i in range(20):
+        y, x = int(rng.integers(0, 300 - 24)), int(rng.integers(0, 520 - 32))
+        lt.append(("t%d" % i, dense[y:y + 24, x:x + 32].copy()))
+    for method, thr in ((5, 0.3), (1, 0.05)):
+        n_above = n_row = 0
+        for _, t in lt:
+            m = O.match_template(dense, t, method).astype(np.float32)
+            q = -m if method == 1 else m
+            above = q > np.float32(-thr if method == 1 else thr)
+            left = np.pad(q[:, :-1], ((0, 0), (1, 0)), constant_values=-np.inf)
+            right = np.pad(q[:, 1:], ((0, 0), (0, 1)), constant_values=-np.inf)
+            n_above += int(above.sum())
+            n_row += int((above & ~(left > q) & ~(right > q)).sum())
+        assert n_row * 2 < n_above, (n_row, n_above)
+        exp = hits_json(O.find_matches(lt, dense, method=method, score_threshold=thr))
+        assert len(exp) > 500
+        # the kernel's row test only sees the 256 pixels of a wave: a few more candidates than the count above
+        for env, cap in (("1", (n_above + 2 * n_row) // 3), ("0", (n_above + 2 * n_row) // 3), ("1", max(64, n_row // 4))):
+            monkeypatch.setenv("MTM_DENSE_ROWMAX", env)
+            c = _lib.Context(0)
+            try:
+                c.set_option(_lib.OPT_HIT_CAPACITY, cap)
+                c.set_templates([(t, None) for _, t in lt], method)
+                for k in range(4):
+                    raw = c.find_matches_image(dense, _lib.PEAKS_LOCAL, thr)
+                    assert c.timing()["hits_only"] == 0
+                    got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in raw]
+                    assert len(got) == len(exp), (method, env, cap, k, len(got), len(exp))
+                    assert_hits_equal(hits_json(got), exp, tol=1e-6, ordered=False)
+            finally:
+                c.close()
+
+
 def test_dense_maps_candidate_overflow(mtm):
     """Smooth images at a low threshold: far more pixels above the threshold than the candidate list holds.  The
     overflowing hits-only launch leaves early, the call is repeated with the maps in memory and the full peak pass;
