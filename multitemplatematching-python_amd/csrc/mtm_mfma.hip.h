@@ -851,7 +851,26 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if (total == 0) return;                                     // uniform over the lanes that are here
         const int leader = (int)__builtin_ctzll(act);
         if (cs_on) {
-            const int cur = cs_cnt[0];                              // (same address for every lane here: a broadcast)
+            int cur = cs_cnt[0];                                    // (same address for every lane here: a broadcast)
+            bool flushed = false;
+            if (cur > 0 && cur + (int)total > kMfCandStage) {
+                // no room for this call's candidates: the staged ones go to the list now - one atomic for up to
+                // kMfCandStage records, the lanes that are here share the copy - and the buffer starts over.  (A wave over a
+                // bright region lists for most of its 32 (template, row) pairs; without this every further pair would
+                // pay its own round trip to the list's counter.)
+                unsigned long long fb = 0ull;
+                if (lane == leader) fb = atomicAdd(p.cand_counter, (unsigned long long)cur);
+                const uint32_t flo = __builtin_amdgcn_readlane((uint32_t)fb, leader);
+                const uint32_t fhi = __builtin_amdgcn_readlane((uint32_t)(fb >> 32), leader);
+                fb = ((unsigned long long)fhi << 32) | flo;
+                const int n_act = __popcll(act);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                for (int r = rank; r < cur; r += n_act)
+                    if (fb + (unsigned long long)r < p.cand_cap) p.cand_hits[fb + (unsigned long long)r] = cs_rec[r];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the records are read: their slots may be rewritten
+                cur = 0;
+                flushed = true;
+            }
             if (cur + (int)total <= kMfCandStage) {
                 if (m) {
                     const int tglob = tlist[li];
@@ -876,7 +895,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 return;
             }
-            // (no room left: this call's candidates go straight to the list, as before)
+            // (more candidates in this one call than the buffer holds: they go straight to the list, as before)
+            if (flushed) {
+                if (lane == leader) cs_cnt[0] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
         }
         unsigned long long base = 0ull;
         if (lane == leader) base = atomicAdd(p.cand_counter, (unsigned long long)total);
@@ -913,7 +936,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // lanes of the wave that are in the epilogue call this together (the neighbours' values come from the adjacent lanes).
     auto rowmax_mask = [&](const float (&out)[4]) -> unsigned {
         const float sgn = p.cand_min ? -1.0f : 1.0f;
-        const float q0 = sgn * out[0], q1 = sgn * out[1], q2 = sgn * out[2], q3 = sgn * out[3];
+        // (pixels right of the last output column do not exist: they exceed nothing)
+        const float q0 = sgn * out[0], q1 = xq + 1 < p.ow ? sgn * out[1] : -INFINITY, q2 = xq + 2 < p.ow ? sgn * out[2] : -INFINITY,
+                    q3 = xq + 3 < p.ow ? sgn * out[3] : -INFINITY;
         float lf = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, __float_as_int(q3)));
         float rt = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(q0)));
         if (lane == 0) lf = -INFINITY;

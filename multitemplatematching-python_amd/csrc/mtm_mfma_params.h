@@ -33,7 +33,7 @@ __host__ __device__ constexpr int mf_stat_bytes_per_wave(int ch) { return (ch + 
 // full, [4..7] the start values of the shader-clock probe (two 64-bit counters)
 constexpr int kMfItemBytes = 32;
 // Wave-private staging of peak candidates in LDS (hits-only / candidate mode): [count, pad x 3][kMfCandStage records]
-constexpr int kMfCandStage = 96;
+constexpr int kMfCandStage = 128;
 constexpr int kMfCandStageBytes = 16 + kMfCandStage * 24;
 // METHOD value of the raw mode: the biased int8 accumulators are stored as they are (uint16 images:
 // the first of two byte-plane passes, see kMfU16; sum I^2 M of masked classes; slabs).

@@ -2207,6 +2207,8 @@ def test_dense_route_row_maxima_candidates(mtm, monkeypatch):
     for i in range(20):
         y, x = int(rng.integers(0, 300 - 24)), int(rng.integers(0, 520 - 32))
         lt.append(("t%d" % i, dense[y:y + 24, x:x + 32].copy()))
+    lt.append(("right", dense[100:124, 488:520].copy()))     # exact copies at the last column / the last row of their maps:
+    lt.append(("bottom", dense[276:300, 200:232].copy()))    # peaks whose right / lower neighbours do not exist
     for method, thr in ((5, 0.3), (1, 0.05)):
         n_above = n_row = 0
         for _, t in lt:
