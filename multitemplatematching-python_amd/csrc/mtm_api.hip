@@ -473,10 +473,13 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
             if (use_fused && (int64_t)ncand > cand_cap) {
                 use_fused = false;                  // dense maps: candidate list overflowed
-                // the next calls on this context go straight to map mode + full peak pass; the period doubles while
-                // the retries keep overflowing
-                c->fuse_backoff = c->backoff_len;
-                c->backoff_len = std::min(2 * c->backoff_len, 1024);
+                // the next calls on this context go straight to map mode (dense route, or the full peak pass); the period
+                // doubles while the retries keep overflowing.  (An overflow of the dense route's own list - row maxima
+                // only - is no retry: the back-off it runs under keeps counting down, this call takes the full peak pass.)
+                if (!c->cand_rowmax_now) {
+                    c->fuse_backoff = c->backoff_len;
+                    c->backoff_len = std::min(2 * c->backoff_len, 1024);
+                }
                 if (c->hits_only_now) {
                     // no maps in memory: compute them (this call pays twice - the overflowed launch left early)
                     c->hits_only_now = false;
@@ -488,7 +491,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 }
                 continue;
             }
-            if (use_fused && !pp_mode) c->backoff_len = 16;     // the candidates fitted
+            if (use_fused && !pp_mode && !c->cand_rowmax_now) c->backoff_len = 16;     // the candidates fitted
             if ((int64_t)count <= c->hit_cap) {
                 hits.resize((size_t)count);
                 const size_t got = std::min<size_t>((size_t)count, first);

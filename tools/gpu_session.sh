@@ -86,6 +86,10 @@ for st in "$@"; do
         env $e python bench.py --no-cpu-baseline --skip-extras --steps ${LIB_STEPS:-200} 2>>$OUT/bench.err | clean | tail -1 |
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$e', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/env_ab.txt
       done; done ;;
+    dense_ab)       # the dense regime (photograph-like 4K image x 32 templates, threshold 0.5) under environment switches
+      for e in "X=0" ${ENV_AB:-MTM_DENSE_ROWMAX=0 MTM_CAND_STAGE=0}; do
+        env $e timeout 200 python tools/probes/dense_probe.py 0.5 2>&1 | grep -A1 "HITS_ONLY=1\|dense call" | sed "s/^/$e /" | cut -c1-360 >> $OUT/dense_ab.txt
+      done; stamp "dense_ab: $(grep -c 'call median' $OUT/dense_ab.txt) runs" ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
