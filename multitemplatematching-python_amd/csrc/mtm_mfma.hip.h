@@ -939,10 +939,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // (pixels right of the last output column do not exist: they exceed nothing)
         const float q0 = sgn * out[0], q1 = xq + 1 < p.ow ? sgn * out[1] : -INFINITY, q2 = xq + 2 < p.ow ? sgn * out[2] : -INFINITY,
                     q3 = xq + 3 < p.ow ? sgn * out[3] : -INFINITY;
-        float lf = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, __float_as_int(q3)));
-        float rt = __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, __float_as_int(q0)));
-        if (lane == 0) lf = -INFINITY;
-        if (lane == 63 || xq + 4 >= p.ow) rt = -INFINITY;
+        // DPP wave shifts (VALU moves, no LDS traffic - a ds_bpermute and the wait for it in the template loop cost the
+        // epilogue its software pipelining): wave_shr:1 = lane i receives lane i - 1, wave_shl:1 = lane i + 1; a lane without
+        // a source, or whose source is inactive, keeps the -inf passed in (tools/ubench/dpp checks exactly that on the box)
+        const int ninf = __float_as_int(-INFINITY);
+        const float lf = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(q3), 0x138, 0xf, 0xf, false));
+        float rt = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(q0), 0x130, 0xf, 0xf, false));
+        if (xq + 4 >= p.ow) rt = -INFINITY;
         unsigned m = 0;
         m |= (!(lf > q0) && !(q1 > q0)) ? 1u : 0u;
         m |= (!(q0 > q1) && !(q2 > q1)) ? 2u : 0u;
