@@ -162,8 +162,12 @@ struct mtm_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sq_ev;       // event pairs of the sum I^2 M passes (timing.masked_stat_ms)
-    int dense_rowmax = 1;       // MTM_DENSE_ROWMAX: while the back-off lasts (dense maps), map mode + row-local-maximum candidates
-                                // + verify_peaks_kernel instead of the full peak pass (0: round 3's peaks_kernel over every map)
+    // MTM_DENSE_ROWMAX=1 (experiment of round 4, default 0): while the back-off lasts (dense maps), map mode + candidates that
+    // no neighbour in their own row exceeds + verify_peaks_kernel instead of the full peak pass over every map.  Correct
+    // (tests/test_gpu_parity.py::test_dense_route_row_maxima_candidates) and the peak pass does shrink from 0.39 to 0.12 ms
+    // at 4K x 32 templates - but listing the 1.2e5 row maxima costs the score kernel 0.45 ms (0.90 -> 1.35 ms; 6.7 % of
+    // its (segment, row, template) triples hold one), so the call is slower: 2.55 against 2.41 ms (profiles/r04h/dense_ab.txt).
+    int dense_rowmax = 0;
     bool cand_rowmax_now = false;   // this call takes that route
     int cand_stage = 1;         // MTM_CAND_STAGE: peak candidates of a wave collected in LDS, one atomic per wave and work item (0: one per emission)
     int rm_edges = 1;           // MTM_RM_EDGES: one-group K steps where a row-multiplexed wave's other group has no template row (0: off)

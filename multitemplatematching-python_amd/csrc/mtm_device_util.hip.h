@@ -123,4 +123,38 @@ __device__ __forceinline__ void peaks_load_row(const float* __restrict__ m, int 
     }
 }
 
+// peaks_load_row in two halves, so that a kernel can request a row's pixels rows ahead of using them: peaks_fetch_row
+// issues the loads (nothing depends on their values), peaks_finish_row negates for minima and exchanges the edge pixels
+// with the neighbouring lanes.  Same values as peaks_load_row.
+struct PeakRow {
+    float4 q;       // pixels xb .. xb + 3 as loaded (pad value outside the map)
+    float el, er;   // pixels xb - 1 / xb + 4 for lanes 0 / 63 (the strip's neighbours in memory), pad value otherwise
+};
+__device__ __forceinline__ PeakRow peaks_fetch_row(const float* __restrict__ m, int pitch, int oh, int ow, int y, int xb, int lane,
+                                                   float padv_raw) {
+    PeakRow r;
+    r.q = make_float4(padv_raw, padv_raw, padv_raw, padv_raw);
+    r.el = r.er = padv_raw;
+    if (y < 0 || y >= oh) return r;
+    const float* row = m + (size_t)y * pitch;
+    if (xb + 3 < ow) {
+        r.q = *reinterpret_cast<const float4*>(row + xb);
+    } else {
+        if (xb < ow) r.q.x = row[xb];
+        if (xb + 1 < ow) r.q.y = row[xb + 1];
+        if (xb + 2 < ow) r.q.z = row[xb + 2];
+    }
+    if (lane == 0 && xb - 1 >= 0) r.el = row[xb - 1];
+    if (lane == 63 && xb + 4 < ow) r.er = row[xb + 4];
+    return r;
+}
+// padv_raw = the pad value as it would sit in memory (mode_min: the negated pad), so that one negation serves all
+__device__ __forceinline__ void peaks_finish_row(const PeakRow& r, int lane, bool mode_min, float (&v)[4], float& hl, float& hr) {
+    const float s = mode_min ? -1.0f : 1.0f;
+    v[0] = s * r.q.x; v[1] = s * r.q.y; v[2] = s * r.q.z; v[3] = s * r.q.w;
+    const float left = __shfl_up(v[3], 1), right = __shfl_down(v[0], 1);
+    hl = lane == 0 ? s * r.el : left;
+    hr = lane == 63 ? s * r.er : right;
+}
+
 }  // namespace mtm
