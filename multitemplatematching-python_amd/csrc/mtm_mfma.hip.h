@@ -849,6 +849,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         const unsigned n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
         const unsigned total = n0 + n1 + n2 + n3;
         if (total == 0) return;                                     // uniform over the lanes that are here
+        if (p.dbg & 4) return;          // probe (MTM_MFMA_DBG=4): no emission at all behind the counts (results invalid)
         const int leader = (int)__builtin_ctzll(act);
         if (cs_on) {
             int cur = cs_cnt[0];                                    // (same address for every lane here: a broadcast)
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 flushed = true;
             }
             if (cur + (int)total <= kMfCandStage) {
-                if (m) {
+                if (m && !(p.dbg & 8)) {            // probe (MTM_MFMA_DBG=8): counts only, no records
                     const int tglob = tlist[li];
                     const unsigned long long bb[4] = {b0, b1, b2, b3};
                     const unsigned pre[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
@@ -1784,8 +1785,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
             const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
             base = ((unsigned long long)bhi << 32) | blo;
-            for (int r = lane; r < n_st; r += 64)
-                if (base + (unsigned long long)r < p.cand_cap) p.cand_hits[base + (unsigned long long)r] = cs_rec[r];
+            if (!(p.dbg & 16))                   // probe (MTM_MFMA_DBG=16): the atomic without the copy
+                for (int r = lane; r < n_st; r += 64)
+                    if (base + (unsigned long long)r < p.cand_cap) p.cand_hits[base + (unsigned long long)r] = cs_rec[r];
         }
     }
     }   // epilogue scope

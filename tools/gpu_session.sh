@@ -90,6 +90,10 @@ for st in "$@"; do
       for e in "X=0" ${ENV_AB:-MTM_DENSE_ROWMAX=0 MTM_CAND_STAGE=0}; do
         env $e timeout 200 python tools/probes/dense_probe.py 0.5 2>&1 | grep -A1 "HITS_ONLY=1\|dense call" | sed "s/^/$e /" | cut -c1-360 >> $OUT/dense_ab.txt
       done; stamp "dense_ab: $(grep -c 'call median' $OUT/dense_ab.txt) runs" ;;
+    emit_probe)     # where the time of listing ~1e6 candidates goes: hits-only mode with a list that holds them, emission stages switched off one at a time (results invalid, timing only)
+      for e in "MTM_MFMA_DBG=0" "MTM_MFMA_DBG=4" "MTM_MFMA_DBG=8" "MTM_MFMA_DBG=16" "MTM_MFMA_DBG=24" "MTM_CAND_STAGE=0"; do
+        env DENSE_HIT_CAP=1048576 $e timeout 200 python tools/probes/dense_probe.py 0.5 2>&1 | grep "HITS_ONLY=1" | sed "s/^/$e /" | cut -c1-200 >> $OUT/emit_probe.txt
+      done; stamp "emit_probe: $(grep -c 'call median' $OUT/emit_probe.txt) runs" ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;

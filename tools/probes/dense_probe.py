@@ -14,6 +14,8 @@ import synth
 nat = synth.smooth_u8(11, (2160, 3840))
 lt = synth.cut_templates(5, nat, 32, 64)
 ctx = _lib.default_context()
+if os.environ.get("DENSE_HIT_CAP"):            # e.g. 1048576: a candidate list that holds every pixel above the threshold
+    ctx.set_option(_lib.OPT_HIT_CAPACITY, int(os.environ["DENSE_HIT_CAP"]))
 THRS = [float(v) for v in sys.argv[1:]] or [0.5, 0.7, 0.9]
 for thr in THRS:
     for honly in (1, 0):
