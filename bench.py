@@ -269,7 +269,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # --gpus N without a launcher: one process, N devices (mtm_group).  With WORLD_SIZE set: one process per GPU.
-    group_n = args.gpus if ("WORLD_SIZE" not in os.environ and args.gpus > 1) else 0
+    # (BENCH_GROUP_SINGLE=1: the group path with ONE device - on a one-GPU box the only way to run the in-process RCCL
+    # exchange end to end, as a communicator of one rank; never set by the driver)
+    group_n = args.gpus if ("WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("BENCH_GROUP_SINGLE"))) else 0
     if not group_n and world != args.gpus:
         args.gpus = world
 
@@ -303,6 +305,8 @@ def main():
         if n_vis < group_n and not os.environ.get("BENCH_GROUP_ALIAS"):
             sys.exit("bench.py --gpus %d: only %d GPU(s) visible" % (group_n, n_vis))
         group_devices = [i % max(n_vis, 1) for i in range(group_n)]
+        if group_n == 1:
+            os.environ["MTM_DEVICES_FORCE_GROUP"] = "1"      # (a one-device list normally resolves to a plain context)
         group = _lib.Group(group_devices)
         group.set_option(_lib.OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[args.kernel])
         _lib._engines[tuple(group_devices)] = group          # MTM.matchTemplates(devices=...) below runs on this group

@@ -12,7 +12,7 @@ names = {"bench.json": "%s_bench.json", "bench_configs.jsonl": "%s_bench_configs
          "bench_under_rocprof_banded.json": "%s_bench_under_rocprof_banded.json",
          "bench_under_rocprof_single.json": "%s_bench_under_rocprof_single_launch.json",
          "bench_driver.json": "%s_bench_driver_flags.json", "bench_group2.json": "%s_bench_group2_one_gpu.json",
-         "bench_group8.json": "%s_bench_group8_one_gpu.json"}
+         "bench_group8.json": "%s_bench_group8_one_gpu.json", "bench_group1_rccl.json": "%s_bench_group1_rccl.json"}
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b % tag))

@@ -39,7 +39,8 @@ for st in "$@"; do
     group)
       BENCH_GROUP_ALIAS=1 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group2.json
       BENCH_GROUP_ALIAS=1 python bench.py --gpus 8 --steps 10 --warmup 2 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group8.json
-      stamp "group: $(cut -c1-120 $OUT/bench_group2.json) | $(cut -c1-120 $OUT/bench_group8.json)" ;;
+      BENCH_GROUP_SINGLE=1 python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --skip-extras 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group1_rccl.json
+      stamp "group: $(cut -c1-120 $OUT/bench_group2.json) | $(cut -c1-120 $OUT/bench_group8.json) | $(python -c "import json;print(json.load(open('$OUT/bench_group1_rccl.json'))['multi_gpu'])" 2>&1 | cut -c1-200)" ;;
     probes)
       for pr in ${PROBES:-call_breakdown dense_probe coins_probe}; do timeout 300 python tools/probes/$pr.py > $OUT/$pr.txt 2>&1; stamp "$pr: $(tail -3 $OUT/$pr.txt | tr '\n' '|' | cut -c1-300)"; done ;;
     bands_ab)       # upload-band layouts x one / two score streams, per-call metric
