@@ -35,7 +35,10 @@ for st in "$@"; do
     profile)
       bash tools/profile_round.sh ${PROFILE_TAG:-$TAG/profile} > $OUT/profile.log 2>&1; stamp "profile done" ;;
     alt_quick)
-      ALT_K="not cfg and not full_size" bash tools/alt_modes.sh > $OUT/alt_modes.txt 2>&1; stamp "alt: $(grep -c passed $OUT/alt_modes.txt) modes" ;;
+      ALT_K="${ALT_K:-not cfg and not full_size}" bash tools/alt_modes.sh > $OUT/alt_modes.txt 2>&1; stamp "alt: $(grep -c passed $OUT/alt_modes.txt) modes, $(grep -c failed $OUT/alt_modes.txt) with failures" ;;
+    configs)        # the BASELINE configs on one GPU (roofline.traffic from the committed PMC table)
+      for cfg in cfg2 cfg3 cfg4 cfg5; do python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 >> $OUT/bench_configs.jsonl; done
+      stamp "configs: $(wc -l < $OUT/bench_configs.jsonl) lines" ;;
     group)
       BENCH_GROUP_ALIAS=1 python bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group2.json
       BENCH_GROUP_ALIAS=1 python bench.py --gpus 8 --steps 10 --warmup 2 --no-cpu-baseline 2>>$OUT/bench.err | clean | tail -1 > $OUT/bench_group8.json
