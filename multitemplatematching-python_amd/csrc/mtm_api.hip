@@ -117,7 +117,12 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
             any_bf16 = any_bf16 || b;
             all_bf16 = all_bf16 && b;
         }
-        if (any_bf16 && c->f32_mfma == 1) {
+        // raw sums (TM_SQDIFF / TM_CCORR / TM_CCOEFF): only the refined global extremum runs on the matrix cores - maps and
+        // thresholds on unnormalised sums have no error the bf16 pieces could promise (an exact copy is TM_SQDIFF 0)
+        const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
+        if (any_bf16 && raw_m && (mode != MTM_PEAKS_GLOBAL || c->f32_mfma != 1)) {
+            c->f32_exact_now = true;
+        } else if (any_bf16 && c->f32_mfma == 1) {
             if (all_bf16) c->refine_now = true;
             else c->f32_exact_now = true;
         }
@@ -620,8 +625,13 @@ int mtm_score_map(mtm_ctx* c, int templ_idx, float* out, int64_t out_row_stride_
     c->timing = mtm_timing{};
     StatPlanes st;
     MTMC(ensure_maps(c));
-    MTMC(launch_stats(c, sc, &st));
-    MTMC(launch_ncc(c, sc, sc.tlist_off + pos, 1, st, pos));
+    // float32 classes: maps of the raw-sum methods come from the float64 kernel (see fm_begin)
+    c->f32_exact_now = resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32 &&
+                       (c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF);
+    const int rc_st = launch_stats(c, sc, &st);
+    const int rc_nc = rc_st == MTM_OK ? launch_ncc(c, sc, sc.tlist_off + pos, 1, st, pos) : rc_st;
+    c->f32_exact_now = false;
+    MTMC(rc_nc);
     HIPC(hipMemcpy2DAsync(out, (size_t)out_row_stride_bytes, c->maps.as<float>() + d.map_off,
                           sizeof(float) * d.map_pitch, sizeof(float) * d.ow, d.oh, hipMemcpyDeviceToHost,
                           c->stream));

@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             }
             k.templ_norm = T.templ_norm;
             k.templ_sum2 = T.templ_sum2;
+            {
+                double c2 = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < kMaxChans; ++cc)
+                    if (cc < p.chans) c2 += T.centre[cc] * T.centre[cc];
+                k.t2c = fmax(T.templ_sum2 - (double)p.h * (double)p.w * c2, 0.0);
+            }
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             const int sc = min(x0 + (lane & 7) * (p.lds_cols - 1) / 7, p.cols - 1);
             float v = plane[(size_t)sr * p.pitch + sc];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0) *s_mu = v * (1.0f / 64.0f);
+            if (lane == 0) s_mu[c] = v * (1.0f / 64.0f);          // (one slot per channel: the epilogue's error bound reads them back)
         }
         __syncthreads();
-        const float mu = *s_mu;
+        const float mu = s_mu[c];
         for (int cy0 = 0; cy0 < p.h; cy0 += p.chunk_h) {
             const int ch = min(p.chunk_h, p.h - cy0);
             const int trows = ch + kBfRows - 1;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const int xq = x0 + 8 * j;
     const bool lane_on = y < p.oh && xq < p.ow;
     const int method = p.method;
-    const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
+    const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED || (p.ext_on && p.ext_raw);
     const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
     // (the two halves of a lane's eight pixels as a generic lambda over a compile-time constant: every accumulator index
     // below must be one, or the accumulators leave the register file)
@@ -288,7 +295,29 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     out[i] = bf_finish(method, corr, ts[i], s2[i], sq[i], T, p.chans);
                 }
                 const int xb = xq + 4 * half;
-                if (p.ext_on && p.ext_margin > 0.0f) {       // refined extremum mode: the outputs are looked at again below
+                float key_v[4] = {out[0], out[1], out[2], out[3]};      // what the published key is built from
+                if (p.ext_on && p.ext_raw) {
+                    // raw-sum methods, refined: bounds instead of scores (see Bf16Params::ext_raw).  The accumulator
+                    // registers take the upper bound of the quality, the key the lower bound (as a score).
+                    const double escale = (method == MTM_TM_SQDIFF ? 2.0 : 1.0) * (double)p.ext_eps;
+                    const double area = (double)p.h * (double)p.w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double s2c = s2[i];
+#pragma unroll
+                        for (int cc = 0; cc < kMaxChans; ++cc)
+                            if (cc < p.chans) {
+                                const double m = (double)s_mu[cc];
+                                s2c += m * (area * m - 2.0 * ts[i][cc]);
+                            }
+                        const double q = p.cand_min ? -(double)out[i] : (double)out[i];
+                        // + the rounding of the score to float32 and of the bounds below
+                        const double E = escale * sqrt(fmax(s2c, 0.0) * T.t2c) * 1.000001 + fabs(q) * 2.4e-7 + 1e-30;
+                        acc[mb][4 * half + i][e] = (float)(q + E);
+                        const float lq = (float)(q - E);
+                        key_v[i] = p.cand_min ? -lq : lq;
+                    }
+                } else if (p.ext_on && p.ext_margin > 0.0f) {       // refined extremum mode: the outputs are looked at again below
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[mb][4 * half + i][e] = out[i];
                 }
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     unsigned long long bestk = 0ull;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float v = out[i];
+                        const float v = key_v[i];
                         if (xb + i < p.ow && v == v) {
                             const uint32_t o = mf_float_order(v);
                             const unsigned long long key = ((unsigned long long)(p.cand_min ? ~o : o) << 32) |
@@ -383,13 +412,14 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                                 const uint32_t hiw = (uint32_t)(gk >> 32);
                                 const float sc = mf_order_float(p.cand_min ? ~hiw : hiw);
                                 const float ql = p.cand_min ? -sc : sc;
-                                lo = ql - p.ext_margin * fmaxf(1.0f, fabsf(ql));
+                                lo = p.ext_raw ? nextafterf(ql, -INFINITY) : ql - p.ext_margin * fmaxf(1.0f, fabsf(ql));
                             }
                             const int xb = xq + 4 * half;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const float v = acc[mb][4 * half + i][e];
-                                const float ql = p.cand_min ? -v : v;
+                                // (raw-sum methods: the register holds the upper bound of the QUALITY already)
+                                const float ql = p.ext_raw ? v : (p.cand_min ? -v : v);
                                 mtm_hit hrec;
                                 hrec.templ_idx = tcl[lt].tglob;
                                 hrec.x = xb + i;

@@ -45,6 +45,14 @@ struct Bf16Params {
     int ext_on;
     float ext_margin;        // > 0: refined extremum mode - outputs within this margin of the running best are listed (cand_hits)
     unsigned long long* ext_best;
+    // Refined extremum mode of the raw-sum methods (TM_SQDIFF / TM_CCORR / TM_CCOEFF; round 4).  Their extremum can be a
+    // difference of large terms (an exact copy has TM_SQDIFF 0), so no margin relative to the score is safe.  Instead every
+    // output carries a rigorous error bound E = ext_eps * sqrt(sum (I - mu)^2 * sum (T - centre)^2) (Cauchy-Schwarz over the
+    // dropped piece products and the float32 accumulation; twice that for TM_SQDIFF), the kernel publishes the best LOWER
+    // bound q - E of a template and lists every output whose UPPER bound q + E reaches it: the exact extremum - and every
+    // exact tie with it - is always listed, whatever the order the waves finish in.
+    int ext_raw;
+    float ext_eps;
 };
 
 // Per-template constants of a work item, staged in LDS once (the epilogue reads them as LDS broadcasts).
@@ -52,6 +60,7 @@ struct BfTemplConst {
     double mean[kMaxChans];
     double centre[kMaxChans];
     double templ_norm, templ_sum2;
+    double t2c;              // sum over channels of sum (T - centre)^2 (error bound of the refined raw-sum extremum)
     long long map_off;
     int map_pitch, all_ones, tglob, pad_;
 };

@@ -757,6 +757,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.cand_on = 1;
             p.hits_only = 1;
             p.ext_margin = c->refine_now ? kRefineThrMargin : 0.0f;
+            const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
+            if (raw_m && c->refine_now) {
+                // rigorous bounds instead of a relative margin (Bf16Params::ext_raw): 2^-15 for the dropped piece products
+                // and the two 16-bit representations, 2^-24 per float32 accumulation (three MFMAs per 32-tap block)
+                p.ext_raw = 1;
+                p.ext_eps = (float)(3.0518e-5 + 3.0 * (double)c->chans * h * p.nkb * 5.97e-8);
+            }
         }
         const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
         const int grid = ((p.n_work + 7) / 8) * 8;

@@ -132,9 +132,11 @@ bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
 // TM_CCORR, TM_CCOEFF) are as accurate relative to the sums they are built from (~1e-7), but they can cancel to
 // values far smaller than those sums (an exact copy: SQDIFF = 0), where no relative bound holds: float64 kernel.
 bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
-    const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED || c->method == MTM_TM_CCOEFF_NORMED;
+    // All six methods (round 4).  The raw-sum methods only take this kernel for the refined global extremum
+    // (N_object == 1; mtm_api.hip decides per call) - everything else they do runs the float64 kernel, for which a
+    // bf16 class carries its float64 weights anyway.
     // (1-D and 1x1 score maps go through scipy's find_peaks on the host, which has no refinement: float64 kernel)
-    return c->f32_mfma && normed && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW &&
+    return c->f32_mfma && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW &&
            c->rows > sc.h && c->cols > sc.w;
 }
 inline int bf16_nkb(int w) { return (w + 31) / 32; }

@@ -999,18 +999,35 @@ def test_float32_hit_lists_are_the_float64_kernels(coins):
                         assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), \
                             (name, method, thr, cap, honly, tm["f32_route"])
             # N_object == 1: the global extremum per template (first occurrence on exact ties)
-            for method in (5, 3, 1):
+            # (round 4: the raw-sum methods 0 / 2 / 4 too - their refined extremum lists by rigorous error bounds, an
+            # exact copy is TM_SQDIFF 0 and the templates of the piecewise-constant image have exact ties)
+            for method in (5, 3, 1, 0, 2, 4):
                 ref = exact.search(templs, im, method, _lib.PEAKS_GLOBAL, 0.0)
                 for cap in (1 << 18, 64):
                     fast.set_option(_lib.OPT_HIT_CAPACITY, cap)
                     fast.set_option(_lib.OPT_HITS_ONLY, 1)
                     got = fast.search(templs, im, method, _lib.PEAKS_GLOBAL, 0.0)
                     routes.add(fast.timing()["f32_route"])
+                    if cap == 1 << 18 and name != "blocks":
+                        assert fast.timing()["f32_route"] == 1 and fast.timing()["kernel_used"] == 5, (name, method, fast.timing())
                     assert len(got) == len(ref) == len(lt)
                     for f in ("templ_idx", "x", "y"):
                         assert np.array_equal(got[f], ref[f]), (name, method, cap, f, fast.timing()["f32_route"])
                     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (name, method, cap)
         assert routes == {1, 2, 3}, routes          # every way of refining has been exercised
+        # raw sums with thresholds, and their maps, stay on the float64 kernel (no error the bf16 pieces could promise there)
+        name, im, lt = cases[0]
+        fast.set_option(_lib.OPT_HIT_CAPACITY, 1 << 18)
+        got = fast.search([(t, None) for t in lt[:4]], im, 4, _lib.PEAKS_LOCAL, 1e6)
+        assert fast.timing()["f32_route"] == 3
+        ref = exact.search([(t, None) for t in lt[:4]], im, 4, _lib.PEAKS_LOCAL, 1e6)
+        assert got.tobytes() == ref.tobytes()
+        shape = (im.shape[0] - lt[0].shape[0] + 1, im.shape[1] - lt[0].shape[1] + 1)
+        fast.set_templates([(lt[0], None)], 0)
+        exact.set_templates([(lt[0], None)], 0)
+        fast.set_image(im)
+        exact.set_image(im)
+        assert np.array_equal(fast.score_map(0, shape), exact.score_map(0, shape))
         # MTM_OPT_F32_MFMA = 2: the bf16 scores as they are (no re-scoring), still within tolerance of the exact ones
         fast.set_option(_lib.OPT_HIT_CAPACITY, 1 << 18)
         fast.set_option(_lib.OPT_F32_MFMA, 2)
