@@ -138,13 +138,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             }
             k.templ_norm = T.templ_norm;
             k.templ_sum2 = T.templ_sum2;
-            {
-                double c2 = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < kMaxChans; ++cc)
-                    if (cc < p.chans) c2 += T.centre[cc] * T.centre[cc];
-                k.t2c = fmax(T.templ_sum2 - (double)p.h * (double)p.w * c2, 0.0);
-            }
+            k.t2c = T.centred_sum2 * 1.000001;        // (a float64 variance times the area: its own rounding covered)
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;

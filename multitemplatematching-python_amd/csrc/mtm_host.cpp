@@ -75,6 +75,7 @@ TemplStats templ_stats_from_sums(const double* sum, const double* sumsq, double 
         mean[c] = sum[c] / n;
         const double var = sumsq[c] / n - mean[c] * mean[c];
         sdv[c] = std::sqrt(std::max(var, 0.0));
+        st.centred_sum2 += std::max(var, 0.0) * n + 1e-15 * sumsq[c];       // (+ the cancellation in sumsq / n - mean^2)
     }
     if (method == MTM_TM_CCORR) return st;
     const int num_type = (method == MTM_TM_CCORR || method == MTM_TM_CCORR_NORMED) ? 0

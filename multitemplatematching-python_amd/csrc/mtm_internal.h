@@ -20,6 +20,8 @@ struct TemplStats {
     double inv_area = 0;
     int all_ones = 0;                // TM_CCOEFF_NORMED with a constant template: map == 1
     double templ2_mask2_sum = 0;     // masked path: sum((T*M)^2)
+    double centred_sum2 = 0;         // sum over channels of sum (T - channel mean)^2, whatever the method (error bound of the
+                                     // refined raw-sum extremum of float32 classes, mtm_bf16.hip.h)
 };
 
 // px: planar float64 copies of the template (and mask weights, or nullptr), chans planes of

@@ -21,6 +21,7 @@ struct TemplDev {
     double templ_norm;
     double templ_sum2;
     double templ2_mask2_sum;
+    double centred_sum2;    // sum over channels of sum (T - channel mean)^2 (all methods)
     double mfma_k;          // 128*sum(T) - 16384*w*h*C: bias correction of the int8 MFMA path
     double centre[kMaxChans];   // float32 templates on the bf16 matrix cores: the per-channel mean the packed template
                                 // was centred by (sum I*T = sum I*(T - centre) + centre * S1)

@@ -451,6 +451,7 @@ int place_templates(mtm_ctx* c) {
         for (int k = 0; k < kMaxChans; ++k) d.mean[k] = t.st.mean[k];
         d.templ_norm = t.st.templ_norm;
         d.templ_sum2 = t.st.templ_sum2;
+        d.centred_sum2 = t.st.centred_sum2;
         d.templ2_mask2_sum = t.st.templ2_mask2_sum;
         d.all_ones = t.st.all_ones;
         {
