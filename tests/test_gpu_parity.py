@@ -1974,7 +1974,7 @@ def test_fused_global_extremum_uint16_float32(mtm, dtype):
                 res.append(c.find_matches(_lib.PEAKS_GLOBAL, 0.5).copy())
                 tm = c.timing()
                 if not any(os.environ.get(k) for k in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY", "MTM_F32_MFMA")):
-                    fused_here = dtype == "uint16" or method in (1, 3, 5)      # float32 raw sums: float64 kernel + maps
+                    fused_here = True      # (round 4: float32 raw sums too - refined extremum by rigorous error bounds)
                     # float32 with the maps in memory: no fused extremum to refine - the float64 kernel decides (route 3)
                     on_mfma = fused_here and (dtype == "uint16" or honly == 1)
                     assert tm["kernel_used"] == (4 if dtype == "uint16" else 5 if on_mfma else 0), tm
