@@ -15,15 +15,20 @@ name = sys.argv[1]
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ctx = _lib.Context(0)
 method, thr = 5, 0.5
+mode = _lib.PEAKS_LOCAL
 if name in ("cfg2", "cfg3", "cfg4", "cfg5"):
     img, units, _ = synth.make_config(name)
     method, thr = (3, 0.9) if name == "cfg5" else (5, 0.5)
     tl = [(u[1], u[2] if len(u) >= 3 else None) for u in units]
-elif name in ("u16_4k32", "f32_4k32"):
+elif name in ("u16_4k32", "f32_4k32", "f32_4k32_raw_n1", "f32_4k32_raw_n1_f64"):
     img, units, _ = synth.make_config("cfg3_32")
     dt = np.uint16 if name.startswith("u16") else np.float32
     img = img.astype(dt) * 257
     tl = [(u[1].astype(dt) * 257, None) for u in units]
+    if "raw_n1" in name:           # TM_CCOEFF (raw sums), N_object == 1: the refined extremum on the bf16 matrix cores (round 4)
+        method, mode = 4, _lib.PEAKS_GLOBAL
+        if name.endswith("_f64"):  # ... against the float64 kernel
+            ctx.set_option(_lib.OPT_F32_MFMA, 0)
 elif name == "f64_1080p8":
     img, units, _ = synth.make_config("cfg2")
     img = img.astype(np.float32) * 0.5
@@ -38,13 +43,13 @@ elif name == "dense_4k32":
     tl = [(u[1], None) for u in synth.cut_templates(5, img, 32, 64)]
 else:
     sys.exit("unknown workload " + name)
-ctx.search(tl, img, method, _lib.PEAKS_LOCAL, thr)          # placement, allocation
+ctx.search(tl, img, method, mode, thr)          # placement, allocation
 for _ in range(3):
-    ctx.search(tl, img, method, _lib.PEAKS_LOCAL, thr)
+    ctx.search(tl, img, method, mode, thr)
 st = []
 for _ in range(calls):
     t0 = time.perf_counter()
-    h = ctx.search(tl, img, method, _lib.PEAKS_LOCAL, thr)
+    h = ctx.search(tl, img, method, mode, thr)
     st.append(time.perf_counter() - t0)
 tm = ctx.timing()
 px = img.shape[0] * img.shape[1]
