@@ -82,7 +82,10 @@ extern "C" {
                                    3-channel templates) the per-template best is kept inside the score kernel;
                                    0: always materialise the maps.  Results are identical either way. */
 #define MTM_OPT_F32_MFMA 7      /* float32 images (every non-uint8, non-uint16 input: MTM/__init__.py:71-74), unmasked
-                                   templates, normalised methods.  1 (default): scores on the bf16 matrix cores (within
+                                   templates; the normalised methods, and the raw-sum methods for the global extremum
+                                   (N_object == 1: listed by rigorous per-pixel error bounds, re-scored exactly; raw sums
+                                   with a threshold, and their maps, always take the float64 kernel).
+                                   1 (default): scores on the bf16 matrix cores (within
                                    ~1e-5 of cv2's float64 result) as a SCREEN - everything that could be a peak, the
                                    global extremum or a threshold case by that margin is re-scored with the float64
                                    arithmetic of the exact kernel, so mtm_find_matches returns the exact kernel's hit
