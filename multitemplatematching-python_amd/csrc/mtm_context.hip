@@ -211,7 +211,8 @@ int mtm_device_count(void) {
 
 void* mtm_host_alloc(size_t bytes) {
     void* p = nullptr;
-    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    // portable: a device group stages ONE image there and every device of the process copies from it (mtm_group.cpp)
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped);
     if (e != hipSuccess) {
         set_error(std::string("mtm_host_alloc: ") + hipGetErrorString(e));
         return nullptr;

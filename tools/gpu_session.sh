@@ -98,6 +98,11 @@ for st in "$@"; do
       for e in "MTM_MFMA_DBG=0" "MTM_MFMA_DBG=4" "MTM_MFMA_DBG=8" "MTM_MFMA_DBG=16" "MTM_MFMA_DBG=24" "MTM_CAND_STAGE=0"; do
         env DENSE_HIT_CAP=1048576 $e timeout 200 python tools/probes/dense_probe.py 0.5 2>&1 | grep "HITS_ONLY=1" | sed "s/^/$e /" | cut -c1-200 >> $OUT/emit_probe.txt
       done; stamp "emit_probe: $(grep -c 'call median' $OUT/emit_probe.txt) runs" ;;
+    bands_fine)     # the first band's share of the rows, finely (per-call metric; alternating)
+      for rep in 1 2; do for b in ${BANDS_FINE:-"0.25,1" "0.235,1" "0.265,1" "0.28,1"}; do
+        MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps 200 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('bands=$b', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['frac'])" | tee -a $OUT/bands_fine.txt
+      done; done ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
