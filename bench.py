@@ -675,6 +675,15 @@ def main():
         elif world > 1:
             out["multi_gpu"] = {"mode": "one process per GPU", "exchange": exchange_kind, "communicator_ranks": comm_ranks}
         out.update(extras)
+        ri = extras.get("resident_inputs")
+        if ri and tinfo["kernel_used"] == 3 and ri.get("kernel_ms_per_launch"):
+            # the same kernel as ONE full-image launch per step (inputs resident: no upload to overlap, so no bands): its
+            # efficiency without the second launch tail and the copy / layout / statistics kernels running beside it
+            fl = 2.0 * macs / (ri["kernel_ms_per_launch"] * 1e-3) / 1e12
+            roof["full_image_launch"] = {"kernel_ms": ri["kernel_ms_per_launch"], "achieved": round(fl, 1),
+                                         "frac": round(fl / I8_MFMA_PEAK_TOPS, 4),
+                                         "frac_of_power_limited_ceiling": round(fl / I8_MFMA_RANDOM_OPERANDS_TOPS, 4),
+                                         "sclk_mhz_in_kernel": ri.get("sclk_mhz_in_kernel")}
         if not args.no_cpu_baseline and world == 1 and not group_n:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) acc[mb][k] = acc[mb][k] << 8;
+                    for (int k = 0; k < 16; ++k) acc[mb][k] = acc[mb][k] * 256;
             }
         }
         if constexpr (METHOD == kMfU16) {
