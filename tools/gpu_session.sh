@@ -103,6 +103,11 @@ for st in "$@"; do
         MTM_UPLOAD_BANDS="$b" python bench.py --no-cpu-baseline --skip-extras --steps 200 2>>$OUT/bench.err | clean | tail -1 |
           python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('bands=$b', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['frac'])" | tee -a $OUT/bands_fine.txt
       done; done ;;
+    lone_wave)      # one work-group per CU (persistent launch): what a wave achieves without a partner on its SIMD
+      for e in "MTM_MFMA_PER_CU=2" "MTM_MFMA_PER_CU=1" "MTM_MFMA_PER_CU=1 MTM_MFMA_DBG=2" "MTM_MFMA_PER_CU=2 MTM_MFMA_DBG=2"; do
+        env MTM_MFMA_PERSISTENT=1 MTM_MFMA_STAGGER=0 MTM_UPLOAD_BANDS=1 $e python bench.py --no-cpu-baseline --skip-extras --steps 100 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$e', d['ms_per_step'], r['kernel_ms_per_step'], r['frac'], r.get('sclk_mhz_in_kernel'))" | tee -a $OUT/lone_wave.txt
+      done ;;
     ubench)         # prebuilt micro-benchmarks (tools/ubench/<name>/ub)
       for u in ${UBENCH:-step}; do echo "== $u" >> $OUT/ubench.txt; timeout 120 tools/ubench/$u/ub >> $OUT/ubench.txt 2>&1; done
       stamp "ubench: $(grep -c cycles $OUT/ubench.txt) lines" ;;
