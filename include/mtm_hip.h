@@ -130,7 +130,11 @@ typedef struct mtm_hit {
 
 /* timing of the last mtm_find_matches call, measured with HIP events on the context's stream */
 typedef struct mtm_timing {
-    float total_ms;      /* first kernel launch -> last kernel done                      */
+    float total_ms;      /* first kernel launch -> last kernel done.  Calls whose image arrives in row bands
+                            (mtm_find_matches_image, one bandable size class) start this clock once the FIRST band's copy is
+                            on its way - with a pageable source that copy call blocks the host while the rows are staged -
+                            so total_ms of a banded call excludes up to that band's upload (25 % of the image by default);
+                            unbanded calls include the whole upload.  Wall-clock figures (bench.py `value`) are not affected. */
     float score_ms;      /* window statistics + score-map kernels                        */
     float peaks_ms;      /* peak-extraction kernels                                      */
     float ncc_kernel_ms; /* the dominant score-map kernel(s) alone: time during which at least one launch ran */
