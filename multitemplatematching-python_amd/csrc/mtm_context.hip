@@ -278,12 +278,16 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_CAND_STAGE")) c->cand_stage = std::atoi(v);
     if (const char* v = std::getenv("MTM_DENSE_ROWMAX")) c->dense_rowmax = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_STREAMS")) c->band_streams = std::max(1, std::min(2, std::atoi(v)));
+    if (const char* v = std::getenv("MTM_BAND_INLINE")) c->band_inline = std::atoi(v);
+    if (const char* v = std::getenv("MTM_BAND_MERGE")) c->band_merge = std::atoi(v);
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));
     if (const char* v = std::getenv("MTM_SLAB_STREAMS")) c->slab_concurrency = std::max(1, std::min(8, std::atoi(v)));
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
     if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SLAB_CW")) c->slab_cw = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SLAB_MERGE")) c->slab_merge = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
@@ -314,7 +318,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
         static const char* kPhase[16] = {"entry", "args checked", "templates placed", "call set up", "band 0 copy queued",
                                          "band 0 layout + statistics queued", "band 0 score queued", "last band copy queued",
                                          "last band score queued", "score pass queued", "stream synchronised", "hits verified",
-                                         "hits sorted", "", "", "return"};
+                                         "hits sorted", "(banded: image slot prepared)", "(banded: before the first copy call)", "return"};
         for (int k = 0; k < 16; ++k)
             if (c->trace_n[k] > 0)
                 std::fprintf(stderr, "[mtm host trace] %-36s %9.1f us after entry (mean of %lld)\n", kPhase[k],

@@ -199,6 +199,8 @@ struct mtm_ctx {
     hipStream_t copy_stream_b = nullptr;
     std::vector<hipEvent_t> band_copy_ev;
     int band_streams = 1;
+    int band_merge = 0;                     // MTM_BAND_MERGE: score launches only behind the first and the last upload band
+    int band_inline = 1;                    // MTM_BAND_INLINE: the first band of a banded call on `stream` itself (run_score_banded)
     hipEvent_t next_ready = nullptr;
     // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
     // statistics of the rows that became computable); the score kernel of a band waits for its event
@@ -238,6 +240,7 @@ struct mtm_ctx {
         hipEvent_t slab_fork = nullptr;
     };
     std::vector<Lane> lanes;                // lanes 1 .. n - 1
+    bool slab_fork_early = false;           // run_score_classes recorded slab_fork ahead of the class's statistics pass
     hipEvent_t lane_fork = nullptr;
     hipEvent_t f32_built = nullptr;         // multi-lane calls: the float32 plane rebuilt after a banded upload (run_score_classes)
     int class_lanes = 2;                    // MTM_CLASS_LANES (1: classes one after another on the main stream)
@@ -246,7 +249,7 @@ struct mtm_ctx {
     std::vector<hipStream_t> slab_streams;
     std::vector<hipEvent_t> slab_done;
     hipEvent_t slab_fork = nullptr;
-    int slab_concurrency = 4;               // MTM_SLAB_STREAMS (1: one after another on the main stream)
+    int slab_concurrency = 8;               // MTM_SLAB_STREAMS (1: one after another on the main stream)
     std::vector<hipEvent_t> band_ev;
     int banded_cls = -1;                    // the size class a banded call runs under the upload (banded_ok)
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
@@ -271,6 +274,11 @@ struct mtm_ctx {
     size_t maps_floats = 0;
     std::vector<UnitSrc> usrc_host;                 // the unit views (device copy: usrc_dev), slab views appended at placement
     size_t usrc_units = 0;                          // entries that are units (the rest are slab views)
+    std::vector<uint8_t> tstage;                    // host image of the source arena's prefix (set_templates_device)
+    bool stage_pending = false;                     // copies from tstage / usrc_host may be in flight on `stream`
+    bool place_pending = false;                     // copies from td_host / tlist_host may be in flight on `stream`
+    int slab_merge = 1;                             // MTM_SLAB_MERGE: equal-shaped slabs of a class in one launch (launch_ncc)
+    int slab_cw = 0;                                // MTM_SLAB_CW: 64 / 128 = fixed slab width for <= 16 templates (0: chosen per shape)
     int slab_mfma = 1;                              // MTM_SLAB_MFMA: large templates as slabs on the MFMA kernel
     DevBuf slab_raw;                                // raw int32 maps of the slabs
     DevBuf tsrc, usrc_dev, tsums_dev, tgather;      // template source arena, unit views, source sums, gather scratch

@@ -33,6 +33,9 @@ TemplStats compute_templ_stats(const double* px, const double* mask, int rows, i
 TemplStats templ_stats_from_sums(const double* sum, const double* sumsq, double templ2_mask2_sum, bool masked, int rows,
                                  int cols, int chans, int method);
 
+// exact sum v / sum v^2 of n bytes, added to *sum / *sumsq
+void u8_run_sums(const uint8_t* p, size_t n, unsigned long long* sum, unsigned long long* sumsq);
+
 // scipy.signal.find_peaks(x, height=h)[0]
 std::vector<int> find_peaks_1d(const float* x, int n, int stride, float height, bool negate);
 

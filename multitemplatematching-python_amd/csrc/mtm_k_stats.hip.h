@@ -617,9 +617,22 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
             SumT a = 0, b = 0;
             const AccT* p1 = hs1 + c * hs_plane + (size_t)y0 * hs_pitch + x;
             const AccT* p2 = hs2 + c * hs_plane + (size_t)y0 * hs_pitch + x;
-            for (int dy = 0; dy < h; ++dy) {
-                a += (SumT)p1[(size_t)dy * hs_pitch];
-                b += (SumT)p2[(size_t)dy * hs_pitch];
+            // 8 rows per batch, all sixteen loads in flight before the first add (same order of additions: a tall window
+            // - 400 rows in the reference's benchmark shape - is a chain of 400 dependent memory latencies otherwise)
+            for (int d0 = 0; d0 < h; d0 += 8) {
+                AccT v1[8], v2[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const size_t o = (size_t)min(d0 + i, h - 1) * hs_pitch;
+                    v1[i] = p1[o];
+                    v2[i] = p2[o];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (d0 + i < h) {
+                        a += (SumT)v1[i];
+                        b += (SumT)v2[i];
+                    }
             }
             s1[c] = a;
             s2[c] = b;
@@ -627,6 +640,20 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
     }
     const int y1 = min(y0 + kVsumBand, oh);
     for (int y = y0; y < y1; ++y) {
+        // the four values of the slide at the end of this iteration are requested now: their latency hides behind the
+        // float64 statistics and the stores
+        AccT n1[kMaxChans], o1[kMaxChans], n2[kMaxChans], o2[kMaxChans];
+#pragma unroll
+        for (int c = 0; c < kMaxChans; ++c) {
+            n1[c] = o1[c] = n2[c] = o2[c] = 0;
+            if (c < chans && y + 1 < y1) {
+                const size_t o = c * hs_plane + x;
+                n1[c] = hs1[o + (size_t)(y + h) * hs_pitch];
+                o1[c] = hs1[o + (size_t)y * hs_pitch];
+                n2[c] = hs2[o + (size_t)(y + h) * hs_pitch];
+                o2[c] = hs2[o + (size_t)y * hs_pitch];
+            }
+        }
         double wnd_mean2 = 0.0, wnd_sum2 = 0.0;
 #pragma unroll
         for (int c = 0; c < kMaxChans; ++c) {
@@ -648,9 +675,8 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
 #pragma unroll
             for (int c = 0; c < kMaxChans; ++c) {
                 if (c < chans) {
-                    const size_t o = c * hs_plane + x;
-                    s1[c] += (SumT)hs1[o + (size_t)(y + h) * hs_pitch] - (SumT)hs1[o + (size_t)y * hs_pitch];
-                    s2[c] += (SumT)hs2[o + (size_t)(y + h) * hs_pitch] - (SumT)hs2[o + (size_t)y * hs_pitch];
+                    s1[c] += (SumT)n1[c] - (SumT)o1[c];
+                    s2[c] += (SumT)n2[c] - (SumT)o2[c];
                 }
             }
         }

@@ -333,6 +333,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     }
     auto& evp = c->ncc_ev[c->timing.ncc_launches];
     hipStream_t ncc_s = (c->ncc_stream && (kernel == MTM_KERNEL_MFMA || kernel == MTM_KERNEL_MFMA16)) ? c->ncc_stream : c->stream;
+    // (The events are stream commands of their own.  Handing them to the launch itself - hipExtLaunchKernelGGL's start /
+    // stop events - was measured in round 4: the gaps around the launches stayed, the call got 14 us SLOWER;
+    // profiles/r04_r04w.)
+    bool ev_own = false;                // a branch below records the pair itself (on the stream its launch goes to)
     HIPC(hipEventRecord(evp.first, ncc_s));
 
     if (kernel == MTM_KERNEL_NAIVE) {
@@ -364,6 +368,17 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const int cus = c->n_cus > 0 ? c->n_cus : 256;
             if (items < 4LL * cus) n_side = (int)std::min<long long>(std::min(S, c->slab_concurrency), (4LL * cus + items - 1) / items);
         }
+        // MTM_SLAB_MERGE (default 1): slabs of equal height and block count go out as ONE launch (MfmaParams::n_slab) - the
+        // hardware fills the chip from one grid and back-fills as work-groups finish, where several launches on several
+        // streams share four hardware queues (the fourth of four side-by-side slab launches started when the first had
+        // ended: profiles/r04_r04v_slab) - on one side stream, so that the statistics pass still runs under it.
+        bool merged = rmr && S > 1 && c->slab_merge;
+        for (int k = 1; k < S && merged; ++k) {
+            const SizeClass::Slab &a = sc.slabs[0], &b = sc.slabs[(size_t)k];
+            merged = (b.r1 - b.r0) == (a.r1 - a.r0) && (b.c1 - b.c0 + 63) / 64 == (a.c1 - a.c0 + 63) / 64 &&
+                     b.apack_off - a.apack_off == (long long)k * rm_pack_bytes(a.r1 - a.r0, a.c1 - a.c0, sc.slab_R);
+        }
+        if (merged) n_side = c->slab_fork_early ? 2 : 1;        // (2: "side streams in use"; only the first one is)
         if (n_side > 1) {
             while ((int)c->slab_streams.size() < n_side) {
                 hipStream_t s2;
@@ -374,13 +389,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 c->slab_done.push_back(e2);
             }
             if (!c->slab_fork) HIPC(hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
-            HIPC(hipEventRecord(c->slab_fork, ncc_s));
+            if (!c->slab_fork_early) HIPC(hipEventRecord(c->slab_fork, ncc_s));      // (else: recorded ahead of the statistics)
             for (int i = 0; i < n_side; ++i) HIPC(hipStreamWaitEvent(c->slab_streams[(size_t)i], c->slab_fork, 0));
         }
-        for (int k = 0; k < S; ++k) {
+        for (int k = 0; k < (merged ? 1 : S); ++k) {
             const SizeClass::Slab& sl = sc.slabs[(size_t)k];
             const int hs = sl.r1 - sl.r0, ws = sl.c1 - sl.c0;
-            hipStream_t slab_s = n_side > 1 ? c->slab_streams[(size_t)(k % n_side)] : ncc_s;
+            hipStream_t slab_s = n_side > 1 ? c->slab_streams[(size_t)(merged ? 0 : k % n_side)] : ncc_s;
             MfmaParams p{};
             p.img = c->slot[c->cur].u8b.as<uint8_t>() + (size_t)sl.ch * img.u8_plane + (size_t)sl.r0 * img.u8_pitch + sl.c0;
             p.pitch = img.u8_pitch;
@@ -423,6 +438,18 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 tile_rows = std::min(hs, kMfChunkH) + kMfRows - 1;
             }
             p.n_work = p.nseg * p.nyb * p.ntg;
+            if (merged) {                       // every slab of the class: slab 0's geometry (the widest), S times the items
+                int ncb = 0;
+                for (const auto& q : sc.slabs) ncb += (q.ch == sl.ch && q.r0 == sl.r0) ? 1 : 0;
+                p.n_slab = S;
+                p.slab_ncb = ncb;
+                p.slab_nrb = S / (ncb * c->chans);
+                p.slab_cw = ncb > 1 ? sc.slabs[1].c0 - sl.c0 : 0;
+                p.slab_rh = hs;
+                p.slab_ap_step = rm_pack_bytes(hs, ws, sc.slab_R);
+                p.slab_raw_step = (long long)n_all * raw_map;
+                p.n_work *= S;
+            }
             const size_t lds_main = (std::max<size_t>((size_t)tile_rows * p.lds_pitch, (size_t)kMfRows * kMfEpiBytesPerWave) + 15) &
                                     ~(size_t)15;
             p.tc_off = (int)lds_main;
@@ -430,10 +457,17 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const size_t lds = (size_t)p.st_off + (rmr ? 0 : (size_t)kMfRows * kMfStatBytesPerWave);
             const int grid = ((p.n_work + 7) / 8) * 8;
             const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
+            // (merged launch on a side stream: the timing pair goes there too - on the score stream it would bracket
+            // the fork and the join, not the launch)
+            if (merged && slab_s != ncc_s) HIPC(hipEventRecord(evp.first, slab_s));
             hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, slab_s, p, td,
                                c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+            if (merged && slab_s != ncc_s) {
+                HIPC(hipEventRecord(evp.second, slab_s));
+                ev_own = true;
+            }
         }
-        for (int i = 0; i < n_side && n_side > 1; ++i) {
+        for (int i = 0; i < (merged ? 1 : n_side) && n_side > 1; ++i) {
             HIPC(hipEventRecord(c->slab_done[(size_t)i], c->slab_streams[(size_t)i]));
             HIPC(hipStreamWaitEvent(ncc_s, c->slab_done[(size_t)i], 0));
         }
@@ -808,7 +842,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         if (c->timing.kernel_used == 0) c->timing.kernel_used = MTM_KERNEL_AUTO;
     }
     HIPC(hipGetLastError());
-    HIPC(hipEventRecord(evp.second, ncc_s));
+    if (!ev_own) HIPC(hipEventRecord(evp.second, ncc_s));
     c->timing.ncc_launches++;
     return MTM_OK;
 }
@@ -969,8 +1003,18 @@ static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
         ++k_cls;
         LaneScope scope(c, lane > 0 ? &c->lanes[(size_t)(lane - 1)] : nullptr);
         StatPlanes st;
-        MTMC(launch_stats(c, sc, &st));
-        MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st));
+        // slabs: the raw launches read no statistics (slab_combine_kernel does) - their side streams fork HERE, ahead of
+        // the statistics pass, which then runs under them (2048^2 x 414x400: hsum + vsum took 0.25 of the call's 1.16 ms)
+        c->slab_fork_early = false;
+        if (!sc.slabs.empty() && c->slab_concurrency > 1 && resolved_kernel(c, sc) == MTM_KERNEL_MFMA) {
+            if (!c->slab_fork) HIPC(hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
+            HIPC(hipEventRecord(c->slab_fork, c->stream));
+            c->slab_fork_early = true;
+        }
+        const int rc_st = launch_stats(c, sc, &st);
+        const int rc_ncc = rc_st == MTM_OK ? launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st) : rc_st;
+        c->slab_fork_early = false;
+        MTMC(rc_ncc);
         if (c->refine_now && !c->f32_exact_now && resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32) {
             if (c->refine_scan_now) {
                 MTMC(launch_refine_scan(c, sc));
@@ -1090,8 +1134,14 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     mtm_ctx::ImageSlot& sl = c->slot[c->cur];
     SlotGeom g{};
     const bool u16 = a.dtype == MTM_U16;
-    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, c->copy_stream, 1, &g));
     const int nb = (int)c->upload_bands.size();
+    // MTM_BAND_INLINE (default 1): the FIRST band's copy, layout conversion and statistics go to c->stream itself, ahead
+    // of its score launch - stream order instead of an event between two streams, which the hardware takes ~20 us to
+    // pass on (profiles/r03_tl2: statistics end -> score launch start) - and the second band's copy waits for the first
+    // band's COPY on the copy stream, not for the first band's kernels.
+    const bool inline0 = c->band_inline && nb > 1 && c->band_streams <= 1 && !c->dual_stream;
+    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, inline0 ? c->stream : c->copy_stream, 1, &g));
+    host_trace(c, 13);
     while ((int)c->band_ev.size() < nb) {
         hipEvent_t e;
         HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1104,6 +1154,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     }
     const bool two_streams = c->band_streams > 1 && nb > 1;
     int k_prev = -1;                        // the band queued before this one (bands without rows are skipped)
+    int k_inline = -1;                      // the band on c->stream (inline0)
     const int h = sc.h, oh = a.rows - h + 1;
     const int RB = u16 ? kMfRows : sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
@@ -1125,6 +1176,15 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         hipEvent_t cdone = two_streams ? c->band_copy_ev[(size_t)k] : nullptr;
         hipEvent_t kwait = (two_streams && k_prev >= 0) ? c->band_ev[(size_t)k_prev] : nullptr;
         if (two_streams && k_prev >= 0) HIPC(hipStreamWaitEvent(bs, c->band_copy_ev[(size_t)k_prev], 0));
+        const bool on_main = inline0 && r_done == 0;            // this band rides on c->stream
+        if (on_main) {
+            bs = c->stream;
+            cdone = c->band_copy_ev[(size_t)k];
+        } else if (inline0 && k_prev >= 0 && k_prev == k_inline) {
+            HIPC(hipStreamWaitEvent(bs, c->band_copy_ev[(size_t)k_prev], 0));
+        }
+        if (on_main) k_inline = k;
+        if (r_done == 0) host_trace(c, 14);
         if (u16)
             MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, bs, cdone, kwait));
         else
@@ -1152,9 +1212,12 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         k_prev = k;
         if (k == 0) host_trace(c, 5);                            // layout conversion + statistics of band 0 submitted
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
-        if (yb1 > yb_done) {
+        // MTM_BAND_MERGE=1: only the first and the last band launch the score kernel - the bands in between are upload,
+        // layout conversion and statistics pieces (the last band's statistics pass, which gates the last launch, covers
+        // fewer rows)
+        if (yb1 > yb_done && (!c->band_merge || n_launch == 0 || last)) {
             hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
-            HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
+            if (s != bs) HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
             c->ncc_stream = s;
             const int rc2 = launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1);
             c->ncc_stream = nullptr;

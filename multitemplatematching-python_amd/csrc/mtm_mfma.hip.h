@@ -350,7 +350,21 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     }
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
-    const int seg = rest % p.nseg, yb = rest / p.nseg;
+    const int seg = rest % p.nseg;
+    int yb = rest / p.nseg;
+    // several slabs in one launch (MfmaParams::n_slab): which slab, where its image window, A pack and raw maps are
+    long long slab_img = 0, slab_ap = 0, slab_raw = 0;
+    if constexpr (RM && METHOD == kMfRaw && !KP) {
+        if (p.n_slab > 1) {
+            const int k = yb / p.nyb;
+            yb -= k * p.nyb;
+            const int cb = k % p.slab_ncb, rbk = k / p.slab_ncb;
+            const int rb = rbk % p.slab_nrb, ch = rbk / p.slab_nrb;
+            slab_img = (long long)ch * p.plane + (long long)rb * p.slab_rh * p.pitch + (long long)cb * p.slab_cw;
+            slab_ap = (long long)k * p.slab_ap_step;
+            slab_raw = (long long)k * p.slab_raw_step;
+        }
+    }
     const int x0 = seg * kMfSeg, y0 = (yb + p.yb0) * (RM ? 8 * p.rm_R : (R2 ? MB * kMfRows : kMfRows));
     // Lane coordinates of this work item, derived from an opaque copy of the thread index: whatever the prologue
     // computes from them is then computed HERE, per item, instead of once ahead of the item loop - where it stayed
@@ -466,10 +480,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
 
-    const uint8_t* apack_g = apack + (long long)tg * (R2 ? 1 : MB) * p.group_bytes + (size_t)lane * 16;
+    const uint8_t* apack_g = apack + slab_ap + (long long)tg * (R2 ? 1 : MB) * p.group_bytes + (size_t)lane * 16;
 
     for (int c = 0; c < p.chans; ++c) {
-        const uint8_t* plane = p.img + c * p.plane;
+        const uint8_t* plane = p.img + slab_img + c * p.plane;
         // channel of the A pack (uint16: both byte planes meet the same [T_hi | T_lo]; sum I^2 M: both planes meet the mask)
         const int cpk = (METHOD == kMfU16 || (RM && METHOD == kMfRaw && p.sq_fused)) ? 0 : c;
         if constexpr (RM && METHOD == kMfRaw && !KP) {
@@ -1060,7 +1074,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const int yy = y0 + wave * wave_rows + mb * R + rho;
                         if (t >= p.n_list || yy >= p.oh) continue;              // wave-uniform
                         const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
-                        int* orow = p.raw_out + (size_t)t * p.raw_map + (size_t)yy * p.raw_pitch + xq;
+                        int* orow = p.raw_out + slab_raw + (size_t)t * p.raw_map + (size_t)yy * p.raw_pitch + xq;
                         if (xq + 3 < p.ow) {
                             *reinterpret_cast<v4i*>(orow) = a4;
                         } else {

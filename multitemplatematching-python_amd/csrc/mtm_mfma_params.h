@@ -85,6 +85,12 @@ struct MfmaParams {
     int rm_R, rm_nt, rm_log2nt, rm_steps;
     long long rm_cstride;    // bytes between the packs of two channels (RM with 3 channels)
     const double* rm_rsq;    // 1 / sqrt plane of the class (0 for flat windows), pitch = st.pitch
+    // slabs of one large-template class in ONE launch (raw row-multiplexed mode, slabs of equal height and block count):
+    // work items [k nseg nyb, (k + 1) nseg nyb) belong to slab k = (channel * slab_nrb + row block) * slab_ncb + column
+    // block, whose image window starts slab_rh rows / slab_cw columns per block further in, whose A pack lies
+    // slab_ap_step bytes and whose raw maps slab_raw_step ints behind the previous slab's (0 / 1: a launch per slab)
+    int n_slab, slab_ncb, slab_nrb, slab_cw, slab_rh;
+    long long slab_ap_step, slab_raw_step;
     int* raw_out;            // METHOD == kMfRaw: int32 accumulators of list position li at raw_out + li * raw_map
     long long raw_map;       //   (+ y * raw_pitch + x); kMfU16: the raw maps of the first pass (read)
     int raw_pitch;

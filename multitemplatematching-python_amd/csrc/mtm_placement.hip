@@ -1,5 +1,6 @@
 // libmtm_hip.so - template sets: pixels -> size classes, device-resident sources and unit views, operand packs for every
 // kernel family, per-template constants (place_templates).
+#include <functional>
 #include "mtm_ctx.h"
 
 using namespace mtm;
@@ -42,15 +43,60 @@ std::vector<SizeClass::Slab> slab_layout(const mtm_ctx* c, const SizeClass& sc) 
     if (!c->slab_mfma || sc.masked || !sc.all_u8 || c->dtype != MTM_U8) return out;
     for (int m : sc.members)
         if (!c->templs[(size_t)m].on_device) return out;
-    const int cw = sc.members.size() <= 16 ? 128 : 256;
-    const int rows_max = 131071 / std::min(cw, ((sc.w + 63) / 64) * 64);
-    const int nrb = (sc.h + rows_max - 1) / rows_max, rh = (sc.h + nrb - 1) / nrb;
-    for (int ch = 0; ch < c->chans; ++ch)
-        for (int r0 = 0; r0 < sc.h; r0 += rh)
-            for (int c0 = 0; c0 < sc.w; c0 += cw)
-                out.push_back(SizeClass::Slab{r0, std::min(sc.h, r0 + rh), c0, std::min(sc.w, c0 + cw), ch, 0, 0});
-    if (out.size() > 24) out.clear();            // absurdly large: the VALU kernel takes it
-    return out;
+    auto layout = [&](int cw) {
+        std::vector<SizeClass::Slab> v;
+        const int rows_max = 131071 / std::min(cw, ((sc.w + 63) / 64) * 64);
+        const int nrb = (sc.h + rows_max - 1) / rows_max, rh = (sc.h + nrb - 1) / nrb;
+        for (int ch = 0; ch < c->chans; ++ch)
+            for (int r0 = 0; r0 < sc.h; r0 += rh)
+                for (int c0 = 0; c0 < sc.w; c0 += cw)
+                    v.push_back(SizeClass::Slab{r0, std::min(sc.h, r0 + rh), c0, std::min(sc.w, c0 + cw), ch, 0, 0});
+        if (v.size() > 24) v.clear();            // absurdly large: the VALU kernel takes it
+        return v;
+    };
+    if (sc.members.size() > 16) return layout(256);
+    // <= 16 templates (row-multiplexed raw launches): column blocks of 128 or 64 taps.  A slab launch is few, long work
+    // items - 91 of 128 output rows x 256 columns for 2048^2 x 414x400 - whose waves cannot be split: with 128-tap slabs
+    // that shape is 1.24 waves' worth of work per SIMD and the launches take as long as the SIMDs that got two.  Half as
+    // wide slabs are twice as many waves of half the length (and more raw planes for slab_combine_kernel to add): the
+    // width whose greedy schedule over the CUs ends first is taken (MTM_SLAB_CW: fixed width).
+    if (c->slab_cw == 64 || c->slab_cw == 128) return layout(c->slab_cw);
+    std::vector<SizeClass::Slab> best = layout(128);
+    if (!c->have_image || c->rows < sc.h || c->cols < sc.w) return best;
+    const int oh = c->rows - sc.h + 1, ow = c->cols - sc.w + 1;
+    const int cus = c->n_cus > 0 ? c->n_cus : 256;
+    auto makespan = [&](const std::vector<SizeClass::Slab>& v) {
+        if (v.empty()) return 1e300;
+        int hs = 0, ws = 0;
+        for (const auto& sl : v) {
+            hs = std::max(hs, sl.r1 - sl.r0);
+            ws = std::max(ws, sl.c1 - sl.c0);
+        }
+        int nt = 1;
+        while (nt < (int)sc.members.size()) nt <<= 1;
+        const size_t lds_pitch = (size_t)(16 + 4 * ((ws + 63) / 64) + 1) * 16;
+        auto tile_bytes = [&](int R) { return (size_t)(std::min(hs + 2 * R - 1, kMfChunkH) + 6 * R) * lds_pitch; };
+        while (nt < 16 && tile_bytes(16 / nt) > 72 * 1024) nt <<= 1;
+        const int R = 16 / nt;
+        const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + 8 * R - 1) / (8 * R));
+        std::vector<double> cost;                         // one entry per work-group, longest first
+        for (const auto& sl : v)
+            cost.insert(cost.end(), (size_t)items, (double)((sl.c1 - sl.c0 + 63) / 64) * (sl.r1 - sl.r0 + 2 * R - 1));
+        std::sort(cost.begin(), cost.end(), std::greater<double>());
+        std::vector<double> load((size_t)cus, 0.0);       // min-heap of CU loads
+        auto cmp = std::greater<double>();
+        for (double x : cost) {
+            std::pop_heap(load.begin(), load.end(), cmp);
+            load.back() += x;
+            std::push_heap(load.begin(), load.end(), cmp);
+        }
+        // every slab's raw plane is written once and read once by the combine pass: ~5 us per 4 B x 2 x oh x ow at
+        // 2048^2, against ~0.2 us per (block x template row) step of a work-group - in units of steps
+        return *std::max_element(load.begin(), load.end()) + 25.0 * (double)v.size() * ((double)oh * ow / 2.7e6);
+    };
+    std::vector<SizeClass::Slab> narrow = layout(64);
+    if (makespan(narrow) < 0.9 * makespan(best)) best.swap(narrow);
+    return best;
 }
 
 bool mfma_class_ok(const mtm_ctx* c, const SizeClass& sc) {
@@ -351,6 +397,10 @@ int place_templates(mtm_ctx* c) {
         return MTM_E_STATE;
     }
     if (c->placed) return MTM_OK;
+    if (c->place_pending) {             // the previous placement's tables are released below: their copies first
+        HIPC(hipStreamSynchronize(c->stream));
+        c->place_pending = false;
+    }
     const int n = (int)c->templs.size();
     // Everything is derived into locals and committed at the end: a failure half-way (an allocation, a copy)
     // leaves the context exactly as it was - templates set, not placed.
@@ -671,7 +721,11 @@ int place_templates(mtm_ctx* c) {
     // device-side packing: gathers the A operands straight from the unit views (the template list is in place)
     for (size_t k = 0; k < classes.size(); ++k)
         if (dev_pack[k]) MTMC(pack_class_on_device(c, classes[k]));
-    HIPC(hipStreamSynchronize(c->stream));   // host staging vectors go out of scope
+    // host staging vectors go out of scope; the tables that stay in the context (td_host, tlist_host) need no wait
+    // (set_templates_device)
+    const bool local_sources = any_host_pack || w_off || p_off || ts_off || units_all.size() > c->usrc_units;
+    if (local_sources) HIPC(hipStreamSynchronize(c->stream));
+    c->place_pending = !local_sources;
     if (units_all.size() > c->usrc_units) c->usrc_host.swap(units_all);
     c->classes.swap(classes);
     c->td_host.swap(td_host);
@@ -740,7 +794,16 @@ int set_templates_device(mtm_ctx* c, const mtm_templ* bases, int n_bases, const 
         unsigned long long mask_hash = 0;
     };
     std::vector<Source> srcs;
-    std::vector<uint8_t> stage;                     // host image of the arena prefix (the bases)
+    // The host image of the arena prefix (the bases), the unit table and - place_templates - the constants tables are
+    // copied from context-owned vectors that live until the next template set: no host wait for those copies here, the
+    // template work queues ahead of the call's image upload and runs under it.  Before the vectors are rewritten the
+    // stream is drained (idle by then in any ordinary sequence of calls).
+    if (c->stage_pending) {
+        HIPC(hipStreamSynchronize(c->stream));
+        c->stage_pending = false;
+    }
+    std::vector<uint8_t>& stage = c->tstage;
+    stage.clear();
     auto alloc = [&](size_t& cursor, size_t bytes) {
         const size_t off = cursor;
         cursor = round_up(cursor + bytes, 16);
@@ -769,6 +832,11 @@ int set_templates_device(mtm_ctx* c, const mtm_templ* bases, int n_bases, const 
                 const uint8_t* mp = t.mask ? (const uint8_t*)t.mask + (size_t)y * t.mask_row_stride + ch : nullptr;
                 uint8_t* o = dpx + ch * plane + (size_t)y * t.cols;
                 uint8_t* om = dmk ? dmk + ch * plane + (size_t)y * t.cols : nullptr;
+                if (t.chans == 1 && !mp) {       // the common case: a row is a run of bytes
+                    std::memcpy(o, rp, (size_t)t.cols);
+                    u8_run_sums(rp, (size_t)t.cols, &s, &sq);
+                    continue;
+                }
                 for (int x = 0; x < t.cols; ++x) {
                     const unsigned v = rp[(size_t)x * t.chans];
                     o[x] = (uint8_t)v;
@@ -923,9 +991,9 @@ int set_templates_device(mtm_ctx* c, const mtm_templ* bases, int n_bases, const 
     MTMC(c->usrc_dev.ensure(sizeof(UnitSrc) * std::max<size_t>(1, units.size())));
     if (!units.empty())
         HIPC(hipMemcpyAsync(c->usrc_dev.p, units.data(), sizeof(UnitSrc) * units.size(), hipMemcpyHostToDevice, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));      // `stage` goes out of scope
     c->usrc_units = units.size();
-    c->usrc_host.swap(units);
+    c->usrc_host.swap(units);                   // (the previous table - now `units` - was drained above)
+    c->stage_pending = true;
     return MTM_OK;
 }
 

@@ -257,6 +257,20 @@ static void test_host(std::mt19937& rng) {
             CHECK(a.inv_area > 0.0 && b.templ2_mask2_sum >= 0.0);
         }
     }
+    // byte-run sums (the SSE2 pass over fresh template bytes): exact at every length and alignment, incl. all-255 runs
+    // long enough to wrap a 32-bit lane if the block length were wrong
+    std::vector<uint8_t> bytes((size_t)(16 * 8192 * 3 + 77));
+    for (int rep = 0; rep < 40; ++rep) {
+        for (auto& v : bytes) v = rep == 0 ? 255 : (uint8_t)(rng() & 255);
+        const size_t off = rep == 0 ? 0 : rng() % 33, n = rep < 2 ? bytes.size() - off : rng() % 5000;
+        unsigned long long s = 7, q = 9, rs = 7, rq = 9;
+        u8_run_sums(bytes.data() + off, n, &s, &q);
+        for (size_t i = 0; i < n; ++i) {
+            rs += bytes[off + i];
+            rq += (unsigned long long)bytes[off + i] * bytes[off + i];
+        }
+        CHECK(s == rs && q == rq);
+    }
     int64_t nk = 0;
     CHECK(mtm_nms(nullptr, 5, 0.5, 0, -1, 0.5, nullptr, &nk) == MTM_E_INVALID && std::strlen(mtm_last_error()) > 0);
 }

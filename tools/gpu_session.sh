@@ -85,6 +85,20 @@ for st in "$@"; do
       MTM_HOST_TRACE=1 timeout 120 python tools/probes/loop_calls.py 0 200 > $OUT/host_trace.txt 2>&1
       timeout 120 python tools/probes/call_breakdown.py >> $OUT/host_trace.txt 2>&1
       stamp "trace: $(grep -c 'host trace' $OUT/host_trace.txt) phases" ;;
+    timeline)       # rocprofv3 kernel + copy timelines of the fused call (TL_CASES, tools/probes/timeline.sh)
+      bash tools/probes/timeline.sh $TAG > $OUT/timeline.log 2>&1; stamp "timeline: $(ls $OUT/timeline_*.csv 2>/dev/null | wc -l) cases" ;;
+    wl_ab)          # a named workload (tools/probes/workload.py) under environment switches: WL_NAME=slab_414 WL_ENVS="X=0;MTM_SLAB_CW=128;MTM_SLAB_CW=64 MTM_SLAB_STREAMS=8"
+      IFS=';' read -ra WLE <<< "${WL_ENVS:-X=0}"
+      for rep in 1 2; do for e in "${WLE[@]}"; do
+        env $e timeout 200 python tools/probes/workload.py ${WL_NAME:-slab_414} 30 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); print('${WL_NAME:-slab_414}', '$e', 'call', d['median_ms_per_call'], 'gpu', d['gpu_ms'], 'ncc', d['ncc_kernel_ms'], 'hits', d['hits'])" | tee -a $OUT/wl_ab.txt
+      done; done ;;
+    env_cases)      # the bench workload per call under combinations of switches: ENV_CASES="X=0;MTM_A=1 MTM_B=2;..." (ENV_REPS rounds, alternating)
+      IFS=';' read -ra ECS <<< "${ENV_CASES:-X=0}"
+      for rep in $(seq 1 ${ENV_REPS:-2}); do for e in "${ECS[@]}"; do
+        env $e python bench.py --no-cpu-baseline --skip-extras --steps ${LIB_STEPS:-200} 2>>$OUT/bench.err | clean | tail -1 |
+          python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$e |', d['ms_per_step'], d['median_ms_per_call'], r['kernel_ms_per_step'], r['frac'])" | tee -a $OUT/env_cases.txt
+      done; done ;;
     env_ab)         # any environment switch against the default, per-call metric: ENV_AB="MTM_BAND_STREAMS=1 MTM_CAND_STAGE=0"
       for rep in 1 2 3; do for e in "X=0" ${ENV_AB:-MTM_BAND_STREAMS=1}; do
         env $e python bench.py --no-cpu-baseline --skip-extras --steps ${LIB_STEPS:-200} 2>>$OUT/bench.err | clean | tail -1 |

@@ -1,15 +1,16 @@
 #!/bin/bash
-# rocprofv3 kernel + memory-copy timelines of matchTemplates calls (GPU box): pageable / pinned image, band layouts.
-# Output: gpurun_out/<tag>/timeline_*.csv
+# rocprofv3 kernel + memory-copy timelines of matchTemplates calls (GPU box).
+# Usage: timeline.sh <tag>          cases from TL_CASES="name env=.. env=..;name2 env=.." (default: the shipped layout and
+#                                   the first band on the copy stream); pageable image, 30 calls traced, 200 timed
+#                                   TL_CMD="tools/probes/workload.py slab_414": the command traced instead of loop_calls.py
+# Output: gpurun_out/<tag>/timeline_<name>.csv (the last 40 GPU activities) + summary.txt (per-call medians)
 TAG=${1:-tl}; R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-one() { name=$1; pin=$2; shift 2
-  env "$@" python $R/tools/probes/loop_calls.py $pin 200 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
-  env "$@" timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/tl_$name -o tl -- python $R/tools/probes/loop_calls.py $pin 30 > $OUT/tl_$name.log 2>&1
+CMD=${TL_CMD:-tools/probes/loop_calls.py 0}
+one() { name=$1; shift
+  env "$@" python $R/$CMD 200 2>/dev/null | tail -1 | cut -c1-300 | sed "s/^/$name: /" | tee -a $OUT/summary.txt
+  env "$@" timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/tl_$name -o tl -- python $R/$CMD 30 > $OUT/tl_$name.log 2>&1
   DB=$(find $OUT/tl_$name -name "*.db" | head -1)
-  python $R/tools/rocpd_timeline.py $DB 0 100000 | tail -40 > $OUT/timeline_$name.csv 2>&1
+  python $R/tools/rocpd_timeline.py $DB 0 100000 | tail -${TL_TAIL:-40} > $OUT/timeline_$name.csv 2>&1
   rm -rf $OUT/tl_$name $OUT/tl_$name.log; }
-one pageable 0 MTM_X=0
-one pinned 1 MTM_X=0
-one pinned_b3 1 MTM_UPLOAD_BANDS=0.25,0.6,1
-one pageable_b3 0 MTM_UPLOAD_BANDS=0.25,0.6,1
-for b in "0.3,1" "0.2,0.55,1" "0.35,1" "0.2,1"; do MTM_UPLOAD_BANDS=$b python $R/tools/probes/loop_calls.py 0 200 2>/dev/null | tail -1 | tee -a $OUT/summary.txt; MTM_UPLOAD_BANDS=$b python $R/tools/probes/loop_calls.py 1 200 2>/dev/null | tail -1 | tee -a $OUT/summary.txt; done
+IFS=';' read -ra CASES <<< "${TL_CASES:-inline MTM_BAND_INLINE=1;copy_stream MTM_BAND_INLINE=0}"
+for cs in "${CASES[@]}"; do one $cs; done
