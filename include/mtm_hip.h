@@ -141,7 +141,8 @@ typedef struct mtm_timing {
     int32_t ncc_launches;
     int32_t kernel_used; /* MTM_KERNEL_* actually dispatched for the uint8 path           */
     int64_t n_hits;
-    int32_t hits_only;   /* 1: the last mtm_find_matches ran without materialising the score maps */
+    int32_t hits_only;   /* 1: the last mtm_find_matches ran without materialising the score maps; 2: maps in memory and
+                            the peak pass over the flagged row segments only (dense images) */
     float   sclk_mhz;    /* shader clock the score kernel ran at, measured inside it (s_memtime ticks per
                             s_memrealtime tick x 100 MHz) by one mid-grid work-group; 0 when not measured */
     float   ncc_sum_ms;  /* plain sum of the score-kernel launch durations (= ncc_kernel_ms unless launches of a

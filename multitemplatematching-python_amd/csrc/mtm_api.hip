@@ -99,6 +99,29 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         if (!dense_route) fused = false;
     }
     c->cand_rowmax_now = dense_route;
+    // Segment flags (the default route while the back-off lasts): the maps go to memory as in map mode, and the score kernel
+    // sets a flag per row segment (a wave's 256 outputs of one template row) in which something passes the threshold;
+    // peaks_sparse_kernel visits those instead of scanning 1 GB of maps (4K x 32 templates).  A first version wrote only
+    // the flagged segments, from the hits-only screens: no faster - on such images the screens pass nearly everywhere.
+    // uint8 classes on the lean 1- / 3-channel MFMA epilogue, every map 2-D.
+    c->sparse_now = false;
+    if (mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0 && !fused && !dense_route && c->sparse_maps && c->hits_only &&
+        c->dtype == MTM_U8 && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n) {
+        bool ok = true;
+        int max_oh = 0, max_nseg = 0;
+        for (const SizeClass& sc : c->classes) {
+            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() && sc.rm_R == 0;
+            max_oh = std::max(max_oh, c->rows - sc.h + 1);
+            max_nseg = std::max(max_nseg, (c->cols - sc.w + 1 + kMfSeg - 1) / kMfSeg);
+        }
+        if (ok && (long long)n * max_oh * max_nseg < (1ll << 30)) {
+            c->flag_rstride = max_nseg;
+            c->flag_tstride = max_oh * max_nseg;
+            MTMC(c->seg_flags.ensure((size_t)n * c->flag_tstride));
+            HIPC(hipMemsetAsync(c->seg_flags.p, 0, (size_t)n * c->flag_tstride, c->stream));
+            c->sparse_now = true;
+        }
+    }
     for (const SizeClass& sc : c->classes) {
         const int rk = resolved_kernel(c, sc);
         fused = fused && (rk == MTM_KERNEL_MFMA || rk == MTM_KERNEL_MFMA16 || rk == MTM_KERNEL_MFMA_F32);
@@ -106,6 +129,10 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     c->cand_on = false;
     c->hits_only_now = false;
     c->ext_now = false;
+    if (c->sparse_now) {                // the threshold the score kernel flags against (launch_ncc)
+        c->cand_min = mode_min;
+        c->cand_thr = mode_min ? -thr : thr;
+    }
     // float32 images on the bf16 matrix cores: the kernel's scores are a screen, the decisions are taken on exact
     // float64 scores (mtm_refine.hip.h).  Calls that mix bf16 classes with float64-kernel ones (float masks) run
     // everything on the float64 kernel.
@@ -149,6 +176,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
             c->cand_thr = 0.0f;
         }
     }
+    host_trace(c, 18);
     const int64_t cand_cap = std::min<int64_t>(c->hit_cap, 4096LL * 256);
     if (mode == MTM_PEAKS_GLOBAL && c->refine_now && !c->ext_now) {
         // no fused extremum in this configuration (maps requested, MTM_FUSE_PEAKS=0): the float64 kernel + extremum_kernel
@@ -439,9 +467,27 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                     max_ow = std::max(max_ow, c->td_host[t].ow);
                 }
                 const dim3 grd((max_ow + kPkCols - 1) / kPkCols, (max_oh + 4 * kPkRows - 1) / (4 * kPkRows), n2d);
-                hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
-                                   c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
-                                   c->opt_border, dhits, (unsigned long long)c->hit_cap, counter, flags);
+                if (c->sparse_now) {
+                    const dim3 grd((max_ow + kPkCols - 1) / kPkCols, (max_oh + 4 * kPkSparseRows - 1) / (4 * kPkSparseRows), n2d);
+                    // a list per (template, strip column) (at most 64 MB of them) + their counters, then one list for the host
+                    const unsigned long long n_lists = (unsigned long long)n2d * grd.x;
+                    const unsigned long long cap_t = std::max<unsigned long long>(
+                        256ull, std::min<unsigned long long>((unsigned long long)c->hit_cap / 8, (64ull << 20) / sizeof(mtm_hit) / n_lists));
+                    const size_t cnt_bytes = round_up(sizeof(unsigned long long) * (size_t)n_lists, 256);
+                    MTMC(c->hits_t.ensure(cnt_bytes + sizeof(mtm_hit) * (size_t)cap_t * (size_t)n_lists));
+                    unsigned long long* counts_t = c->hits_t.as<unsigned long long>();
+                    mtm_hit* hits_t = reinterpret_cast<mtm_hit*>(c->hits_t.as<uint8_t>() + cnt_bytes);
+                    HIPC(hipMemsetAsync(counts_t, 0, cnt_bytes, c->stream));
+                    hipLaunchKernelGGL(peaks_sparse_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
+                                       c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
+                                       c->opt_border, hits_t, cap_t, counts_t, flags, c->seg_flags.as<uint8_t>(),
+                                       c->flag_tstride, c->flag_rstride);
+                    hipLaunchKernelGGL(compact_hits_kernel, dim3((unsigned)n_lists), dim3(256), 0, c->stream, hits_t, cap_t, counts_t,
+                                       (int)n_lists, dhits, (unsigned long long)c->hit_cap, counter);
+                } else
+                    hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
+                                       c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
+                                       c->opt_border, dhits, (unsigned long long)c->hit_cap, counter, flags);
             }
             HIPC(hipGetLastError());
             HIPC(hipEventRecord(c->ev[2], c->stream));
@@ -524,7 +570,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                                           const TemplDev& d = c->td_host[h.templ_idx];
                                           if (d.oh <= 1 || d.ow <= 1) return true;   // 1-D / 1x1 maps: host path below
                                           if (use_fused) return (long long)tflags[h.templ_idx] == (long long)d.oh * d.ow;
-                                          return tflags[h.templ_idx] == 0;
+                                          // (bytes 1 and 2: peaks_sparse_kernel - segments above and below the threshold exist)
+                                          const unsigned f = (unsigned)tflags[h.templ_idx];
+                                          return (f & 0xFFu) == 0 && !((f & 0xFF00u) != 0 && (f & 0xFF0000u) != 0);
                                       }),
                        hits.end());
         }
@@ -567,10 +615,11 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     HIPC(hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[2]));
     MTMC(collect_ncc_time(c));
     c->timing.n_hits = (int64_t)hits.size();
-    c->timing.hits_only = c->hits_only_now ? 1 : 0;
+    c->timing.hits_only = c->sparse_now ? 2 : c->hits_only_now ? 1 : 0;
     c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
     c->maps_valid = !c->hits_only_now && !c->ext_now;
     c->refine_now = c->refine_scan_now = c->f32_exact_now = false;      // states of this call only
+    c->sparse_now = false;
     *n_out = (int64_t)hits.size();
     c->last_hits.swap(hits);
     if ((int64_t)c->last_hits.size() > capacity) {

@@ -279,7 +279,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_DENSE_ROWMAX")) c->dense_rowmax = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_STREAMS")) c->band_streams = std::max(1, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("MTM_BAND_INLINE")) c->band_inline = std::atoi(v);
-    if (const char* v = std::getenv("MTM_BAND_MERGE")) c->band_merge = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SPARSE_MAPS")) c->sparse_maps = std::atoi(v);
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));
@@ -315,11 +315,12 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
 void mtm_ctx_destroy(mtm_ctx* c) {
     if (!c) return;
     if (c->host_trace) {
-        static const char* kPhase[16] = {"entry", "args checked", "templates placed", "call set up", "band 0 copy queued",
+        static const char* kPhase[24] = {"entry", "args checked", "templates placed", "call set up", "band 0 copy queued",
                                          "band 0 layout + statistics queued", "band 0 score queued", "last band copy queued",
                                          "last band score queued", "score pass queued", "stream synchronised", "hits verified",
-                                         "hits sorted", "(banded: image slot prepared)", "(banded: before the first copy call)", "return"};
-        for (int k = 0; k < 16; ++k)
+                                         "hits sorted", "(banded: image slot prepared)", "(banded: before the first copy call)", "return",
+                                         "(banded: score pass entered)", "(banded: copy stream ready)", "(fm_begin: decisions taken)", "", "", "", "", ""};
+        for (int k = 0; k < 24; ++k)
             if (c->trace_n[k] > 0)
                 std::fprintf(stderr, "[mtm host trace] %-36s %9.1f us after entry (mean of %lld)\n", kPhase[k],
                              c->trace_acc[k] / (double)c->trace_n[k], c->trace_n[k]);
@@ -330,7 +331,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
-    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw}) b->release();
+    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw, &c->seg_flags, &c->hits_t}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->stats_blk, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})

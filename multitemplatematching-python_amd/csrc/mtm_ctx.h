@@ -199,8 +199,14 @@ struct mtm_ctx {
     hipStream_t copy_stream_b = nullptr;
     std::vector<hipEvent_t> band_copy_ev;
     int band_streams = 1;
-    int band_merge = 0;                     // MTM_BAND_MERGE: score launches only behind the first and the last upload band
-    int band_inline = 1;                    // MTM_BAND_INLINE: the first band of a banded call on `stream` itself (run_score_banded)
+    // segment flags (MTM_SPARSE_MAPS, default 1): the route of a call on dense maps (candidate list overflowed recently)
+    // when every class runs the lean MFMA epilogue - maps in memory, one flag per row segment that holds something above the
+    // threshold, peaks_sparse_kernel over the flagged segments instead of the full scan (MfmaParams::seg_flags)
+    int sparse_maps = 1;
+    bool sparse_now = false;
+    DevBuf seg_flags, hits_t;               // (hits_t: per-template peak lists of peaks_sparse_kernel + their counters)
+    int flag_tstride = 0, flag_rstride = 0;
+    int band_inline = 0;                    // MTM_BAND_INLINE: the first band of a banded call on `stream` itself (run_score_banded)
     hipEvent_t next_ready = nullptr;
     // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
     // statistics of the rows that became computable); the score kernel of a band waits for its event
@@ -255,8 +261,9 @@ struct mtm_ctx {
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
     // MTM_HOST_TRACE=1: host time stamps at the phases of a fused call, averaged and printed when the context is destroyed
     bool host_trace = false;
-    double trace_acc[16] = {0};
-    long long trace_n[16] = {0};
+    double trace_acc[24] = {0};
+    long long trace_n[24] = {0};
+    long long trace_calls = 0;
     double trace_t0 = 0.0;
     double band_min_fill = 1.0;                     // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work
                                                     // items fill the resident work-group slots this many times (banded_ok)
@@ -353,7 +360,11 @@ inline double host_now_us() {
 inline void host_trace(mtm_ctx* c, int k) {
     if (!c->host_trace) return;
     const double t = host_now_us();
-    if (k == 0) c->trace_t0 = t;
+    if (k == 0) {
+        c->trace_t0 = t;
+        ++c->trace_calls;
+    }
+    if (c->trace_calls <= 8) return;        // (the first calls create streams, events and buffers: not the steady state)
     c->trace_acc[k] += t - c->trace_t0;
     ++c->trace_n[k];
 }

@@ -102,6 +102,177 @@ __global__ __launch_bounds__(256) void peaks_kernel(const float* __restrict__ ma
     if (__syncthreads_or(nontriv) && threadIdx.x == 0) nontrivial[t] = 1;
 }
 
+// The same scan over the FLAGGED row segments only (MfmaParams::seg_flags): the score kernel set a flag per row segment -
+// the 256 outputs of one of its waves, which is one row of a strip here - in which some output passes the threshold; a
+// row segment without the flag holds no peak (a peak is above the threshold).  A wave reads the 32 flags of its strip in
+// one load, and for every flagged row fetches the three rows it needs (6.7 % of the rows on a photograph-like 4K image
+// at threshold 0.5; the full scan reads 1 GB of maps for 4K x 32 templates).  The maps themselves are complete.
+// nontrivial[t]: byte 0 as peaks_kernel, over the flagged rows; byte 1 = some segment flagged, byte 2 = some segment not
+// flagged.  Both together mean a pixel above the threshold and one below it exist, i.e. the map is not constant; if every
+// segment is flagged, byte 0 saw every pixel.  The host reads  nontrivial = byte 0 or (byte 1 and byte 2).
+// Peaks go to a list per (template, strip column) - region blockIdx.z * gridDim.x + blockIdx.x of `hits_t`, `cap_t` records
+// each, its own counter - staged per wave in LDS and appended with one atomic per 64 records; compact_hits_kernel then
+// builds the one list the host reads (same-address atomics again: 480 counters share what one counter would queue up).
+constexpr int kPkStage = 64;        // records staged per wave
+// rows per wave: flagged rows cluster (bright regions), and a wave works through its flagged rows one memory latency after
+// the other - with the 32-row strips of the full scan the pass took as long as the fully flagged strips did, four
+// generations of them: 0.30 ms; the rows of the next flagged row are requested before the current one is evaluated
+constexpr int kPkSparseRows = 8;
+__global__ __launch_bounds__(256) void peaks_sparse_kernel(const float* __restrict__ maps, const TemplDev* __restrict__ td,
+                                                           const int* __restrict__ tlist, int mode_min, float thr, int border,
+                                                           mtm_hit* __restrict__ hits_t, unsigned long long cap_t,
+                                                           unsigned long long* __restrict__ counts_t,
+                                                           int* __restrict__ nontrivial, const uint8_t* __restrict__ seg_flags,
+                                                           int flag_tstride, int flag_rstride) {
+    __shared__ mtm_hit stage[4][kPkStage];
+    const int t = tlist[blockIdx.z];
+    const TemplDev T = td[t];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sx = blockIdx.x, xs = sx * kPkCols;
+    const int y0 = (blockIdx.y * 4 + wave) * kPkSparseRows;
+    if (!(xs < T.ow && y0 < T.oh)) return;               // (whole waves; no work-group barrier below)
+    const float* m = maps + T.map_off;
+    const int y1 = min(y0 + kPkSparseRows, T.oh);
+    static_assert(kPkSparseRows <= 64, "one flag per lane");
+    const bool mine = lane < y1 - y0 && seg_flags[(size_t)t * flag_tstride + (size_t)(y0 + lane) * flag_rstride + sx] != 0;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(mine);
+    const int n_rows = y1 - y0;
+    int bits = (todo ? 2 : 0) | (__popcll(todo) < n_rows ? 4 : 0);
+    const float padv = (border == MTM_BORDER_CONSTANT) ? 0.0f : -INFINITY;
+    const float padr = mode_min ? -padv : padv;           // the pad value as it would sit in memory
+    const float thr2 = mode_min ? -thr : thr;
+    const int xb = xs + 4 * lane;
+    const unsigned list = blockIdx.z * gridDim.x + blockIdx.x;
+    mtm_hit* region = hits_t + (size_t)list * cap_t;
+    mtm_hit* st = stage[wave];
+    int n_st = 0;                                         // staged records (wave-uniform)
+    auto flush = [&]() {
+        if (n_st == 0) return;
+        unsigned long long base = 0ull;
+        if (lane == 0) base = atomicAdd(&counts_t[list], (unsigned long long)n_st);
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        base = ((unsigned long long)bhi << 32) | blo;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < n_st && base + (unsigned long long)lane < cap_t) region[base + (unsigned long long)lane] = st[lane];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the records are read: their slots may be rewritten
+        n_st = 0;
+    };
+    auto hmax = [](const float (&v)[4], float hl, float hr, float (&h)[4]) {
+        h[0] = fmaxf(fmaxf(hl, v[0]), v[1]);
+        h[1] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+        h[2] = fmaxf(fmaxf(v[1], v[2]), v[3]);
+        h[3] = fmaxf(fmaxf(v[2], v[3]), hr);
+    };
+    int nontriv = 0;
+    PeakRow na{}, nb{}, nc{};                             // the rows of the next flagged row, requested one iteration ahead
+    int y_next = -1;
+    if (todo) {
+        y_next = y0 + (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        na = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next - 1, xb, lane, padr);
+        nb = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next, xb, lane, padr);
+        nc = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next + 1, xb, lane, padr);
+    }
+    while (y_next >= 0) {                                 // wave-uniform
+        const int y = y_next;
+        const PeakRow ra = na, rb = nb, rc = nc;
+        y_next = -1;
+        if (todo) {
+            y_next = y0 + (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            na = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next - 1, xb, lane, padr);
+            nb = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next, xb, lane, padr);
+            nc = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next + 1, xb, lane, padr);
+        }
+        float va[4], vb[4], vc[4], hl, hr, hm_a[4], hm_b[4], hm_c[4];
+        peaks_finish_row(ra, lane, mode_min != 0, va, hl, hr);
+        hmax(va, hl, hr, hm_a);
+        peaks_finish_row(rb, lane, mode_min != 0, vb, hl, hr);
+        hmax(vb, hl, hr, hm_b);
+        peaks_finish_row(rc, lane, mode_min != 0, vc, hl, hr);
+        hmax(vc, hl, hr, hm_c);
+        unsigned pk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (xb + k < T.ow) {
+                const float v = vb[k];
+                const float mx = fmaxf(fmaxf(hm_a[k], hm_b[k]), hm_c[k]);
+                if (!(v == mx)) nontriv = 1;
+                else if (v > thr2) pk |= 1u << k;
+            }
+        }
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64((pk & 1u) != 0), b1 = __builtin_amdgcn_ballot_w64((pk & 2u) != 0);
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64((pk & 4u) != 0), b3 = __builtin_amdgcn_ballot_w64((pk & 8u) != 0);
+        const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+        const int total = n0 + n1 + n2 + n3;
+        if (total == 0) continue;
+        if (n_st + total > kPkStage) flush();
+        const unsigned long long bb[4] = {b0, b1, b2, b3};
+        const int pre[4] = {0, n0, n0 + n1, n0 + n1 + n2};
+        unsigned long long gbase = 0ull;                  // a row with more peaks than the buffer holds: straight to the region
+        const bool direct = total > kPkStage;
+        if (direct) {
+            if (lane == 0) gbase = atomicAdd(&counts_t[list], (unsigned long long)total);
+            const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)gbase), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(gbase >> 32));
+            gbase = ((unsigned long long)bhi << 32) | blo;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((pk >> k) & 1u) {
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bb[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb[k], 0u));
+                mtm_hit hrec;
+                hrec.templ_idx = t;
+                hrec.x = xb + k;
+                hrec.y = y;
+                hrec.w = T.cols;
+                hrec.h = T.rows;
+                hrec.score = mode_min ? -vb[k] : vb[k];
+                if (direct) {
+                    const unsigned long long slot = gbase + (unsigned long long)(pre[k] + below);
+                    if (slot < cap_t) region[slot] = hrec;
+                } else {
+                    st[n_st + pre[k] + below] = hrec;
+                }
+            }
+        if (!direct) n_st += total;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    flush();
+    if (__builtin_amdgcn_ballot_w64(nontriv != 0) != 0ull) bits |= 1;
+    // plain byte stores (one byte of nontrivial[t] per bit), not atomicOr: a returning atomic on an address every wave of the
+    // launch goes to costs ~0.25 us a piece on this chip - they queue up at the memory side - and made the pass as slow as
+    // the number of its waves (0.30 ms with 32 k waves, 1.1 ms with 126 k)
+    if (lane == 0) {
+        uint8_t* nb8 = reinterpret_cast<uint8_t*>(&nontrivial[t]);
+        if (bits & 1) nb8[0] = 1;
+        if (bits & 2) nb8[1] = 1;
+        if (bits & 4) nb8[2] = 1;
+    }
+}
+
+// The per-template lists of peaks_sparse_kernel -> the one list (and count) the host fetches.  Block z copies region z behind
+// the regions before it; a region that overflowed makes the reported count exceed `hit_cap` (the host grows the lists and
+// repeats the pass, as it does for the single list).
+__global__ __launch_bounds__(256) void compact_hits_kernel(const mtm_hit* __restrict__ hits_t, unsigned long long cap_t,
+                                                           const unsigned long long* __restrict__ counts_t, int n_lists,
+                                                           mtm_hit* __restrict__ hits, unsigned long long hit_cap,
+                                                           unsigned long long* __restrict__ counter) {
+    const int z = blockIdx.x;
+    unsigned long long off = 0ull, total = 0ull;
+    bool over = false;
+    for (int i = 0; i < n_lists; ++i) {
+        const unsigned long long ci = counts_t[i];
+        if (i < z) off += min(ci, cap_t);
+        total += ci;
+        over = over || ci > cap_t;
+    }
+    if (z == 0 && threadIdx.x == 0) counter[0] = over ? max(total, hit_cap + 1ull) : total;
+    const unsigned long long n = min(counts_t[z], cap_t);
+    const mtm_hit* src = hits_t + (size_t)z * cap_t;
+    for (unsigned long long r = threadIdx.x; r < n; r += blockDim.x)
+        if (off + r < hit_cap) hits[off + r] = src[r];
+}
+
 // Second half of the fused peak extraction: the score-map kernel has appended every pixel above the
 // threshold to `cands`; a candidate is a peak iff it equals the maximum of its 3x3 neighbourhood
 // (same border rule and minima handling as peaks_kernel).  tcount[t] counts the peaks of template t:

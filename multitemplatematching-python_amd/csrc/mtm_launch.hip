@@ -541,6 +541,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_min = c->cand_min ? 1 : 0;
         p.cand_thr = c->cand_thr;
         p.cand_rowmax = (c->cand_rowmax_now && p.cand_on && !p.hits_only) ? 1 : 0;
+        if (c->sparse_now && only_li < 0 && !rm) {     // maps in memory + a flag per row segment that holds something above the threshold
+            p.seg_flags = c->seg_flags.as<uint8_t>();
+            p.flag_tstride = c->flag_tstride;
+            p.flag_rstride = c->flag_rstride;
+        }
         p.cand_cap = (unsigned long long)c->hit_cap;
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
@@ -1129,16 +1134,18 @@ static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass
 // blocks the host while its rows are staged - the kernels queued before it run meanwhile.
 int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     const SizeClass& sc = c->classes[(size_t)c->banded_cls];
+    host_trace(c, 16);
     if (!c->hits_only_now) MTMC(ensure_maps(c));
     MTMC(ensure_copy_stream(c));
+    host_trace(c, 17);
     mtm_ctx::ImageSlot& sl = c->slot[c->cur];
     SlotGeom g{};
     const bool u16 = a.dtype == MTM_U16;
     const int nb = (int)c->upload_bands.size();
-    // MTM_BAND_INLINE (default 1): the FIRST band's copy, layout conversion and statistics go to c->stream itself, ahead
-    // of its score launch - stream order instead of an event between two streams, which the hardware takes ~20 us to
-    // pass on (profiles/r03_tl2: statistics end -> score launch start) - and the second band's copy waits for the first
-    // band's COPY on the copy stream, not for the first band's kernels.
+    // MTM_BAND_INLINE=1 (default 0): the FIRST band's copy, layout conversion and statistics on c->stream itself, ahead of
+    // its score launch - stream order instead of an event between two streams - and the second band's copy behind the first
+    // band's COPY on the copy stream.  Measured on three boxes in round 4 (profiles/r04_r04v, _r04w, _r04x): +0.5 % /
+    // -0.5 % / -1 %: the gap between the statistics kernel and the score launch (16 us) is there in stream order too.
     const bool inline0 = c->band_inline && nb > 1 && c->band_streams <= 1 && !c->dual_stream;
     MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, inline0 ? c->stream : c->copy_stream, 1, &g));
     host_trace(c, 13);
@@ -1212,10 +1219,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         k_prev = k;
         if (k == 0) host_trace(c, 5);                            // layout conversion + statistics of band 0 submitted
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
-        // MTM_BAND_MERGE=1: only the first and the last band launch the score kernel - the bands in between are upload,
-        // layout conversion and statistics pieces (the last band's statistics pass, which gates the last launch, covers
-        // fewer rows)
-        if (yb1 > yb_done && (!c->band_merge || n_launch == 0 || last)) {
+        if (yb1 > yb_done) {
             hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
             if (s != bs) HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
             c->ncc_stream = s;

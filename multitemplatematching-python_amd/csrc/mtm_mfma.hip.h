@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 k.ext_thr_lo = __hiloint2double(ninf_hi, 0);
             }
             k.ext_hi = 0u;
-            k.ext_pad_ = 0;
+            k.flag_base = tlist[li] * p.flag_tstride;
             if (EXT) {
                 const unsigned long long bk = __hip_atomic_load(&p.ext_best[2 * tlist[li] + p.cand_min], __ATOMIC_RELAXED,
                                                                 __HIP_MEMORY_SCOPE_AGENT);
@@ -1306,28 +1306,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         const int method = p.method;
         const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
         const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
-        double us1[4] = {0.0, 0.0, 0.0, 0.0}, up1[4], usum2[4] = {0.0, 0.0, 0.0, 0.0}, usq[4] = {0.0, 0.0, 0.0, 0.0}, ursq[4];
-        if (lane_on) {
-            const size_t sidx = (size_t)y * st.pitch + xq;       // pitch is a multiple of 4: the 4 values exist
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
-                us1[2 * hh] = a.x, us1[2 * hh + 1] = a.y;
-                if (need_sum2) {
-                    const double2 d = *reinterpret_cast<const double2*>(st.sum2 + sidx + 2 * hh);
-                    usum2[2 * hh] = d.x, usum2[2 * hh + 1] = d.y;
-                }
-                if (normed) {
-                    const double2 d = *reinterpret_cast<const double2*>(st.sq + sidx + 2 * hh);
-                    usq[2 * hh] = d.x, usq[2 * hh + 1] = d.y;
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            up1[i] = 32896.0 * us1[i];
-            ursq[i] = (normed && usq[i] > 0.0) ? 1.0 / usq[i] : 0.0;
-        }
         const int n_here = min(16, p.n_list - tg * 16);
         // ---- hits-only screen (TM_CCORR_NORMED / TM_CCOEFF_NORMED): the per-lane bound of the 8-bit tilings (see the
         // row-multiplexed epilogue) on the three partial sums.  Lane (j, q) holds templates 4 q + e at the 16 outputs
@@ -1367,6 +1345,31 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 pass1 = pass1 || (live && (thr_lo_e < 0.0 || could));
             }
             if (__builtin_amdgcn_ballot_w64(pass1) == 0ull) continue;      // wave-uniform; no work-group barrier below
+        }
+        // the window statistics of this lane's four outputs - behind the screen: 40 registers that would otherwise be
+        // live across it next to the 192 accumulator registers (they went to scratch memory in every work item: 63 MB of
+        // HBM writes per 4K launch), and plane reads that the waves the screen sends away never need
+        double us1[4] = {0.0, 0.0, 0.0, 0.0}, up1[4], usum2[4] = {0.0, 0.0, 0.0, 0.0}, usq[4] = {0.0, 0.0, 0.0, 0.0}, ursq[4];
+        if (lane_on) {
+            const size_t sidx = (size_t)y * st.pitch + xq;       // pitch is a multiple of 4: the 4 values exist
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
+                us1[2 * hh] = a.x, us1[2 * hh + 1] = a.y;
+                if (need_sum2) {
+                    const double2 d = *reinterpret_cast<const double2*>(st.sum2 + sidx + 2 * hh);
+                    usum2[2 * hh] = d.x, usum2[2 * hh + 1] = d.y;
+                }
+                if (normed) {
+                    const double2 d = *reinterpret_cast<const double2*>(st.sq + sidx + 2 * hh);
+                    usq[2 * hh] = d.x, usq[2 * hh + 1] = d.y;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            up1[i] = 32896.0 * us1[i];
+            ursq[i] = (normed && usq[i] > 0.0) ? 1.0 / usq[i] : 0.0;
         }
         unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
         if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
@@ -1730,7 +1733,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                             if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, yrow, allow);
                         }
-                        if (!p.hits_only) store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, out);
+                        if (!p.hits_only) {
+                            store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, out);
+                            if constexpr (!EXT) if (p.seg_flags != nullptr) {
+                                // segment flags (dense images): the peak pass only visits row segments in which some output
+                                // passes the threshold
+                                const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                                const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                                if (__builtin_amdgcn_ballot_w64((p.cand_min ? -lo : hi) > p.cand_thr) != 0ull)
+                                    p.seg_flags[(size_t)T.flag_base + (size_t)yrow * p.flag_rstride + (x0 >> 8)] = 1;
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // reads above, next stage's writes below

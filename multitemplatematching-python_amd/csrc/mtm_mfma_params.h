@@ -126,6 +126,13 @@ struct MfmaParams {
     int cs_off;              // byte offset in LDS of the candidate staging buffers (4 waves x kMfCandStageBytes); 0 = none
     int sq_fused;
     int rm_edges;            // row-multiplexed tilings: 1 = the edge steps (one group's A operand all zero) run the one-group step
+    // segment flags (dense images, maps in memory, the lean single- / three-channel epilogue): when one of the 256 outputs
+    // of a wave's row of a template passes the candidate test, the byte
+    // seg_flags[flag_base(template) + row * flag_rstride + segment] is set - the peak pass visits only those row segments
+    // ("everything else is <= threshold" is all a 3x3 maximum above the threshold needs to know).
+    // flag_base = template index * flag_tstride.  nullptr: off
+    uint8_t* seg_flags;
+    int flag_tstride, flag_rstride;
     int cand_rowmax;         // 1 (maps in memory only): list only candidates no neighbour in their own row exceeds
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
@@ -144,7 +151,7 @@ struct MfTemplConst {
     int map_pitch, all_ones;
     double ext_thr_lo;       // ext_on: quality (score, or -score for minima) of the best output seen so far,
     unsigned ext_hi;         //   lowered by 1e-6 relative; high word of its key (0: none yet)
-    int ext_pad_;
+    int flag_base;           // first byte of this template's row-segment flags (MfmaParams::seg_flags)
 };
 
 // One instantiation of ncc_mfma_kernel (defined in the mtm_mfma_*.hip units).

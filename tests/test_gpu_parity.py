@@ -2248,12 +2248,92 @@ def test_dense_route_row_maxima_candidates(mtm, monkeypatch):
                 c.set_templates([(t, None) for _, t in lt], method)
                 for k in range(4):
                     raw = c.find_matches_image(dense, _lib.PEAKS_LOCAL, thr)
-                    assert c.timing()["hits_only"] == 0
+                    assert c.timing()["hits_only"] in (0, 2)      # (2: the flagged-segment peak pass of the back-off calls)
                     got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in raw]
                     assert len(got) == len(exp), (method, env, cap, k, len(got), len(exp))
                     assert_hits_equal(hits_json(got), exp, tol=1e-6, ordered=False)
             finally:
                 c.close()
+
+
+def test_sparse_maps_route_equals_the_full_maps_route(mtm):
+    """Calls under the dense-map back-off write only the row segments in which something passes the threshold and scan
+    those (sparse maps, timing hits_only == 2).  Against a context with MTM_SPARSE_MAPS=0 (full maps + full peak pass):
+    the same records bit for bit - maxima and minima methods, both border rules, RGB, two size classes, a threshold
+    nothing passes, a negative threshold (every segment flagged), a constant image (skimage: no peaks in a map every
+    pixel of which equals its local maximum) and plateaus at segment borders."""
+    from MTM import _lib
+    rng = np.random.default_rng(77)
+    dense = synth.smooth_u8(17, (260, 700), scales=(3, 9, 27), noise=0.1)
+    dense_rgb = np.stack([dense, np.roll(dense, 5, 0), np.roll(dense, 7, 1)], axis=2)
+    flat = np.full((260, 700), 90, np.uint8)
+    blocky = np.kron(rng.integers(0, 256, (26, 70), dtype=np.uint8), np.ones((10, 10), np.uint8)).astype(np.uint8)   # plateaus
+    def templates(img, sizes, n):
+        out = []
+        for i in range(n):
+            h, w = sizes[i % len(sizes)]
+            y, x = int(rng.integers(0, img.shape[0] - h)), int(rng.integers(0, img.shape[1] - w))
+            out.append((np.ascontiguousarray(img[y:y + h, x:x + w]), None))
+        return out
+    cases = [
+        ("ccoeff_normed", dense, templates(dense, [(24, 32)], 20), 5, 0.3),
+        ("two classes", dense, templates(dense, [(24, 32), (17, 40)], 40), 5, 0.35),
+        ("sqdiff_normed (minima)", dense, templates(dense, [(24, 32)], 20), 1, 0.6),
+        ("ccorr_normed", dense, templates(dense, [(24, 32)], 20), 3, 0.97),
+        ("rgb", dense_rgb, templates(dense_rgb, [(24, 32)], 20), 5, 0.3),
+        ("nothing passes", dense, templates(dense, [(24, 32)], 20), 5, 1.5),
+        ("negative threshold", dense, templates(dense, [(24, 32)], 20), 5, -0.5),
+        ("constant image", flat, templates(dense, [(24, 32)], 20), 5, -0.5),
+        ("plateaus", blocky, templates(blocky, [(20, 30)], 20), 5, 0.2),
+    ]
+    def make(sparse):
+        old = os.environ.get("MTM_SPARSE_MAPS")
+        os.environ["MTM_SPARSE_MAPS"] = "1" if sparse else "0"
+        try:
+            c = _lib.Context(0)
+        finally:
+            if old is None:
+                del os.environ["MTM_SPARSE_MAPS"]
+            else:
+                os.environ["MTM_SPARSE_MAPS"] = old
+        c.set_option(_lib.OPT_HIT_CAPACITY, 1024)
+        return c
+    ca, cb = make(True), make(False)
+    try:
+        forced = any(os.environ.get(v) for v in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY", "MTM_ROW_MUX", "MTM_SPARSE_MAPS"))
+        routes = []
+        for border in (_lib.BORDER_CONSTANT, _lib.BORDER_NEAREST):
+            for c in (ca, cb):
+                c.set_option(_lib.OPT_PEAK_BORDER, border)
+            for name, img, tl, method, thr in cases:
+                # the dense image first: its candidates overflow the 1024-record list and start the back-off
+                warm_img = dense_rgb if img.ndim == 3 else dense
+                warm = templates(warm_img, [(24, 32)], 20)
+                # (from a cleared back-off state - MTM_OPT_HITS_ONLY clears it -: the next 16 calls run under it)
+                for c in (ca, cb):
+                    if not forced:
+                        c.set_option(_lib.OPT_HITS_ONLY, 1)
+                    c.set_option(_lib.OPT_HIT_CAPACITY, 1024)     # (a call with more peaks than that has grown it)
+                    c.search(warm, warm_img, 5, _lib.PEAKS_LOCAL, 0.3)
+                ra = ca.search(tl, img, method, _lib.PEAKS_LOCAL, thr)
+                route = ca.timing()["hits_only"]
+                rb = cb.search(tl, img, method, _lib.PEAKS_LOCAL, thr)
+                assert cb.timing()["hits_only"] != 2
+                routes.append((name, route))
+                assert len(ra) == len(rb), (name, border, len(ra), len(rb))
+                assert ra.tobytes() == rb.tobytes(), (name, border)
+                if name in ("nothing passes", "constant image"):
+                    assert len(ra) == 0, name
+                if name in ("ccoeff_normed", "plateaus") and border == _lib.BORDER_CONSTANT:
+                    lt = [("t%d" % i, t) for i, (t, _) in enumerate(tl)]
+                    exp = hits_json(O.find_matches(lt, img, method=method, score_threshold=thr))
+                    got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in ra]
+                    assert_hits_equal(hits_json(got), exp, tol=1e-6, ordered=False)
+        if not forced:          # every case ran under the back-off, on the flagged-segment route
+            assert [x for x in routes if x[1] != 2] == []
+    finally:
+        ca.close()
+        cb.close()
 
 
 def test_dense_maps_candidate_overflow(mtm):
@@ -2289,7 +2369,8 @@ def test_dense_maps_candidate_overflow(mtm):
             keys = [(int(r["templ_idx"]), -float(r["score"]), int(r["y"]), int(r["x"])) for r in raw]
             assert keys == sorted(keys), k
         if not any(os.environ.get(v) for v in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY")):
-            assert modes[0] == 0 and modes[1] == 0            # overflow -> maps; then the back-off period
+            # overflow -> maps; then the back-off period, on sparse maps (round 4) unless they are switched off
+            assert modes[0] == 0 and modes[1] == (0 if os.environ.get("MTM_SPARSE_MAPS") == "0" else 2)
             for _ in range(80):                               # sparse again: hits-only is back once the period ran out
                 raw = c.find_matches_image(sparse, _lib.PEAKS_LOCAL, 0.3)
                 assert len(raw) == len(exp_sparse)
