@@ -110,7 +110,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         bool ok = true;
         int max_oh = 0, max_nseg = 0;
         for (const SizeClass& sc : c->classes) {
-            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty() && sc.rm_R == 0;
+            ok = ok && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty();
             max_oh = std::max(max_oh, c->rows - sc.h + 1);
             max_nseg = std::max(max_nseg, (c->cols - sc.w + 1 + kMfSeg - 1) / kMfSeg);
         }

@@ -541,7 +541,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_min = c->cand_min ? 1 : 0;
         p.cand_thr = c->cand_thr;
         p.cand_rowmax = (c->cand_rowmax_now && p.cand_on && !p.hits_only) ? 1 : 0;
-        if (c->sparse_now && only_li < 0 && !rm) {     // maps in memory + a flag per row segment that holds something above the threshold
+        if (c->sparse_now && only_li < 0) {     // maps in memory + a flag per row segment that holds something above the threshold
             p.seg_flags = c->seg_flags.as<uint8_t>();
             p.flag_tstride = c->flag_tstride;
             p.flag_rstride = c->flag_rstride;

@@ -1248,7 +1248,15 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                             if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy, allow);
                         }
-                        if (!p.hits_only) store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, out);
+                        if (!p.hits_only) {
+                            store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, out);
+                            if constexpr (!EXT) if (p.seg_flags != nullptr) {      // segment flags (see the plain tiling's epilogue)
+                                const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                                const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                                if (__builtin_amdgcn_ballot_w64((p.cand_min ? -lo : hi) > p.cand_thr) != 0ull)
+                                    p.seg_flags[(size_t)T.flag_base + (size_t)yy * p.flag_rstride + (x0 >> 8)] = 1;
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

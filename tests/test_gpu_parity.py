@@ -2278,6 +2278,8 @@ def test_sparse_maps_route_equals_the_full_maps_route(mtm):
     cases = [
         ("ccoeff_normed", dense, templates(dense, [(24, 32)], 20), 5, 0.3),
         ("two classes", dense, templates(dense, [(24, 32), (17, 40)], 40), 5, 0.35),
+        ("row-multiplexed tiling (5 templates)", dense, templates(dense, [(24, 32)], 5), 5, 0.3),
+        ("one template + a class of 20", dense, templates(dense, [(30, 30)], 1) + templates(dense, [(24, 32)], 20), 1, 0.6),
         ("sqdiff_normed (minima)", dense, templates(dense, [(24, 32)], 20), 1, 0.6),
         ("ccorr_normed", dense, templates(dense, [(24, 32)], 20), 3, 0.97),
         ("rgb", dense_rgb, templates(dense_rgb, [(24, 32)], 20), 5, 0.3),
