@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 4
+#define MTM_ABI_VERSION 5
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -234,6 +234,17 @@ int mtm_find_matches(mtm_ctx* ctx, int mode, double score_threshold,
 int mtm_find_matches_image(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
                            int64_t row_stride_bytes, int mode, double score_threshold,
                            mtm_hit* out, int64_t capacity, int64_t* n_out);
+
+/* mtm_find_matches_image (local extrema) followed by MTM's non-maxima suppression - what MTM.matchTemplates does with
+ * the hits of all templates (MTM/__init__.py:290-296 -> MTM/NMS.py:53-84 -> cv2.dnn.NMSBoxes): hits whose score passes
+ * `score_threshold` (1 - score for TM_SQDIFF_NORMED, as NMS.py:73-75 transforms it), best first, each kept unless it
+ * overlaps an already kept one by more than `max_overlap` (intersection over union, OpenCV's float expression); at most
+ * `n_object` of them (n_object < 0: all).  Returns the kept hits in that order - the list mtm_nms would select from the
+ * list mtm_find_matches_image returns.  Of thousands of peaks (dense images) the ones a neighbourhood's best peak suppresses
+ * are dropped on the device and never cross PCIe; mtm_timing.n_hits is the number of peaks before the suppression. */
+int mtm_find_matches_image_nms(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
+                               int64_t row_stride_bytes, double score_threshold, double max_overlap, int64_t n_object,
+                               mtm_hit* out, int64_t capacity, int64_t* n_out);
 
 /* Stream form of mtm_find_matches ("thousands of images", reference
  * tutorials/Tutorial3-SpeedingUp.ipynb:564: same templates, one image after the other): returns the

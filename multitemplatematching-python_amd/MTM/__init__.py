@@ -140,10 +140,13 @@ def _validate_search(listTemplates, image, N_object, searchBox):
 _U8 = np.dtype(np.uint8)
 
 
-def _raw_matches(listTemplates, image, method, N_object, score_threshold, context=None, devices=None):
+def _raw_matches(listTemplates, image, method, N_object, score_threshold, context=None, devices=None, nms=None):
     """Batched equivalent of one _multi_compute per template (MTM/__init__.py:179-244).
     Returns a structured array of hits (template index, box relative to `image`, score) ordered by
-    template index, then descending quality, then row-major position."""
+    template index, then descending quality, then row-major position.
+    ``nms = [maxOverlap]`` (matchTemplates, N_object != 1, method != TM_SQDIFF): where the engine can run the non-maxima
+    suppression inside the same native call (one GPU context, the usual 8-bit path) the hits returned are already the
+    kept ones in NMS order, and ``nms`` is emptied to say so."""
     mode = _lib.PEAKS_GLOBAL if N_object == 1 else _lib.PEAKS_LOCAL
     ichans = image.shape[2] if image.ndim == 3 else 1
     # the usual call - 8-bit image, 8-bit templates - needs no pixel policy at all: one pass over the list
@@ -171,6 +174,11 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
             warnings.warn(_MSG_MASK_UNSUPPORTED)
         engine = context or _lib.engine_for(devices)
         with engine.lock:
+            if nms and hasattr(engine, "search_nms"):
+                n_obj = -1 if N_object == float("inf") else int(N_object)
+                hits = engine.search_nms(units, image, method, score_threshold, nms[0], n_obj)
+                del nms[:]
+                return hits
             return engine.search(units, image, method, mode, score_threshold)
 
     # general case: the pixel policy is per template (MTM/__init__.py:67-88)
@@ -286,13 +294,14 @@ def matchTemplates(listTemplates: List[TemplateTuple], image: np.ndarray, method
         raise ValueError("Maximal overlap between bounding box is in range [0-1]")
 
     image_s, xOffset, yOffset = _validate_search(listTemplates, image, N_object, searchBox)
-    raw = _raw_matches(listTemplates, image_s, method, N_object, score_threshold, devices=devices)
+    nms = [maxOverlap] if (N_object != 1 and method != 0) else None      # (N_object == 1: no suppression, the best hit)
+    raw = _raw_matches(listTemplates, image_s, method, N_object, score_threshold, devices=devices, nms=nms)
 
     if method == 0:     # as in the reference, only after the search ran (MTM/__init__.py:291)
         raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
 
     sortAscending = (method == 1)
-    kept = _nms_raw(raw, score_threshold, sortAscending, N_object, maxOverlap)
+    kept = raw if nms == [] else _nms_raw(raw, score_threshold, sortAscending, N_object, maxOverlap)
     return _to_hit_list(kept, listTemplates, xOffset, yOffset)
 
 

@@ -5,6 +5,7 @@
 using namespace mtm;
 using namespace mtmi;
 #include "mtm_k_peaks.hip.h"
+#include "mtm_k_nms.hip.h"
 
 namespace {
 
@@ -283,6 +284,66 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     return MTM_OK;
 }
 
+// The device's share of the non-maxima suppression of the `count` peaks at `dhits` (mtm_k_nms.hip.h): the hits a
+// neighbourhood's best hit suppresses stay on the device; the rest (any order) lands in `rest` for the host's pass.
+int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, bool ascending, std::vector<mtm_hit>& rest) {
+    int cell = 1;
+    for (const TemplDev& d : c->td_host) cell = std::max(cell, std::max(d.rows, d.cols));
+    NmsParams p{};
+    p.hits = dhits;
+    p.n = (unsigned)count;
+    p.ascending = ascending ? 1 : 0;
+    // MTM/NMS.py:73-78: the scores are float32 (1 - score for the difference methods), the threshold a python float
+    // transformed in double and narrowed by the cv2 binding
+    p.thr_score = (float)(ascending ? (1.0 - c->nms_req.score_threshold) : c->nms_req.score_threshold);
+    p.thr_overlap = (float)c->nms_req.max_overlap;
+    p.cell = cell;
+    p.gw = c->cols / cell + 3;
+    p.gh = c->rows / cell + 3;
+    const size_t n_cells = (size_t)p.gw * p.gh;
+    const size_t off_rank = round_up(sizeof(unsigned) * (n_cells + 1), 256), off_status = off_rank + round_up(sizeof(unsigned) * count, 256);
+    const size_t off_sorted = off_status + round_up(sizeof(int) * count, 256);
+    const size_t off_hdr = off_sorted + round_up(sizeof(mtm_hit) * count, 256), off_out = off_hdr + 256;
+    MTMC(c->nms_buf.ensure(off_out + sizeof(mtm_hit) * count));
+    uint8_t* b = c->nms_buf.as<uint8_t>();
+    p.cell_cnt = reinterpret_cast<unsigned*>(b);
+    p.rank = reinterpret_cast<unsigned*>(b + off_rank);
+    p.status = reinterpret_cast<int*>(b + off_status);
+    p.sorted = reinterpret_cast<mtm_hit*>(b + off_sorted);
+    p.out_count = reinterpret_cast<unsigned long long*>(b + off_hdr);
+    p.out = reinterpret_cast<mtm_hit*>(b + off_out);
+    HIPC(hipMemsetAsync(p.cell_cnt, 0, sizeof(unsigned) * (n_cells + 1), c->stream));
+    HIPC(hipMemsetAsync(b + off_hdr, 0, 16, c->stream));
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, p);
+    hipLaunchKernelGGL(nms_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(nms_champion_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    hipLaunchKernelGGL(nms_prune_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(c->ev[2], c->stream));
+    // the count and - optimistically - the first records in one copy
+    const size_t first = std::min<size_t>(4096, (size_t)count);
+    std::vector<uint8_t> land(256 + sizeof(mtm_hit) * first);
+    HIPC(hipMemcpyAsync(land.data(), b + off_hdr, land.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    unsigned long long n_rest = 0;
+    std::memcpy(&n_rest, land.data(), sizeof(n_rest));
+    if (n_rest > count) {
+        set_error("mtm_find_matches_image_nms: internal state (pruned list longer than the peak list)");
+        return MTM_E_STATE;
+    }
+    rest.resize((size_t)n_rest);
+    const size_t got = std::min<size_t>((size_t)n_rest, first);
+    if (got) std::memcpy(rest.data(), land.data() + 256, sizeof(mtm_hit) * got);
+    if (n_rest > got) {
+        HIPC(hipMemcpyAsync(rest.data() + got, p.out + got, sizeof(mtm_hit) * ((size_t)n_rest - got), hipMemcpyDeviceToHost,
+                            c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    return MTM_OK;
+}
+
 // Synchronising half: waits for the stream, verifies / extracts the peaks, delivers the hits.
 int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t* n_out) {
     HIPC(hipSetDevice(c->device));
@@ -544,6 +605,20 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
             if (use_fused && !pp_mode && !c->cand_rowmax_now) c->backoff_len = 16;     // the candidates fitted
             if ((int64_t)count <= c->hit_cap) {
+                // thousands of peaks and a suppression request: decide on the device, fetch the kept ones
+                if (c->nms_req.on && c->nms_device && c->sparse_now && !use_fused && (long long)count >= c->nms_device_min &&
+                    count <= (1ull << 18) && c->nms_req.max_overlap >= 0.0) {
+                    bool trivial = false;       // (a map every pixel of which equals its local maximum loses its peaks below)
+                    for (int t : c->list2d) {
+                        const unsigned f = (unsigned)tflags[(size_t)t];
+                        trivial = trivial || ((f & 0xFFu) == 0 && !((f & 0xFF00u) != 0 && (f & 0xFF0000u) != 0));
+                    }
+                    if (!trivial) {
+                        MTMC(run_device_nms(c, dhits, count, mode_min, hits));
+                        c->nms_raw_count = (long long)count;
+                        break;
+                    }
+                }
                 hits.resize((size_t)count);
                 const size_t got = std::min<size_t>((size_t)count, first);
                 if (got) std::memcpy(hits.data(), host_buf.data() + hdr_bytes, sizeof(mtm_hit) * got);
@@ -606,7 +681,22 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         }
         // deterministic order: template, then descending quality, then row-major position
         host_trace(c, 11);
+        // (the device may have pruned the list already - run_device_nms -: the count of peaks is the one before that)
+        const int64_t n_raw = c->nms_raw_count >= 0 ? (int64_t)c->nms_raw_count : (int64_t)hits.size();
         sort_hits(hits, mode_min);
+        if (c->nms_req.on && n_raw > 1) {               // MTM.NMS through mtm_nms (a list of one hit is returned as it is:
+            std::vector<float> scores(hits.size());     // MTM/NMS.py:53-55)
+            for (size_t i = 0; i < hits.size(); ++i) scores[i] = mode_min ? (1.0f - hits[i].score) : hits[i].score;
+            const float thr_s = (float)(mode_min ? (1.0 - c->nms_req.score_threshold) : c->nms_req.score_threshold);
+            std::vector<int32_t> keep;
+            nms_boxes(hits.data(), (int64_t)hits.size(), scores.data(), thr_s, (float)c->nms_req.max_overlap, keep);
+            std::vector<mtm_hit> kept(keep.size());
+            for (size_t i = 0; i < keep.size(); ++i) kept[i] = hits[(size_t)keep[i]];
+            hits.swap(kept);
+        }
+        if (c->nms_req.on && c->nms_req.n_object >= 0 && (long long)hits.size() > c->nms_req.n_object)
+            hits.resize((size_t)c->nms_req.n_object);          // MTM/NMS.py:81-82
+        c->timing.n_hits = n_raw;
         host_trace(c, 12);
     }
     HIPC(hipEventSynchronize(c->ev[2]));       // already complete: every path above synchronised the stream
@@ -614,7 +704,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     HIPC(hipEventElapsedTime(&c->timing.peaks_ms, c->ev[1], c->ev[2]));
     HIPC(hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[2]));
     MTMC(collect_ncc_time(c));
-    c->timing.n_hits = (int64_t)hits.size();
+    if (mode != MTM_PEAKS_LOCAL || !c->nms_req.on) c->timing.n_hits = (int64_t)hits.size();
+    c->nms_raw_count = -1;
     c->timing.hits_only = c->sparse_now ? 2 : c->hits_only_now ? 1 : 0;
     c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
     c->maps_valid = !c->hits_only_now && !c->ext_now;
@@ -704,6 +795,27 @@ int mtm_find_matches_image(mtm_ctx* c, const void* px, int rows, int cols, int c
     MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image"));
     const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
     const int rc = find_matches_impl(c, mode, score_threshold, out, capacity, n_out, nullptr, &up);
+    host_trace(c, 15);
+    return rc;
+}
+
+int mtm_find_matches_image_nms(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                               double score_threshold, double max_overlap, int64_t n_object, mtm_hit* out, int64_t capacity,
+                               int64_t* n_out) {
+    if (!c) {
+        set_error("mtm_find_matches_image_nms: null context");
+        return MTM_E_INVALID;
+    }
+    host_trace(c, 0);
+    MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image_nms"));
+    const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
+    c->nms_req.on = true;
+    c->nms_req.score_threshold = score_threshold;
+    c->nms_req.max_overlap = max_overlap;
+    c->nms_req.n_object = n_object;
+    const int rc = find_matches_impl(c, MTM_PEAKS_LOCAL, score_threshold, out, capacity, n_out, nullptr, &up);
+    c->nms_req.on = false;
+    c->nms_raw_count = -1;
     host_trace(c, 15);
     return rc;
 }

@@ -199,6 +199,18 @@ struct mtm_ctx {
     hipStream_t copy_stream_b = nullptr;
     std::vector<hipEvent_t> band_copy_ev;
     int band_streams = 1;
+    // mtm_find_matches_image_nms: MTM.matchTemplates' non-maxima suppression as part of the call (the host's nms_boxes on
+    // the fetched list).  Thousands of peaks on the device (the flagged-segment route of dense images) are pruned there
+    // first (mtm_k_nms.hip.h; MTM_NMS_DEVICE=0: never): what a neighbourhood's best hit suppresses never crosses PCIe.
+    struct NmsRequest {
+        bool on = false;
+        double score_threshold = 0.0, max_overlap = 0.0;
+        long long n_object = -1;
+    } nms_req;
+    long long nms_raw_count = -1;           // >= 0: the device pruned this call's peak list; the count before that
+    int nms_device = 1;
+    long long nms_device_min = 4096;        // fewer peaks than this: the host is as fast
+    DevBuf nms_buf;
     // segment flags (MTM_SPARSE_MAPS, default 1): the route of a call on dense maps (candidate list overflowed recently)
     // when every class runs the lean MFMA epilogue - maps in memory, one flag per row segment that holds something above the
     // threshold, peaks_sparse_kernel over the flagged segments instead of the full scan (MfmaParams::seg_flags)

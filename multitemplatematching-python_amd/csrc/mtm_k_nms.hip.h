@@ -1,0 +1,143 @@
+// Non-maxima suppression, the device's share (reference MTM/NMS.py:53-84: cv2.dnn.NMSBoxes over the hits of all templates),
+// for calls whose peak pass leaves thousands of hits on the device (dense images).  Greedy NMS keeps a hit iff no EARLIER
+// hit (mtm_nms_core.h: nms_earlier) that is itself kept overlaps it by more than the threshold.  Two facts need no
+// sequential pass: a hit that no earlier hit overlaps at all ("champion": the best of its neighbourhood) is kept, and a
+// hit that a champion overlaps is suppressed - and a suppressed hit never suppresses anything, so the host's greedy pass
+// over the list WITHOUT those gives the same result as over the whole list.  On a photograph-like image most hits sit in
+// clusters around a champion: of 16,773 peaks a few thousand cross PCIe and reach the host's sort and NMS.
+// Hits only interact within a box side of each other: every hit looks at the hits of the 3 x 3 grid cells around its
+// corner (cell = the largest box side), the hits sorted by cell.  (A first version decided everything on the device, every thread waiting for the
+// earlier hits it depends on: correct, but in dense fields a hit has hundreds of earlier neighbours and the waiting
+// scans took 1 ms - twice the host's pass.)  Launched by mtm_api.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+#include "mtm_nms_core.h"
+
+namespace mtm {
+
+struct NmsParams {
+    const mtm_hit* hits;     // the peak list (device), any order
+    unsigned n;
+    int ascending;           // difference methods: scores become 1 - score
+    float thr_score;         // NMSBoxes score_threshold (already transformed)
+    float thr_overlap;       // NMSBoxes nms_threshold (>= 0)
+    int cell, gw, gh;        // grid: cell side, cells per row / column (one empty ring included)
+    // the candidates sorted by grid cell (a counting sort: nms_count_kernel, nms_offsets_kernel, nms_scatter_kernel) - a
+    // cell's hits are one contiguous run, read with independent loads (linked lists cost a memory latency per element)
+    unsigned* cell_cnt;      // gw * gh + 1: hits per cell, then - in place - the exclusive prefix (cell_cnt[c] .. cell_cnt[c + 1])
+    unsigned* rank;          // n: position inside its cell (0xFFFFFFFF: not a candidate)
+    mtm_hit* sorted;         // n_cand records, cell by cell
+    int* status;             // per sorted position: 0 undecided, 1 champion (kept)
+    mtm_hit* out;            // the hits the host still has to decide about, champions included (any order)
+    unsigned long long* out_count;
+};
+
+constexpr int kNmsUndecided = 0, kNmsKept = 1;
+
+__device__ __forceinline__ int nms_cell_of(const NmsParams& p, const mtm_hit& h) {
+    const int cx = min(max(h.x / p.cell, 0), p.gw - 3) + 1, cy = min(max(h.y / p.cell, 0), p.gh - 3) + 1;
+    return cy * p.gw + cx;
+}
+
+__global__ __launch_bounds__(256) void nms_count_kernel(NmsParams p) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const mtm_hit h = p.hits[i];
+    const bool cand = nms_score(h, p.ascending) > p.thr_score;          // (false for NaN)
+    p.rank[i] = cand ? atomicAdd(&p.cell_cnt[nms_cell_of(p, h)], 1u) : 0xFFFFFFFFu;
+}
+
+// exclusive prefix over the cells, in place (one work-group; cell_cnt[n_cells] becomes the number of candidates)
+__global__ __launch_bounds__(1024) void nms_offsets_kernel(NmsParams p) {
+    __shared__ unsigned part[1024];
+    const int n_cells = p.gw * p.gh, t = threadIdx.x;
+    const int per = (n_cells + 1023) / 1024, c0 = t * per, c1 = min(c0 + per, n_cells);
+    unsigned s = 0;
+    for (int c = c0; c < c1; ++c) s += p.cell_cnt[c];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {           // inclusive scan of the per-thread sums
+        const unsigned v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = t ? part[t - 1] : 0u;
+    for (int c = c0; c < c1; ++c) {
+        const unsigned v = p.cell_cnt[c];
+        p.cell_cnt[c] = run;
+        run += v;
+    }
+    if (t == 1023) p.cell_cnt[n_cells] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void nms_scatter_kernel(NmsParams p) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const unsigned r = p.rank[i];
+    if (r == 0xFFFFFFFFu) return;
+    const mtm_hit h = p.hits[i];
+    const unsigned pos = p.cell_cnt[nms_cell_of(p, h)] + r;
+    p.sorted[pos] = h;
+    p.status[pos] = kNmsUndecided;
+}
+
+// champions: candidates that no earlier candidate overlaps by more than the threshold (one thread per sorted position)
+__global__ __launch_bounds__(256) void nms_champion_kernel(NmsParams p) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.cell_cnt[p.gw * p.gh]) return;
+    const mtm_hit a = p.sorted[i];
+    const int c = nms_cell_of(p, a);
+    bool champion = true;
+    for (int dy = -1; dy <= 1 && champion; ++dy) {
+        // the three cells of a grid row are neighbours in the sorted list too: one run
+        const unsigned j0 = p.cell_cnt[c + dy * p.gw - 1], j1 = p.cell_cnt[c + dy * p.gw + 2];
+        for (unsigned j = j0; j < j1; ++j) {
+            const mtm_hit b = p.sorted[j];
+            if (b.x >= a.x + a.w || a.x >= b.x + b.w || b.y >= a.y + a.h || a.y >= b.y + b.h) continue;     // disjoint (or itself? no:)
+            if (j == i) continue;
+            if (!nms_earlier(b, a, p.ascending)) continue;
+            if (nms_rect_overlap(a, b) <= p.thr_overlap) continue;
+            champion = false;
+            break;
+        }
+    }
+    if (champion) p.status[i] = kNmsKept;
+}
+
+// candidates a champion overlaps are out; everything else (champions and undecided hits) goes to the host's list
+__global__ __launch_bounds__(256) void nms_prune_kernel(NmsParams p) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    mtm_hit a{};
+    if (i < p.cell_cnt[p.gw * p.gh]) {
+        a = p.sorted[i];
+        keep = true;
+        if (p.status[i] != kNmsKept) {
+            const int c = nms_cell_of(p, a);
+            for (int dy = -1; dy <= 1 && keep; ++dy) {
+                const unsigned j0 = p.cell_cnt[c + dy * p.gw - 1], j1 = p.cell_cnt[c + dy * p.gw + 2];
+                for (unsigned j = j0; j < j1; ++j) {
+                    if (p.status[j] != kNmsKept) continue;               // champions only (they precede whatever they overlap)
+                    if (nms_rect_overlap(a, p.sorted[j]) <= p.thr_overlap) continue;
+                    keep = false;
+                    break;
+                }
+            }
+        }
+    }
+    // one slot per surviving hit, taken per wave
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(keep);
+    if (act == 0ull) return;
+    const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(act);
+    unsigned long long base = 0ull;
+    if (lane == leader) base = atomicAdd(p.out_count, (unsigned long long)__popcll(act));
+    const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+    base = ((unsigned long long)bhi << 32) | blo;
+    const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+    if (keep) p.out[base + below] = a;
+}
+
+}  // namespace mtm

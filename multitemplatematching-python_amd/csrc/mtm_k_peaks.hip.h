@@ -258,14 +258,32 @@ __global__ __launch_bounds__(256) void compact_hits_kernel(const mtm_hit* __rest
                                                            mtm_hit* __restrict__ hits, unsigned long long hit_cap,
                                                            unsigned long long* __restrict__ counter) {
     const int z = blockIdx.x;
+    // (every work-group sums the counters itself, 256 at a time: hundreds of lists, one dependent load each otherwise)
+    __shared__ unsigned long long s_off[256], s_tot[256];
+    __shared__ int s_over[256];
     unsigned long long off = 0ull, total = 0ull;
-    bool over = false;
-    for (int i = 0; i < n_lists; ++i) {
+    int over = 0;
+    for (int i = threadIdx.x; i < n_lists; i += 256) {
         const unsigned long long ci = counts_t[i];
         if (i < z) off += min(ci, cap_t);
         total += ci;
-        over = over || ci > cap_t;
+        over |= ci > cap_t ? 1 : 0;
     }
+    s_off[threadIdx.x] = off;
+    s_tot[threadIdx.x] = total;
+    s_over[threadIdx.x] = over;
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step) {
+            s_off[threadIdx.x] += s_off[threadIdx.x + step];
+            s_tot[threadIdx.x] += s_tot[threadIdx.x + step];
+            s_over[threadIdx.x] |= s_over[threadIdx.x + step];
+        }
+        __syncthreads();
+    }
+    off = s_off[0];
+    total = s_tot[0];
+    over = s_over[0];
     if (z == 0 && threadIdx.x == 0) counter[0] = over ? max(total, hit_cap + 1ull) : total;
     const unsigned long long n = min(counts_t[z], cap_t);
     const mtm_hit* src = hits_t + (size_t)z * cap_t;

@@ -4,6 +4,7 @@
 // API the group drives (mtm_ctx_create, mtm_set_templates, mtm_find_matches_image, ...) is replaced by a fake that
 // returns deterministic hits - so the group's threading protocol runs thousands of jobs under the sanitizers.
 // Built and run by tests/test_native_sanitizers_cpu.py.
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -11,9 +12,11 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../multitemplatematching-python_amd/csrc/mtm_internal.h"
+#include "../../multitemplatematching-python_amd/csrc/mtm_nms_core.h"
 
 using namespace mtm;
 
@@ -256,6 +259,44 @@ static void test_host(std::mt19937& rng) {
             const TemplStats b = compute_templ_stats(px.data(), mk.data(), th, tw, tc, method, true);
             CHECK(a.inv_area > 0.0 && b.templ2_mask2_sum >= 0.0);
         }
+    }
+    // the device's NMS is built from two decisions (mtm_nms_core.h): "a precedes b" and "a suppresses b".  Greedy NMS written
+    // with them, over hit lists in the order mtm_find_matches returns (sort_hits), must select what mtm_nms selects - ties in
+    // the transformed score (few distinct scores, several templates), maxima and minima methods, every overlap threshold
+    for (int rep = 0; rep < 200; ++rep) {
+        const int n = 2 + (int)(rng() % 400), asc = rep & 1;
+        std::vector<mtm_hit> hits((size_t)n);
+        for (auto& h : hits) {
+            h.templ_idx = (int)(rng() % 4);
+            h.w = 20 + 10 * (h.templ_idx & 1);
+            h.h = 24;
+            h.x = (int)(rng() % 160);
+            h.y = (int)(rng() % 120);
+            h.score = rep % 3 == 0 ? 0.25f * (float)(rng() % 5) : uf(rng);
+        }
+        // (a pixel is listed once per template)
+        std::sort(hits.begin(), hits.end(), [](const mtm_hit& a, const mtm_hit& b) {
+            return std::tie(a.templ_idx, a.y, a.x) < std::tie(b.templ_idx, b.y, b.x); });
+        hits.erase(std::unique(hits.begin(), hits.end(), [](const mtm_hit& a, const mtm_hit& b) {
+            return a.templ_idx == b.templ_idx && a.y == b.y && a.x == b.x; }), hits.end());
+        sort_hits(hits, asc != 0);
+        const double thr = 0.1 * (double)(rng() % 8), ov = 0.1 * (double)(rng() % 11);
+        std::vector<int32_t> keep(hits.size());
+        int64_t nk = 0;
+        CHECK(mtm_nms(hits.data(), (int64_t)hits.size(), thr, asc, -1, ov, keep.data(), &nk) == MTM_OK);
+        std::vector<int> order;
+        const float thr_s = (float)(asc ? 1.0 - thr : thr);
+        for (int i = 0; i < (int)hits.size(); ++i)
+            if (nms_score(hits[(size_t)i], asc) > thr_s) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return nms_earlier(hits[(size_t)a], hits[(size_t)b], asc); });
+        std::vector<int> kept;
+        for (int i : order) {
+            bool ok = true;
+            for (int k : kept) ok = ok && nms_rect_overlap(hits[(size_t)i], hits[(size_t)k]) <= (float)ov;
+            if (ok) kept.push_back(i);
+        }
+        CHECK((int64_t)kept.size() == nk);
+        for (size_t i = 0; i < kept.size(); ++i) CHECK(kept[i] == keep[i]);
     }
     // byte-run sums (the SSE2 pass over fresh template bytes): exact at every length and alignment, incl. all-255 runs
     // long enough to wrap a 32-bit lane if the block length were wrong

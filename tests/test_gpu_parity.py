@@ -2338,6 +2338,50 @@ def test_sparse_maps_route_equals_the_full_maps_route(mtm):
         cb.close()
 
 
+def test_fused_nms_call_equals_find_then_nms(mtm, monkeypatch):
+    """mtm_find_matches_image_nms (what MTM.matchTemplates calls on the 8-bit path) returns the hits mtm_nms selects from the
+    list mtm_find_matches_image returns, in the same order, bit for bit - on the host route (few hits), and on the device
+    route (dense image under the back-off, the peaks suppressed on the GPU: forced down to short lists here), for maxima
+    and minima methods, several overlap limits, a finite N_object, ties in the score (exact copies score 1.0) and two
+    template sizes (grid cell = the larger box)."""
+    from MTM import _lib
+    rng = np.random.default_rng(5)
+    dense = synth.smooth_u8(23, (300, 640), scales=(3, 9, 27), noise=0.1)
+    sparse = rng.integers(0, 256, dense.shape, dtype=np.uint8)
+    lt = []
+    for i in range(24):
+        h, w = ((24, 32), (30, 20))[i % 2]
+        y, x = int(rng.integers(0, 300 - h)), int(rng.integers(0, 640 - w))
+        lt.append((dense[y:y + h, x:x + w].copy(), None))
+        for _ in range(3):                                           # exact copies: equal scores of 1.0 in both images
+            yy, xx = int(rng.integers(0, 300 - h)), int(rng.integers(0, 640 - w))
+            sparse[yy:yy + h, xx:xx + w] = lt[-1][0]
+    monkeypatch.setenv("MTM_NMS_DEVICE_MIN", "32")
+    c = _lib.Context(0)
+    ref = _lib.Context(0)
+    try:
+        routes = set()
+        for method, thr in ((5, 0.3), (1, 0.55), (3, 0.95)):
+            for img in (sparse, dense, dense, dense):
+                for c_ in (c, ref):
+                    c_.set_option(_lib.OPT_HIT_CAPACITY, 2048 if img is dense else 1 << 18)
+                for overlap, n_obj in ((0.25, -1), (0.0, -1), (0.6, 7), (1.0, -1)):
+                    raw = ref.search(lt, img, method, _lib.PEAKS_LOCAL, thr)
+                    idx = _lib.nms_hits(raw, thr, overlap, ascending=(method == 1))
+                    exp = raw[idx] if n_obj < 0 else raw[idx][:n_obj]
+                    got = c.search_nms(lt, img, method, thr, overlap, n_obj)
+                    tm = c.timing()
+                    routes.add(tm["hits_only"])
+                    assert tm["n_hits"] == len(raw), (method, overlap, tm["n_hits"], len(raw))
+                    assert len(got) == len(exp), (method, overlap, n_obj, len(got), len(exp), len(raw))
+                    assert got.tobytes() == exp.tobytes(), (method, overlap, n_obj)
+        if not any(os.environ.get(v) for v in ("MTM_FUSE_PEAKS", "MTM_KERNEL", "MTM_HITS_ONLY", "MTM_SPARSE_MAPS", "MTM_NMS_DEVICE")):
+            assert 2 in routes and 1 in routes, routes      # the device's suppression ran (flagged-segment route) and the host's
+    finally:
+        c.close()
+        ref.close()
+
+
 def test_dense_maps_candidate_overflow(mtm):
     """Smooth images at a low threshold: far more pixels above the threshold than the candidate list holds.  The
     overflowing hits-only launch leaves early, the call is repeated with the maps in memory and the full peak pass;

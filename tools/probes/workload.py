@@ -3,7 +3,8 @@
     workload.py <name> [calls]
 names: cfg2 cfg3 cfg4 cfg5 (BASELINE configs; cfg4 = its 256 units on one GPU), u16_4k32 / f32_4k32 (4K x 32 templates 64x64 as uint16 / float32 pixels),
 f64_1080p8 (float32 pixels on the float64 kernel, MTM_OPT_F32_MFMA = 0), slab_414 (2048^2 x one 414x400 template: the
-reference's published benchmark shape, slabs on the MFMA kernel), dense_4k32 (photograph-like image: map mode + peak pass)."""
+reference's published benchmark shape, slabs on the MFMA kernel), dense_4k32 (photograph-like image: map mode + peak pass),
+dense_4k32_nms (the same through mtm_find_matches_image_nms)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "multitemplatematching-python_amd"))
@@ -38,9 +39,11 @@ elif name == "slab_414":
     img = synth.smooth_u8(21, (2048, 2048))
     tl = [(np.ascontiguousarray(img[300:700, 500:914]), None)]
     thr = 0.9
-elif name == "dense_4k32":
+elif name in ("dense_4k32", "dense_4k32_nms"):      # (_nms: search + non-maxima suppression in one native call)
     img = synth.smooth_u8(11, (2160, 3840))
     tl = [(u[1], None) for u in synth.cut_templates(5, img, 32, 64)]
+    if name.endswith("_nms"):
+        ctx.search = lambda tl_, img_, method_, mode_, thr_: ctx.search_nms(tl_, img_, method_, thr_, 0.25)
 else:
     sys.exit("unknown workload " + name)
 ctx.search(tl, img, method, mode, thr)          # placement, allocation
