@@ -7,7 +7,7 @@ set -u
 TAG=${1:-rXX}; shift
 R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-NAMES=${*:-cfg2 cfg3 cfg4 cfg5 u16_4k32 f32_4k32 f64_1080p8 slab_414 dense_4k32}
+NAMES=${*:-cfg2 cfg3 cfg4 cfg5 u16_4k32 f32_4k32 f64_1080p8 slab_414 dense_4k32 dense_4k32_nms}
 cd /tmp
 for n in $NAMES; do
   python $R/tools/probes/workload.py $n 2>/dev/null | tail -1 > $OUT/wl_${n}.json
