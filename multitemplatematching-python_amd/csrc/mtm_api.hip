@@ -631,6 +631,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
             c->hit_cap = (int64_t)count + 1024;     // grow and rerun the compaction pass
             use_fused = false;
+            // (the per-segment lists of the flagged route are bounded in total: if growing did not help, the full scan with
+            // its single list takes over - the maps are complete)
+            if (c->sparse_now && attempt >= 1) c->sparse_now = false;
         }
         if (n2d == 0) {
             HIPC(hipEventRecord(c->ev[2], c->stream));

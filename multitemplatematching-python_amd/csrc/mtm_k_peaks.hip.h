@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void compact_hits_kernel(const mtm_hit* __rest
     for (int i = threadIdx.x; i < n_lists; i += 256) {
         const unsigned long long ci = counts_t[i];
         if (i < z) off += min(ci, cap_t);
-        total += ci;
+        // (a list that overflowed counts 8 times - the lists are an eighth of the capacity the host then grows)
+        total += ci > cap_t ? 8ull * ci : ci;
         over |= ci > cap_t ? 1 : 0;
     }
     s_off[threadIdx.x] = off;

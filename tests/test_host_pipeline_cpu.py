@@ -97,6 +97,41 @@ def test_pipeline_against_reference_runs(mtm):
         mtm.matchTemplates([("small", small)], coins, method=0)
 
 
+def test_fused_search_and_nms_entry_is_used_and_equivalent(mtm, monkeypatch):
+    """matchTemplates hands the non-maxima suppression to the engine where the engine offers `search_nms` (one native call:
+    mtm_find_matches_image_nms) - for every N_object but 1, never for TM_SQDIFF, never for the general (non 8-bit) path -
+    and returns what the two-step route returns.  The stand-in's search_nms is search + the library's host NMS (mtm_nms)."""
+    from MTM import _lib
+    calls = []
+
+    class FusedContext(OracleContext):
+        def search_nms(self, templates, image, method, thr, max_overlap, n_object=-1):
+            calls.append((method, n_object))
+            raw = self.search(templates, image, method, 0, thr)
+            if len(raw) <= 1:                                   # MTM/NMS.py:53-55
+                return raw
+            idx = _lib.nms_hits(raw, thr, max_overlap, ascending=(method == 1))
+            return raw[idx] if n_object < 0 else raw[idx][:n_object]
+
+    coins = load_coins()
+    small, big = coin_templates(coins)
+    lt = [("small", small), ("big", big)]
+    cases = [dict(score_threshold=0.3, method=5, maxOverlap=0.25), dict(score_threshold=0.3, method=5, maxOverlap=0.0, N_object=3),
+             dict(method=1, score_threshold=0.2, maxOverlap=0.1), dict(score_threshold=0.5, maxOverlap=0, searchBox=(10, 20, 300, 200)),
+             dict(score_threshold=0.3, method=3, maxOverlap=0.3, N_object=0), dict(score_threshold=0.99, method=5)]
+    two_step = [mtm.matchTemplates(lt, coins, **kw) for kw in cases]
+    best = mtm.matchTemplates(lt, coins, method=5, N_object=1)
+    monkeypatch.setattr(mtm._lib, "_default_ctx", FusedContext(mtm._lib.HIT_DTYPE))
+    assert [mtm.matchTemplates(lt, coins, **kw) for kw in cases] == two_step
+    assert calls == [(5, -1), (5, 3), (1, -1), (5, -1), (3, 0), (5, -1)]
+    assert mtm.matchTemplates(lt, coins, method=5, N_object=1) == best and len(calls) == 6           # the global extremum: search()
+    with pytest.raises(ValueError, match="TM_SQDIFF is not supported"):
+        mtm.matchTemplates(lt, coins, method=0)
+    assert len(calls) == 6
+    img_f = coins.astype(np.float32)                                                                # general path: per-dtype groups, two steps
+    assert mtm.matchTemplates([("s", small.astype(np.float32))], img_f, score_threshold=0.5) and len(calls) == 6
+
+
 def test_mixed_dtype_units_are_grouped(mtm):
     """The pixel policy is per template (MTM/__init__.py:71): a float32 template next to a uint8
     one is matched in float32 against the float32 image, the uint8 one stays 8-bit."""
