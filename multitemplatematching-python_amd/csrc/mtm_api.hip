@@ -285,8 +285,10 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
 }
 
 // The device's share of the non-maxima suppression of the `count` peaks at `dhits` (mtm_k_nms.hip.h): the hits a
-// neighbourhood's best hit suppresses stay on the device; the rest (any order) lands in `rest` for the host's pass.
-int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, bool ascending, std::vector<mtm_hit>& rest) {
+// neighbourhood's best hit suppresses stay on the device; the rest lands in `rest` for the host's pass - first the *n_sure
+// hits that are certainly kept (nothing earlier overlaps them), then the undecided ones, each part in any order.
+int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, bool ascending, std::vector<mtm_hit>& rest,
+                   long long* n_sure) {
     int cell = 1;
     for (const TemplDev& d : c->td_host) cell = std::max(cell, std::max(d.rows, d.cols));
     NmsParams p{};
@@ -322,25 +324,24 @@ int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, b
     hipLaunchKernelGGL(nms_prune_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(c->ev[2], c->stream));
-    // the count and - optimistically - the first records in one copy
-    const size_t first = std::min<size_t>(4096, (size_t)count);
-    std::vector<uint8_t> land(256 + sizeof(mtm_hit) * first);
-    HIPC(hipMemcpyAsync(land.data(), b + off_hdr, land.size(), hipMemcpyDeviceToHost, c->stream));
+    // the two counts, then the champions (front of `out`) and the undecided hits (its back)
+    unsigned long long cnt[2] = {0ull, 0ull};
+    HIPC(hipMemcpyAsync(cnt, b + off_hdr, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    unsigned long long n_rest = 0;
-    std::memcpy(&n_rest, land.data(), sizeof(n_rest));
-    if (n_rest > count) {
+    if (cnt[0] + cnt[1] > count) {
         set_error("mtm_find_matches_image_nms: internal state (pruned list longer than the peak list)");
         return MTM_E_STATE;
     }
-    rest.resize((size_t)n_rest);
-    const size_t got = std::min<size_t>((size_t)n_rest, first);
-    if (got) std::memcpy(rest.data(), land.data() + 256, sizeof(mtm_hit) * got);
-    if (n_rest > got) {
-        HIPC(hipMemcpyAsync(rest.data() + got, p.out + got, sizeof(mtm_hit) * ((size_t)n_rest - got), hipMemcpyDeviceToHost,
+    if (c->host_trace && c->trace_calls <= 12)
+        std::fprintf(stderr, "[mtm host trace] device NMS: %llu peaks -> %llu champions + %llu for the host's pass\n", count, cnt[0],
+                     cnt[1]);
+    rest.resize((size_t)(cnt[0] + cnt[1]));
+    if (cnt[0]) HIPC(hipMemcpyAsync(rest.data(), p.out, sizeof(mtm_hit) * (size_t)cnt[0], hipMemcpyDeviceToHost, c->stream));
+    if (cnt[1])
+        HIPC(hipMemcpyAsync(rest.data() + cnt[0], p.out + (count - cnt[1]), sizeof(mtm_hit) * (size_t)cnt[1], hipMemcpyDeviceToHost,
                             c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
-    }
+    HIPC(hipStreamSynchronize(c->stream));
+    *n_sure = (long long)cnt[0];
     return MTM_OK;
 }
 
@@ -614,7 +615,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                         trivial = trivial || ((f & 0xFFu) == 0 && !((f & 0xFF00u) != 0 && (f & 0xFF0000u) != 0));
                     }
                     if (!trivial) {
-                        MTMC(run_device_nms(c, dhits, count, mode_min, hits));
+                        MTMC(run_device_nms(c, dhits, count, mode_min, hits, &c->nms_sure));
                         c->nms_raw_count = (long long)count;
                         break;
                     }
@@ -686,16 +687,16 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         host_trace(c, 11);
         // (the device may have pruned the list already - run_device_nms -: the count of peaks is the one before that)
         const int64_t n_raw = c->nms_raw_count >= 0 ? (int64_t)c->nms_raw_count : (int64_t)hits.size();
-        sort_hits(hits, mode_min);
-        if (c->nms_req.on && n_raw > 1) {               // MTM.NMS through mtm_nms (a list of one hit is returned as it is:
-            std::vector<float> scores(hits.size());     // MTM/NMS.py:53-55)
-            for (size_t i = 0; i < hits.size(); ++i) scores[i] = mode_min ? (1.0f - hits[i].score) : hits[i].score;
+        if (c->nms_req.on && n_raw > 1) {               // MTM.NMS (a list of one hit is returned as it is: MTM/NMS.py:53-55)
             const float thr_s = (float)(mode_min ? (1.0 - c->nms_req.score_threshold) : c->nms_req.score_threshold);
             std::vector<int32_t> keep;
-            nms_boxes(hits.data(), (int64_t)hits.size(), scores.data(), thr_s, (float)c->nms_req.max_overlap, keep);
+            nms_select(hits.data(), (int64_t)hits.size(), mode_min ? 1 : 0, thr_s, (float)c->nms_req.max_overlap, keep,
+                       c->nms_raw_count >= 0 ? c->nms_sure : 0);
             std::vector<mtm_hit> kept(keep.size());
             for (size_t i = 0; i < keep.size(); ++i) kept[i] = hits[(size_t)keep[i]];
             hits.swap(kept);
+        } else {
+            sort_hits(hits, mode_min);
         }
         if (c->nms_req.on && c->nms_req.n_object >= 0 && (long long)hits.size() > c->nms_req.n_object)
             hits.resize((size_t)c->nms_req.n_object);          // MTM/NMS.py:81-82
@@ -709,6 +710,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     MTMC(collect_ncc_time(c));
     if (mode != MTM_PEAKS_LOCAL || !c->nms_req.on) c->timing.n_hits = (int64_t)hits.size();
     c->nms_raw_count = -1;
+    c->nms_sure = 0;
     c->timing.hits_only = c->sparse_now ? 2 : c->hits_only_now ? 1 : 0;
     c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
     c->maps_valid = !c->hits_only_now && !c->ext_now;

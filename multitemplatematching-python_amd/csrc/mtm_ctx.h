@@ -208,6 +208,7 @@ struct mtm_ctx {
         long long n_object = -1;
     } nms_req;
     long long nms_raw_count = -1;           // >= 0: the device pruned this call's peak list; the count before that
+    long long nms_sure = 0;                 // ... and its first nms_sure hits are kept for certain (the neighbourhoods' best)
     int nms_device = 1;
     long long nms_device_min = 4096;        // fewer peaks than this: the host is as fast
     DevBuf nms_buf;

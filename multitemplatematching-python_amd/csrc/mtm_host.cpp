@@ -12,6 +12,7 @@
 #endif
 
 #include "mtm_internal.h"
+#include "mtm_nms_core.h"
 
 namespace mtm {
 
@@ -260,6 +261,9 @@ void sort_hits(std::vector<mtm_hit>& hits, bool mode_min) {
     hits.swap(out);
 }
 
+static void nms_greedy(const mtm_hit* hits, const std::vector<int32_t>& cand, float nms_threshold, std::vector<int32_t>& keep,
+                       int64_t n_sure = 0);
+
 void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_threshold,
                float nms_threshold, std::vector<int32_t>& keep) {
     std::vector<int32_t> cand;
@@ -283,6 +287,37 @@ void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_
         std::stable_sort(cand.begin(), cand.end(),
                          [&](int32_t a, int32_t b) { return scores[a] > scores[b]; });
     }
+    nms_greedy(hits, cand, nms_threshold, keep);
+}
+
+// MTM's NMS on a hit list in ANY order (mtm_find_matches_image_nms): what nms_boxes selects from the list in the order
+// mtm_find_matches returns, without producing that order first - one radix sort by the transformed score, and only runs of
+// equal scores (exact copies at 1.0) are put into the order they would arrive in (mtm_nms_core.h: nms_earlier).
+void nms_select(const mtm_hit* hits, int64_t n, int ascending, float score_threshold, float nms_threshold,
+                std::vector<int32_t>& keep, int64_t n_sure) {
+    std::vector<ScoreRec> rec;
+    rec.reserve((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const float s = nms_score(hits[i], ascending);
+        if (s > score_threshold) rec.push_back(ScoreRec{~float_order(s), (uint32_t)i});      // (false for NaN)
+    }
+    if (rec.size() >= 64) radix_sort<ScoreRec, 4>(rec);
+    else std::sort(rec.begin(), rec.end(), [](const ScoreRec& a, const ScoreRec& b) { return a.key < b.key; });
+    for (size_t a = 0; a < rec.size();) {
+        size_t b = a + 1;
+        while (b < rec.size() && rec[b].key == rec[a].key) ++b;
+        if (b - a > 1)
+            std::sort(rec.begin() + (long)a, rec.begin() + (long)b,
+                      [&](const ScoreRec& p, const ScoreRec& q) { return nms_earlier(hits[p.idx], hits[q.idx], ascending); });
+        a = b;
+    }
+    std::vector<int32_t> cand(rec.size());
+    for (size_t k = 0; k < rec.size(); ++k) cand[k] = (int32_t)rec[k].idx;
+    nms_greedy(hits, cand, nms_threshold, keep, n_sure);
+}
+
+static void nms_greedy(const mtm_hit* hits, const std::vector<int32_t>& cand, float nms_threshold, std::vector<int32_t>& keep,
+                       int64_t n_sure) {
     keep.clear();
 
     // Same greedy decisions as OpenCV's NMSFast_ (a candidate is kept iff its overlap with EVERY kept
@@ -359,7 +394,7 @@ void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_
         const int bx2 = b.x + b.w, by2 = b.y + b.h;
         const double barea = (double)((long long)b.w * b.h);
         bool ok = true;
-        for (int o = 0; o < 9 && ok; ++o)
+        for (int o = 0; o < 9 && ok && idx >= n_sure; ++o)       // (idx < n_sure: kept for certain, straight into the grid)
             for (int32_t k = head[(size_t)((cy + kOrder[o][0]) * gw + cx + kOrder[o][1])]; k >= 0; k = kb[(size_t)k].next) {
                 const Kept& q = kb[(size_t)k];
                 const int iw = std::min(bx2, q.x2) - std::max(b.x, q.x);

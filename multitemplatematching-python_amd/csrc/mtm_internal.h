@@ -43,6 +43,11 @@ std::vector<int> find_peaks_1d(const float* x, int n, int stride, float height, 
 void nms_boxes(const mtm_hit* hits, int64_t n, const float* scores, float score_threshold,
                float nms_threshold, std::vector<int32_t>& keep);
 
+// the same selection from a list in any order, returned in NMSBoxes' order (score ties as mtm_find_matches' order resolves them)
+// (`n_sure`: the first n_sure hits are known to be kept - no earlier hit overlaps them beyond the threshold -: they are not tested)
+void nms_select(const mtm_hit* hits, int64_t n, int ascending, float score_threshold, float nms_threshold,
+                std::vector<int32_t>& keep, int64_t n_sure = 0);
+
 // The order in which mtm_find_matches returns its records: template, then descending quality (score, or -score for the
 // difference methods), then row-major position.  Deterministic whatever order the GPU appended them in; thousands
 // of records (smooth images at a low threshold) are sorted by an LSD radix sort on the same key.

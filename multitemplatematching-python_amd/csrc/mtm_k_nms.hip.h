@@ -30,8 +30,8 @@ struct NmsParams {
     unsigned* rank;          // n: position inside its cell (0xFFFFFFFF: not a candidate)
     mtm_hit* sorted;         // n_cand records, cell by cell
     int* status;             // per sorted position: 0 undecided, 1 champion (kept)
-    mtm_hit* out;            // the hits the host still has to decide about, champions included (any order)
-    unsigned long long* out_count;
+    mtm_hit* out;            // n slots: champions from the front, the hits the host still has to decide about from the back
+    unsigned long long* out_count;     // [champions, undecided]
 };
 
 constexpr int kNmsUndecided = 0, kNmsKept = 1;
@@ -128,16 +128,22 @@ __global__ __launch_bounds__(256) void nms_prune_kernel(NmsParams p) {
             }
         }
     }
-    // one slot per surviving hit, taken per wave
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(keep);
-    if (act == 0ull) return;
-    const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(act);
-    unsigned long long base = 0ull;
-    if (lane == leader) base = atomicAdd(p.out_count, (unsigned long long)__popcll(act));
-    const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
-    base = ((unsigned long long)bhi << 32) | blo;
-    const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-    if (keep) p.out[base + below] = a;
+    // one slot per surviving hit, taken per wave: champions from the front of `out`, undecided hits from its back (the host
+    // inserts the champions into its grid without testing them)
+    const bool champ = keep && p.status[min(i, p.n - 1)] == kNmsKept;
+    const int lane = threadIdx.x & 63;
+    for (int side = 0; side < 2; ++side) {
+        const bool mine = keep && (side == 0 ? champ : !champ);
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(mine);
+        if (act == 0ull) continue;
+        const int leader = (int)__builtin_ctzll(act);
+        unsigned long long base = 0ull;
+        if (lane == leader) base = atomicAdd(p.out_count + side, (unsigned long long)__popcll(act));
+        const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+        base = ((unsigned long long)bhi << 32) | blo;
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+        if (mine) p.out[side == 0 ? base + below : (unsigned long long)p.n - 1ull - (base + below)] = a;
+    }
 }
 
 }  // namespace mtm

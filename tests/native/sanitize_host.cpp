@@ -297,6 +297,43 @@ static void test_host(std::mt19937& rng) {
         }
         CHECK((int64_t)kept.size() == nk);
         for (size_t i = 0; i < kept.size(); ++i) CHECK(kept[i] == keep[i]);
+        // nms_select (mtm_find_matches_image_nms): the same hits in the same order from the list in ANY order
+        std::vector<mtm_hit> shuffled = hits;
+        std::shuffle(shuffled.begin(), shuffled.end(), rng);
+        std::vector<int32_t> sel;
+        nms_select(shuffled.data(), (int64_t)shuffled.size(), asc, thr_s, (float)ov, sel);
+        CHECK((int64_t)sel.size() == nk);
+        for (size_t i = 0; i < sel.size(); ++i)
+            CHECK(std::memcmp(&shuffled[(size_t)sel[i]], &hits[(size_t)keep[i]], sizeof(mtm_hit)) == 0);
+        // ... and what the device does first (mtm_k_nms.hip.h): "champions" - candidates no earlier candidate overlaps
+        // beyond the limit - are kept for certain, what a champion overlaps beyond the limit is dropped; the selection from
+        // [champions | undecided rest], champions untested, is the same again
+        std::vector<mtm_hit> champs, rest;
+        std::vector<char> is_champ(hits.size(), 0), doomed(hits.size(), 0);
+        for (int i : order) {
+            bool c = true;
+            for (int k : order) {
+                if (k == i) break;                              // `order` is sorted: everything before i is earlier
+                if (nms_rect_overlap(hits[(size_t)i], hits[(size_t)k]) > (float)ov) { c = false; break; }
+            }
+            is_champ[(size_t)i] = c;
+        }
+        for (int i : order)
+            for (int k : order)
+                if (is_champ[(size_t)k] && k != i && nms_rect_overlap(hits[(size_t)i], hits[(size_t)k]) > (float)ov) doomed[(size_t)i] = 1;
+        for (int i : order) {
+            if (is_champ[(size_t)i]) champs.push_back(hits[(size_t)i]);
+            else if (!doomed[(size_t)i]) rest.push_back(hits[(size_t)i]);
+        }
+        if (ov >= 0.0) {
+            std::vector<mtm_hit> pruned = champs;
+            std::shuffle(rest.begin(), rest.end(), rng);
+            pruned.insert(pruned.end(), rest.begin(), rest.end());
+            nms_select(pruned.data(), (int64_t)pruned.size(), asc, thr_s, (float)ov, sel, (int64_t)champs.size());
+            CHECK((int64_t)sel.size() == nk);
+            for (size_t i = 0; i < sel.size(); ++i)
+                CHECK(std::memcmp(&pruned[(size_t)sel[i]], &hits[(size_t)keep[i]], sizeof(mtm_hit)) == 0);
+        }
     }
     // byte-run sums (the SSE2 pass over fresh template bytes): exact at every length and alignment, incl. all-255 runs
     // long enough to wrap a 32-bit lane if the block length were wrong
