@@ -2275,6 +2275,8 @@ def test_sparse_maps_route_equals_the_full_maps_route(mtm):
             y, x = int(rng.integers(0, img.shape[0] - h)), int(rng.integers(0, img.shape[1] - w))
             out.append((np.ascontiguousarray(img[y:y + h, x:x + w]), None))
         return out
+    yy, xx = np.mgrid[0:24, 0:32]
+    disc = (((yy - 11.5) / 12.0) ** 2 + ((xx - 15.5) / 16.0) ** 2 <= 1.0).astype(np.uint8) * 255
     cases = [
         ("ccoeff_normed", dense, templates(dense, [(24, 32)], 20), 5, 0.3),
         ("two classes", dense, templates(dense, [(24, 32), (17, 40)], 40), 5, 0.35),
@@ -2283,6 +2285,8 @@ def test_sparse_maps_route_equals_the_full_maps_route(mtm):
         ("sqdiff_normed (minima)", dense, templates(dense, [(24, 32)], 20), 1, 0.6),
         ("ccorr_normed", dense, templates(dense, [(24, 32)], 20), 3, 0.97),
         ("rgb", dense_rgb, templates(dense_rgb, [(24, 32)], 20), 5, 0.3),
+        ("masked ccorr_normed (20 templates, one disc mask)", dense, [(t, disc) for t, _ in templates(dense, [(24, 32)], 20)], 3, 0.97),
+        ("masked sqdiff_normed (3 templates)", dense, [(t, disc) for t, _ in templates(dense, [(24, 32)], 3)], 1, 0.5),
         ("nothing passes", dense, templates(dense, [(24, 32)], 20), 5, 1.5),
         ("negative threshold", dense, templates(dense, [(24, 32)], 20), 5, -0.5),
         ("constant image", flat, templates(dense, [(24, 32)], 20), 5, -0.5),
