@@ -28,6 +28,7 @@ SOURCES = ["mtm_context.hip", "mtm_placement.hip", "mtm_launch.hip", "mtm_api.hi
 HEADERS = ["mtm_ctx.h", "mtm_k_image.hip.h", "mtm_k_stats.hip.h", "mtm_k_score.hip.h", "mtm_k_peaks.hip.h", "mtm_score_params.h",
            "mtm_templates_params.h", "mtm_device_util.hip.h", "mtm_mfma.hip.h", "mtm_mfma_params.h", "mtm_templates.hip.h",
            "mtm_bf16.hip.h", "mtm_bf16_params.h", "mtm_refine.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
+           "mtm_k_nms.hip.h", "mtm_nms_core.h",
            os.path.join("..", "..", "include", "mtm_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default"]
