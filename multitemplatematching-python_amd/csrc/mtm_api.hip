@@ -284,16 +284,26 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     return MTM_OK;
 }
 
-// The device's share of the non-maxima suppression of the `count` peaks at `dhits` (mtm_k_nms.hip.h): the hits a
-// neighbourhood's best hit suppresses stay on the device; the rest lands in `rest` for the host's pass - first the *n_sure
-// hits that are certainly kept (nothing earlier overlaps them), then the undecided ones, each part in any order.
-int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, bool ascending, std::vector<mtm_hit>& rest,
-                   long long* n_sure) {
+// The device's share of the non-maxima suppression (mtm_k_nms.hip.h), queued right behind the peak pass: the length of the
+// peak list at `dhits` is still on the device (`dcount`), the launches read it there and do nothing unless it lies in
+// [nms_device_min, n_max].  What a neighbourhood's best hit suppresses stays on the device; fetch_device_nms() brings the
+// rest: first the hits that are certainly kept (nothing earlier overlaps them), then the undecided ones.
+struct DeviceNms {
+    bool queued = false;
+    unsigned n_max = 0;
+    unsigned long long cnt[2] = {0ull, 0ull};      // landing buffer of the two counters (champions, undecided)
+    const mtm_hit* out = nullptr;
+};
+
+int queue_device_nms(mtm_ctx* c, const mtm_hit* dhits, const unsigned long long* dcount, bool ascending, DeviceNms* q) {
     int cell = 1;
     for (const TemplDev& d : c->td_host) cell = std::max(cell, std::max(d.rows, d.cols));
+    const size_t n_max = (size_t)std::min<int64_t>(c->hit_cap, 1ll << 18);
     NmsParams p{};
     p.hits = dhits;
-    p.n = (unsigned)count;
+    p.n_ptr = dcount;
+    p.n_min = (unsigned)std::min<long long>(c->nms_device_min, 1ll << 30);
+    p.n_max = (unsigned)n_max;
     p.ascending = ascending ? 1 : 0;
     // MTM/NMS.py:73-78: the scores are float32 (1 - score for the difference methods), the threshold a python float
     // transformed in double and narrowed by the cv2 binding
@@ -303,10 +313,10 @@ int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, b
     p.gw = c->cols / cell + 3;
     p.gh = c->rows / cell + 3;
     const size_t n_cells = (size_t)p.gw * p.gh;
-    const size_t off_rank = round_up(sizeof(unsigned) * (n_cells + 1), 256), off_status = off_rank + round_up(sizeof(unsigned) * count, 256);
-    const size_t off_sorted = off_status + round_up(sizeof(int) * count, 256);
-    const size_t off_hdr = off_sorted + round_up(sizeof(mtm_hit) * count, 256), off_out = off_hdr + 256;
-    MTMC(c->nms_buf.ensure(off_out + sizeof(mtm_hit) * count));
+    const size_t off_rank = round_up(sizeof(unsigned) * (n_cells + 1), 256), off_status = off_rank + round_up(sizeof(unsigned) * n_max, 256);
+    const size_t off_sorted = off_status + round_up(sizeof(int) * n_max, 256);
+    const size_t off_hdr = off_sorted + round_up(sizeof(mtm_hit) * n_max, 256), off_out = off_hdr + 256;
+    MTMC(c->nms_buf.ensure(off_out + sizeof(mtm_hit) * n_max));
     uint8_t* b = c->nms_buf.as<uint8_t>();
     p.cell_cnt = reinterpret_cast<unsigned*>(b);
     p.rank = reinterpret_cast<unsigned*>(b + off_rank);
@@ -316,32 +326,36 @@ int run_device_nms(mtm_ctx* c, const mtm_hit* dhits, unsigned long long count, b
     p.out = reinterpret_cast<mtm_hit*>(b + off_out);
     HIPC(hipMemsetAsync(p.cell_cnt, 0, sizeof(unsigned) * (n_cells + 1), c->stream));
     HIPC(hipMemsetAsync(b + off_hdr, 0, 16, c->stream));
-    const unsigned blocks = (unsigned)((count + 255) / 256);
+    const unsigned blocks = (unsigned)((n_max + 255) / 256);
     hipLaunchKernelGGL(nms_count_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(nms_offsets_kernel, dim3(1), dim3(1024), 0, c->stream, p);
     hipLaunchKernelGGL(nms_scatter_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(nms_champion_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(nms_prune_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     HIPC(hipGetLastError());
-    HIPC(hipEventRecord(c->ev[2], c->stream));
-    // the two counts, then the champions (front of `out`) and the undecided hits (its back)
-    unsigned long long cnt[2] = {0ull, 0ull};
-    HIPC(hipMemcpyAsync(cnt, b + off_hdr, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    if (cnt[0] + cnt[1] > count) {
+    HIPC(hipMemcpyAsync(q->cnt, b + off_hdr, sizeof(q->cnt), hipMemcpyDeviceToHost, c->stream));
+    q->queued = true;
+    q->n_max = (unsigned)n_max;
+    q->out = p.out;
+    return MTM_OK;
+}
+
+// after the stream was synchronised (q.cnt has landed): the pruned list of `count` peaks -> `rest`, *n_sure = champions
+int fetch_device_nms(mtm_ctx* c, const DeviceNms& q, unsigned long long count, std::vector<mtm_hit>& rest, long long* n_sure) {
+    if (q.cnt[0] + q.cnt[1] > count) {
         set_error("mtm_find_matches_image_nms: internal state (pruned list longer than the peak list)");
         return MTM_E_STATE;
     }
     if (c->host_trace && c->trace_calls <= 12)
-        std::fprintf(stderr, "[mtm host trace] device NMS: %llu peaks -> %llu champions + %llu for the host's pass\n", count, cnt[0],
-                     cnt[1]);
-    rest.resize((size_t)(cnt[0] + cnt[1]));
-    if (cnt[0]) HIPC(hipMemcpyAsync(rest.data(), p.out, sizeof(mtm_hit) * (size_t)cnt[0], hipMemcpyDeviceToHost, c->stream));
-    if (cnt[1])
-        HIPC(hipMemcpyAsync(rest.data() + cnt[0], p.out + (count - cnt[1]), sizeof(mtm_hit) * (size_t)cnt[1], hipMemcpyDeviceToHost,
-                            c->stream));
+        std::fprintf(stderr, "[mtm host trace] device NMS: %llu peaks -> %llu champions + %llu for the host's pass\n", count,
+                     q.cnt[0], q.cnt[1]);
+    rest.resize((size_t)(q.cnt[0] + q.cnt[1]));
+    if (q.cnt[0]) HIPC(hipMemcpyAsync(rest.data(), q.out, sizeof(mtm_hit) * (size_t)q.cnt[0], hipMemcpyDeviceToHost, c->stream));
+    if (q.cnt[1])
+        HIPC(hipMemcpyAsync(rest.data() + q.cnt[0], q.out + (count - q.cnt[1]), sizeof(mtm_hit) * (size_t)q.cnt[1],
+                            hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    *n_sure = (long long)cnt[0];
+    *n_sure = (long long)q.cnt[0];
     return MTM_OK;
 }
 
@@ -493,7 +507,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         if (!verified_on_host && c->hits_only_now)
             HIPC(hipMemsetAsync(c->chash.p, 0, ((size_t)hash_mask + 1) * sizeof(unsigned long long), c->stream));
         if (pp_mode) use_fused = true;          // the potential peaks are in the candidate buffer, their neighbourhoods in the maps
+        DeviceNms dnms;                 // (the device's share of a suppression request, queued behind the flagged-segment peak pass)
         for (int attempt = 0; attempt < 5 && n2d > 0 && !verified_on_host; ++attempt) {
+            dnms.queued = false;
             MTMC(c->hits.ensure(hdr_bytes + sizeof(mtm_hit) * (size_t)c->hit_cap));
             uint8_t* dbase = c->hits.as<uint8_t>();
             HIPC(hipMemsetAsync(dbase, 0, hdr_bytes, c->stream));
@@ -546,6 +562,10 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                                        c->flag_tstride, c->flag_rstride);
                     hipLaunchKernelGGL(compact_hits_kernel, dim3((unsigned)n_lists), dim3(256), 0, c->stream, hits_t, cap_t, counts_t,
                                        (int)n_lists, dhits, (unsigned long long)c->hit_cap, counter);
+                    // a suppression request: its device share follows at once (it reads the list's length on the device)
+                    dnms = DeviceNms{};
+                    if (c->nms_req.on && c->nms_device && c->nms_req.max_overlap >= 0.0)
+                        MTMC(queue_device_nms(c, dhits, counter, mode_min, &dnms));
                 } else
                     hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
                                        c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
@@ -607,15 +627,14 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             if (use_fused && !pp_mode && !c->cand_rowmax_now) c->backoff_len = 16;     // the candidates fitted
             if ((int64_t)count <= c->hit_cap) {
                 // thousands of peaks and a suppression request: decide on the device, fetch the kept ones
-                if (c->nms_req.on && c->nms_device && c->sparse_now && !use_fused && (long long)count >= c->nms_device_min &&
-                    count <= (1ull << 18) && c->nms_req.max_overlap >= 0.0) {
+                if (dnms.queued && c->sparse_now && !use_fused && (long long)count >= c->nms_device_min && count <= dnms.n_max) {
                     bool trivial = false;       // (a map every pixel of which equals its local maximum loses its peaks below)
                     for (int t : c->list2d) {
                         const unsigned f = (unsigned)tflags[(size_t)t];
                         trivial = trivial || ((f & 0xFFu) == 0 && !((f & 0xFF00u) != 0 && (f & 0xFF0000u) != 0));
                     }
                     if (!trivial) {
-                        MTMC(run_device_nms(c, dhits, count, mode_min, hits, &c->nms_sure));
+                        MTMC(fetch_device_nms(c, dnms, count, hits, &c->nms_sure));
                         c->nms_raw_count = (long long)count;
                         break;
                     }

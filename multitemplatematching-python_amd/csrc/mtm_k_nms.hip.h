@@ -19,7 +19,11 @@ namespace mtm {
 
 struct NmsParams {
     const mtm_hit* hits;     // the peak list (device), any order
-    unsigned n;
+    // its length lives on the device (the peak pass's counter): the launches are queued right behind that pass, without a
+    // round trip to the host in between (118 us of idle GPU in the timeline of a dense call), and do nothing unless
+    // n_min <= *n_ptr <= n_max
+    const unsigned long long* n_ptr;
+    unsigned n_min, n_max;
     int ascending;           // difference methods: scores become 1 - score
     float thr_score;         // NMSBoxes score_threshold (already transformed)
     float thr_overlap;       // NMSBoxes nms_threshold (>= 0)
@@ -36,6 +40,11 @@ struct NmsParams {
 
 constexpr int kNmsUndecided = 0, kNmsKept = 1;
 
+__device__ __forceinline__ unsigned nms_n(const NmsParams& p) {
+    const unsigned long long c = *p.n_ptr;
+    return (c < (unsigned long long)p.n_min || c > (unsigned long long)p.n_max) ? 0u : (unsigned)c;
+}
+
 __device__ __forceinline__ int nms_cell_of(const NmsParams& p, const mtm_hit& h) {
     const int cx = min(max(h.x / p.cell, 0), p.gw - 3) + 1, cy = min(max(h.y / p.cell, 0), p.gh - 3) + 1;
     return cy * p.gw + cx;
@@ -43,7 +52,7 @@ __device__ __forceinline__ int nms_cell_of(const NmsParams& p, const mtm_hit& h)
 
 __global__ __launch_bounds__(256) void nms_count_kernel(NmsParams p) {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
+    if (i >= nms_n(p)) return;
     const mtm_hit h = p.hits[i];
     const bool cand = nms_score(h, p.ascending) > p.thr_score;          // (false for NaN)
     p.rank[i] = cand ? atomicAdd(&p.cell_cnt[nms_cell_of(p, h)], 1u) : 0xFFFFFFFFu;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(1024) void nms_offsets_kernel(NmsParams p) {
 
 __global__ __launch_bounds__(256) void nms_scatter_kernel(NmsParams p) {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n) return;
+    if (i >= nms_n(p)) return;
     const unsigned r = p.rank[i];
     if (r == 0xFFFFFFFFu) return;
     const mtm_hit h = p.hits[i];
@@ -130,7 +139,8 @@ __global__ __launch_bounds__(256) void nms_prune_kernel(NmsParams p) {
     }
     // one slot per surviving hit, taken per wave: champions from the front of `out`, undecided hits from its back (the host
     // inserts the champions into its grid without testing them)
-    const bool champ = keep && p.status[min(i, p.n - 1)] == kNmsKept;
+    const unsigned n = nms_n(p);
+    const bool champ = keep && p.status[i] == kNmsKept;               // (keep implies i < candidates <= n)
     const int lane = threadIdx.x & 63;
     for (int side = 0; side < 2; ++side) {
         const bool mine = keep && (side == 0 ? champ : !champ);
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void nms_prune_kernel(NmsParams p) {
         const uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader), bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
         base = ((unsigned long long)bhi << 32) | blo;
         const unsigned below = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-        if (mine) p.out[side == 0 ? base + below : (unsigned long long)p.n - 1ull - (base + below)] = a;
+        if (mine) p.out[side == 0 ? base + below : (unsigned long long)n - 1ull - (base + below)] = a;
     }
 }
 
