@@ -704,7 +704,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         }
         // deterministic order: template, then descending quality, then row-major position
         host_trace(c, 11);
-        // (the device may have pruned the list already - run_device_nms -: the count of peaks is the one before that)
+        // (the device may have pruned the list already - queue_device_nms / fetch_device_nms -: the count of peaks is the one before that)
         const int64_t n_raw = c->nms_raw_count >= 0 ? (int64_t)c->nms_raw_count : (int64_t)hits.size();
         if (c->nms_req.on && n_raw > 1) {               // MTM.NMS (a list of one hit is returned as it is: MTM/NMS.py:53-55)
             const float thr_s = (float)(mode_min ? (1.0 - c->nms_req.score_threshold) : c->nms_req.score_threshold);
