@@ -226,6 +226,36 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         MTMC(c->chash.ensure(hsz * (sizeof(unsigned long long) + sizeof(int))));
     }
 
+    // The landing buffer of the candidate list (pinned).  Round 5: when every class of the call runs ncc_mfma_kernel's own
+    // epilogue, the waves that fill the first slots of the list write them there as well (MfmaParams::cand_pin) and the
+    // host finds them when the last score launch has ended - no fetch kernel (or copy command) with its kernel boundary
+    // behind the score pass.  The window starts out as "no record" (template index -1) in every slot.
+    c->cand_pin_now = false;
+    const bool want_prefetch = mode == MTM_PEAKS_LOCAL && fused && !c->list2d.empty();
+    const size_t nfetch_w = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
+    if (want_prefetch) {
+        const size_t fetch_bytes = 16 + sizeof(mtm_hit) * nfetch_w;
+        if (c->pinned_cap < fetch_bytes) {
+            if (c->pinned) (void)hipHostFree(c->pinned);
+            c->pinned = nullptr;
+            c->pinned_cap = 0;
+            HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
+            c->pinned_cap = fetch_bytes;
+        }
+        bool pin = c->cand_pinned != 0 && !c->refine_now && !dense_route;
+        for (const SizeClass& sc : c->classes) {
+            const int rk = resolved_kernel(c, sc);
+            pin = pin && ((rk == MTM_KERNEL_MFMA && sc.slabs.empty()) || rk == MTM_KERNEL_MFMA16);
+        }
+        if (pin) {
+            uint8_t* land = static_cast<uint8_t*>(c->pinned);
+            std::memset(land, 0, 16);
+            mtm_hit* w = reinterpret_cast<mtm_hit*>(land + 16);
+            for (size_t i = 0; i < nfetch_w; ++i) w[i].templ_idx = -1;
+            c->cand_pin_now = true;
+            c->cand_pin_n = nfetch_w;
+        }
+    }
     host_trace(c, 3);
     // start of the GPU time of the call (timing.total_ms).  Banded: recorded by run_score_banded once the first band's
     // copy is on its way - nothing is queued ahead of that copy that does not have to be (every API call is 5-10 us)
@@ -244,6 +274,8 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     HIPC(hipEventRecord(c->ev[1], c->stream));
     host_trace(c, 9);
     c->cand_on = false;
+    const bool pin_direct = c->cand_pin_now;
+    c->cand_pin_now = false;
     // stream mode: the kernels of this image are on their way - start the upload of the next one now.
     // (Not later: the device-to-host copy of the hit records below lands in pageable memory, which
     // the runtime executes synchronously, i.e. after the kernels.)
@@ -258,22 +290,12 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     S.hash_mask = hash_mask;
     S.prefetched = false;
     S.pp_mode = pp_mode;
-    if (mode == MTM_PEAKS_LOCAL && fused && !c->list2d.empty()) {
-        // Few candidates (the usual case): they come back in one copy and the 3x3 test runs on the host
-        // (fm_end).  Pinned landing buffer: the copy is a plain DMA instead of a staged one.
-        const size_t nfetch = std::min<size_t>(kHitPrefetch, (size_t)cand_cap);
-        const size_t fetch_bytes = 16 + sizeof(mtm_hit) * nfetch;
-        if (c->pinned_cap < fetch_bytes) {
-            if (c->pinned) (void)hipHostFree(c->pinned);
-            c->pinned = nullptr;
-            c->pinned_cap = 0;
-            HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
-            c->pinned_cap = fetch_bytes;
-        }
-        static const bool kFetchByCopy = std::getenv("MTM_FETCH_COPY") != nullptr;        // (A/B: the copy command of round 2)
-        if (kFetchByCopy) {
-            HIPC(hipMemcpyAsync(c->pinned, c->cands.p, fetch_bytes, hipMemcpyDeviceToHost, c->stream));
-        } else {
+    S.pin_direct = pin_direct;
+    if (want_prefetch) {
+        // Few candidates (the usual case): they are in the pinned landing buffer when the stream is done and the 3x3 test
+        // runs on the host (fm_end) - written there by the score kernel itself (pin_direct), else by a one-group kernel
+        const size_t nfetch = nfetch_w;
+        if (!pin_direct) {
             hipLaunchKernelGGL(fetch_cands_kernel, dim3(1), dim3(256), 0, c->stream, c->cands.as<uint4>(),
                                static_cast<uint4*>(c->pinned), (unsigned long long)nfetch);
             HIPC(hipGetLastError());
@@ -445,8 +467,19 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
             HIPC(hipStreamSynchronize(c->stream));
             host_trace(c, 10);
-            const uint8_t* land = static_cast<const uint8_t*>(c->pinned);
+            uint8_t* land = static_cast<uint8_t*>(c->pinned);
             unsigned long long ncand = 0;
+            if (S.pin_direct) {
+                // the window's slots fill from 0 upwards (every reserved slot below the capacity is written before the
+                // launch ends): the count is the first slot that still says "no record"
+                const mtm_hit* w = reinterpret_cast<const mtm_hit*>(land + 16);
+                while (ncand < nfetch && w[ncand].templ_idx >= 0) ++ncand;
+                if (ncand == nfetch) {      // window full: the list's real length is on the device (dense maps; rare)
+                    HIPC(hipMemcpyAsync(&ncand, c->cands.p, sizeof(ncand), hipMemcpyDeviceToHost, c->stream));
+                    HIPC(hipStreamSynchronize(c->stream));
+                }
+                std::memcpy(land, &ncand, sizeof(ncand));
+            }
             std::memcpy(&ncand, land, sizeof(ncand));
             std::memcpy(&c->timing.sclk_mhz, land + 8, sizeof(float));
             if (ncand <= nfetch && !c->cand_rowmax_now) {       // (dense route: the list is a preselection, the maps decide)

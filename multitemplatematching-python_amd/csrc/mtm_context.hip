@@ -54,7 +54,7 @@ int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols,
 // `copy_done` (optional): recorded right behind the copy; `before_kernels` (optional): the conversion kernels wait for it
 // (banded uploads on two streams: the next band's copy starts behind this one's copy, not behind its kernels).
 int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                     hipStream_t stream, bool skip_f32, hipEvent_t copy_done, hipEvent_t before_kernels) {
+                     hipStream_t stream, bool skip_f32, hipEvent_t copy_done, hipEvent_t before_kernels, bool convert) {
     const int cols = g.cols, nrows = r1 - r0;
     if (nrows <= 0) return MTM_OK;
     uint8_t* raw = sl.raw.as<uint8_t>() + (size_t)r0 * cols;
@@ -62,6 +62,10 @@ int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src,
                           nrows, hipMemcpyHostToDevice, stream));
     if (copy_done) HIPC(hipEventRecord(copy_done, stream));
     if (before_kernels) HIPC(hipStreamWaitEvent(stream, before_kernels, 0));
+    if (!convert) {             // (the band's statistics launch converts the rows: stats_u8_kernel's StatLayout)
+        sl.f32_valid = false;
+        return MTM_OK;
+    }
     uint8_t* u8 = sl.u8.as<uint8_t>() + (size_t)r0 * g.pitch;
     uint8_t* u8b = sl.u8b.as<uint8_t>() + (size_t)r0 * g.pitch;
     // no float32 plane here: nothing in a banded call reads it (33 of the 50 MB this conversion would write at 4K);
@@ -267,6 +271,8 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         }
     }
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
+    if (const char* v = std::getenv("MTM_CAND_PINNED")) c->cand_pinned = std::atoi(v);
+    if (const char* v = std::getenv("MTM_FUSE_LAYOUT")) c->fuse_layout = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_MIN_FILL")) c->band_min_fill = std::atof(v);
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);

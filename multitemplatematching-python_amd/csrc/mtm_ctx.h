@@ -142,6 +142,7 @@ struct FmState {
     int mode = 0;
     float thr = 0.0f;
     bool mode_min = false, fused = false, prefetched = false;
+    bool pin_direct = false;    // the score kernel wrote the head of the candidate list into the pinned window itself (no fetch)
     bool pp_mode = false;       // float32 refinement by map scan: the candidate buffer holds potential peaks whose
                                 // neighbourhoods in the maps are exact - decisions by verify_peaks_kernel, never from the list alone
     int n = 0;
@@ -169,6 +170,12 @@ struct mtm_ctx {
     // its (segment, row, template) triples hold one), so the call is slower: 2.55 against 2.41 ms (profiles/r04h/dense_ab.txt).
     int dense_rowmax = 0;
     bool cand_rowmax_now = false;   // this call takes that route
+    int cand_pinned = 1;        // MTM_CAND_PINNED: the score kernel writes the first records of its candidate list into the pinned
+                                // landing buffer itself (MfmaParams::cand_pin) - no fetch kernel behind the score launch (0: round 4)
+    bool cand_pin_now = false;  // ... in the launches being queued
+    size_t cand_pin_n = 0;
+    int fuse_layout = 1;        // MTM_FUSE_LAYOUT: banded uploads convert a band's rows inside its statistics launch (0: planarize kernel)
+    int lay_r0 = 0, lay_r1 = 0; // ... the rows the statistics launch being queued converts (run_score_banded -> launch_stats)
     int cand_stage = 1;         // MTM_CAND_STAGE: peak candidates of a wave collected in LDS, one atomic per wave and work item (0: one per emission)
     int rm_edges = 1;           // MTM_RM_EDGES: one-group K steps where a row-multiplexed wave's other group has no template row (0: off)
     int masksq_fused = 1;       // MTM_MASKSQ_FUSED: sum I^2 M of a masked class as ONE launch over both byte planes of I^2 that
@@ -439,7 +446,8 @@ struct SlotGeom {
 int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols, int chans, int dtype, hipStream_t stream,
                  int factor, SlotGeom* out);
 int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
-                     hipStream_t stream, bool skip_f32, hipEvent_t copy_done = nullptr, hipEvent_t before_kernels = nullptr);
+                     hipStream_t stream, bool skip_f32, hipEvent_t copy_done = nullptr, hipEvent_t before_kernels = nullptr,
+                     bool convert = true);
 int upload_rows_u16c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
                       hipStream_t stream, hipEvent_t copy_done = nullptr, hipEvent_t before_kernels = nullptr);
 int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t src_stride, int src_rows, int src_cols,

@@ -135,10 +135,22 @@ __global__ __launch_bounds__(256) void hsum_u8_kernel(const uint8_t* __restrict_
 #endif
 constexpr int kStatBand4 = MTM_STAT_BAND4;    // stats_u8_kernel: output rows per work-group
 constexpr int kStatStrip = 1024;               // image columns per work-group (4 per thread)
+#ifndef MTM_STAT_PRO_BATCH
+#define MTM_STAT_PRO_BATCH 32
+#endif
+constexpr int kStatProBatch = MTM_STAT_PRO_BATCH;   // stats_u8_kernel: image rows of the column-sum prologue requested together
 
 // output columns per work-group for a template width (multiple of 16: strips start dword-aligned, and the 16-pixel
 // column blocks whose statistic ranges the kernel can write - `blk` - never straddle two strips)
 inline int stats_u8_owg(int w) { return (kStatStrip + 1 - w) & ~15; }
+
+// layout conversion fused into a banded statistics launch (stats_u8_kernel); u8b == nullptr: none
+struct StatLayout {
+    uint8_t* u8 = nullptr;
+    uint8_t* u8b = nullptr;
+    int pitch = 0;          // of the planes
+    int r0 = 0, r1 = 0;     // image rows to convert
+};
 
 __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict__ img, int pitch, int h, int w,
                                                        int oh, int ow, int owg, double inv_area, int num_type,
@@ -146,11 +158,36 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
                                                        double* __restrict__ sum2, double* __restrict__ sq,
                                                        int st_pitch, double* __restrict__ rsq = nullptr,
                                                        int yb_off = 0, double* __restrict__ blk = nullptr,
-                                                       int blk_pitch = 0) {
+                                                       int blk_pitch = 0, StatLayout lay = StatLayout{}) {
     __shared__ __attribute__((aligned(16))) uint32_t E1[kStatStrip + 4], E2[kStatStrip + 4];   // exclusive prefixes
     __shared__ uint32_t wsum[2][4];
     const int x0 = blockIdx.x * owg, y0 = ((int)blockIdx.y + yb_off) * kStatBand4;   // yb_off: banded launches
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (lay.u8b != nullptr) {
+        // Round 5: the layout conversion of a band's rows rides on its statistics launch (`img` is then the RAW upload buffer,
+        // `pitch` its row length - a multiple of 4).  The band's image rows lay.r0 .. lay.r1 - 1 are split evenly over the
+        // launch's row blocks, the columns over its strips (the last strip takes the rest of the row): dword in, the
+        // padded uint8 plane and its int8 view (byte ^ 0x80, what the LDS-DMA of the score kernel reads) out.
+        const int nby = (int)gridDim.y, q = (lay.r1 - lay.r0 + nby - 1) / nby;
+        const int ra = lay.r0 + (int)blockIdx.y * q, rb = min(lay.r1, ra + q);
+        const int xe = blockIdx.x + 1 == gridDim.x ? pitch : min(pitch, x0 + owg);
+        const int x = x0 + 4 * t;
+        if (x < xe) {
+            for (int r = ra; r < rb; r += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = r + i < rb ? *reinterpret_cast<const uint32_t*>(img + (size_t)(r + i) * pitch + x) : 0u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (r + i < rb) {
+                        const size_t o = (size_t)(r + i) * lay.pitch + x;
+                        *reinterpret_cast<uint32_t*>(lay.u8 + o) = v[i];
+                        *reinterpret_cast<uint32_t*>(lay.u8b + o) = v[i] ^ 0x80808080u;
+                    }
+            }
+        }
+    }
     const int L = owg + w - 1;                       // image columns of this strip (<= kStatStrip)
     // the image is padded by kPadCols columns only: quads further right (beyond every valid window) read 0
     const bool ld = 4 * t < L && x0 + 4 * t + 3 < pitch;
@@ -162,14 +199,15 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
         b[2] = (v >> 16) & 255u;
         b[3] = v >> 24;
     };
-    // 8 rows per batch: the loads of a batch are all in flight before the first add needs one
-    for (int r0 = 0; r0 < h; r0 += 8) {
-        uint32_t v[8];
+    // kStatProBatch rows per batch: the loads of a batch are all in flight before the first add needs one.  (Round 5: 32
+    // instead of 8 - the kernel is a chain of memory latencies, a 64-row window was eight of them before the first output row.)
+    for (int r0 = 0; r0 < h; r0 += kStatProBatch) {
+        uint32_t v[kStatProBatch];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kStatProBatch; ++i)
             v[i] = ld ? *reinterpret_cast<const uint32_t*>(base + (size_t)min(r0 + i, h - 1) * pitch) : 0u;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kStatProBatch; ++i)
             if (r0 + i < h) {
                 uint32_t b[4];
                 unpack(v[i], b);

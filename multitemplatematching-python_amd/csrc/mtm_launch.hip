@@ -125,9 +125,24 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         }
         if (b1 > sb0) {
             const dim3 gs((ow + owg - 1) / owg, b1 - sb0);
-            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, img.u8,
-                               img.u8_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, want_sum2, tp[0],
-                               sum2, sq, st.pitch, rsq, sb0, blk, st.blk_pitch);
+            // banded upload with the layout conversion of the band's rows on this launch (run_score_banded): the kernel reads
+            // the raw upload buffer (every row that has arrived so far is there) and writes the planes of the new rows
+            StatLayout lay{};
+            const uint8_t* src = img.u8;
+            int src_pitch = img.u8_pitch;
+            if (c->lay_r1 > c->lay_r0) {
+                mtm_ctx::ImageSlot& sl = c->slot[c->cur];
+                lay.u8 = sl.u8.as<uint8_t>();
+                lay.u8b = sl.u8b.as<uint8_t>();
+                lay.pitch = img.u8_pitch;
+                lay.r0 = c->lay_r0;
+                lay.r1 = c->lay_r1;
+                src = sl.raw.as<uint8_t>();
+                src_pitch = c->cols;
+            }
+            hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, src,
+                               src_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, want_sum2, tp[0],
+                               sum2, sq, st.pitch, rsq, sb0, blk, st.blk_pitch, lay);
         }
     } else if (u8 && c->chans == 3 && w <= 768 && 3.0 * w * h * 65025.0 < 4294967296.0 && c->fuse_stats) {
         // RGB: the fused kernel with one scan per channel + one for the squares (sum2 always written:
@@ -551,6 +566,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         // the 8 spare bytes of the candidate header carry the shader clock the kernel measured (fetched with it)
         p.clk_out = (p.cand_on && c->cands.p) ? reinterpret_cast<float*>(c->cands.as<uint8_t>() + 8) : nullptr;
+        if (c->cand_pin_now && p.cand_on && c->pinned) {       // the head of the list also into the host's landing buffer
+            p.cand_pin = reinterpret_cast<mtm_hit*>(static_cast<uint8_t*>(c->pinned) + 16);
+            p.cand_pin_n = (unsigned long long)c->cand_pin_n;
+            p.clk_out = reinterpret_cast<float*>(static_cast<uint8_t*>(c->pinned) + 8);
+        }
         int tg0 = 0;
         if (only_li >= 0 && !rm) {   // one template: just its group
             tg0 = only_li / tgsz;
@@ -725,6 +745,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
+        if (c->cand_pin_now && p.cand_on && c->pinned) {
+            p.cand_pin = reinterpret_cast<mtm_hit*>(static_cast<uint8_t*>(c->pinned) + 16);
+            p.cand_pin_n = (unsigned long long)c->cand_pin_n;
+        }
         p.cand_thr_lo = (double)c->cand_thr - 1e-6 * std::max(1.0, std::fabs((double)c->cand_thr));
         p.screen_hi = std::min(p.cand_thr_lo, 0.999999) - 1e-6;
         p.sq_floor = 0.99 / std::sqrt((double)w * (double)h);
@@ -1192,10 +1216,18 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         }
         if (on_main) k_inline = k;
         if (r_done == 0) host_trace(c, 14);
+        // Round 5 (MTM_FUSE_LAYOUT, default 1): a band whose rows complete new statistics blocks gets ONE kernel for layout
+        // conversion + window statistics instead of two launches with a kernel boundary between them (stats_u8_kernel's
+        // StatLayout; row lengths that are multiples of 4, no float32 plane asked for)
+        const int avail_k = r1 - h + 1;
+        const int sb1_k = last ? nsb : std::max(sb_done, avail_k > 0 ? avail_k / kStatBand4 : 0);
+        const bool fuse_lay = c->fuse_layout != 0 && !u16 && (a.cols % 4) == 0 && c->skip_f32 != 0 && sb1_k > sb_done;
         if (u16)
             MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, bs, cdone, kwait));
         else
-            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, bs, c->skip_f32 != 0, cdone, kwait));
+            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, bs, c->skip_f32 != 0, cdone, kwait, !fuse_lay));
+        c->lay_r0 = fuse_lay ? r_done : 0;
+        c->lay_r1 = fuse_lay ? r1 : 0;
         if (two_streams) (void)hipStreamQuery(bs);
         if (r_done == 0) {
             HIPC(hipEventRecord(c->ev[0], c->stream));           // (see fm_begin)
@@ -1212,6 +1244,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         c->stats_stream = bs;
         const int rc = launch_stats(c, sc, &st, sb_done, sb1);
         c->stats_stream = nullptr;
+        c->lay_r0 = c->lay_r1 = 0;
         MTMC(rc);
         sb_done = sb1;
         HIPC(hipEventRecord(c->band_ev[(size_t)k], bs));

@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 const int n_act = __popcll(act);
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
                 for (int r = rank; r < cur; r += n_act)
-                    if (fb + (unsigned long long)r < p.cand_cap) p.cand_hits[fb + (unsigned long long)r] = cs_rec[r];
+                    mf_put_cand(p, fb + (unsigned long long)r, cs_rec[r]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the records are read: their slots may be rewritten
                 cur = 0;
                 flushed = true;
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         hrec.w = p.w;
                         hrec.h = p.h;
                         hrec.score = out[i];
-                        p.cand_hits[slot] = hrec;
+                        mf_put_cand(p, slot, hrec);
                     }
                 }
         }
@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             base = ((unsigned long long)bhi << 32) | blo;
             if (!(p.dbg & 16))                   // probe (MTM_MFMA_DBG=16): the atomic without the copy
                 for (int r = lane; r < n_st; r += 64)
-                    if (base + (unsigned long long)r < p.cand_cap) p.cand_hits[base + (unsigned long long)r] = cs_rec[r];
+                    mf_put_cand(p, base + (unsigned long long)r, cs_rec[r]);
         }
     }
     }   // epilogue scope

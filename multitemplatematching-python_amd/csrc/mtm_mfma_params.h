@@ -137,7 +137,18 @@ struct MfmaParams {
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)
+    // Round 5: the first cand_pin_n slots of the candidate list are ALSO written into page-locked host memory by the
+    // wave that fills them (a handful of 24-byte stores over PCIe per call) - the host reads them when the launch has
+    // ended, without a fetch kernel / copy command and its kernel boundary behind the score launch.  0 = off.
+    mtm_hit* cand_pin;
+    unsigned long long cand_pin_n;
 };
+
+// one record of the candidate list: device list (slots below the capacity) + the host-visible window
+__device__ __forceinline__ void mf_put_cand(const MfmaParams& p, unsigned long long slot, const mtm_hit& h) {
+    if (slot < p.cand_cap) p.cand_hits[slot] = h;
+    if (slot < p.cand_pin_n) p.cand_pin[slot] = h;
+}
 
 // Per-template constants staged in LDS once per work-group (the epilogue reads them with LDS
 // broadcasts instead of dependent scalar loads per template).
