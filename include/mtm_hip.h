@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 5
+#define MTM_ABI_VERSION 6
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -311,6 +311,13 @@ int      mtm_group_shards(const mtm_group* g, const mtm_templ* templs, int n_tem
 int      mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, int method,
                                 const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
                                 int mode, double score_threshold, mtm_hit* out, int64_t capacity, int64_t* n_out);
+/* The same + MTM's non-maxima suppression on the merged list inside the call (round 5; what mtm_find_matches_image_nms is
+ * to a single context): local extrema, the kept hits in cv2.dnn.NMSBoxes' order, at most n_object of them (-1: all).
+ * Replaces MTM.matchTemplates -> findMatches + NMS (MTM/__init__.py:289-296) for a device group in ONE native call. */
+int      mtm_group_find_matches_nms(mtm_group* g, const mtm_templ* templs, int n_templ, int method,
+                                    const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                                    double score_threshold, double max_overlap, int64_t n_object,
+                                    mtm_hit* out, int64_t capacity, int64_t* n_out);
 int      mtm_group_last_hits(mtm_group* g, mtm_hit* out, int64_t capacity, int64_t* n_out);
 /* The hit exchange of a group as north_star / SURVEY 8e name it: a single process, ncclCommInitAll over the group's
  * devices, one stream per device, ONE all-gather of fixed-size slots of 24-byte hit records per device inside

@@ -25,7 +25,7 @@ OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, 
 E_OVERFLOW = -5
 E_HIP = -2
 COMM_ID_BYTES = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class MtmTempl(ctypes.Structure):
@@ -106,6 +106,10 @@ SYMBOLS = {
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                               ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int64,
                                               _P(ctypes.c_int64)]),
+    "mtm_group_find_matches_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                  ctypes.c_double, ctypes.c_double, ctypes.c_int64, ctypes.c_void_p,
+                                                  ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_group_last_hits": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_group_comm_init": (ctypes.c_int, [ctypes.c_void_p]),
     "mtm_group_comm_ranks": (ctypes.c_int, [ctypes.c_void_p]),
@@ -556,6 +560,25 @@ class Group(_RecordMemo):
             out = np.empty(cap, dtype=HIT_DTYPE)
             rc = self._lib.mtm_group_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
         check(rc, "mtm_group_find_matches")
+        return out[:n.value]
+
+
+    def search_nms(self, templates, image, method, score_threshold, max_overlap, n_object=-1):
+        """search() + MTM's non-maxima suppression on the merged list in one native call (mtm_group_find_matches_nms)."""
+        rec = self._records(templates)
+        a, ptr, stride = _pixel_rows(image)
+        chans = 1 if a.ndim == 2 else a.shape[2]
+        cap = 4096
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_group_find_matches_nms(self._h, rec.ctypes.data, len(templates), int(method), ptr, a.shape[0],
+                                                  a.shape[1], chans, _dtype_code(a), stride, float(score_threshold),
+                                                  float(max_overlap), int(n_object), out.ctypes.data, cap, ctypes.byref(n))
+        if rc == E_OVERFLOW:
+            cap = int(n.value)
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            rc = self._lib.mtm_group_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        check(rc, "mtm_group_find_matches_nms")
         return out[:n.value]
 
 

@@ -194,18 +194,31 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
         c->cands_zeroed = nullptr;
     }
+    // the refined routes' own thresholds: rig_thr the exact one, rig_cap the widest error bound the map scan's tolerances
+    // cover (4 x the largest class constant: windows whose mean lies within ~4 standard deviations of their tile's)
+    if (c->refine_now) {
+        const float tq = mode_min ? -thr : thr;
+        c->rig_thr = tq;
+        float eps = 0.0f;
+        for (const SizeClass& sc : c->classes)
+            if (resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32) eps = std::max(eps, bf16_rig_eps(c->chans, sc.h, bf16_nkb(sc.w)));
+        c->rig_cap = c->f32_rig ? std::max(kRefineThrMargin, 4.0f * eps) : kRefineThrMargin;
+        c->scan_thr = tq - c->rig_cap * std::max(1.0f, std::fabs(tq));
+    }
     if (pp_mode) {
         c->refine_scan_now = true;
         c->cand_min = mode_min;
-        const float tq = mode_min ? -thr : thr;
-        c->cand_thr = tq - kRefineThrMargin * std::max(1.0f, std::fabs(tq));
+        c->cand_thr = c->scan_thr;
     }
     if (fused) {
         const size_t cands_cap = c->cands.cap;
         MTMC(c->cands.ensure(16 + sizeof(mtm_hit) * (size_t)c->hit_cap));
         if (c->cands.cap != cands_cap) c->cands_zeroed = nullptr;      // reallocated (possibly at the same address)
-        // the counter is normally cleared right after the previous call fetched it (off the critical path)
-        if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+        // the counter is normally cleared right after the previous call fetched it (off the critical path); round 5: a banded
+        // uint8 call lets its first statistics launch do it (zero_pending; run_score_banded) - no fill command at all
+        c->zero_pending = false;
+        if (banded && c->zero_in_stats && c->dtype == MTM_U8) c->zero_pending = true;
+        else if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
         c->cands_zeroed = nullptr;
         c->cand_on = true;
         c->cand_min = mode_min;
@@ -291,6 +304,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     S.prefetched = false;
     S.pp_mode = pp_mode;
     S.pin_direct = pin_direct;
+    S.banded_u8 = banded && c->dtype == MTM_U8;
     if (want_prefetch) {
         // Few candidates (the usual case): they are in the pinned landing buffer when the stream is done and the 3x3 test
         // runs on the host (fm_end) - written there by the score kernel itself (pin_direct), else by a one-group kernel
@@ -447,7 +461,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
         // candidate list; verify_peaks_kernel keeps the 3x3 local maxima.  If the candidate list
         // overflowed (dense maps), or on any non-MFMA class, the full peaks_kernel pass runs instead.
         const int n2d = (int)c->list2d.size();
-        const size_t hdr_bytes = round_up(2 * sizeof(unsigned long long) + sizeof(int) * (size_t)std::max(1, n), 16);
+        // [hit count | candidate count | spare word of the candidate header (float32 map mode: the "bound too wide" flag) | per-template ints]
+        const size_t hdr_bytes = round_up(3 * sizeof(unsigned long long) + sizeof(int) * (size_t)std::max(1, n), 16);
         unsigned long long count = 0;
         std::vector<int> tflags((size_t)std::max(1, n), 0);
         std::vector<uint8_t> host_buf;
@@ -484,7 +499,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             std::memcpy(&c->timing.sclk_mhz, land + 8, sizeof(float));
             if (ncand <= nfetch && !c->cand_rowmax_now) {       // (dense route: the list is a preselection, the maps decide)
                 // everything needed is on the host: clear the counter for the next call while this one finishes
-                if (hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess) c->cands_zeroed = c->cands.p;
+                // (unless this context's calls clear it in their own first kernel: zero_in_stats)
+                if (!(c->zero_in_stats && S.banded_u8) && hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess)
+                    c->cands_zeroed = c->cands.p;
                 const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(land + 16);
                 // open-addressing table over the candidates (key -> index), kept in the context between calls
                 size_t tsize = 64;
@@ -547,11 +564,11 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             uint8_t* dbase = c->hits.as<uint8_t>();
             HIPC(hipMemsetAsync(dbase, 0, hdr_bytes, c->stream));
             unsigned long long* counter = reinterpret_cast<unsigned long long*>(dbase);
-            int* flags = reinterpret_cast<int*>(counter + 2);
+            int* flags = reinterpret_cast<int*>(counter + 3);
             mtm_hit* dhits = reinterpret_cast<mtm_hit*>(dbase + hdr_bytes);
             if (use_fused) {
                 // counter[1] <- candidate count (for the overflow check on the host)
-                HIPC(hipMemcpyAsync(counter + 1, c->cands.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                HIPC(hipMemcpyAsync(counter + 1, c->cands.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                                     c->stream));
                 const unsigned blocks = std::min((unsigned)((c->hit_cap + 255) / 256), 4096u);
                 const mtm_hit* dcands = reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16);
@@ -613,7 +630,24 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             unsigned long long ncand = 0;
             std::memcpy(&count, host_buf.data(), sizeof(count));
             std::memcpy(&ncand, host_buf.data() + sizeof(count), sizeof(ncand));
-            std::memcpy(tflags.data(), host_buf.data() + 2 * sizeof(count), sizeof(int) * n);
+            std::memcpy(tflags.data(), host_buf.data() + 3 * sizeof(count), sizeof(int) * n);
+            unsigned int rig_wide = 0;
+            if (use_fused) std::memcpy(&rig_wide, host_buf.data() + 2 * sizeof(count), sizeof(rig_wide));
+            if (pp_mode && c->refine_now && c->f32_rig && rig_wide != 0) {
+                // float32 map mode: some output that could pass the threshold has an error bound beyond what the scan's
+                // tolerances cover (a low-contrast window beside a brightness step) - the float64 kernel decides
+                c->cand_on = false;
+                c->hits_only_now = false;
+                c->timing.ncc_launches = 0;
+                c->timing.sq_launches = 0;
+                pp_mode = false;
+                use_fused = false;
+                c->refine_now = c->refine_scan_now = false;
+                c->f32_exact_now = true;
+                MTMC(run_score_all(c));
+                HIPC(hipEventRecord(c->ev[1], c->stream));
+                continue;
+            }
             if (use_fused && (int64_t)ncand > cand_cap && c->refine_now) {
                 // float32 refinement, list overflowed.  Kernel candidates (everything above the threshold): take the
                 // potential peaks of a map scan instead - far fewer.  Those too (plateau-rich maps): the float64 kernel.

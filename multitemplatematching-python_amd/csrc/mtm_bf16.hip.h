@@ -63,6 +63,44 @@ __device__ __forceinline__ float bf_finish(int method, double corr, const double
     return (float)num;
 }
 
+// bf_finish + what the error bound of the refined routes applies to: for a normalised method the ratio num / t BEFORE
+// the saturation rules (*r_out), or *exact_out = true when the rules yield a constant whatever the numerator is (flat
+// window, constant template: t == 0).  Same operations as bf_finish, same results.
+__device__ __forceinline__ float bf_finish_r(int method, double corr, const double (&t)[kMaxChans], double sum2, double sq,
+                                             const BfTemplConst& T, int chans, double* r_out, bool* exact_out) {
+    *r_out = 0.0;
+    *exact_out = false;
+    if (T.all_ones) {
+        *exact_out = true;
+        return 1.0f;
+    }
+    if (method == MTM_TM_CCORR) return (float)corr;
+    const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
+                       : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
+    const bool normed = (method == MTM_TM_SQDIFF_NORMED) || (method == MTM_TM_CCORR_NORMED) ||
+                        (method == MTM_TM_CCOEFF_NORMED);
+    double num = corr;
+    if (num_type == 1) {
+#pragma unroll
+        for (int c = 0; c < kMaxChans; ++c)
+            if (c < chans) num -= t[c] * T.mean[c];
+    } else if (num_type == 2) {
+        num = sum2 - 2.0 * num + T.templ_sum2;
+        num = fmax(num, 0.0);
+    }
+    if (normed) {
+        const double tt = sq * T.templ_norm;
+        const double an = fabs(num);
+        const double r = num / tt;
+        if (tt > 0.0) *r_out = r;
+        else *exact_out = true;
+        if (an < tt) num = r;
+        else if (an < tt * 1.125) num = (num > 0.0) ? 1.0 : -1.0;
+        else num = (method == MTM_TM_SQDIFF_NORMED) ? 1.0 : 0.0;
+    }
+    return (float)num;
+}
+
 // One K step: 32 taps x 8 phases x MB template groups x 3 piece products.  h0/h1 (l0/l1): the lane's two aligned
 // 16-byte chunks of the first (second) piece plane; a0 / a1: the packed template pieces.
 template <int MB>
@@ -139,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             k.templ_norm = T.templ_norm;
             k.templ_sum2 = T.templ_sum2;
             k.t2c = T.centred_sum2 * 1.000001;        // (a float64 variance times the area: its own rounding covered)
+            k.bfac = T.templ_norm > 0.0 ? (p.method == MTM_TM_SQDIFF_NORMED ? 2.0 : 1.0) * sqrt(k.t2c) / T.templ_norm * 1.000001 : 0.0;
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
@@ -256,8 +295,9 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const int xq = x0 + 8 * j;
     const bool lane_on = y < p.oh && xq < p.ow;
     const int method = p.method;
-    const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED || (p.ext_on && p.ext_raw);
     const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
+    const bool rig = p.rig != 0 && normed;      // listing decisions by the per-output error bound (Bf16Params::rig)
+    const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED || (p.ext_on && p.ext_raw) || rig;
     // (the two halves of a lane's eight pixels as a generic lambda over a compile-time constant: every accumulator index
     // below must be one, or the accumulators leave the register file)
     auto epilogue_half = [&](auto half_c) {
@@ -272,6 +312,25 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             s2[i] = need_sum2 ? st.sum2[sidx] : 0.0;
             sq[i] = normed ? st.sq[sidx] : 0.0;
         }
+        // rig: the pixel's share of the bound, rig_eps * sqrt(sum (I - mu)^2) / sq (0 where the window is flat: the
+        // normalisation rules return a constant there)
+        double bp[4] = {0.0, 0.0, 0.0, 0.0};
+        if (rig) {
+            const double area = (double)p.h * (double)p.w;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double s2c = s2[i];
+#pragma unroll
+                for (int cc = 0; cc < kMaxChans; ++cc)
+                    if (cc < p.chans) {
+                        const double m = (double)s_mu[cc];
+                        s2c += m * (area * m - 2.0 * ts[i][cc]);
+                    }
+                // (+ the cancellation in s2c itself: three terms of the size of s2 and area mu^2)
+                s2c = fmax(s2c, 0.0) * 1.000001 + 1e-12 * (fabs(s2[i]) + area * (double)s_mu[0] * (double)s_mu[0]);
+                bp[i] = sq[i] > 0.0 ? (double)p.rig_eps * sqrt(s2c) / sq[i] : 0.0;
+            }
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
@@ -280,17 +339,51 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;
                 const BfTemplConst& T = tcl[lt];
                 float out[4];
+                double qv[4], Mv[4];        // rig: quality before the saturation rules, bound of its error
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     double corr = (double)acc[mb][4 * half + i][e];
 #pragma unroll
                     for (int cc = 0; cc < kMaxChans; ++cc)
                         if (cc < p.chans) corr += T.centre[cc] * ts[i][cc];
-                    out[i] = bf_finish(method, corr, ts[i], s2[i], sq[i], T, p.chans);
+                    double r;
+                    bool ex;
+                    out[i] = bf_finish_r(method, corr, ts[i], s2[i], sq[i], T, p.chans, &r, &ex);
+                    if (ex) r = (double)out[i];
+                    qv[i] = p.cand_min ? -r : r;
+                    // (+ the rounding of the exact score to float32 and of this arithmetic)
+                    Mv[i] = ex ? 0.0 : bp[i] * T.bfac + 3e-7 * fmax(1.0, fabs(r));
                 }
                 const int xb = xq + 4 * half;
+                if (rig && p.rig_flag != nullptr) {
+                    // map mode: the scan that follows works with tolerances of rig_cap - an output that could pass the
+                    // threshold with a larger bound than that takes the call to the float64 kernel
+                    bool wide = false;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        wide = wide || (xb + i < p.ow && Mv[i] > (double)p.rig_cap && (p.list_all || qv[i] + Mv[i] > (double)p.rig_thr));
+                    if (wide) *p.rig_flag = 1u;
+                }
                 float key_v[4] = {out[0], out[1], out[2], out[3]};      // what the published key is built from
-                if (p.ext_on && p.ext_raw) {
+                if (p.ext_on && p.ext_raw && rig) {
+                    // normalised methods, refined: bounds of the exact QUALITY instead of scores.  Maxima: the exact score is
+                    // sat(r) <= min(r, 1), and 0 where |r| >= 1.125; minima (TM_SQDIFF_NORMED): -clamp(r, 0, 1), monotone.
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double up = qv[i] + Mv[i], lo = qv[i] - Mv[i];
+                        if (!p.cand_min) {
+                            lo = fmin(lo, 1.0);
+                            if (up >= 1.125) lo = fmin(lo, 0.0);
+                            up = fmin(up, 1.0);
+                        } else {
+                            up = -fmin(fmax(-up, 0.0), 1.0);
+                            lo = -fmin(fmax(-lo, 0.0), 1.0);
+                        }
+                        acc[mb][4 * half + i][e] = (float)up + fabsf((float)up) * 1.2e-7f;      // (never rounded below the bound)
+                        const float lq = (float)lo - fabsf((float)lo) * 1.2e-7f;
+                        key_v[i] = p.cand_min ? -lq : lq;
+                    }
+                } else if (p.ext_on && p.ext_raw) {
                     // raw-sum methods, refined: bounds instead of scores (see Bf16Params::ext_raw).  The accumulator
                     // registers take the upper bound of the quality, the key the lower bound (as a score).
                     const double escale = (method == MTM_TM_SQDIFF ? 2.0 : 1.0) * (double)p.ext_eps;
@@ -329,6 +422,27 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                         }
                     }
                     if (bestk) atomicMax(&ext_slot[lt], bestk);
+                } else if (p.cand_on && rig) {
+                    // refined route: everything whose exact score could pass the threshold (rig_thr: the exact one)
+                    bool pass[4], any = false;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pass[i] = xb + i < p.ow && (p.list_all != 0 || qv[i] + Mv[i] > (double)p.rig_thr);
+                        any = any || pass[i];
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            mtm_hit hrec;
+                            hrec.templ_idx = T.tglob;
+                            hrec.x = xb + i;
+                            hrec.y = y;
+                            hrec.w = p.w;
+                            hrec.h = p.h;
+                            hrec.score = out[i];
+                            cand_append(pass[i], p.cand_counter, p.cand_cap, p.cand_hits, hrec);
+                        }
+                    }
                 } else if (p.cand_on) {
                     // any-of-4 first (rare on sparse maps); the append itself takes one atomic per wave
                     const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));

@@ -53,6 +53,22 @@ struct Bf16Params {
     // exact tie with it - is always listed, whatever the order the waves finish in.
     int ext_raw;
     float ext_eps;
+    // Round 5: the same bound for the NORMALISED methods, per output, in score units - what the listing decisions of the
+    // refined routes rest on instead of round 3's empirical margins (1e-4 around the threshold, 5e-5 around a 3x3 maximum).
+    //   |approximate ratio - exact ratio|  <=  M = rig_eps * sqrt(sum (I - mu)^2) / sq * (escale sqrt(t2c) / templ_norm)
+    // (sq, templ_norm: the method's own denominators; escale = 2 for TM_SQDIFF_NORMED).  sum (I - mu)^2 / sq^2 is
+    // 1 + A (window mean - mu)^2 / (A var): a low-contrast window beside a brightness step - where the tile constant mu is
+    // far from the window's own mean - gets the large margin it needs, a textured one ~rig_eps.  An output is listed
+    // (candidate list, running best) whenever its UPPER bound passes; exact re-scoring decides.
+    int rig;                 // 1: listing by that bound (cand_thr / the running best are then compared WITHOUT a margin)
+    float rig_eps;
+    int list_all;            // the threshold lies beyond the score range's clamp value on the far side (maxima: < 0, minima:
+                             // > 1): a saturated exact score passes whatever the approximate one says - list everything
+    // map mode (route 2: approximate maps + refine_scan_kernel with tolerances rig_cap / 2 rig_cap): an output that could
+    // pass the threshold while its bound exceeds rig_cap sets *rig_flag - the host then takes the float64 kernel
+    float rig_cap;
+    float rig_thr;           // the exact quality threshold (score_threshold, negated for minima)
+    unsigned int* rig_flag;
 };
 
 // Per-template constants of a work item, staged in LDS once (the epilogue reads them as LDS broadcasts).
@@ -61,6 +77,7 @@ struct BfTemplConst {
     double centre[kMaxChans];
     double templ_norm, templ_sum2;
     double t2c;              // sum over channels of sum (T - centre)^2 (error bound of the refined raw-sum extremum)
+    double bfac;             // normalised methods: escale * sqrt(t2c) / templ_norm (0: constant template, scores exact)
     long long map_off;
     int map_pitch, all_ones, tglob, pad_;
 };

@@ -273,10 +273,13 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
     if (const char* v = std::getenv("MTM_CAND_PINNED")) c->cand_pinned = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_LAYOUT")) c->fuse_layout = std::atoi(v);
+    if (const char* v = std::getenv("MTM_NCC_EVENTS")) c->ncc_events = std::atoi(v);
+    if (const char* v = std::getenv("MTM_ZERO_IN_STATS")) c->zero_in_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_MIN_FILL")) c->band_min_fill = std::atof(v);
     if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
+    if (const char* v = std::getenv("MTM_F32_RIG")) c->f32_rig = std::atoi(v);
     if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);

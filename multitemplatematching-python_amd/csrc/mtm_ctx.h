@@ -142,6 +142,7 @@ struct FmState {
     int mode = 0;
     float thr = 0.0f;
     bool mode_min = false, fused = false, prefetched = false;
+    bool banded_u8 = false;     // the call's image came in row bands (uint8): the next such call clears the candidate header itself
     bool pin_direct = false;    // the score kernel wrote the head of the candidate list into the pinned window itself (no fetch)
     bool pp_mode = false;       // float32 refinement by map scan: the candidate buffer holds potential peaks whose
                                 // neighbourhoods in the maps are exact - decisions by verify_peaks_kernel, never from the list alone
@@ -174,6 +175,9 @@ struct mtm_ctx {
                                 // landing buffer itself (MfmaParams::cand_pin) - no fetch kernel behind the score launch (0: round 4)
     bool cand_pin_now = false;  // ... in the launches being queued
     size_t cand_pin_n = 0;
+    int ncc_events = 1;         // MTM_NCC_EVENTS: 0 = no timing events around the score launches (mtm_timing.ncc_* stay 0)
+    int zero_in_stats = 1;      // MTM_ZERO_IN_STATS: a banded uint8 call clears the candidate header in its first statistics launch
+    bool zero_pending = false;  // ... and has not done so yet
     int fuse_layout = 1;        // MTM_FUSE_LAYOUT: banded uploads convert a band's rows inside its statistics launch (0: planarize kernel)
     int lay_r0 = 0, lay_r1 = 0; // ... the rows the statistics launch being queued converts (run_score_banded -> launch_stats)
     int cand_stage = 1;         // MTM_CAND_STAGE: peak candidates of a wave collected in LDS, one atomic per wave and work item (0: one per emission)
@@ -241,6 +245,11 @@ struct mtm_ctx {
     int f32_mfma = 1;                       // MTM_F32_MFMA / MTM_OPT_F32_MFMA: unmasked float32 classes on the bf16 matrix cores:
                                             // 0 = float64 kernel, 1 = bf16 screen + exact float64 re-scoring of everything
                                             // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are
+    int f32_rig = 1;                        // MTM_F32_RIG: the refined routes list by the rigorous per-output error bound of the bf16
+                                            // scores (Bf16Params::rig); 0 = round 3's empirical margins (kRefineThrMargin / kRefineNbrTol)
+    float rig_thr = 0.0f;                   // the exact quality threshold of the call (the lists' own cand_thr carries a margin in map mode)
+    float scan_thr = 0.0f;                  // map mode: the threshold of refine_scan_kernel (rig_thr lowered by rig_cap)
+    float rig_cap = 0.0f;                   // map mode: the bound up to which the scan's tolerances hold (else: float64 kernel)
     // float32 refinement (mtm_refine.hip.h), state of the current mtm_find_matches
     bool refine_now = false;                // bf16 classes of this call are refined
     bool refine_scan_now = false;           // ... by map scan + ring re-scoring (maps in memory) instead of kernel candidates
@@ -441,6 +450,15 @@ struct SlotGeom {
     int rows, cols, rows_alloc, pitch;
     size_t u8_bytes;
 };
+
+// Error of a bf16-piece correlation relative to sqrt(sum (I - mu)^2 * sum (T - centre)^2) (Cauchy-Schwarz): 2^-15 covers the
+// dropped piece products and the two 16-bit representations (3 * 2^-18 + the float32 rounding of I - mu), the rest the
+// float32 accumulation - three MFMAs per 32-tap block, counted as TWO roundings of 2^-24 each (the matrix core's own
+// 32-term sum is not documented as a single rounding; tests/test_gpu_parity.py::test_float32_error_bound_holds measures
+// the whole bound against the float64 kernel on adversarial and random data).
+inline float bf16_rig_eps(int chans, int h, int nkb) {
+    return (float)(3.0518e-5 + 2.0 * 3.0 * (double)chans * h * nkb * 5.97e-8);
+}
 
 // ---- mtm_context.hip
 int prepare_slot(mtm_ctx* c, mtm_ctx::ImageSlot& sl, int src_rows, int src_cols, int chans, int dtype, hipStream_t stream,

@@ -16,6 +16,7 @@
 // Host-only C++ on top of the C ABI.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +62,12 @@ struct mtm_group {
     unsigned long long generation = 0;
     int pending = 0;
     bool stop = false;
+    // Round 5: the same hand-off through atomics the workers and the caller SPIN on before they sleep on the condition
+    // variables (a wake-up through the futex is 20-50 us, twice per search and on the critical path of every device)
+    std::atomic<unsigned long long> gen_a{0};
+    std::atomic<int> pending_a{0};
+    std::atomic<bool> stop_a{false};
+    long long spin_us = 300;                    // MTM_GROUP_SPIN_US: how long a worker polls for the next job before it sleeps
     Job job;
     std::vector<mtm_hit> last_hits;
     // hit exchange
@@ -126,19 +133,41 @@ void run_job(mtm_group* g, Worker& w) {
     }
 }
 
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
 void worker_main(mtm_group* g, int wi) {
     unsigned long long seen = 0;
     for (;;) {
-        {
+        // poll for the next job first (a loop over images calls again within ~100 us), then sleep
+        bool got = false;
+        if (g->spin_us > 0) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0;; ++i) {
+                if (g->stop_a.load(std::memory_order_acquire) || g->gen_a.load(std::memory_order_acquire) != seen) {
+                    got = true;
+                    break;
+                }
+                cpu_relax();
+                if ((i & 255) == 255 &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > g->spin_us)
+                    break;
+            }
+        }
+        if (!got) {
             std::unique_lock<std::mutex> lk(g->mu);
             g->cv_job.wait(lk, [&] { return g->stop || g->generation != seen; });
-            if (g->stop) return;
-            seen = g->generation;
         }
+        if (g->stop_a.load(std::memory_order_acquire)) return;
+        seen = g->gen_a.load(std::memory_order_acquire);
         run_job(g, g->workers[(size_t)wi]);
-        {
-            std::lock_guard<std::mutex> lk(g->mu);
-            if (--g->pending == 0) g->cv_done.notify_one();
+        if (g->pending_a.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::lock_guard<std::mutex> lk(g->mu);      // (the caller may be asleep on cv_done)
+            g->pending = 0;
+            g->cv_done.notify_one();
         }
     }
 }
@@ -171,6 +200,7 @@ int mtm_group_create(mtm_group** out, const int* device_ids, int n_devices) {
         }
     }
     if (const char* v = std::getenv("MTM_GROUP_STAGE")) g->stage_on = std::atoi(v) != 0;
+    if (const char* v = std::getenv("MTM_GROUP_SPIN_US")) g->spin_us = std::atoll(v);
     for (int i = 0; i < n_devices; ++i) g->workers[(size_t)i].th = std::thread(worker_main, g, i);
     *out = g;
     return MTM_OK;
@@ -219,6 +249,7 @@ void mtm_group_destroy(mtm_group* g) {
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->stop = true;
+        g->stop_a.store(true, std::memory_order_release);
     }
     g->cv_job.notify_all();
     for (Worker& w : g->workers)
@@ -269,9 +300,19 @@ int mtm_group_shards(const mtm_group* g, const mtm_templ* templs, int n_templ, i
     return MTM_OK;
 }
 
-int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, int method, const void* px, int rows,
-                           int cols, int chans, int dtype, int64_t row_stride_bytes, int mode, double score_threshold,
-                           mtm_hit* out, int64_t capacity, int64_t* n_out) {
+}  // extern "C"
+
+namespace {
+struct GroupNms {
+    bool on = false;
+    double score_threshold = 0.0, max_overlap = 0.0;
+    int64_t n_object = -1;
+};
+}  // namespace
+
+static int group_search(mtm_group* g, const mtm_templ* templs, int n_templ, int method, const void* px, int rows,
+                        int cols, int chans, int dtype, int64_t row_stride_bytes, int mode, double score_threshold,
+                        const GroupNms& nms, mtm_hit* out, int64_t capacity, int64_t* n_out) {
     if (!g || n_templ < 0 || (n_templ > 0 && !templs) || !px || !n_out || capacity < 0 || (capacity > 0 && !out)) {
         set_error("mtm_group_find_matches: bad arguments");
         return MTM_E_INVALID;
@@ -307,12 +348,30 @@ int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, i
         std::lock_guard<std::mutex> lk(g->mu);
         g->job = Job{method, mode, score_threshold, px, rows, cols, chans, dtype, row_stride_bytes};
         g->pending = nd;
+        g->pending_a.store(nd, std::memory_order_release);
         ++g->generation;
+        g->gen_a.store(g->generation, std::memory_order_release);
     }
     g->cv_job.notify_all();
     {
-        std::unique_lock<std::mutex> lk(g->mu);
-        g->cv_done.wait(lk, [&] { return g->pending == 0; });
+        // the searches take about a millisecond: poll for their end (this thread has nothing else to do), sleep only
+        // when they take much longer than that
+        bool done = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            if (g->pending_a.load(std::memory_order_acquire) == 0) {
+                done = true;
+                break;
+            }
+            cpu_relax();
+            if ((i & 255) == 255 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 20 * g->spin_us)
+                break;
+        }
+        if (!done) {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_done.wait(lk, [&] { return g->pending_a.load(std::memory_order_acquire) == 0; });
+        }
     }
     for (Worker& w : g->workers)
         if (w.rc != MTM_OK) {
@@ -339,13 +398,34 @@ int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, i
         int64_t n_all = 0;
         const int rcx = mtm_comm_allgather_hits_all(ctxs.data(), nd, local.data(), n_local.data(), all.data(), (int64_t)all.size(),
                                                     counts.data(), &n_all);
-        if (rcx != MTM_OK) return rcx;
-        all.resize((size_t)n_all);
-        g->exchange_used = MTM_GROUP_EXCHANGE_RCCL;
-    } else {
-        for (Worker& w : g->workers) all.insert(all.end(), w.hits.begin(), w.hits.end());
+        if (rcx == MTM_OK) {
+            all.resize((size_t)n_all);
+            g->exchange_used = MTM_GROUP_EXCHANGE_RCCL;
+        } else {
+            // every worker's list is in host memory already: a failed collective (time-out, aborted communicators) costs
+            // the exchange, not the search - this and the following searches merge on the host
+            g->comm_ready = false;
+            g->exchange = MTM_GROUP_EXCHANGE_HOST;
+            all.clear();
+        }
     }
+    if (g->exchange_used == MTM_GROUP_EXCHANGE_HOST)
+        for (Worker& w : g->workers) all.insert(all.end(), w.hits.begin(), w.hits.end());
     std::stable_sort(all.begin(), all.end(), [](const mtm_hit& a, const mtm_hit& b) { return a.templ_idx < b.templ_idx; });
+    if (nms.on) {
+        // MTM.NMS on the merged list, as mtm_find_matches_image_nms runs it on a single context's (MTM/NMS.py:53-84): a list
+        // of one hit is returned as it is, else cv2.dnn.NMSBoxes' selection in its order, then the first N_object
+        const bool ascending = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
+        if (all.size() > 1) {
+            const float thr_s = (float)(ascending ? (1.0 - nms.score_threshold) : nms.score_threshold);
+            std::vector<int32_t> keep;
+            nms_select(all.data(), (int64_t)all.size(), ascending ? 1 : 0, thr_s, (float)nms.max_overlap, keep);
+            std::vector<mtm_hit> kept(keep.size());
+            for (size_t i = 0; i < keep.size(); ++i) kept[i] = all[(size_t)keep[i]];
+            all.swap(kept);
+        }
+        if (nms.n_object >= 0 && (int64_t)all.size() > nms.n_object) all.resize((size_t)nms.n_object);
+    }
     *n_out = (int64_t)all.size();
     g->last_hits.swap(all);
     if ((int64_t)g->last_hits.size() > capacity) {
@@ -354,6 +434,27 @@ int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, i
     }
     if (!g->last_hits.empty()) std::memcpy(out, g->last_hits.data(), sizeof(mtm_hit) * g->last_hits.size());
     return MTM_OK;
+}
+
+extern "C" {
+
+int mtm_group_find_matches(mtm_group* g, const mtm_templ* templs, int n_templ, int method, const void* px, int rows,
+                           int cols, int chans, int dtype, int64_t row_stride_bytes, int mode, double score_threshold,
+                           mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    return group_search(g, templs, n_templ, method, px, rows, cols, chans, dtype, row_stride_bytes, mode, score_threshold,
+                        GroupNms{}, out, capacity, n_out);
+}
+
+int mtm_group_find_matches_nms(mtm_group* g, const mtm_templ* templs, int n_templ, int method, const void* px, int rows,
+                               int cols, int chans, int dtype, int64_t row_stride_bytes, double score_threshold,
+                               double max_overlap, int64_t n_object, mtm_hit* out, int64_t capacity, int64_t* n_out) {
+    GroupNms nms;
+    nms.on = true;
+    nms.score_threshold = score_threshold;
+    nms.max_overlap = max_overlap;
+    nms.n_object = n_object;
+    return group_search(g, templs, n_templ, method, px, rows, cols, chans, dtype, row_stride_bytes, MTM_PEAKS_LOCAL,
+                        score_threshold, nms, out, capacity, n_out);
 }
 
 int mtm_group_last_hits(mtm_group* g, mtm_hit* out, int64_t capacity, int64_t* n_out) {

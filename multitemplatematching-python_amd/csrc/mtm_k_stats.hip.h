@@ -150,6 +150,8 @@ struct StatLayout {
     uint8_t* u8b = nullptr;
     int pitch = 0;          // of the planes
     int r0 = 0, r1 = 0;     // image rows to convert
+    unsigned long long* zero16 = nullptr;   // non-null: 16 bytes the launch clears (the candidate list's header: the first
+                                            // kernel of a banded call does it instead of a fill command between two calls)
 };
 
 __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict__ img, int pitch, int h, int w,
@@ -163,6 +165,10 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
     __shared__ uint32_t wsum[2][4];
     const int x0 = blockIdx.x * owg, y0 = ((int)blockIdx.y + yb_off) * kStatBand4;   // yb_off: banded launches
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (lay.zero16 != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+        lay.zero16[0] = 0ull;
+        lay.zero16[1] = 0ull;
+    }
     if (lay.u8b != nullptr) {
         // Round 5: the layout conversion of a band's rows rides on its statistics launch (`img` is then the RAW upload buffer,
         // `pitch` its row length - a multiple of 4).  The band's image rows lay.r0 .. lay.r1 - 1 are split evenly over the

@@ -140,6 +140,10 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
                 src = sl.raw.as<uint8_t>();
                 src_pitch = c->cols;
             }
+            if (c->zero_pending && c->stats_stream != nullptr) {        // banded call: the candidate header is cleared here
+                lay.zero16 = c->cands.as<unsigned long long>();
+                c->zero_pending = false;
+            }
             hipLaunchKernelGGL(stats_u8_kernel, gs, dim3(256), 0, c->stats_stream ? c->stats_stream : c->stream, src,
                                src_pitch, h, w, oh, ow, owg, inv_area, num_type, normed ? 1 : 0, want_t, want_sum2, tp[0],
                                sum2, sq, st.pitch, rsq, sb0, blk, st.blk_pitch, lay);
@@ -351,8 +355,8 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     // (The events are stream commands of their own.  Handing them to the launch itself - hipExtLaunchKernelGGL's start /
     // stop events - was measured in round 4: the gaps around the launches stayed, the call got 14 us SLOWER;
     // profiles/r04_r04w.)
-    bool ev_own = false;                // a branch below records the pair itself (on the stream its launch goes to)
-    HIPC(hipEventRecord(evp.first, ncc_s));
+    bool ev_own = !c->ncc_events;       // a branch below records the pair itself (on the stream its launch goes to)
+    if (c->ncc_events) HIPC(hipEventRecord(evp.first, ncc_s));
 
     if (kernel == MTM_KERNEL_NAIVE) {
         const dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4, n_list);
@@ -474,11 +478,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
             // (merged launch on a side stream: the timing pair goes there too - on the score stream it would bracket
             // the fork and the join, not the launch)
-            if (merged && slab_s != ncc_s) HIPC(hipEventRecord(evp.first, slab_s));
+            if (merged && slab_s != ncc_s && c->ncc_events) HIPC(hipEventRecord(evp.first, slab_s));
             hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, slab_s, p, td,
                                c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
             if (merged && slab_s != ncc_s) {
-                HIPC(hipEventRecord(evp.second, slab_s));
+                if (c->ncc_events) HIPC(hipEventRecord(evp.second, slab_s));
                 ev_own = true;
             }
         }
@@ -814,18 +818,32 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_counter = c->cands.as<unsigned long long>();
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
+        const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
+        if (c->refine_now && !raw_m && c->f32_rig && only_li < 0) {
+            // Round 5: the listing decisions of the refined routes by the rigorous per-output bound (Bf16Params::rig)
+            p.rig = 1;
+            p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb);
+            p.rig_thr = c->rig_thr;
+            p.list_all = c->cand_min ? (c->rig_thr < -1.0f ? 1 : 0) : (c->rig_thr < 0.0f ? 1 : 0);
+            if (c->refine_scan_now) {           // map mode: the scan's tolerances hold while no bound exceeds the cap
+                p.rig_cap = c->rig_cap;
+                p.rig_flag = reinterpret_cast<unsigned int*>(c->cands.as<uint8_t>() + 8);
+            }
+        }
         if (c->ext_now && only_li < 0) {                  // fused global extremum (find_matches_impl checked the classes)
             p.ext_on = 1;
             p.ext_best = c->counters.as<unsigned long long>();
             p.cand_on = 1;
             p.hits_only = 1;
             p.ext_margin = c->refine_now ? kRefineThrMargin : 0.0f;
-            const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
             if (raw_m && c->refine_now) {
                 // rigorous bounds instead of a relative margin (Bf16Params::ext_raw): 2^-15 for the dropped piece products
                 // and the two 16-bit representations, 2^-24 per float32 accumulation (three MFMAs per 32-tap block)
                 p.ext_raw = 1;
                 p.ext_eps = (float)(3.0518e-5 + 3.0 * (double)c->chans * h * p.nkb * 5.97e-8);
+            } else if (p.rig) {
+                p.ext_raw = 1;                              // (bounds of the quality instead of scores: the rig branch of the epilogue)
+                p.list_all = 0;
             }
         }
         const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
@@ -872,7 +890,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     }
     HIPC(hipGetLastError());
     if (!ev_own) HIPC(hipEventRecord(evp.second, ncc_s));
-    c->timing.ncc_launches++;
+    if (c->ncc_events) c->timing.ncc_launches++;
     return MTM_OK;
 }
 
@@ -925,7 +943,8 @@ int launch_refine_scan(mtm_ctx* c, const SizeClass& sc) {
     const int oh = c->rows - sc.h + 1, ow = c->cols - sc.w + 1;
     const dim3 grd((ow + kPkCols - 1) / kPkCols, (oh + 4 * kPkRows - 1) / (4 * kPkRows), (unsigned)sc.members.size());
     hipLaunchKernelGGL(refine_scan_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(), c->td.as<TemplDev>(),
-                       c->tlist.as<int>() + sc.tlist_off, c->cand_min ? 1 : 0, c->cand_thr, kRefineNbrTol, c->opt_border,
+                       c->tlist.as<int>() + sc.tlist_off, c->cand_min ? 1 : 0, c->scan_thr,
+                       c->f32_rig ? 2.0f * c->rig_cap : kRefineNbrTol, c->opt_border,
                        reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16),
                        (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256), c->cands.as<unsigned long long>());
     HIPC(hipGetLastError());
@@ -1254,6 +1273,10 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
         if (yb1 > yb_done) {
             hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
+            if (c->zero_pending) {          // (no statistics launch took the clearing of the candidate header along)
+                HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+                c->zero_pending = false;
+            }
             if (s != bs) HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
             c->ncc_stream = s;
             const int rc2 = launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1);

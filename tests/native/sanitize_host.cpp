@@ -89,6 +89,7 @@ void* mtm_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
 void mtm_host_free(void* p) { std::free(p); }
 // the in-process communicator calls: rank i = context i; the "all-gather" concatenates the lists in rank order
 static std::atomic<int> g_comm_calls{0};
+static std::atomic<bool> g_comm_fail{false};
 int mtm_comm_init_all(mtm_ctx* const* ctxs, int n) {
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < i; ++k)
@@ -102,6 +103,10 @@ int mtm_comm_count(mtm_ctx*) { return 1; }
 int mtm_comm_allgather_hits_all(mtm_ctx* const*, int n, const mtm_hit* const* local, const int64_t* n_local, mtm_hit* out,
                                 int64_t cap, int64_t* counts, int64_t* n_out) {
     ++g_comm_calls;
+    if (g_comm_fail.load()) {
+        set_error("fake: the collective timed out");
+        return MTM_E_COMM;
+    }
     int64_t o = 0;
     for (int r = 0; r < n; ++r) {
         counts[r] = n_local[r];
@@ -188,6 +193,65 @@ static void test_group(std::mt19937& rng) {
             }
         }
         CHECK(unique_devs ? g_comm_calls.load() > calls0 : g_comm_calls.load() == calls0);
+        // mtm_group_find_matches_nms == mtm_nms over mtm_group_find_matches' list (overlapping boxes: the fake's hits of one
+        // template sit one pixel apart), for both exchanges, finite N_object and an overflowing capacity
+        for (int job = 0; job < 60; ++job) {
+            const int n = 1 + (int)(rng() % 24);
+            std::vector<mtm_templ> t((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                std::memset(&t[i], 0, sizeof(mtm_templ));
+                t[i].px = &pixel;
+                t[i].rows = 1 + (int)(rng() % 40);
+                t[i].cols = 14 + (int)(rng() % 3);          // few distinct widths: boxes of different templates coincide
+                t[i].chans = 1;
+            }
+            if (unique_devs) CHECK(mtm_group_set_exchange(g, job & 1 ? MTM_GROUP_EXCHANGE_RCCL : MTM_GROUP_EXCHANGE_HOST) == MTM_OK);
+            const int method = job % 3 == 0 ? 1 : 5;
+            const double thr = 0.5, ov = (job % 4) * 0.25;
+            const int64_t nobj = job % 5 == 0 ? 2 : -1;
+            std::vector<mtm_hit> all(4096), fused(4096);
+            int64_t n_all = -1, n_fused = -1;
+            CHECK(mtm_group_find_matches(g, t.data(), n, method, &pixel, 500, 600, 1, MTM_U8, 600, 0, thr, all.data(), 4096, &n_all) == MTM_OK);
+            const int64_t cap = job % 7 == 0 ? 1 : 4096;
+            int rc = mtm_group_find_matches_nms(g, t.data(), n, method, &pixel, 500, 600, 1, MTM_U8, 600, thr, ov, nobj, fused.data(), cap, &n_fused);
+            if (rc == MTM_E_OVERFLOW) {
+                CHECK(n_fused > cap);
+                rc = mtm_group_last_hits(g, fused.data(), 4096, &n_fused);
+            }
+            CHECK(rc == MTM_OK);
+            std::vector<int32_t> keep((size_t)std::max<int64_t>(n_all, 1));
+            int64_t nk = 0;
+            if (n_all > 1) {
+                CHECK(mtm_nms(all.data(), n_all, thr, method == 1, nobj, ov, keep.data(), &nk) == MTM_OK);
+            } else {                                            // MTM/NMS.py:53-55: a list of one hit is returned as it is
+                nk = n_all;
+                keep[0] = 0;
+                if (nobj >= 0 && nk > nobj) nk = nobj;
+            }
+            CHECK(nk == n_fused);
+            for (int64_t i = 0; i < nk; ++i) CHECK(std::memcmp(&all[(size_t)keep[(size_t)i]], &fused[(size_t)i], sizeof(mtm_hit)) == 0);
+        }
+        // a failing collective costs the exchange, not the search: the lists are merged on the host, now and afterwards
+        if (unique_devs) {
+            CHECK(mtm_group_set_exchange(g, MTM_GROUP_EXCHANGE_RCCL) == MTM_OK);
+            g_comm_fail.store(true);
+            std::vector<mtm_templ> t(3);
+            for (int i = 0; i < 3; ++i) {
+                std::memset(&t[i], 0, sizeof(mtm_templ));
+                t[i].px = &pixel;
+                t[i].rows = 5 + i;
+                t[i].cols = 20;
+                t[i].chans = 1;
+            }
+            std::vector<mtm_hit> out(4096);
+            int64_t got = -1;
+            CHECK(mtm_group_find_matches(g, t.data(), 3, 5, &pixel, 500, 600, 1, MTM_U8, 600, 0, 0.5, out.data(), 4096, &got) == MTM_OK);
+            CHECK(got == 5 + 6 + 0 && mtm_group_exchange_used(g) == MTM_GROUP_EXCHANGE_HOST);
+            g_comm_fail.store(false);
+            CHECK(mtm_group_set_exchange(g, MTM_GROUP_EXCHANGE_RCCL) == MTM_E_STATE);      // until mtm_group_comm_init runs again
+            CHECK(mtm_group_find_matches(g, t.data(), 3, 5, &pixel, 500, 600, 1, MTM_U8, 600, 0, 0.5, out.data(), 4096, &got) == MTM_OK && got == 11);
+            CHECK(mtm_group_comm_init(g) == MTM_OK);
+        }
         // an image of a megabyte and more goes through the group's shared page-locked staging buffer: every worker copies
         // its slice of the rows (strided and contiguous sources), waits for the others, searches from the buffer
         if (nd > 1) {

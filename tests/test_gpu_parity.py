@@ -2577,3 +2577,153 @@ def test_4k_photograph_default_mode_hit_lists(mtm):
     assert len(got) == len(exp9) >= 4
     assert_hits_equal(hits_json(got), hits_json(exp9), tol=1e-6, ordered=False)
     MTM._lib.default_context().set_option(MTM._lib.OPT_HITS_ONLY, 1)      # clears the back-off for the tests that follow
+
+
+# ---- round 5: the float32 route's listing decisions rest on a per-output error bound, not on empirical margins ----------
+def _bf16_bound_map(img, templ, method):
+    """numpy restatement of Bf16Params::rig's bound M(x, y) for a single-channel float32 image and one template:
+    rig_eps * sqrt(sum (I - mu)^2) / sq * (escale * sqrt(sum (T - mean)^2) / templ_norm), with mu the constant the
+    bf16 kernel's work item (128 columns x 4 rows of outputs) subtracts: the mean of an 8 x 8 sample grid over its patch."""
+    I = img.astype(np.float64)
+    T = templ.astype(np.float64)
+    rows, cols = I.shape
+    h, w = T.shape
+    oh, ow = rows - h + 1, cols - w + 1
+    A = float(h * w)
+    nkb = (w + 31) // 32
+    lds_cols = 128 + 32 * nkb
+    eps = 3.0518e-5 + 2.0 * 3.0 * h * nkb * 5.97e-8
+    c1 = np.zeros((rows + 1, cols + 1))
+    c1[1:, 1:] = I.cumsum(0).cumsum(1)
+    c2 = np.zeros((rows + 1, cols + 1))
+    c2[1:, 1:] = (I * I).cumsum(0).cumsum(1)
+    box = lambda c: c[h:, w:] - c[:-h, w:] - c[h:, :-w] + c[:-h, :-w]     # noqa: E731
+    S1, S2 = box(c1), box(c2)
+    mu = np.zeros((oh, ow))
+    for y0 in range(0, oh, 4):
+        sr = np.minimum(y0 + (np.arange(8) * (h + 2)) // 7, rows - 1)
+        for x0 in range(0, ow, 128):
+            sc = np.minimum(x0 + (np.arange(8) * (lds_cols - 1)) // 7, cols - 1)
+            mu[y0:y0 + 4, x0:x0 + 128] = np.float32(img[np.ix_(sr, sc)].astype(np.float32).mean())
+    s2c = np.maximum(S2 - 2.0 * mu * S1 + A * mu * mu, 0.0) * 1.000001 + 1e-12 * (np.abs(S2) + A * mu * mu)
+    t2c = ((T - T.mean()) ** 2).sum()
+    if method == 5:
+        diff2 = np.maximum(S2 - S1 * S1 / A, 0.0)
+        tn = np.sqrt(t2c)
+        esc = 1.0
+    else:
+        diff2 = S2
+        tn = np.sqrt((T * T).sum())
+        esc = 2.0 if method == 1 else 1.0
+    flat = diff2 <= np.minimum(0.5, 10.0 * np.finfo(np.float32).eps * S2)
+    sq = np.where(flat, 0.0, np.sqrt(diff2))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        M = eps * np.sqrt(s2c) / sq * (esc * np.sqrt(t2c) / tn) + 3e-7
+    return np.where(sq > 0.0, M, 0.0), sq > 0.0
+
+
+def _step_image(seed, shape=(300, 420), lo=0.0, hi=1.0, noise=2e-3):
+    """A 0 -> 1 brightness step down the middle with low-contrast texture on both sides: windows a few columns away
+    from the step are nearly flat while their work item's tile constant sits half way up the step."""
+    rng = np.random.default_rng(seed)
+    im = np.full(shape, lo, np.float32)
+    im[:, shape[1] // 2:] = hi
+    im += rng.normal(0.0, noise, shape).astype(np.float32)
+    im[40:90, 20:90] += rng.normal(0.0, 0.2, (50, 70)).astype(np.float32)     # one textured patch on the dark side
+    return im
+
+
+@pytest.mark.gpu
+def test_float32_error_bound_holds():
+    """|bf16 kernel score - float64 kernel score| <= M at every output, M the bound the refined routes list by
+    (Bf16Params::rig): on the adversarial geometry (low-contrast windows beside a brightness step, templates cut across
+    the step) and on random data, for the three normalised methods.  Also reports how tight the bound is.
+    Reference: MTM/__init__.py:71-74 (everything not uint8 is matched as float32)."""
+    from MTM import _lib
+    fast, exact = _lib.Context(0), _lib.Context(0)
+    fast.set_option(_lib.OPT_F32_MFMA, 2)           # the bf16 scores as they are
+    exact.set_option(_lib.OPT_F32_MFMA, 0)
+    rng = np.random.default_rng(5)
+    step = _step_image(1)
+    rnd = rng.normal(10.0, 3.0, (260, 400)).astype(np.float32)
+    ramp = (np.linspace(0, 500, 400, dtype=np.float32)[None, :] + rng.normal(0, 0.05, (260, 400)).astype(np.float32))
+    worst = 0.0
+    try:
+        for name, im in (("step", step), ("random", rnd), ("ramp", ramp)):
+            cx = im.shape[1] // 2
+            templs = [np.ascontiguousarray(im[100:132, cx - 20:cx + 20]),     # across the step
+                      np.ascontiguousarray(im[10:34, 30:54]), np.ascontiguousarray(im[150:214, cx + 40:cx + 104])]
+            for method in (5, 3, 1):
+                for t in templs:
+                    shape = (im.shape[0] - t.shape[0] + 1, im.shape[1] - t.shape[1] + 1)
+                    maps = []
+                    for ctx in (fast, exact):
+                        ctx.set_image(im)
+                        ctx.set_templates([(t, None)], method)
+                        maps.append(ctx.score_map(0, shape).astype(np.float64))
+                    assert fast.timing()["kernel_used"] == 5 and exact.timing()["kernel_used"] == 0
+                    M, live = _bf16_bound_map(im, t, method)
+                    unsat = live & (np.abs(maps[1]) < 1.0) & (np.abs(maps[0]) < 1.0)
+                    d = np.abs(maps[0] - maps[1])
+                    assert (d[unsat] <= M[unsat]).all(), (name, method, t.shape, float((d[unsat] / M[unsat]).max()))
+                    if unsat.any():
+                        worst = max(worst, float((d[unsat] / M[unsat]).max()))
+        print("float32 bound: worst |error| / bound = %.3f" % worst)
+        assert worst <= 1.0
+    finally:
+        fast.close()
+        exact.close()
+
+
+@pytest.mark.gpu
+def test_float32_adversarial_lists_equal_the_float64_kernels():
+    """The case the empirical margins of rounds 3-4 did not cover: flat / low-contrast windows adjacent to a brightness
+    step (their tile constant is far from their own mean, so the bf16 pieces carry the brightness, not the contrast),
+    templates cut across the step, and thresholds placed within 1e-5 of true peak scores.  The default float32 route must
+    return the float64 kernel's records - same pixels, order and float32 scores - by local extrema (hits-only and with maps
+    in memory) and by global extremum.  Reference: MTM/__init__.py:71-74, :45, :226."""
+    if not default_routes():
+        pytest.skip("asserts the default float32 routes")
+    from MTM import _lib
+    fast, exact = _lib.Context(0), _lib.Context(0)
+    exact.set_option(_lib.OPT_F32_MFMA, 0)
+    routes = set()
+    try:
+        for seed, (lo, hi, noise) in enumerate(((0.0, 1.0, 2e-3), (0.0, 255.0, 0.5), (100.0, 101.0, 1e-2), (0.0, 1.0, 2e-5))):
+            im = _step_image(seed + 3, lo=lo, hi=hi, noise=noise)
+            cx = im.shape[1] // 2
+            lt = [np.ascontiguousarray(im[100:132, cx - 20:cx + 20]), np.ascontiguousarray(im[200:232, cx - 8:cx + 32]),
+                  np.ascontiguousarray(im[45:77, 30:70]), np.ascontiguousarray(im[20:52, cx + 60:cx + 100]),
+                  np.ascontiguousarray(im[150:182, 10:50])]
+            templs = [(t, None) for t in lt]
+            for method in (5, 3, 1):
+                base_thr = {5: 0.3, 3: 0.9, 1: 0.2}[method]
+                ref0 = exact.search(templs, im, method, _lib.PEAKS_LOCAL, base_thr)
+                # thresholds a hair on either side of true peak scores (and the base threshold itself)
+                thrs = [base_thr]
+                for s in np.unique(ref0["score"])[:: max(1, len(np.unique(ref0["score"])) // 6)][:6]:
+                    if 0.0 < float(s) < 1.0:
+                        thrs += [float(s) - 1e-5, float(s) + 1e-5, float(np.nextafter(np.float32(s), np.float32(0)))]
+                for thr in thrs:
+                    ref = exact.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
+                    for honly in (1, 0):
+                        fast.set_option(_lib.OPT_HITS_ONLY, honly)
+                        got = fast.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
+                        tm = fast.timing()
+                        routes.add(tm["f32_route"])
+                        assert tm["f32_route"] in (1, 2, 3), tm
+                        assert len(got) == len(ref), (seed, method, thr, honly, tm["f32_route"], len(got), len(ref))
+                        for f in ("templ_idx", "x", "y", "w", "h"):
+                            assert np.array_equal(got[f], ref[f]), (seed, method, thr, honly, tm["f32_route"], f)
+                        assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (seed, method, thr, honly)
+                fast.set_option(_lib.OPT_HITS_ONLY, 1)
+                ref = exact.search(templs, im, method, _lib.PEAKS_GLOBAL, 0.0)
+                got = fast.search(templs, im, method, _lib.PEAKS_GLOBAL, 0.0)
+                routes.add(fast.timing()["f32_route"])
+                for f in ("templ_idx", "x", "y"):
+                    assert np.array_equal(got[f], ref[f]), (seed, method, f, fast.timing()["f32_route"])
+                assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (seed, method)
+        assert 1 in routes, routes
+    finally:
+        fast.close()
+        exact.close()
