@@ -612,6 +612,8 @@ def main():
         my_units = sub
         launches = timed_launches
         k_step = float(np.mean(k_ms))                               # score-kernel time of one step (all its launches)
+        if not k_step > 0.0:                                        # (MTM_NCC_EVENTS=0, an experiment: no kernel timing -> rates of 0)
+            k_step = float("inf")
         hits_only = bool(tinfo.get("hits_only", 0))
         bytes_step = (algorithmic_bytes_hits_only if hits_only else algorithmic_bytes)(img, my_units)
         macs = score_kernel_macs(img, my_units)

@@ -74,8 +74,11 @@ extern "C" {
 #define MTM_OPT_PEAK_BORDER 2
 #define MTM_OPT_HIT_CAPACITY 3
 #define MTM_OPT_DOT4_VARIANT 4  /* register-blocking variant of the dot4 kernel (tuning) */
-#define MTM_OPT_EXACT_DIV 5     /* 1: IEEE division in the MFMA epilogue (bit-identical to the other kernels);
-                                   0 (default): reciprocal multiplies, <= 1 ulp(float32) on ~1e-8 of the pixels */
+#define MTM_OPT_EXACT_DIV 5     /* 1 (default since round 5: measured free on the hits-only path): IEEE division in the MFMA
+                                   epilogue, bit-identical to the other kernels and to the oracle;
+                                   0: correctly rounded reciprocals, <= 1 ulp(float32) on ~1e-8 of the pixels (round 1-4's
+                                   default; what the fused global extremum of MASKED classes still uses under 1);
+                                   2: strict - that extremum too goes through maps + extremum_kernel */
 #define MTM_OPT_HITS_ONLY 6     /* 1 (default): mtm_find_matches does not write the score maps to memory when every
                                    template runs the int8 MFMA kernel: in local-extrema mode the peaks come from
                                    the in-kernel candidate list, in global-extremum mode (unmasked 1- or

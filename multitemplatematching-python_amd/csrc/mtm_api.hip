@@ -115,7 +115,9 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
             max_oh = std::max(max_oh, c->rows - sc.h + 1);
             max_nseg = std::max(max_nseg, (c->cols - sc.w + 1 + kMfSeg - 1) / kMfSeg);
         }
-        if (ok && (long long)n * max_oh * max_nseg < (1ll << 30)) {
+        // (bounded: the flags are cleared on every call and compact_hits_kernel sums the per-(template, strip) counters in
+        // every block - with thousands of templates the flagged route would cost more than the full scan it replaces)
+        if (ok && (long long)n * max_oh * max_nseg <= (64ll << 20) && (long long)n * max_nseg <= 4096) {
             c->flag_rstride = max_nseg;
             c->flag_tstride = max_oh * max_nseg;
             MTMC(c->seg_flags.ensure((size_t)n * c->flag_tstride));
@@ -165,7 +167,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         bool ok = true;
         for (const SizeClass& sc : c->classes)
             ok = ok && ((resolved_kernel(c, sc) == MTM_KERNEL_MFMA &&
-                         (!sc.masked || (!c->exact_div && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED))) ||
+                         (!sc.masked || (c->exact_div < 2 && c->chans == 1 && c->method <= MTM_TM_CCORR_NORMED))) ||
                         resolved_kernel(c, sc) == MTM_KERNEL_MFMA16 || resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32);
         if (ok) {
             MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * (size_t)n));
@@ -327,12 +329,14 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
 struct DeviceNms {
     bool queued = false;
     unsigned n_max = 0;
-    unsigned long long cnt[2] = {0ull, 0ull};      // landing buffer of the two counters (champions, undecided)
+    const unsigned long long* cnt_pin = nullptr;   // landing buffer of the two counters (champions, undecided), page-locked
     const mtm_hit* out = nullptr;
 };
 
 int queue_device_nms(mtm_ctx* c, const mtm_hit* dhits, const unsigned long long* dcount, bool ascending, DeviceNms* q) {
-    int cell = 1;
+    // (a cell larger than the largest box side is still correct - the 3x3 cell neighbourhood covers every partner - and
+    // small templates on a large image would otherwise make millions of cells to clear and scan on every attempt)
+    int cell = 32;
     for (const TemplDev& d : c->td_host) cell = std::max(cell, std::max(d.rows, d.cols));
     const size_t n_max = (size_t)std::min<int64_t>(c->hit_cap, 1ll << 18);
     NmsParams p{};
@@ -369,7 +373,11 @@ int queue_device_nms(mtm_ctx* c, const mtm_hit* dhits, const unsigned long long*
     hipLaunchKernelGGL(nms_champion_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     hipLaunchKernelGGL(nms_prune_kernel, dim3(blocks), dim3(256), 0, c->stream, p);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpyAsync(q->cnt, b + off_hdr, sizeof(q->cnt), hipMemcpyDeviceToHost, c->stream));
+    // (into page-locked memory: a device-to-host copy into a pageable stack slot may hold the host until the whole peak pass
+    // is done - the round trip this queueing exists to avoid)
+    if (!c->pin_small) HIPC(hipHostMalloc(&c->pin_small, 64, hipHostMallocDefault));
+    q->cnt_pin = static_cast<unsigned long long*>(c->pin_small);
+    HIPC(hipMemcpyAsync(c->pin_small, b + off_hdr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     q->queued = true;
     q->n_max = (unsigned)n_max;
     q->out = p.out;
@@ -377,7 +385,11 @@ int queue_device_nms(mtm_ctx* c, const mtm_hit* dhits, const unsigned long long*
 }
 
 // after the stream was synchronised (q.cnt has landed): the pruned list of `count` peaks -> `rest`, *n_sure = champions
-int fetch_device_nms(mtm_ctx* c, const DeviceNms& q, unsigned long long count, std::vector<mtm_hit>& rest, long long* n_sure) {
+int fetch_device_nms(mtm_ctx* c, const DeviceNms& qd, unsigned long long count, std::vector<mtm_hit>& rest, long long* n_sure) {
+    struct {
+        unsigned long long cnt[2];
+        const mtm_hit* out;
+    } q{{qd.cnt_pin ? qd.cnt_pin[0] : 0ull, qd.cnt_pin ? qd.cnt_pin[1] : 0ull}, qd.out};
     if (q.cnt[0] + q.cnt[1] > count) {
         set_error("mtm_find_matches_image_nms: internal state (pruned list longer than the peak list)");
         return MTM_E_STATE;

@@ -175,6 +175,8 @@ struct mtm_ctx {
                                 // landing buffer itself (MfmaParams::cand_pin) - no fetch kernel behind the score launch (0: round 4)
     bool cand_pin_now = false;  // ... in the launches being queued
     size_t cand_pin_n = 0;
+    int eager_copy_stream = 1;  // MTM_EAGER_COPY_STREAM: the copy-side stream is created with the context (0: by the first banded call)
+    int band_align = 1;         // MTM_BAND_ALIGN: upload bands end where their score launch is a whole number of work-group generations
     int ncc_events = 1;         // MTM_NCC_EVENTS: 0 = no timing events around the score launches (mtm_timing.ncc_* stay 0)
     int zero_in_stats = 1;      // MTM_ZERO_IN_STATS: a banded uint8 call clears the candidate header in its first statistics launch
     bool zero_pending = false;  // ... and has not done so yet
@@ -351,7 +353,9 @@ struct mtm_ctx {
     bool fm_in_flight = false;
     const void* cands_zeroed = nullptr;   // candidate buffer whose counter was cleared after the previous call's fetch
     bool ext_now = false;      // this call: global extrema come out of the MFMA epilogue (no maps, no extremum_kernel)
-    int exact_div = 0;         // MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-exact mode)
+    int exact_div = 1;         // MTM_OPT_EXACT_DIV: 1 (default since round 5) = IEEE division in the MFMA epilogue, bit-identical to the
+                               // oracle; 0 = correctly rounded reciprocals (<= 1 ulp(float32) on ~1e-8 of the outputs); 2 = strict: also
+                               // the fused extremum of masked classes (reciprocal-only kernels) goes through maps + extremum_kernel
     int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
     int mfma_stagger = -1;     // < 0: automatic
     int mfma_stagger_mode = 0;
@@ -361,6 +365,7 @@ struct mtm_ctx {
 
     mtm_timing timing{};
     std::vector<mtm_hit> last_hits;     // result of the last mtm_find_matches (for mtm_last_hits)
+    void* pin_small = nullptr;          // 64 page-locked bytes: landing place of small device-to-host copies (device NMS counters)
     void* pinned = nullptr;             // pinned host buffer the candidate records land in
     size_t pinned_cap = 0;
     void* comm_pin = nullptr;           // pinned staging of the hit exchange: [my slot | gathered slots]

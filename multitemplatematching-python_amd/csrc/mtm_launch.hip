@@ -634,12 +634,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         // the instantiation of ncc_mfma_kernel for this class (the kernels live in the mtm_mfma_*.hip units)
         MfmaSel sel;
         sel.mb = mb;
-        sel.exact_div = c->exact_div != 0;
         sel.masked = sc.masked;
         sel.rm = rm;
         sel.ch = (c->chans == 3 && !sc.masked) ? 3 : 1;
         sel.method = (c->chans == 1 || sel.ch == 3) ? c->method : -1;     // other channel counts: the generic epilogue
         sel.ext = ext;
+        // IEEE division in the epilogue (the default since round 5: measured free on the hits-only path, profiles/r05*).  The
+        // fused global extremum of MASKED classes only exists with the reciprocal normalisation (<= 1 ulp(float32) on ~1e-8
+        // of the outputs); exact_div == 2 (strict) sends those calls through maps + extremum_kernel instead (fm_begin).
+        sel.exact_div = c->exact_div != 0 && !(ext && sc.masked);
         sel.r2 = r2;
         sel.kp = sc.kp_nseg > 0;
         const MfmaFn fn = mfma_kernel(sel);
@@ -1217,10 +1220,34 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         HIPC(hipEventRecord(c->stream2_done, c->stream));
         HIPC(hipStreamWaitEvent(c->stream2, c->stream2_done, 0));
     }
+    // Round 5 (MTM_BAND_ALIGN, default 1): a band ends where its score launch is a whole number of generations of resident
+    // work-groups (two per CU).  Measured at 4K x 32 templates (profiles/r05b): a first band of 0.25 of the rows is 3.46
+    // generations - the last, part-filled one runs as long as a full one - and costs 11 us of kernel time against 0.28
+    // (3.93 generations); 0.30 (4.28) costs 13 us more than 0.28.  The configured fractions are moved to the nearest such
+    // boundary (at least one generation per launch).
+    double gen_blocks = 0.0;                // output row blocks per generation
+    if (c->band_align) {
+        const int ow = a.cols - sc.w + 1, n = (int)sc.members.size();
+        const int tg = u16 ? (n + 15) / 16 : sc.rm_R > 0 ? 1 : (n + (sc.r2 ? 16 : 32) - 1) / (sc.r2 ? 16 : 32);
+        const int per_block = ((ow + kMfSeg - 1) / kMfSeg) * tg;
+        const int cus = c->n_cus > 0 ? c->n_cus : 256;
+        gen_blocks = 2.0 * cus / (double)per_block;
+    }
+    int yb_target = 0;
     for (int k = 0; k < nb; ++k) {
-        const bool last = k == nb - 1;
+        bool last = k == nb - 1;
         int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
+        if (!last && gen_blocks > 0.0) {
+            const double want = c->upload_bands[(size_t)k] * nyb - yb_target;                  // row blocks of this band's launch
+            const int gens = std::max(1, (int)std::floor(want / gen_blocks + 0.5));
+            yb_target = std::min(nyb, yb_target + std::max(1, (int)std::floor(gens * gen_blocks)));
+            // the rows that complete those blocks' windows (and their statistics blocks of kStatBand4 rows)
+            const int need = ((yb_target * RB + kStatBand4 - 1) / kStatBand4) * kStatBand4 + h - 1;
+            r1 = std::min(a.rows, (need + 7) & ~7);
+            if (yb_target >= nyb) r1 = a.rows;
+        }
         if (r1 <= r_done) continue;
+        last = last || r1 >= a.rows;            // (a band that reaches the end of the image is the last one: every block left)
         // the band's stream: with two of them the copy waits for the previous band's COPY, the kernels for its kernels
         hipStream_t bs = (two_streams && (k & 1)) ? c->copy_stream_b : c->copy_stream;
         hipEvent_t cdone = two_streams ? c->band_copy_ev[(size_t)k] : nullptr;
@@ -1270,7 +1297,8 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         (void)hipStreamQuery(bs);                                // submit now (the runtime batches commands)
         k_prev = k;
         if (k == 0) host_trace(c, 5);                            // layout conversion + statistics of band 0 submitted
-        const int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
+        int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
+        if (!last && gen_blocks > 0.0) yb1 = std::min(yb1, yb_target);      // (exactly the whole generations, not the rows' rounding on top)
         if (yb1 > yb_done) {
             hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
             if (c->zero_pending) {          // (no statistics launch took the clearing of the candidate header along)
@@ -1295,7 +1323,8 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     }
     // the other size classes, on the complete image: the first of them on a lane behind the last band's event - under
     // the banded class's last launch - the rest alternating as in run_score_all
-    if (c->classes.size() > 1) MTMC(run_score_classes(c, c->banded_cls, c->band_ev[(size_t)nb - 1]));
+    // (k_prev: the last band that was queued - trailing bands without rows of their own record no event)
+    if (c->classes.size() > 1) MTMC(run_score_classes(c, c->banded_cls, c->band_ev[(size_t)(k_prev >= 0 ? k_prev : nb - 1)]));
     return MTM_OK;
 }
 

@@ -695,6 +695,15 @@ int place_templates(mtm_ctx* c) {
                 units_all.push_back(v);
             }
         }
+    // From here on copies from this function's own vectors are in flight: an error return below drains the stream before
+    // they go out of scope (the normal path hands the long-lived ones to the context and says so in place_pending).
+    struct DrainGuard {
+        hipStream_t s;
+        bool armed = true;
+        ~DrainGuard() {
+            if (armed) (void)hipStreamSynchronize(s);
+        }
+    } drain{c->stream};
     if (units_all.size() > c->usrc_units) {
         MTMC(c->usrc_dev.ensure(sizeof(UnitSrc) * units_all.size()));
         HIPC(hipMemcpyAsync(c->usrc_dev.p, units_all.data(), sizeof(UnitSrc) * units_all.size(), hipMemcpyHostToDevice, c->stream));
@@ -726,6 +735,7 @@ int place_templates(mtm_ctx* c) {
     const bool local_sources = any_host_pack || w_off || p_off || ts_off || units_all.size() > c->usrc_units;
     if (local_sources) HIPC(hipStreamSynchronize(c->stream));
     c->place_pending = !local_sources;
+    drain.armed = false;
     if (units_all.size() > c->usrc_units) c->usrc_host.swap(units_all);
     c->classes.swap(classes);
     c->td_host.swap(td_host);
@@ -902,6 +912,8 @@ int set_templates_device(mtm_ctx* c, const mtm_templ* bases, int n_bases, const 
             srcs.push_back(sc);
         }
     MTMC(c->tsrc.ensure(std::max<size_t>(16, cursor)));
+    // (set BEFORE the copy is queued: an error return further down must not leave a copy from `tstage` in flight unrecorded)
+    c->stage_pending = true;
     if (!stage.empty()) HIPC(hipMemcpyAsync(c->tsrc.p, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream));
     uint8_t* arena = c->tsrc.as<uint8_t>();
     for (int b = 0; b < n_bases; ++b)
