@@ -87,26 +87,17 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // known to be dense (the last attempts overflowed the candidate list: smooth images at a low threshold), where the
     // full peak pass over the maps is the cheaper route
     bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
-    // Dense route (round 4), taken while the back-off lasts: the maps go to memory as before, but the score kernel still
-    // lists candidates - only those no neighbour in their own row exceeds (a sixth of the pixels above the threshold on
-    // a photograph-like image) - and verify_peaks_kernel tests that list against the maps instead of peaks_kernel reading
-    // every map again (0.38 ms for 1 GB at 4K x 32 templates).  uint8 classes on the 1- / 3-channel MFMA kernel only.
-    bool dense_route = false;
     if (fused && c->fuse_backoff > 0) {
         --c->fuse_backoff;
-        dense_route = c->dense_rowmax != 0 && (c->chans == 1 || c->chans == 3);
-        for (const SizeClass& sc : c->classes)
-            dense_route = dense_route && resolved_kernel(c, sc) == MTM_KERNEL_MFMA && sc.slabs.empty();
-        if (!dense_route) fused = false;
+        fused = false;
     }
-    c->cand_rowmax_now = dense_route;
     // Segment flags (the default route while the back-off lasts): the maps go to memory as in map mode, and the score kernel
     // sets a flag per row segment (a wave's 256 outputs of one template row) in which something passes the threshold;
     // peaks_sparse_kernel visits those instead of scanning 1 GB of maps (4K x 32 templates).  A first version wrote only
     // the flagged segments, from the hits-only screens: no faster - on such images the screens pass nearly everywhere.
     // uint8 classes on the lean 1- / 3-channel MFMA epilogue, every map 2-D.
     c->sparse_now = false;
-    if (mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0 && !fused && !dense_route && c->sparse_maps && c->hits_only &&
+    if (mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0 && !fused && c->sparse_maps && c->hits_only &&
         c->dtype == MTM_U8 && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n) {
         bool ok = true;
         int max_oh = 0, max_nseg = 0;
@@ -228,7 +219,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         // (float32 refinement: everything within the margin of the threshold is listed and re-scored)
         if (c->refine_now) c->cand_thr -= kRefineThrMargin * std::max(1.0f, std::fabs(c->cand_thr));
         // hits-only: single-channel MFMA classes, every map 2-D, no recent candidate overflow
-        bool honly = c->hits_only && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n && !dense_route;
+        bool honly = c->hits_only && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n;
         c->hits_only_now = honly;
     }
     // hash table of the candidate positions (hits-only verification on the device: only when the
@@ -257,7 +248,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
             HIPC(hipHostMalloc(&c->pinned, fetch_bytes, hipHostMallocDefault));
             c->pinned_cap = fetch_bytes;
         }
-        bool pin = c->cand_pinned != 0 && !c->refine_now && !dense_route;
+        bool pin = c->cand_pinned != 0 && !c->refine_now;
         for (const SizeClass& sc : c->classes) {
             const int rk = resolved_kernel(c, sc);
             pin = pin && ((rk == MTM_KERNEL_MFMA && sc.slabs.empty()) || rk == MTM_KERNEL_MFMA16);
@@ -280,7 +271,6 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         if (rc != MTM_OK) {
             c->have_image = false;                   // possibly half an image on the device
             (void)hipStreamSynchronize(c->copy_stream);
-            if (c->copy_stream_b) (void)hipStreamSynchronize(c->copy_stream_b);
             return rc;
         }
     } else {
@@ -509,7 +499,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             }
             std::memcpy(&ncand, land, sizeof(ncand));
             std::memcpy(&c->timing.sclk_mhz, land + 8, sizeof(float));
-            if (ncand <= nfetch && !c->cand_rowmax_now) {       // (dense route: the list is a preselection, the maps decide)
+            if (ncand <= nfetch) {
                 // everything needed is on the host: clear the counter for the next call while this one finishes
                 // (unless this context's calls clear it in their own first kernel: zero_in_stats)
                 if (!(c->zero_in_stats && S.banded_u8) && hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess)
@@ -688,10 +678,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 // the next calls on this context go straight to map mode (dense route, or the full peak pass); the period
                 // doubles while the retries keep overflowing.  (An overflow of the dense route's own list - row maxima
                 // only - is no retry: the back-off it runs under keeps counting down, this call takes the full peak pass.)
-                if (!c->cand_rowmax_now) {
-                    c->fuse_backoff = c->backoff_len;
-                    c->backoff_len = std::min(2 * c->backoff_len, 1024);
-                }
+                c->fuse_backoff = c->backoff_len;
+                c->backoff_len = std::min(2 * c->backoff_len, 1024);
                 if (c->hits_only_now) {
                     // no maps in memory: compute them (this call pays twice - the overflowed launch left early)
                     c->hits_only_now = false;
@@ -703,7 +691,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 }
                 continue;
             }
-            if (use_fused && !pp_mode && !c->cand_rowmax_now) c->backoff_len = 16;     // the candidates fitted
+            if (use_fused && !pp_mode) c->backoff_len = 16;     // the candidates fitted
             if ((int64_t)count <= c->hit_cap) {
                 // thousands of peaks and a suppression request: decide on the device, fetch the kept ones
                 if (dnms.queued && c->sparse_now && !use_fused && (long long)count >= c->nms_device_min && count <= dnms.n_max) {

@@ -198,11 +198,7 @@ int ensure_copy_stream(mtm_ctx* c) {
     if (c->copy_stream) return MTM_OK;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIPC(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, c->copy_prio ? hi : 0));
-    // (the second copy-side stream only where MTM_BAND_STREAMS=2 asks for it: the runtime maps streams onto FOUR hardware
-    // queues, an idle stream still takes a place in that rotation)
-    if (c->band_streams > 1)
-        HIPC(hipStreamCreateWithPriority(&c->copy_stream_b, hipStreamNonBlocking, c->copy_prio ? hi : 0));
+    HIPC(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, hi));
     return MTM_OK;
 }
 
@@ -255,10 +251,6 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
         delete c;
         return MTM_E_HIP;
     }
-    if (const char* v = std::getenv("MTM_AUTO_KERNEL")) {
-        if (!std::strcmp(v, "mfma")) c->auto_kernel = MTM_KERNEL_MFMA;
-        if (!std::strcmp(v, "dot4")) c->auto_kernel = MTM_KERNEL_DOT4;
-    }
     if (const char* v = std::getenv("MTM_UPLOAD_BANDS")) {      // e.g. "0.2,0.6,1": cumulative row fractions; "1": one piece
         std::vector<double> f;
         for (const char* q = v; *q;) {
@@ -273,26 +265,20 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
             c->upload_bands = f;
         }
     }
-    if (const char* v = std::getenv("MTM_COPY_PRIO")) c->copy_prio = std::atoi(v);
     if (const char* v = std::getenv("MTM_CAND_PINNED")) c->cand_pinned = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_LAYOUT")) c->fuse_layout = std::atoi(v);
-    if (const char* v = std::getenv("MTM_NCC_EVENTS")) c->ncc_events = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_ALIGN")) c->band_align = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SINGLE_BAND")) c->single_band = std::atoi(v);
     if (const char* v = std::getenv("MTM_EAGER_COPY_STREAM")) c->eager_copy_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_ZERO_IN_STATS")) c->zero_in_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_MIN_FILL")) c->band_min_fill = std::atof(v);
-    if (const char* v = std::getenv("MTM_DUAL_STREAM")) c->dual_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_RIG")) c->f32_rig = std::atoi(v);
-    if (const char* v = std::getenv("MTM_SKIP_F32")) c->skip_f32 = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
     if (const char* v = std::getenv("MTM_RM_EDGES")) c->rm_edges = std::atoi(v);
     if (const char* v = std::getenv("MTM_CAND_STAGE")) c->cand_stage = std::atoi(v);
-    if (const char* v = std::getenv("MTM_DENSE_ROWMAX")) c->dense_rowmax = std::atoi(v);
-    if (const char* v = std::getenv("MTM_BAND_STREAMS")) c->band_streams = std::max(1, std::min(2, std::atoi(v)));
-    if (const char* v = std::getenv("MTM_BAND_INLINE")) c->band_inline = std::atoi(v);
     if (const char* v = std::getenv("MTM_SPARSE_MAPS")) c->sparse_maps = std::atoi(v);
     if (const char* v = std::getenv("MTM_NMS_DEVICE")) c->nms_device = std::atoi(v);
     if (const char* v = std::getenv("MTM_NMS_DEVICE_MIN")) c->nms_device_min = std::max(1, std::atoi(v));
@@ -305,7 +291,6 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_SLAB_CW")) c->slab_cw = std::atoi(v);
     if (const char* v = std::getenv("MTM_SLAB_MERGE")) c->slab_merge = std::atoi(v);
     if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MFMA_DBG")) c->mfma_dbg = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
     if (const char* v = std::getenv("MTM_ROW_MUX")) c->row_mux = std::atoi(v);
@@ -313,9 +298,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MFMA_STAGGER_MODE")) c->mfma_stagger_mode = std::atoi(v);
     if (const char* v = std::getenv("MTM_MFMA_PER_CU")) c->mfma_per_cu = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MFMA_STAGGER_NP")) c->mfma_stagger_np = std::atoi(v);
     if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
         const int k = std::atoi(v);
         if (dot_variant_ok(k)) c->dot_variant = k;
@@ -329,6 +312,8 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     // (mtm_group_comm_init) and shared a hardware queue with them - the band's statistics launch then started 67 us
     // after its copy ended instead of 8, every call (profiles/r05c: group + RCCL 1.04 ms against 0.87 with the host merge).
     if (c->eager_copy_stream && ensure_copy_stream(c) != MTM_OK) c->copy_stream = nullptr;
+    // (the first side lane of multi-class calls likewise: third in the rotation, a hardware queue of its own)
+    if (c->eager_copy_stream && c->class_lanes > 1) (void)ensure_lanes(c, 1);
     *out = c;
     return MTM_OK;
 }
@@ -362,7 +347,6 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->comm_pin) (void)hipHostFree(c->comm_pin);
     if (c->next_ready) (void)hipEventDestroy(c->next_ready);
     for (hipEvent_t e : c->band_ev) (void)hipEventDestroy(e);
-    if (c->stream2_done) (void)hipEventDestroy(c->stream2_done);
     if (c->lane_fork) (void)hipEventDestroy(c->lane_fork);
     if (c->f32_built) (void)hipEventDestroy(c->f32_built);
     for (auto& L : c->lanes) {
@@ -386,16 +370,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
         (void)hipStreamSynchronize(s2);
         (void)hipStreamDestroy(s2);
     }
-    if (c->stream2) {
-        (void)hipStreamSynchronize(c->stream2);
-        (void)hipStreamDestroy(c->stream2);
-    }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->copy_stream_b) {
-        (void)hipStreamSynchronize(c->copy_stream_b);
-        (void)hipStreamDestroy(c->copy_stream_b);
-    }
-    for (hipEvent_t e : c->band_copy_ev) (void)hipEventDestroy(e);
     for (auto* evs : {&c->ncc_ev, &c->sq_ev})
         for (auto& p : *evs) {
             (void)hipEventDestroy(p.first);

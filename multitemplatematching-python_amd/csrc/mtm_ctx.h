@@ -164,20 +164,14 @@ struct mtm_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ncc_ev;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> sq_ev;       // event pairs of the sum I^2 M passes (timing.masked_stat_ms)
-    // MTM_DENSE_ROWMAX=1 (experiment of round 4, default 0): while the back-off lasts (dense maps), map mode + candidates that
-    // no neighbour in their own row exceeds + verify_peaks_kernel instead of the full peak pass over every map.  Correct
-    // (tests/test_gpu_parity.py::test_dense_route_row_maxima_candidates) and the peak pass does shrink from 0.39 to 0.12 ms
-    // at 4K x 32 templates - but listing the 1.2e5 row maxima costs the score kernel 0.45 ms (0.90 -> 1.35 ms; 6.7 % of
-    // its (segment, row, template) triples hold one), so the call is slower: 2.55 against 2.41 ms (profiles/r04h/dense_ab.txt).
-    int dense_rowmax = 0;
-    bool cand_rowmax_now = false;   // this call takes that route
     int cand_pinned = 1;        // MTM_CAND_PINNED: the score kernel writes the first records of its candidate list into the pinned
                                 // landing buffer itself (MfmaParams::cand_pin) - no fetch kernel behind the score launch (0: round 4)
     bool cand_pin_now = false;  // ... in the launches being queued
     size_t cand_pin_n = 0;
     int eager_copy_stream = 1;  // MTM_EAGER_COPY_STREAM: the copy-side stream is created with the context (0: by the first banded call)
+    int single_band = 1;        // MTM_SINGLE_BAND: one-class uint8 calls below the banding size take the banded path as one band
+    bool single_band_now = false;
     int band_align = 1;         // MTM_BAND_ALIGN: upload bands end where their score launch is a whole number of work-group generations
-    int ncc_events = 1;         // MTM_NCC_EVENTS: 0 = no timing events around the score launches (mtm_timing.ncc_* stay 0)
     int zero_in_stats = 1;      // MTM_ZERO_IN_STATS: a banded uint8 call clears the candidate header in its first statistics launch
     bool zero_pending = false;  // ... and has not done so yet
     int fuse_layout = 1;        // MTM_FUSE_LAYOUT: banded uploads convert a band's rows inside its statistics launch (0: planarize kernel)
@@ -203,15 +197,6 @@ struct mtm_ctx {
     DevBuf sq_planes;           // two planes: [high byte of I^2 ^ 0x80][low byte ^ 0x80] of the current uint8 image
     bool sq_valid = false;
     hipStream_t copy_stream = nullptr;
-    // banded uploads, experiment of round 4 (MTM_BAND_STREAMS=2; default 1 = one copy-side stream): consecutive bands
-    // alternate between copy_stream and copy_stream_b, a band's COPY waits for the previous band's copy only
-    // (band_copy_ev), its conversion / statistics kernels for the previous band's kernels (band_ev), so that the copy
-    // engine does not idle while a band's kernels run.  Measured at 4K x 32 templates, three alternating pairs on one box
-    // (profiles/r04e/env_ab.txt): 0.8755 / 0.8944 / 0.8907 ms per call against 0.8807 / 0.8802 / 0.8809 with one stream -
-    // no gain (the second band's copy now competes with the first band's kernels for the start of the first score launch).
-    hipStream_t copy_stream_b = nullptr;
-    std::vector<hipEvent_t> band_copy_ev;
-    int band_streams = 1;
     // mtm_find_matches_image_nms: MTM.matchTemplates' non-maxima suppression as part of the call (the host's nms_boxes on
     // the fetched list).  Thousands of peaks on the device (the flagged-segment route of dense images) are pruned there
     // first (mtm_k_nms.hip.h; MTM_NMS_DEVICE=0: never): what a neighbourhood's best hit suppresses never crosses PCIe.
@@ -232,18 +217,12 @@ struct mtm_ctx {
     bool sparse_now = false;
     DevBuf seg_flags, hits_t;               // (hits_t: per-template peak lists of peaks_sparse_kernel + their counters)
     int flag_tstride = 0, flag_rstride = 0;
-    int band_inline = 0;                    // MTM_BAND_INLINE: the first band of a banded call on `stream` itself (run_score_banded)
     hipEvent_t next_ready = nullptr;
     // mtm_find_matches_image: the image arrives in row bands on copy_stream (copy, layout conversion, window
     // statistics of the rows that became computable); the score kernel of a band waits for its event
     hipStream_t stats_stream = nullptr;     // non-null while a banded call queues its statistics launches
-    hipStream_t stream2 = nullptr;          // second compute stream: the score launches of consecutive bands alternate
-                                            // between `stream` and this one, so the tail of one launch (its last
-                                            // work-groups draining) is filled by the next launch instead of idling
-    hipStream_t ncc_stream = nullptr;       // non-null: launch_ncc queues the MFMA kernel (and its timing events) here
     int screen_l1 = 1;                      // MTM_SCREEN_L1: the hits-only screen starts with the per-lane bound (0: round 2's screen alone)
     int kpack = 1;                          // MTM_KPACK: packed K for template widths that are not multiples of 64
-    int skip_f32 = 1;                       // MTM_SKIP_F32: banded uploads leave the float32 plane out (rebuilt on demand)
     int f32_mfma = 1;                       // MTM_F32_MFMA / MTM_OPT_F32_MFMA: unmasked float32 classes on the bf16 matrix cores:
                                             // 0 = float64 kernel, 1 = bf16 screen + exact float64 re-scoring of everything
                                             // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are
@@ -257,11 +236,7 @@ struct mtm_ctx {
     bool refine_scan_now = false;           // ... by map scan + ring re-scoring (maps in memory) instead of kernel candidates
     bool f32_exact_now = false;             // bf16 classes run the float64 kernel in this call (refinement lists overflowed)
     int mfma_r2 = 1;                        // MTM_MFMA_R2: 1 = two-row variant of the MFMA kernel where it applies, 3 = three rows, 0 = off
-    int dual_stream = 0;                    // MTM_DUAL_STREAM=1: score launches of consecutive bands alternate between two
-                                            // streams (their tails overlap; per-launch durations then overlap too)
     int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
-    int copy_prio = 1;                      // MTM_COPY_PRIO: 1 = the copy stream gets the highest stream priority
-    hipEvent_t stream2_done = nullptr;
     // lanes of a multi-class call: size classes are independent (their own statistics, launches, scratch); consecutive
     // classes go to alternating lanes - a stream plus the per-class scratch buffers - so that the statistics / combine
     // kernels and the tail of one class run under the score kernel of the next.  Lane 0 is the context's own stream and
@@ -332,7 +307,6 @@ struct mtm_ctx {
     // candidates the list is the cheaper way, and that is where it overflows.
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
-    int mfma_dbg = 0;
     int fuse_stats = 1;        // MTM_FUSE_STATS: single-kernel window statistics (uint8, one channel)
     int n_cus = 0;
     std::map<std::pair<const void*, size_t>, int> occupancy_cache;
@@ -358,9 +332,7 @@ struct mtm_ctx {
                                // the fused extremum of masked classes (reciprocal-only kernels) goes through maps + extremum_kernel
     int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
     int mfma_stagger = -1;     // < 0: automatic
-    int mfma_stagger_mode = 0;
     int mfma_per_cu = 2;
-    int mfma_stagger_np = 0;   // > 0: stagger the first wave of blocks of a non-persistent launch by this many s_sleep(127)
     int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};
@@ -479,6 +451,7 @@ void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype);
 int check_image_args(const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes, const char* who);
 int ensure_f32_plane(mtm_ctx* c);
 int ensure_copy_stream(mtm_ctx* c);
+int ensure_lanes(mtm_ctx* c, int n);
 // ---- mtm_placement.hip
 int place_templates(mtm_ctx* c);
 // ---- mtm_launch.hip

@@ -271,11 +271,7 @@ __global__ __launch_bounds__(256) void stats_u8_kernel(const uint8_t* __restrict
                 if (num_type == 1) wnd_mean2 = (tt[k] * tt[k]) * inv_area;
                 const double diff2 = fmax(ws2[k] - wnd_mean2, 0.0);
                 const bool small = diff2 <= fmin(0.5, (10.0 * (double)FLT_EPSILON) * ws2[k]);
-#ifdef MTM_PROBE_STAT_NO_SQRT   /* timing experiment (wrong results) */
-                sqv[k] = small ? 0.0 : diff2;
-#else
                 sqv[k] = small ? 0.0 : sqrt(diff2);
-#endif
                 rs[k] = sqv[k] > 0.0 ? 1.0 / sqv[k] : 0.0;
                 blk_s1[k] = tt[k];
                 blk_sq[k] = sqv[k];

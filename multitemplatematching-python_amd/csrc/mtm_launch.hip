@@ -351,12 +351,12 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         c->ncc_ev.emplace_back(a, b);
     }
     auto& evp = c->ncc_ev[c->timing.ncc_launches];
-    hipStream_t ncc_s = (c->ncc_stream && (kernel == MTM_KERNEL_MFMA || kernel == MTM_KERNEL_MFMA16)) ? c->ncc_stream : c->stream;
+    hipStream_t ncc_s = c->stream;
     // (The events are stream commands of their own.  Handing them to the launch itself - hipExtLaunchKernelGGL's start /
     // stop events - was measured in round 4: the gaps around the launches stayed, the call got 14 us SLOWER;
     // profiles/r04_r04w.)
-    bool ev_own = !c->ncc_events;       // a branch below records the pair itself (on the stream its launch goes to)
-    if (c->ncc_events) HIPC(hipEventRecord(evp.first, ncc_s));
+    bool ev_own = false;                // a branch below records the pair itself (on the stream its launch goes to)
+    HIPC(hipEventRecord(evp.first, ncc_s));
 
     if (kernel == MTM_KERNEL_NAIVE) {
         const dim3 blk(64, 4), grd((ow + 63) / 64, (oh + 3) / 4, n_list);
@@ -478,11 +478,11 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const uint8_t* ap = c->apacks.as<uint8_t>() + sl.apack_off + (rmr ? (long long)sc.slab_R * p.nb * 1024 : 0);
             // (merged launch on a side stream: the timing pair goes there too - on the score stream it would bracket
             // the fork and the join, not the launch)
-            if (merged && slab_s != ncc_s && c->ncc_events) HIPC(hipEventRecord(evp.first, slab_s));
+            if (merged && slab_s != ncc_s) HIPC(hipEventRecord(evp.first, slab_s));
             hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, slab_s, p, td,
                                c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
             if (merged && slab_s != ncc_s) {
-                if (c->ncc_events) HIPC(hipEventRecord(evp.second, slab_s));
+                HIPC(hipEventRecord(evp.second, slab_s));
                 ev_own = true;
             }
         }
@@ -550,7 +550,6 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = sc.group_bytes;
         p.only_li = only_li;
-        p.dbg = c->mfma_dbg;
         p.cand_on = (c->cand_on && only_li < 0) ? 1 : 0;
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
         p.cand_thr_lo = (double)c->cand_thr - 1e-6 * std::max(1.0, std::fabs((double)c->cand_thr));
@@ -559,7 +558,6 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.screen_l1 = c->screen_l1;
         p.cand_min = c->cand_min ? 1 : 0;
         p.cand_thr = c->cand_thr;
-        p.cand_rowmax = (c->cand_rowmax_now && p.cand_on && !p.hits_only) ? 1 : 0;
         if (c->sparse_now && only_li < 0) {     // maps in memory + a flag per row segment that holds something above the threshold
             p.seg_flags = c->seg_flags.as<uint8_t>();
             p.flag_tstride = c->flag_tstride;
@@ -671,22 +669,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 c->n_cus = prop.multiProcessorCount;
             }
             per_cu = std::max(1, std::min(per_cu, c->mfma_per_cu));
-            p.stagger_mode = c->mfma_stagger_mode;
             grid_launch = std::min(p.n_work, per_cu * c->n_cus);
             // one main loop is chans*h*nb*16*MB MFMAs of 16 cycles; s_sleep(127) is ~8128 cycles
             const double main_cycles = (double)c->chans * h * p.nb * 16.0 * mb * 16.0;
             p.stagger_sleeps = c->mfma_stagger >= 0 ? c->mfma_stagger : (int)(0.75 * main_cycles / 8128.0 + 0.5);
-            HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
-        }
-        if (!p.persistent && c->mfma_stagger_np > 0) {
-            if (c->n_cus == 0) {
-                hipDeviceProp_t prop;
-                HIPC(hipGetDeviceProperties(&prop, c->device));
-                c->n_cus = prop.multiProcessorCount;
-            }
-            p.stagger_first = c->mfma_per_cu * c->n_cus;
-            p.stagger_mode = c->mfma_stagger_mode;
-            p.stagger_sleeps = c->mfma_stagger_np;
             HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
         }
         hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps,
@@ -893,7 +879,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
     }
     HIPC(hipGetLastError());
     if (!ev_own) HIPC(hipEventRecord(evp.second, ncc_s));
-    if (c->ncc_events) c->timing.ncc_launches++;
+    c->timing.ncc_launches++;
     return MTM_OK;
 }
 
@@ -912,6 +898,17 @@ int resolved_kernel(const mtm_ctx* c, const SizeClass& sc) {
     if (kernel == MTM_KERNEL_MFMA && (!sc.mfma_ok || (sc.masked && c->method > 3))) kernel = MTM_KERNEL_DOT4;
     if (kernel == MTM_KERNEL_DOT4 && !dot_ok) kernel = MTM_KERNEL_AUTO;
     return kernel;
+}
+
+// side lanes 1 .. n of multi-class calls (mtm_ctx::Lane): a stream + its join event each
+int ensure_lanes(mtm_ctx* c, int n) {
+    while ((int)c->lanes.size() < n) {
+        mtm_ctx::Lane L;
+        HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        c->lanes.push_back(L);
+    }
+    return MTM_OK;
 }
 
 int ensure_maps(mtm_ctx* c) { return c->maps.ensure(sizeof(float) * std::max<size_t>(4, c->maps_floats)); }
@@ -1008,12 +1005,7 @@ static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
     if (c->classes.size() > 1 && n_todo > 0 && c->class_lanes > 1 && !c->refine_now && !c->refine_scan_now && !c->f32_exact_now)
         n_lanes = (int)std::min<size_t>(skip >= 0 ? n_todo + 1 : n_todo, (size_t)c->class_lanes);
     if (n_lanes > 1) {
-        while ((int)c->lanes.size() < n_lanes - 1) {
-            mtm_ctx::Lane L;
-            HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-            HIPC(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
-            c->lanes.push_back(L);
-        }
+        MTMC(ensure_lanes(c, n_lanes - 1));
         if (!c->lane_fork) HIPC(hipEventCreateWithFlags(&c->lane_fork, hipEventDisableTiming));
         MTMC(ensure_square_planes(c));                  // shared by the masked classes of every lane: before the fork
         if (fork == nullptr || c->sq_valid) {           // (the planes of I^2 were just queued on c->stream: fork behind them)
@@ -1135,7 +1127,7 @@ int collect_ncc_time(mtm_ctx* c) {
 // Can the image of a fused call arrive in row bands (copy / layout / statistics of band k+1 under the score
 // kernel of band k)?  One unmasked single-channel uint8 size class on the MFMA kernel with the fused
 // statistics kernel; anything else uploads the image in one piece (still without a round trip to the host).
-static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work);
+static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work, bool any_fill = false);
 
 // Several size classes: the class with the most multiply-accumulates among those that qualify is the one that runs under
 // the upload (c->banded_cls); the others follow on the complete image (run_score_banded).
@@ -1149,16 +1141,28 @@ bool banded_ok(mtm_ctx* c, const ImageArgs& a) {
             c->banded_cls = (int)i;
         }
     }
+    c->single_band_now = false;
+    if (c->banded_cls < 0 && c->single_band && c->classes.size() == 1 && a.dtype == MTM_U8) {
+        // Round 5: a call too small to be worth two score launches (1080p x 8 templates) still takes the banded path's
+        // kernels, as ONE band - layout conversion inside the statistics launch, the candidate header cleared there: two
+        // launches and a fill command fewer than the plain upload path
+        double work = 0.0;
+        if (class_bandable(c, a, c->classes[0], &work, true)) {
+            c->banded_cls = 0;
+            c->single_band_now = true;
+        }
+    }
     return c->banded_cls >= 0;
 }
 
-static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work) {
+static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work, bool any_fill) {
     const bool u16 = a.dtype == MTM_U16;
     if (c->upload_bands.size() < 2 || (a.dtype != MTM_U8 && !u16) || a.chans != 1) return false;
     if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != (u16 ? MTM_KERNEL_MFMA16 : MTM_KERNEL_MFMA))
         return false;
     if (!(sc.w <= 768 && (double)sc.w * sc.h * (u16 ? 65535.0 : 65025.0) < 4294967296.0)) return false;   // the fused statistics
-    if (!((size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256)) return false;
+    if (!any_fill && !((size_t)a.rows * a.cols >= ((size_t)1 << 20) && a.rows - sc.h + 1 >= 256)) return false;
+    if (any_fill) return true;
     // A band's score launch must still fill the chip: two work-groups per CU are resident, and a launch of fewer than a
     // couple of such generations runs at the latency of its last one.  1080p x 8 templates is 512 work items in all -
     // banded 0.26 ms per call (two launches of 55 us for 62 us of work), in one piece 0.22 ms.
@@ -1187,44 +1191,28 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     mtm_ctx::ImageSlot& sl = c->slot[c->cur];
     SlotGeom g{};
     const bool u16 = a.dtype == MTM_U16;
-    const int nb = (int)c->upload_bands.size();
-    // MTM_BAND_INLINE=1 (default 0): the FIRST band's copy, layout conversion and statistics on c->stream itself, ahead of
-    // its score launch - stream order instead of an event between two streams - and the second band's copy behind the first
-    // band's COPY on the copy stream.  Measured on three boxes in round 4 (profiles/r04_r04v, _r04w, _r04x): +0.5 % /
-    // -0.5 % / -1 %: the gap between the statistics kernel and the score launch (16 us) is there in stream order too.
-    const bool inline0 = c->band_inline && nb > 1 && c->band_streams <= 1 && !c->dual_stream;
-    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, inline0 ? c->stream : c->copy_stream, 1, &g));
+    static const std::vector<double> kOneBand{1.0};
+    const std::vector<double>& bands = c->single_band_now ? kOneBand : c->upload_bands;
+    const int nb = (int)bands.size();
+    // (Round 4 measured three other layouts of the same work against this one and round 5 removed their code: the first
+    // band on the score stream itself, consecutive bands on two copy-side streams, score launches alternating between two
+    // streams - all within +-2 %, docs/HISTORY.md.)
+    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, c->copy_stream, 1, &g));
     host_trace(c, 13);
     while ((int)c->band_ev.size() < nb) {
         hipEvent_t e;
         HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->band_ev.push_back(e);
     }
-    while ((int)c->band_copy_ev.size() < nb) {
-        hipEvent_t e;
-        HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->band_copy_ev.push_back(e);
-    }
-    const bool two_streams = c->band_streams > 1 && nb > 1;
     int k_prev = -1;                        // the band queued before this one (bands without rows are skipped)
-    int k_inline = -1;                      // the band on c->stream (inline0)
     const int h = sc.h, oh = a.rows - h + 1;
     const int RB = u16 ? kMfRows : sc.rm_R > 0 ? 8 * sc.rm_R : (sc.r2 ? sc.r2 * kMfRows : kMfRows);   // output rows per score-kernel row block
     const int nyb = (oh + RB - 1) / RB, nsb = (oh + kStatBand4 - 1) / kStatBand4;
-    int r_done = 0, sb_done = 0, yb_done = 0, n_launch = 0;
-    bool used2 = false;
-    if (c->dual_stream) {               // (MTM_DUAL_STREAM=1: the score launches of consecutive bands alternate between two streams)
-        if (!c->stream2) HIPC(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        if (!c->stream2_done) HIPC(hipEventCreateWithFlags(&c->stream2_done, hipEventDisableTiming));
-        // stream2 starts behind whatever the call queued on c->stream so far (counter reset, statistics buffers ...)
-        HIPC(hipEventRecord(c->stream2_done, c->stream));
-        HIPC(hipStreamWaitEvent(c->stream2, c->stream2_done, 0));
-    }
+    int r_done = 0, sb_done = 0, yb_done = 0;
     // Round 5 (MTM_BAND_ALIGN, default 1): a band ends where its score launch is a whole number of generations of resident
-    // work-groups (two per CU).  Measured at 4K x 32 templates (profiles/r05b): a first band of 0.25 of the rows is 3.46
-    // generations - the last, part-filled one runs as long as a full one - and costs 11 us of kernel time against 0.28
-    // (3.93 generations); 0.30 (4.28) costs 13 us more than 0.28.  The configured fractions are moved to the nearest such
-    // boundary (at least one generation per launch).
+    // work-groups (two per CU): the configured fractions are moved to the nearest such boundary, at least one generation
+    // per launch.  (A part-filled last generation runs as long as a full one; on some boxes a first band of 0.25 of the
+    // rows - 3.46 generations at 4K x 32 templates - cost 11 us of kernel time against 0.28 = 3.93, profiles/r05b.)
     double gen_blocks = 0.0;                // output row blocks per generation
     if (c->band_align) {
         const int ow = a.cols - sc.w + 1, n = (int)sc.members.size();
@@ -1234,11 +1222,12 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         gen_blocks = 2.0 * cus / (double)per_block;
     }
     int yb_target = 0;
+    const hipStream_t bs = c->copy_stream;
     for (int k = 0; k < nb; ++k) {
         bool last = k == nb - 1;
-        int r1 = last ? a.rows : std::min(a.rows, (int)(c->upload_bands[(size_t)k] * a.rows) & ~7);
+        int r1 = last ? a.rows : std::min(a.rows, (int)(bands[(size_t)k] * a.rows) & ~7);
         if (!last && gen_blocks > 0.0) {
-            const double want = c->upload_bands[(size_t)k] * nyb - yb_target;                  // row blocks of this band's launch
+            const double want = bands[(size_t)k] * nyb - yb_target;                  // row blocks of this band's launch
             const int gens = std::max(1, (int)std::floor(want / gen_blocks + 0.5));
             yb_target = std::min(nyb, yb_target + std::max(1, (int)std::floor(gens * gen_blocks)));
             // the rows that complete those blocks' windows (and their statistics blocks of kStatBand4 rows)
@@ -1248,33 +1237,19 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         }
         if (r1 <= r_done) continue;
         last = last || r1 >= a.rows;            // (a band that reaches the end of the image is the last one: every block left)
-        // the band's stream: with two of them the copy waits for the previous band's COPY, the kernels for its kernels
-        hipStream_t bs = (two_streams && (k & 1)) ? c->copy_stream_b : c->copy_stream;
-        hipEvent_t cdone = two_streams ? c->band_copy_ev[(size_t)k] : nullptr;
-        hipEvent_t kwait = (two_streams && k_prev >= 0) ? c->band_ev[(size_t)k_prev] : nullptr;
-        if (two_streams && k_prev >= 0) HIPC(hipStreamWaitEvent(bs, c->band_copy_ev[(size_t)k_prev], 0));
-        const bool on_main = inline0 && r_done == 0;            // this band rides on c->stream
-        if (on_main) {
-            bs = c->stream;
-            cdone = c->band_copy_ev[(size_t)k];
-        } else if (inline0 && k_prev >= 0 && k_prev == k_inline) {
-            HIPC(hipStreamWaitEvent(bs, c->band_copy_ev[(size_t)k_prev], 0));
-        }
-        if (on_main) k_inline = k;
         if (r_done == 0) host_trace(c, 14);
         // Round 5 (MTM_FUSE_LAYOUT, default 1): a band whose rows complete new statistics blocks gets ONE kernel for layout
         // conversion + window statistics instead of two launches with a kernel boundary between them (stats_u8_kernel's
         // StatLayout; row lengths that are multiples of 4, no float32 plane asked for)
-        const int avail_k = r1 - h + 1;
-        const int sb1_k = last ? nsb : std::max(sb_done, avail_k > 0 ? avail_k / kStatBand4 : 0);
-        const bool fuse_lay = c->fuse_layout != 0 && !u16 && (a.cols % 4) == 0 && c->skip_f32 != 0 && sb1_k > sb_done;
+        const int avail = r1 - h + 1;                            // output rows whose windows are complete
+        const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);
+        const bool fuse_lay = c->fuse_layout != 0 && !u16 && (a.cols % 4) == 0 && sb1 > sb_done;
         if (u16)
-            MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, bs, cdone, kwait));
+            MTMC(upload_rows_u16c1(sl, g, a.px, a.stride, r_done, r1, bs));
         else
-            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, bs, c->skip_f32 != 0, cdone, kwait, !fuse_lay));
+            MTMC(upload_rows_u8c1(sl, g, a.px, a.stride, r_done, r1, bs, true, nullptr, nullptr, !fuse_lay));
         c->lay_r0 = fuse_lay ? r_done : 0;
         c->lay_r1 = fuse_lay ? r1 : 0;
-        if (two_streams) (void)hipStreamQuery(bs);
         if (r_done == 0) {
             HIPC(hipEventRecord(c->ev[0], c->stream));           // (see fm_begin)
             if (c->classes.size() > 1) {                         // the lanes of the other classes start behind the call's set-up too
@@ -1284,8 +1259,6 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         }
         r_done = r1;
         host_trace(c, k == 0 ? 4 : 7);                           // the band's copy call returned
-        const int avail = r1 - h + 1;                            // output rows whose windows are complete
-        const int sb1 = last ? nsb : std::max(sb_done, avail > 0 ? avail / kStatBand4 : 0);
         StatPlanes st;
         c->stats_stream = bs;
         const int rc = launch_stats(c, sc, &st, sb_done, sb1);
@@ -1300,26 +1273,17 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
         int yb1 = last ? nyb : (sb1 * kStatBand4) / RB;
         if (!last && gen_blocks > 0.0) yb1 = std::min(yb1, yb_target);      // (exactly the whole generations, not the rows' rounding on top)
         if (yb1 > yb_done) {
-            hipStream_t s = (c->dual_stream && (n_launch & 1)) ? c->stream2 : c->stream;
             if (c->zero_pending) {          // (no statistics launch took the clearing of the candidate header along)
                 HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
                 c->zero_pending = false;
             }
-            if (s != bs) HIPC(hipStreamWaitEvent(s, c->band_ev[(size_t)k], 0));
-            c->ncc_stream = s;
+            HIPC(hipStreamWaitEvent(c->stream, c->band_ev[(size_t)k], 0));
             const int rc2 = launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, yb_done, yb1);
-            c->ncc_stream = nullptr;
             MTMC(rc2);
-            (void)hipStreamQuery(s);
+            (void)hipStreamQuery(c->stream);
             host_trace(c, k == 0 ? 6 : 8);                       // the band's score launch is submitted
-            used2 = used2 || s == c->stream2;
-            ++n_launch;
             yb_done = yb1;
         }
-    }
-    if (used2) {                                    // everything after the score pass is queued on c->stream
-        HIPC(hipEventRecord(c->stream2_done, c->stream2));
-        HIPC(hipStreamWaitEvent(c->stream, c->stream2_done, 0));
     }
     // the other size classes, on the complete image: the first of them on a lane behind the last band's event - under
     // the banded class's last launch - the rest alternating as in run_score_all

@@ -274,14 +274,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // sched[1 + cu]) sleeps for about one main loop before its first item.  Placement only
     // affects speed, never results.
     int* s_item = reinterpret_cast<int*>(smem + p.tc_off + 32 * (int)sizeof(MfTemplConst));
-    if (p.persistent || (int)blockIdx.x < p.stagger_first) {
+    if (p.persistent) {
         if (threadIdx.x == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
             const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
             const unsigned cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
             int late = (int)(atomicAdd(&sched[1 + cu], 1u) & 1u);
-            if (p.stagger_mode == 1) late = blockIdx.x >= (gridDim.x >> 1);
-            if (p.stagger_mode == 2) late = (blockIdx.x >> 3) & 1;
             s_item[1] = late;
         }
         __syncthreads();
@@ -525,11 +523,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 int r = (ci * p.cpr_magic) >> 16, d = ci - r * p.cpr;     // ci / cpr for ci < 256 (cpr <= 33), without a division
                 const uint8_t* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
                 uint8_t* lbase_w = smem + wave * 1024;
-#ifdef MTM_PROBE_NO_STAGE      /* timing experiment: skip the image-tile staging loads (wrong results) */
-                for (; ci < 0; ci += 256) {
-#else
                 for (; ci - lane < nchunk; ci += 256) {
-#endif
                     if (ci < nchunk)
                         __builtin_amdgcn_global_load_lds((gptr_t)(grow + (size_t)r * p.pitch + 16 * d), (lptr_t)lbase_w,
                                                          16, 0, 0);
@@ -702,32 +696,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 loff += wrap_ ? row_adv : 64;                       \
                 nb_i = wrap_ ? 0 : nb_i + 1;                        \
             }
-#ifdef MTM_PROBE_FROZEN_A   /* timing experiment: the template operand pointer does not move (wrong results) */
-#define MTM_MF_APTR_STEP
-#else
 #define MTM_MF_APTR_STEP aptr += 1024;
-#endif
 #define MTM_MF_LOAD(QA, QB, A)                                                          \
             QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
             QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
                 A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
-#ifdef MTM_PROBE_NO_LOADS  /* timing experiment: no operand loads at all inside the K loop (wrong results) */
-#define MTM_MF_LOAD_LOOP(QA, QB, A)
-#elif defined(MTM_PROBE_NO_A)  /* timing experiment: no template-operand loads inside the K loop (wrong results) */
-#define MTM_MF_LOAD_LOOP(QA, QB, A)                                                     \
-            QA = *reinterpret_cast<const v4i*>(lbase + loff);                           \
-            QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);
-#elif defined(MTM_PROBE_NO_Q)   /* timing experiment: no LDS operand loads inside the K loop */
-#define MTM_MF_LOAD_LOOP(QA, QB, A)                                                     \
-            _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
-                A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
-#else
 #define MTM_MF_LOAD_LOOP(QA, QB, A) MTM_MF_LOAD(QA, QB, A)
-#endif
-#ifdef MTM_PROBE_NO_MFMA   /* timing experiment: the loop skeleton without MFMAs and operand shifts */
-#define MTM_MF_STEP(QA, QB, A, K) acc[0][K] += QA + QB + A[0] + A[MB - 1];
-#else
             // Row-multiplexed tilings (round 4): a wave's two MFMA groups are output rows [0, R) and [R, 2 R) of the same
             // templates, and image row s of the wave's h + 2 R - 1 holds template rows of group 0 only for s < h + R - 1 and
             // of group 1 only for s >= R - outside, the group's A operand is all zero.  Those edge steps run the
@@ -746,14 +721,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             } else {                                                                    \
                 mfma_kstep<METHOD, MB>(acc, QA, QB, A);                                 \
             }
-#endif
             // hits-only launches: the MFMA main loop outranks the (short) epilogue of the co-resident work-group
             // (-0.9 % kernel time; with the maps written the long epilogue is the one that must not starve: +1 %)
-#ifdef MTM_PROBE_U16_NO_PRIO
-            if (p.hits_only && METHOD != kMfU16) __builtin_amdgcn_s_setprio(3);
-#else
             if (p.hits_only) __builtin_amdgcn_s_setprio(3);
-#endif
             MTM_MF_LOAD(qa0, qb0, a0)            // step 0
             int ks = 0;
             for (; ks + 2 <= nsteps; ks += 2) {
@@ -802,15 +772,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     const int j = lane & 15, q = lane >> 4;
     const int y = y0 + (R2 ? MB : 1) * wave;             // R2: the wave's first row; MFMA group mb is row y + mb
     int* epi = reinterpret_cast<int*>(smem + wave * kMfEpiBytesPerWave);
-    if (p.dbg & 2) {            // probe: no epilogue (keep the accumulators observable)
-        int sum = 0;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int c = 0; c < 16; ++c) sum += acc[mb][c].x ^ acc[mb][c].y ^ acc[mb][c].z ^ acc[mb][c].w;
-        if (sum == 0x7fffffff) maps[0] = 1.0f;
-        continue;
-    }
     const int xq = x0 + 4 * lane;                       // first of this lane's 4 pixels
     // is the candidate list full already?  (dense maps; see emit_at)
     bool emit_full = false;
@@ -863,7 +824,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         const unsigned n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
         const unsigned total = n0 + n1 + n2 + n3;
         if (total == 0) return;                                     // uniform over the lanes that are here
-        if (p.dbg & 4) return;          // probe (MTM_MFMA_DBG=4): no emission at all behind the counts (results invalid)
         const int leader = (int)__builtin_ctzll(act);
         if (cs_on) {
             int cur = cs_cnt[0];                                    // (same address for every lane here: a broadcast)
@@ -887,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 flushed = true;
             }
             if (cur + (int)total <= kMfCandStage) {
-                if (m && !(p.dbg & 8)) {            // probe (MTM_MFMA_DBG=8): counts only, no records
+                if (m) {
                     const int tglob = tlist[li];
                     const unsigned long long bb[4] = {b0, b1, b2, b3};
                     const unsigned pre[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
@@ -944,30 +904,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     };
     auto emit = [&](const float (&out)[4], int li) { emit_at(out, li, y); };
-    // Dense maps with the maps in memory (p.cand_rowmax; round 4): the candidate list is only a preselection there
-    // (verify_peaks_kernel tests every candidate against the map), so it may leave out whatever cannot be a 3x3 maximum:
-    // a pixel with a larger neighbour in its own row.  Bit i of the result: pixel i of this lane's four is not exceeded by its
-    // left / right neighbour (NaN neighbours never exceed; beyond the wave's 256 pixels or the map: unknown - kept).  All
-    // lanes of the wave that are in the epilogue call this together (the neighbours' values come from the adjacent lanes).
-    auto rowmax_mask = [&](const float (&out)[4]) -> unsigned {
-        const float sgn = p.cand_min ? -1.0f : 1.0f;
-        // (pixels right of the last output column do not exist: they exceed nothing)
-        const float q0 = sgn * out[0], q1 = xq + 1 < p.ow ? sgn * out[1] : -INFINITY, q2 = xq + 2 < p.ow ? sgn * out[2] : -INFINITY,
-                    q3 = xq + 3 < p.ow ? sgn * out[3] : -INFINITY;
-        // DPP wave shifts (VALU moves, no LDS traffic - a ds_bpermute and the wait for it in the template loop cost the
-        // epilogue its software pipelining): wave_shr:1 = lane i receives lane i - 1, wave_shl:1 = lane i + 1; a lane without
-        // a source, or whose source is inactive, keeps the -inf passed in (tools/ubench/dpp checks exactly that on the box)
-        const int ninf = __float_as_int(-INFINITY);
-        const float lf = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(q3), 0x138, 0xf, 0xf, false));
-        float rt = __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(q0), 0x130, 0xf, 0xf, false));
-        if (xq + 4 >= p.ow) rt = -INFINITY;
-        unsigned m = 0;
-        m |= (!(lf > q0) && !(q1 > q0)) ? 1u : 0u;
-        m |= (!(q0 > q1) && !(q2 > q1)) ? 2u : 0u;
-        m |= (!(q1 > q2) && !(q3 > q2)) ? 4u : 0u;
-        m |= (!(q2 > q3) && !(rt > q3)) ? 8u : 0u;
-        return m;
-    };
     // global extremum (EXT): the lane's best key not below the template's running best goes to the wave's
     // LDS slot (cv2.minMaxLoc: the first index wins ties, NaN never wins)
     auto ext_update = [&](const float (&out)[4], int yrow, uint32_t best_hi, unsigned long long* slot) {
@@ -986,10 +922,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if (bestk) atomicMax(slot, bestk);
     };
     auto store4 = [&](float* orow, const float (&out)[4]) {
-#ifdef MTM_PROBE_NO_STORE      /* timing experiment: no score-map stores (values kept alive) */
-        if (out[0] + out[1] + out[2] + out[3] == 12345.678f) orow[0] = 1.0f;
-        return;
-#endif
         if (xq + 3 < p.ow) {
             *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
         } else {
@@ -1243,7 +1175,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         if constexpr (EXT) {
                             ext_update(out, yy, T.ext_hi, &ext_slot[t]);
                         } else if (p.cand_on) {
-                            const unsigned allow = p.cand_rowmax ? rowmax_mask(out) : 15u;
+                            const unsigned allow = 15u;
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                             if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy, allow);
@@ -1384,9 +1316,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // (this kernel's transposition buffer has 12 rows per wave - kMfU16EpiBytesPerWave - so that the three sets of a
         // stage's four templates go through it together)
         int* epi3 = reinterpret_cast<int*>(smem + wave * kMfU16EpiBytesPerWave);
-#ifdef MTM_PROBE_U16_NO_EPI     /* timing experiment: the K loops alone (wrong results) */
-        if (p.oh < 0)
-#endif
 #pragma unroll 1
         for (int stage = 0; stage < 4; ++stage) {
             if (4 * stage >= n_here) break;                                   // wave-uniform
@@ -1717,15 +1646,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         float out[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-#ifdef MTM_PROBE_CHEAP_EPI     /* timing experiment: no normalisation (wrong results) */
-                            out[i] = (float)a32[i];
-#else
                             if (MASKED)
                                 out[i] = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
                             else
                                 out[i] = finish_fast<METHOD, EXACT_DIV, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
                                                                             prsq[i], T);
-#endif
                         }
                         if (!MASKED) {
                             const bool ones = T.all_ones != 0;
@@ -1736,7 +1661,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             ext_update(out, yrow, T.ext_hi, &ext_slot[lt0 + s8]);
                         } else if (p.cand_on) {
                             // cheap any-of-4 test; emit_at() repeats the exact per-pixel test (rare)
-                            const unsigned allow = p.cand_rowmax ? rowmax_mask(out) : 15u;
+                            const unsigned allow = 15u;
                             const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                             const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
                             if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, yrow, allow);
@@ -1820,7 +1745,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
             const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
             base = ((unsigned long long)bhi << 32) | blo;
-            if (!(p.dbg & 16))                   // probe (MTM_MFMA_DBG=16): the atomic without the copy
                 for (int r = lane; r < n_st; r += 64)
                     mf_put_cand(p, base + (unsigned long long)r, cs_rec[r]);
         }

@@ -65,12 +65,8 @@ struct MfmaParams {
     int st_off;              // byte offset in LDS of the prefetched window statistics (4 waves)
     int persistent;          // 1: work items are pulled from *work_counter (grid = resident blocks)
     int stagger_sleeps;      // s_sleep(127) count of the second block on a CU before its first item
-    int stagger_first;       // non-persistent launches: block indices below this take part in the staggering (0 = off)
-    int stagger_mode;        // how "second block on a CU" is guessed: 0 per-CU arrival counter (HW_ID),
-                             // 1 upper half of the grid, 2 bit 3 of the block index
-    // fused peak candidates (mtm_find_matches, local-extrema mode): every output with
-    // (cand_min ? -v : v) > cand_thr is appended to cand_hits; verify_peaks_kernel then keeps the
-    // ones that are 3x3 local maxima.  Replaces a full re-read of all score maps.
+    int stagger_first_unused_;
+    int stagger_mode_unused_;
     mtm_hit* cand_hits;
     unsigned long long* cand_counter;
     unsigned long long cand_cap;
@@ -106,8 +102,7 @@ struct MfmaParams {
     // best seen so far, re-read when a work item starts, is that template's threshold for the pre-tests.
     int ext_off;
     unsigned long long* ext_best;
-    int dbg;                 // profiling probe (MTM_MFMA_DBG): 2 = no epilogue (results invalid); the other probes
-                             // are compile-time (-DMTM_PROBE_*)
+    int dbg_unused_;
     // Packed K (kp_nseg > 0; plain and row-multiplexed tilings of unmasked uint8 classes whose width is not a multiple
     // of 64): the K dimension is the STREAM of 16-tap segments of the template rows (kp_nseg = ceil(w / 16) per row),
     // four consecutive segments per MFMA wherever the rows end - lane group q of step b holds segment 4 b + q, i.e.
@@ -133,7 +128,7 @@ struct MfmaParams {
     // flag_base = template index * flag_tstride.  nullptr: off
     uint8_t* seg_flags;
     int flag_tstride, flag_rstride;
-    int cand_rowmax;         // 1 (maps in memory only): list only candidates no neighbour in their own row exceeds
+    int cand_rowmax_unused_;
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)

@@ -728,7 +728,10 @@ def test_banded_call_with_float64_classes_on_two_lanes(mtm, monkeypatch):
 
 
 @pytest.mark.parametrize("env", ["MTM_KERNEL=dot4", "MTM_ROW_MUX=0", "MTM_HITS_ONLY=0", "MTM_MASKSQ_FUSED=0", "MTM_RM_EDGES=0",
-                                 "MTM_MFMA_PERSISTENT=2", "MTM_MFMA_R2=0", "MTM_SCREEN_L1=0", "MTM_CLASS_LANES=1"])
+                                 "MTM_MFMA_PERSISTENT=2", "MTM_MFMA_R2=0", "MTM_SCREEN_L1=0", "MTM_CLASS_LANES=1",
+                                 # round 5: what the fixed-cost work replaced, each still selectable
+                                 "MTM_FUSE_LAYOUT=0", "MTM_CAND_PINNED=0", "MTM_ZERO_IN_STATS=0", "MTM_SINGLE_BAND=0", "MTM_BAND_ALIGN=0",
+                                 "MTM_EXACT_DIV=0"])
 def test_production_reachable_routes_give_the_default_lists(mtm, env, monkeypatch):
     """Every switch that selects a kernel or route a production call can also reach by itself (the VALU kernel for shapes
     the matrix-core path does not take, plain instead of row-multiplexed tiling, maps in memory, the unfused sum I^2 M
@@ -2208,13 +2211,12 @@ def test_context_state_sequences(mtm, seed):
             assert_hits_equal(hits_json(names), hits_json(exp), tol=1e-5, ordered=False)
 
 
-def test_dense_route_row_maxima_candidates(mtm, monkeypatch):
-    """Dense maps, the route taken while the back-off lasts (round 4): maps in memory, the score kernel lists only the
-    pixels above the threshold that no neighbour in their own row exceeds, verify_peaks_kernel tests that list against
-    the maps - no full peak pass.  With a candidate capacity between the number of row maxima and the number of all
-    pixels above the threshold the first call overflows (hits-only), the following ones take the dense route and must
-    return the oracle's hits; so must the route switched off (MTM_DENSE_ROWMAX=0: the full peak pass) and a capacity
-    that even the row maxima overflow.  Maxima and minima (TM_SQDIFF_NORMED), plateaus included (flat patches)."""
+def test_dense_backoff_route_against_the_oracle(mtm):
+    """Dense maps, the route taken while the back-off lasts: with a candidate capacity below the number of pixels above
+    the threshold the first call overflows (hits-only), the following ones go to memory with segment flags (or the full
+    peak pass) and must return the oracle's hits - at two capacities, for maxima and minima (TM_SQDIFF_NORMED), plateaus
+    included (flat patches), peaks in the last column / row.  (Round 4 also listed row maxima as candidates on this
+    route, MTM_DENSE_ROWMAX: slower than what it replaced, removed in round 5.)"""
     from MTM import _lib
     dense = synth.smooth_u8(7, (300, 520), scales=(3, 9, 27), noise=0.1)
     dense[40:70, 100:180] = 90                               # flat patches: plateaus of equal scores
@@ -2240,8 +2242,7 @@ def test_dense_route_row_maxima_candidates(mtm, monkeypatch):
         exp = hits_json(O.find_matches(lt, dense, method=method, score_threshold=thr))
         assert len(exp) > 500
         # the kernel's row test only sees the 256 pixels of a wave: a few more candidates than the count above
-        for env, cap in (("1", (n_above + 2 * n_row) // 3), ("0", (n_above + 2 * n_row) // 3), ("1", max(64, n_row // 4))):
-            monkeypatch.setenv("MTM_DENSE_ROWMAX", env)
+        for cap in ((n_above + 2 * n_row) // 3, max(64, n_row // 4)):
             c = _lib.Context(0)
             try:
                 c.set_option(_lib.OPT_HIT_CAPACITY, cap)
@@ -2250,7 +2251,7 @@ def test_dense_route_row_maxima_candidates(mtm, monkeypatch):
                     raw = c.find_matches_image(dense, _lib.PEAKS_LOCAL, thr)
                     assert c.timing()["hits_only"] in (0, 2)      # (2: the flagged-segment peak pass of the back-off calls)
                     got = [(lt[int(r["templ_idx"])][0], (int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), r["score"]) for r in raw]
-                    assert len(got) == len(exp), (method, env, cap, k, len(got), len(exp))
+                    assert len(got) == len(exp), (method, cap, k, len(got), len(exp))
                     assert_hits_equal(hits_json(got), exp, tol=1e-6, ordered=False)
             finally:
                 c.close()
