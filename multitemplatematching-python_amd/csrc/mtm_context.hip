@@ -276,7 +276,6 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
     if (const char* v = std::getenv("MTM_F32_RIG")) c->f32_rig = std::atoi(v);
     if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MASKSQ_RUNS")) c->masksq_runs = std::atoi(v);
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
     if (const char* v = std::getenv("MTM_RM_EDGES")) c->rm_edges = std::atoi(v);
     if (const char* v = std::getenv("MTM_CAND_STAGE")) c->cand_stage = std::atoi(v);
@@ -338,7 +337,6 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
-    for (DevBuf* b : {&c->sq_prefix, &c->mask_runs}) b->release();
     for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw, &c->seg_flags, &c->hits_t, &c->nms_buf}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->stats_blk, &c->sq_planes, &c->comm_send,

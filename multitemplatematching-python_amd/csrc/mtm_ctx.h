@@ -119,7 +119,6 @@ struct SizeClass {
                                 // output rows x 16 templates per wave; packs of h + r2 - 1 rows per 16-template group (the
                                 // extra rows zero); 0 = off
     long long mask_rm_off = -1; // masked class: row-multiplexed pack (1 "template" = the binary mask, R = 16) in apacks
-    long long runs_off = -1;    // >= 0: every row of the mask is one run; byte offset of its (a, b) table in mtm_ctx::mask_runs
     double mask_ones = 0.0;     // number of set mask pixels
     int n_pad = 0;              // members rounded up to a multiple of 16 (uint16 packs)
     long long tsum_off = -1;    // doubles: [sum(T_hi) per member][sum(T_lo) per member] in the tsum arena
@@ -195,8 +194,6 @@ struct mtm_ctx {
         bool f32_valid = true;      // false after a banded uint8 upload: the float32 plane was skipped (ensure_f32_plane)
     } slot[2];
     int cur = 0;
-    DevBuf sq_prefix, mask_runs;    // exclusive row prefixes of I^2 (uint32) of the current image; run tables of the masked classes
-    int masksq_runs = 1;        // MTM_MASKSQ_RUNS: sum I^2 M of single-run masks from the prefix rows (0: always the matrix-core pass)
     DevBuf sq_planes;           // two planes: [high byte of I^2 ^ 0x80][low byte ^ 0x80] of the current uint8 image
     bool sq_valid = false;
     hipStream_t copy_stream = nullptr;

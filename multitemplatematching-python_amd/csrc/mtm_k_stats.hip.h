@@ -755,147 +755,6 @@ __global__ __launch_bounds__(256) void square_planes_kernel(const uint8_t* __res
                                                   lo[3] ^ 0x80808080u);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Round 5: sum I^2 * M of a BINARY mask as a sum of row runs.  A mask row r that is 1 on [a, b) contributes
-//   sum_{x' in [x + a, x + b)} I[y + r][x']^2  =  P2[y + r][x + b] - P2[y + r][x + a]
-// with P2 the exclusive row prefix of I^2 (uint32: a row of 66051 pixels fits; differences are taken modulo 2^32 and a
-// window's sum is < 2^32 under the fused statistics' condition w * h * 65025 < 2^32).  A mask whose rows are ONE run each
-// (discs, ellipses, rectangles - any horizontally convex shape) costs 2 h LDS reads per output instead of w * h
-// multiply-accumulates on the matrix cores, where this pass - a single "template" row-multiplexed over 16 output rows,
-// staging-bound - ran at 0.23 of the peak (cfg5: 4.1 of 17.6 ms).  Masks with several runs in a row keep that pass.
-// ---------------------------------------------------------------------------------------------
-constexpr int kMqTY = 32;           // output rows per work-group (one uint32 accumulator each per thread)
-constexpr int kMqPad = 512;         // entries behind P2[row][cols], all equal to the row's total
-
-// P2[r][x] = sum_{x' < x} I[r][x']^2 for x = 0 .. cols, then the total up to the end of the row.  One work-group per
-// row, 1024 pixels per step (4 per thread: one dword in, one uint4 out, coalesced).
-__global__ __launch_bounds__(256) void prefix_sq_kernel(const uint8_t* __restrict__ u8, int u8_pitch, int cols,
-                                                        uint32_t* __restrict__ P2, int p2_pitch) {
-    __shared__ uint32_t wsum[2][4];
-    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint8_t* row = u8 + (size_t)r * u8_pitch;
-    uint32_t* out = P2 + (size_t)r * p2_pitch;
-    uint32_t carry = 0;
-    int par = 0;
-    for (int xc = 0; xc < cols; xc += 1024, par ^= 1) {
-        const int x = xc + 4 * t;
-        const uint32_t v = x < cols ? *reinterpret_cast<const uint32_t*>(row + x) : 0u;      // (x is a multiple of 4: inside the padded plane)
-        uint32_t sq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t px = (v >> (8 * k)) & 255u;
-            sq[k] = x + k < cols ? px * px : 0u;
-        }
-        const uint32_t s = sq[0] + sq[1] + sq[2] + sq[3];
-        const uint32_t inc = wave_inclusive_scan_u32(s);
-        if (lane == 63) wsum[par][wave] = inc;
-        __syncthreads();                                    // (two buffers: one barrier per step)
-        uint32_t e = carry + inc - s;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < wave) e += wsum[par][k];
-        if (x < cols) *reinterpret_cast<uint4*>(out + x) = make_uint4(e, e + sq[0], e + sq[0] + sq[1], e + sq[0] + sq[1] + sq[2]);
-        carry += wsum[par][0] + wsum[par][1] + wsum[par][2] + wsum[par][3];
-    }
-    for (int x = cols + t; x < p2_pitch; x += 256) out[x] = carry;      // P2[cols] and the padding: the row's total
-}
-
-// c2(y, x) = sum I^2 M as float64 into `sum2` and its minimum over every 16-pixel column block into blk[..][2] (what the
-// matrix-core pass wrote: MfmaParams::sq_fused).  Work-group: 256 output columns (one per thread) x kMqTY output rows;
-// the prefix rows y0 .. y0 + kMqTY + h - 2 stream through a double-buffered LDS line, each updating the accumulators of
-// the output rows it belongs to: mask row r = image row - output row.  The (a, b) of the kMqTY mask rows in play slide
-// through a register window (uniform values: scalar registers), one table row loaded per step.
-__global__ __launch_bounds__(256) void masksq_runs_kernel(const uint32_t* __restrict__ P2, int p2_pitch,
-                                                          const int2* __restrict__ table, int h, int w, int oh, int ow,
-                                                          double* __restrict__ sum2, int st_pitch, double* __restrict__ blk,
-                                                          int blk_pitch) {
-    __shared__ uint32_t L[2][768 + 8];
-    const int t = threadIdx.x;
-    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * kMqTY;
-    const int ny = min(kMqTY, oh - y0);
-    const int n_rows = ny + h - 1;
-    const int seg = 256 + w + 1;                                 // entries of a staged line (<= 513)
-    uint32_t acc[kMqTY];
-    int ra[kMqTY], rb[kMqTY];                                    // run of mask row (it - j), (0, 0) where there is none
-#pragma unroll
-    for (int j = 0; j < kMqTY; ++j) {
-        acc[j] = 0u;
-        ra[j] = rb[j] = 0;
-    }
-    const uint32_t* g = P2 + (size_t)y0 * p2_pitch + x0;
-    uint32_t v0 = g[t], v1 = g[256 + t], v2 = (512 + t < seg) ? g[512 + t] : 0u;
-    L[0][t] = v0;
-    L[0][256 + t] = v1;
-    L[0][512 + t] = v2;
-    __syncthreads();
-    for (int it = 0; it < n_rows; ++it) {
-        const int buf = it & 1;
-#ifndef MQ_NO_LOADS
-        if (it + 1 < n_rows) {
-            const uint32_t* gn = g + (size_t)(it + 1) * p2_pitch;
-            v0 = gn[t];
-            v1 = gn[256 + t];
-            v2 = (512 + t < seg) ? gn[512 + t] : 0u;
-        }
-#endif
-        // slide the window: output row j now meets the mask row output row j - 1 met in the previous step
-#pragma unroll
-        for (int j = kMqTY - 1; j > 0; --j) {
-            ra[j] = ra[j - 1];
-            rb[j] = rb[j - 1];
-        }
-        {
-            const int2 ab = it < h ? table[it] : make_int2(0, 0);
-            ra[0] = __builtin_amdgcn_readfirstlane(ab.x);
-            rb[0] = __builtin_amdgcn_readfirstlane(ab.y);
-        }
-        // Four output rows at a time: their eight LDS reads go out together (one test per output row made every pair wait for
-        // its own reads).  While every one of the kMqTY output rows meets a mask row (kMqTY - 1 <= it < h: most steps of a
-        // large mask) nothing is tested at all - the scalar unit, one per CU, was the bound: 64 moves for the window and 14
-        // compare / select / and per group and wave, 800 cycles per work-group and step against 512 of LDS time (measured:
-        // 1.6 ms for a 128 x 128 mask at 8K).  On the ramps the rows in play are j <= it resp. j > it - h; an idle row inside
-        // an active group holds (0, 0) and reads Lb[0] - Lb[0].
-        const uint32_t* Lb = &L[buf][t];
-        auto group = [&](int j4) {
-            const uint32_t p0 = Lb[rb[j4]], q0 = Lb[ra[j4]], p1 = Lb[rb[j4 + 1]], q1 = Lb[ra[j4 + 1]];
-            const uint32_t p2 = Lb[rb[j4 + 2]], q2 = Lb[ra[j4 + 2]], p3 = Lb[rb[j4 + 3]], q3 = Lb[ra[j4 + 3]];
-            acc[j4] += p0 - q0;
-            acc[j4 + 1] += p1 - q1;
-            acc[j4 + 2] += p2 - q2;
-            acc[j4 + 3] += p3 - q3;
-        };
-        {
-            const int jlo = it - h + 1;                          // output rows jlo .. it meet a mask row
-#pragma unroll
-            for (int j4 = 0; j4 < kMqTY; j4 += 4) {
-#ifndef MQ_NO_COMPUTE
-                if (j4 <= it && j4 + 3 >= jlo) group(j4);
-#endif
-            }
-        }
-        if (it + 1 < n_rows) {
-            L[buf ^ 1][t] = v0;
-            L[buf ^ 1][256 + t] = v1;
-            L[buf ^ 1][512 + t] = v2;
-        }
-        __syncthreads();
-    }
-    const int x = x0 + t;
-#pragma unroll
-    for (int j = 0; j < kMqTY; ++j) {
-        if (j >= ny) break;                                      // (uniform)
-        const int y = y0 + j;
-        const double c2 = x < ow ? (double)acc[j] : INFINITY;
-        if (x < ow) sum2[(size_t)y * st_pitch + x] = c2;
-        if (blk != nullptr) {
-            double bmin = c2;
-#pragma unroll
-            for (int off = 1; off <= 8; off <<= 1) bmin = fmin(bmin, __shfl_xor(bmin, off));
-            if ((t & 15) == 0 && (x >> 4) < blk_pitch) blk[((size_t)y * blk_pitch + (x >> 4)) * 4 + 2] = bmin;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void masksq_combine_kernel(const int* __restrict__ raw_h, const int* __restrict__ raw_l,
                                                              int raw_pitch, double* __restrict__ sum2, int st_pitch,
                                                              double km257, int oh, int ow, double* __restrict__ blk,

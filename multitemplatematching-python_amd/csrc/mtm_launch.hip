@@ -43,37 +43,22 @@ MfmaFn mfma_raw_fn(bool row_mux, bool packed_k) {
 
 namespace mtmi {
 
-// entries per row of the prefix plane of I^2: x = 0 .. cols, then kMqPad copies of the row's total
-static int sq_prefix_pitch(int cols) { return (int)round_up((size_t)cols + 1 + kMqPad, 64); }
-
 bool dot_variant_ok(int64_t v) { return v >= 0 && v < kNumDotVariants && !kDotVariants[v].wide; }
 
 // The byte planes of I^2 (masked classes: sum I^2 M on the matrix cores), once per image; a no-op for everything but
 // single-channel uint8 images with a masked class on the MFMA kernel.
 int ensure_square_planes(mtm_ctx* c) {
     if (c->sq_valid || c->dtype != MTM_U8 || c->chans != 1) return MTM_OK;
-    bool any = false, any_runs = false;
-    for (const SizeClass& sc : c->classes) {
-        const bool m = sc.masked && sc.mask_rm_off >= 0 && resolved_kernel(c, sc) == MTM_KERNEL_MFMA;
-        const bool r = m && sc.runs_off >= 0 && c->masksq_runs;
-        any = any || (m && !r);             // the matrix-core pass: the byte planes of I^2
-        any_runs = any_runs || r;           // single-run masks: the row prefixes of I^2 (masksq_runs_kernel)
-    }
-    if (!any && !any_runs) return MTM_OK;
+    bool any = false;
+    for (const SizeClass& sc : c->classes)
+        any = any || (sc.masked && sc.mask_rm_off >= 0 && resolved_kernel(c, sc) == MTM_KERNEL_MFMA);
+    if (!any) return MTM_OK;
     const ImageDev img = image_dev(c);
-    if (any) {
-        const size_t plane_bytes = (size_t)img.u8_plane;
-        MTMC(c->sq_planes.ensure(2 * plane_bytes));
-        const size_t n16 = plane_bytes / 16;
-        hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
-                           c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes);
-    }
-    if (any_runs) {
-        const int p2_pitch = sq_prefix_pitch(c->cols);
-        MTMC(c->sq_prefix.ensure(sizeof(uint32_t) * (size_t)p2_pitch * c->rows));
-        hipLaunchKernelGGL(prefix_sq_kernel, dim3((unsigned)c->rows), dim3(256), 0, c->stream, img.u8, img.u8_pitch, c->cols,
-                           c->sq_prefix.as<uint32_t>(), p2_pitch);
-    }
+    const size_t plane_bytes = (size_t)img.u8_plane;
+    MTMC(c->sq_planes.ensure(2 * plane_bytes));
+    const size_t n16 = plane_bytes / 16;
+    hipLaunchKernelGGL(square_planes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, img.u8, n16,
+                       c->sq_planes.as<uint8_t>(), c->sq_planes.as<uint8_t>() + plane_bytes);
     HIPC(hipGetLastError());
     c->sq_valid = true;
     return MTM_OK;
@@ -276,14 +261,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         }
         auto& sqe = c->sq_ev[(size_t)c->timing.sq_launches];
         HIPC(hipEventRecord(sqe.first, c->stream));
-        if (sc.runs_off >= 0 && c->masksq_runs) {
-            // single-run mask (round 5): 2 h LDS reads per output from the row prefixes of I^2 - no matrix-core pass
-            st.sum2 = sum2;
-            const dim3 gr((ow + 255) / 256, (oh + kMqTY - 1) / kMqTY);
-            hipLaunchKernelGGL(masksq_runs_kernel, gr, dim3(256), 0, c->stream, c->sq_prefix.as<uint32_t>(), sq_prefix_pitch(c->cols),
-                               reinterpret_cast<const int2*>(c->mask_runs.as<uint8_t>() + sc.runs_off), h, w, oh, ow, sum2, st.pitch,
-                               const_cast<double*>(st.blk), st.blk_pitch);
-        } else if (fused_sq) {
+        if (fused_sq) {
             // ONE launch: the byte planes of I^2 are its two channels, the epilogue writes sum2 and the block minima
             p.chans = 2;
             p.img = c->sq_planes.as<uint8_t>();

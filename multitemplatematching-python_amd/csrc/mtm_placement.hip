@@ -730,44 +730,11 @@ int place_templates(mtm_ctx* c) {
     // device-side packing: gathers the A operands straight from the unit views (the template list is in place)
     for (size_t k = 0; k < classes.size(); ++k)
         if (dev_pack[k]) MTMC(pack_class_on_device(c, classes[k]));
-    // Round 5: the row runs of every masked class's mask (mask_runs_kernel reads the mask pack that is now on the device,
-    // whichever way it got there); a class whose mask rows are one run each takes sum I^2 M from the prefix rows of I^2
-    // (masksq_runs_kernel) instead of the matrix-core pass.  One small read-back per placement (not per call).
-    bool runs_wait = false;
-    {
-        std::vector<size_t> cand;
-        for (size_t k = 0; k < classes.size(); ++k) {
-            classes[k].runs_off = -1;
-            if (c->masksq_runs && class_kernel[k] == MTM_KERNEL_MFMA && classes[k].mask_rm_off >= 0 && classes[k].slabs.empty() &&
-                classes[k].h <= 256 && classes[k].w <= 256 && c->dtype == MTM_U8 && c->chans == 1 &&
-                (double)c->cols * 65025.0 < 4294967296.0)
-                cand.push_back(k);
-        }
-        if (!cand.empty()) {
-            const size_t tab = 256 * sizeof(int2);
-            MTMC(c->mask_runs.ensure(cand.size() * tab + 256));
-            int* status = reinterpret_cast<int*>(c->mask_runs.as<uint8_t>() + cand.size() * tab);
-            HIPC(hipMemsetAsync(status, 0, 256, c->stream));
-            for (size_t q = 0; q < cand.size() && q < 64; ++q) {
-                const SizeClass& sc = classes[cand[q]];
-                hipLaunchKernelGGL(mask_runs_kernel, dim3(1), dim3(256), 0, c->stream, c->apacks.as<uint8_t>() + sc.mask_rm_off, sc.h,
-                                   sc.w, (sc.w + 63) / 64, reinterpret_cast<int2*>(c->mask_runs.as<uint8_t>() + q * tab),
-                                   status + q);
-            }
-            HIPC(hipGetLastError());
-            int st_host[64] = {0};
-            HIPC(hipMemcpyAsync(st_host, status, sizeof(int) * std::min<size_t>(cand.size(), 64), hipMemcpyDeviceToHost, c->stream));
-            HIPC(hipStreamSynchronize(c->stream));
-            runs_wait = true;
-            for (size_t q = 0; q < cand.size() && q < 64; ++q)
-                if (st_host[q] == 1) classes[cand[q]].runs_off = (long long)(q * tab);
-        }
-    }
     // host staging vectors go out of scope; the tables that stay in the context (td_host, tlist_host) need no wait
     // (set_templates_device)
-    const bool local_sources = (any_host_pack || w_off || p_off || ts_off || units_all.size() > c->usrc_units) && !runs_wait;
+    const bool local_sources = any_host_pack || w_off || p_off || ts_off || units_all.size() > c->usrc_units;
     if (local_sources) HIPC(hipStreamSynchronize(c->stream));
-    c->place_pending = !local_sources && !runs_wait;
+    c->place_pending = !local_sources;
     drain.armed = false;
     if (units_all.size() > c->usrc_units) c->usrc_host.swap(units_all);
     c->classes.swap(classes);

@@ -180,31 +180,4 @@ __global__ void gather_unit_kernel(const uint8_t* __restrict__ arena, UnitSrc u,
     if (mask != nullptr) mask[o] = u.moff >= 0 ? (uint8_t)unit_mask(arena, u, c, y, x) : 0;
 }
 
-// The run table of a class's mask, read from its row-multiplexed mask pack (pack_mask_rm / pack_units_kernel mode 2: the
-// int8 values 0 / 1 at [((dy + 16) nb + dx / 64) * 64 + 16 ((dx % 64) / 16)][dx % 16], A row 0).  Thread r = mask row r:
-// table[r] = (a, b) of its first run ((0, 0): empty row); *max_runs receives the largest run count of a row (the host
-// takes the matrix-core pass when that exceeds 1).
-__global__ __launch_bounds__(256) void mask_runs_kernel(const uint8_t* __restrict__ pack, int h, int w, int nb,
-                                                        int2* __restrict__ table, int* __restrict__ max_runs) {
-    const int r = threadIdx.x;
-    if (r >= h) return;
-    int n = 0, prev = 0, start = 0, a0 = 0, b0 = 0;
-    for (int dx = 0; dx <= w; ++dx) {
-        int m = 0;
-        if (dx < w) m = pack[((((size_t)(r + 16) * nb + dx / 64) * 64) + 16 * ((dx % 64) / 16)) * 16 + dx % 16] != 0;
-        if (m && !prev) start = dx;
-        if (!m && prev) {
-            if (n == 0) {
-                a0 = start;
-                b0 = dx;
-            }
-            ++n;
-        }
-        prev = m;
-    }
-    table[r] = make_int2(a0, b0);
-    atomicMax(max_runs, n);
-}
-
-
 }  // namespace mtm

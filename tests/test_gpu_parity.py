@@ -2728,52 +2728,3 @@ def test_float32_adversarial_lists_equal_the_float64_kernels():
     finally:
         fast.close()
         exact.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("method", [3, 0])
-def test_masked_sum_squares_from_row_runs(mtm, method, monkeypatch):
-    """Round 5: sum I^2 M of a mask whose rows are one run each (discs, ellipses, rectangles, rows left empty) comes from
-    the row prefixes of I^2 (masksq_runs_kernel) instead of a matrix-core pass.  The score maps are those of the
-    matrix-core pass (MTM_MASKSQ_RUNS=0) bit for bit - both sums are exact integers - and the oracle's to 1e-6; masks
-    with several runs in a row (a ring) keep the matrix-core pass.  Sizes up to 128 x 128, an image wider than one
-    work-group's 256 columns, output rows that are no multiple of the work-group's 32.  Reference: MTM/__init__.py:212-219."""
-    from MTM import _lib
-    img = synth.rand_u8(31, 0, (333, 700))
-    yy, xx = np.mgrid[0:128, 0:128]
-    shapes = {"disc128": ((yy - 63.5) ** 2 + (xx - 63.5) ** 2 <= 63.5 ** 2),
-              "ellipse24x56": (((np.mgrid[0:24, 0:56][0] - 11.5) / 12.0) ** 2 + ((np.mgrid[0:24, 0:56][1] - 27.5) / 28.0) ** 2 <= 1.0),
-              "rect_with_empty_rows": np.pad(np.ones((20, 30), bool), ((5, 7), (3, 9))),
-              "full40": np.ones((40, 40), bool),
-              "ring48": ((np.mgrid[0:48, 0:48][0] - 23.5) ** 2 + (np.mgrid[0:48, 0:48][1] - 23.5) ** 2 <= 23.5 ** 2) &
-                        ((np.mgrid[0:48, 0:48][0] - 23.5) ** 2 + (np.mgrid[0:48, 0:48][1] - 23.5) ** 2 >= 10.0 ** 2)}
-    runs_ctx = _lib.Context(0)
-    monkeypatch.setenv("MTM_MASKSQ_RUNS", "0")
-    mfma_ctx = _lib.Context(0)
-    try:
-        for c in (runs_ctx, mfma_ctx):
-            c.set_option(_lib.OPT_EXACT_DIV, 1)
-        for name, m in shapes.items():
-            h, w = m.shape
-            mask = (m * 255).astype(np.uint8)
-            templs = [(np.ascontiguousarray(img[y:y + h, x:x + w]), mask) for y, x in ((5, 9), (150, 400), (333 - h, 700 - w))]
-            shape = (333 - h + 1, 700 - w + 1)
-            maps = []
-            for c in (runs_ctx, mfma_ctx):
-                c.set_image(img)
-                c.set_templates(templs, method)
-                maps.append([c.score_map(i, shape) for i in range(3)])
-                assert c.timing()["kernel_used"] == 3, name
-            for i in range(3):
-                assert np.array_equal(maps[0][i].view(np.uint32), maps[1][i].view(np.uint32)), (name, method, i)
-                exp = O.match_template(img, templs[i][0], method, mask=mask)
-                map_close(maps[0][i], exp, tol=1e-6)
-            # and the lists of a search (hits-only: the masked screen reads the block minima the pass writes)
-            thr = 0.97 if method == 3 else 1e9
-            a = runs_ctx.search(templs, img, method, _lib.PEAKS_LOCAL, thr)
-            b = mfma_ctx.search(templs, img, method, _lib.PEAKS_LOCAL, thr)
-            assert np.array_equal(a, b), (name, method)
-            assert len(a) >= (3 if method == 3 else 0)
-    finally:
-        runs_ctx.close()
-        mfma_ctx.close()
