@@ -88,17 +88,18 @@ extern "C" {
                                    templates; the normalised methods, and the raw-sum methods for the global extremum
                                    (N_object == 1: listed by rigorous per-pixel error bounds, re-scored exactly; raw sums
                                    with a threshold, and their maps, always take the float64 kernel).
-                                   1 (default): scores on the bf16 matrix cores (within
-                                   ~1e-5 of cv2's float64 result) as a SCREEN - everything that could be a peak, the
-                                   global extremum or a threshold case by that margin is re-scored with the float64
-                                   arithmetic of the exact kernel, so mtm_find_matches returns the exact kernel's hit
-                                   lists as long as the bf16 scores stay inside the screen's margins (1e-4 around the
-                                   threshold / the running best, 5e-5 between 3x3 neighbours: empirical margins, not a
-                                   bound - the observed error is <= 1e-5 and 900 fuzz cases show no difference, but a
-                                   low-contrast window next to a much brighter region can in principle exceed them);
-                                   score maps read back with mtm_score_map keep the ~1e-5 tolerance;
-                                   0: the float64 kernel for everything (10x slower, maps exact to rounding) - the
-                                   setting that guarantees the exact lists;
+                                   1 (default): scores on the bf16 matrix cores (within ~1e-5 of cv2's float64 result)
+                                   as a SCREEN - every output whose exact score COULD be a peak, the global extremum or
+                                   pass the threshold is re-scored with the float64 arithmetic of the exact kernel.
+                                   Since round 5 "could" is decided by a per-output error bound, not by margins:
+                                   |bf16 ratio - exact ratio| <= eps sqrt(sum (I - mu)^2) / sq * (sqrt(sum (T - mean)^2) /
+                                   templ_norm), large where it has to be (a low-contrast window beside a much brighter
+                                   region) and ~5e-5 on textured windows (one hardware assumption, stated in
+                                   bf16_rig_eps and measured by tests/test_gpu_parity.py::test_float32_error_bound_holds);
+                                   mtm_find_matches then returns the exact kernel's hit lists.  MTM_F32_RIG=0: the
+                                   empirical margins of rounds 3-4 (1e-4 / 5e-5).  Score maps read back with mtm_score_map
+                                   keep the ~1e-5 tolerance;
+                                   0: the float64 kernel for everything (10x slower, maps exact to rounding);
                                    2: bf16 scores as they are, no re-scoring.  Environment: MTM_F32_MFMA. */
 
 /* error codes */
