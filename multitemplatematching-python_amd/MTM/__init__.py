@@ -13,6 +13,7 @@ No OpenCV, scikit-image, scipy or PyTorch on this path, and no CPU fallback: a m
 GPU raises.
 """
 import warnings
+from operator import is_ as _is
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -121,6 +122,11 @@ def _validate_search(listTemplates, image, N_object, searchBox):
         xOffset = yOffset = 0
 
     ishape = image.shape
+    # (a loop over images passes the SAME template tuples call after call: their checks against an image of the same shape
+    # are remembered - see _ListMemo; an error is never remembered)
+    memo = _list_memo
+    if memo is not None and memo.ishape == ishape and memo.matches(listTemplates):
+        return image, xOffset, yOffset
     for index, tempTuple in enumerate(listTemplates):
         if not isinstance(tempTuple, tuple) or len(tempTuple) < 2:
             raise ValueError("listTemplates should be a list of tuples as ('name','array') or ('name', 'array', 'mask')")
@@ -134,7 +140,40 @@ def _validate_search(listTemplates, image, N_object, searchBox):
             where = "searchBox" if (searchBox is not None) else "image"
             raise ValueError("Template '{}' at index {} in the list of templates is larger than {}.".format(
                 tempTuple[0], index, where))
+    _remember_list(listTemplates, ishape)
     return image, xOffset, yOffset
+
+
+class _ListMemo:
+    """What the last validated template list was, by IDENTITY of its tuples plus the shapes of their arrays (the one thing
+    about an array that can change in place and matters to the checks; changed PIXELS are the library's business - it
+    compares the bytes with the copy it packed from in every call), and what the per-call loops over it produced: the
+    reference's checks against an image of this shape (MTM/__init__.py:147-167), the engine units of the 8-bit path, the
+    label column of the hit list.  One immutable snapshot, replaced as a whole: safe to read without a lock."""
+    __slots__ = ("items", "shapes", "ishape", "units_pack", "labels")
+
+    def __init__(self, listTemplates, ishape):
+        self.items = tuple(listTemplates)            # (keeps the tuples alive: an id cannot be recycled)
+        self.shapes = [t[1].shape for t in self.items]
+        self.ishape = ishape
+        self.units_pack = None                       # (key, units, ignored masks): ONE attribute, replaced as a whole
+        self.labels = None
+
+    def matches(self, listTemplates):
+        it = self.items
+        return len(listTemplates) == len(it) and all(map(_is, listTemplates, it)) and \
+            [t[1].shape for t in listTemplates] == self.shapes
+
+
+_list_memo = None
+
+
+def _remember_list(listTemplates, ishape):
+    global _list_memo
+    try:
+        _list_memo = _ListMemo(listTemplates, ishape)
+    except Exception:  # noqa: BLE001 - exotic template objects: no memo, every call checks
+        _list_memo = None
 
 
 _U8 = np.dtype(np.uint8)
@@ -151,7 +190,13 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
     ichans = image.shape[2] if image.ndim == 3 else 1
     # the usual call - 8-bit image, 8-bit templates - needs no pixel policy at all: one pass over the list
     units = None
-    if image.dtype == _U8 and image.ndim in (2, 3) and ichans <= 4:
+    memo = _list_memo
+    ukey = (method in (0, 3), image.ndim, ichans)
+    ignored_masks = 0
+    pack = memo.units_pack if memo is not None else None
+    if image.dtype == _U8 and pack is not None and pack[0] == ukey and memo.matches(listTemplates):
+        units, ignored_masks = pack[1], pack[2]                      # the same tuples as last time: the same units
+    elif image.dtype == _U8 and image.ndim in (2, 3) and ichans <= 4:
         units = []
         ignored_masks = 0           # warnings only once the list is known to take this path (the general loop below warns itself)
         for tempTuple in listTemplates:
@@ -169,6 +214,9 @@ def _raw_matches(listTemplates, image, method, N_object, score_threshold, contex
                 units = None
                 break
             units.append((t, mask))
+        if units is not None and memo is not None and memo.matches(listTemplates):
+            units = _lib.FrozenUnits(units)
+            memo.units_pack = (ukey, units, ignored_masks)
     if units is not None:
         for _ in range(ignored_masks):      # one per template, as the reference's loop emits them (MTM/__init__.py:216-221)
             warnings.warn(_MSG_MASK_UNSUPPORTED)
@@ -239,9 +287,15 @@ def _nms_raw(raw, scoreThreshold, sortAscending, N_object, maxOverlap):
 def _to_hit_list(raw, listTemplates, xOffset, yOffset):
     """Structured hit array -> the reference's list of (label, (x, y, w, h), np.float32 score)
     (MTM/__init__.py:241).  Column-wise tolist() keeps this cheap for thousands of hits."""
-    labels = np.empty(len(listTemplates), dtype=object)
-    for i, t in enumerate(listTemplates):          # element-wise: a label may be any object (even a tuple)
-        labels[i] = t[0]
+    memo = _list_memo
+    if memo is not None and memo.labels is not None and memo.matches(listTemplates):
+        labels = memo.labels
+    else:
+        labels = np.empty(len(listTemplates), dtype=object)
+        for i, t in enumerate(listTemplates):          # element-wise: a label may be any object (even a tuple)
+            labels[i] = t[0]
+        if memo is not None and memo.matches(listTemplates):
+            memo.labels = labels
     boxes = zip((raw["x"] + xOffset).tolist(), (raw["y"] + yOffset).tolist(), raw["w"].tolist(), raw["h"].tolist())
     return list(zip(labels[raw["templ_idx"]].tolist(), boxes, list(raw["score"])))
 

@@ -233,6 +233,11 @@ def templ_records(templates):
     return np.frombuffer(buf, dtype=TEMPL_DTYPE), keep
 
 
+class FrozenUnits(list):
+    """A list of (template, mask) units that its owner promises never to mutate (MTM._ListMemo)."""
+    __slots__ = ()
+
+
 def _zero_copy(templates, keep):
     """True if templ_records handed the caller's own buffers to the library (no array had to be copied)."""
     it = iter(keep)
@@ -271,13 +276,16 @@ def pinned_empty(shape, dtype=np.uint8):
 
 class _RecordMemo:
     """Marshalled template lists, memoised (shared by Context and Group)."""
-    _rec_key = _rec = _rec_keep = None
+    _rec_key = _rec = _rec_keep = _rec_src = None
 
     def _records(self, templates):
         """templ_records(templates), memoised on the identity (and shape) of the arrays: a caller that passes the same
         template objects call after call - the usual loop over images - pays for the marshalling once.  The arrays are
         kept referenced, so an id cannot be recycled; changed PIXELS are the library's business (it compares the bytes
         with the copy it packed from in every mtm_set_templates)."""
+        # (a unit list MTM's own memo hands over again - never mutated, shapes re-checked by the caller in this very call)
+        if type(templates) is FrozenUnits and templates is self._rec_src and self._rec_key is not None:
+            return self._rec
         key = [(id(t), t.shape, id(m)) for t, m in templates]
         if key != self._rec_key:
             self._rec, keep = templ_records(templates)
@@ -286,6 +294,7 @@ class _RecordMemo:
             # (np.rot90(base), base[:, ::-1], base.T ...) would otherwise be matched from the copy of the FIRST call
             # for ever, even after the caller edited the array in place - the reference re-reads it on every call.
             self._rec_key = key if _zero_copy(templates, keep) else None
+        self._rec_src = templates
         return self._rec
 
 

@@ -1584,7 +1584,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                 for (int cc = 1; cc < CH; ++cc) s1all += ps1[i][cc];
                 pp1[i] = 128.0 * s1all;
-                prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+                // (IEEE-division builds of the unmasked normalised methods need no reciprocal at all - kExactNoRcp below:
+                // four float64 divisions per lane and row, and the registers that made the epilogue spill, saved)
+                prsq[i] = (kNormed && !(EXACT_DIV && !MASKED) && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
         };
@@ -1630,6 +1632,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             // constant templates always take the exact path below.
                             bool pass = T.all_ones != 0;
                             const double rt = T.rtempl_norm;
+                            constexpr bool kExactNoRcp = EXACT_DIV && !MASKED;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 double num = (double)a32[i] + T.mfma_k;
@@ -1637,9 +1640,19 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 for (int cc = 0; cc < CH; ++cc)
                                     num = fma(ps1[i][cc], METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[cc] : 128.0, num);
                                 if (METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(psum2[i] - 2.0 * num + T.templ_sum2, 0.0);
-                                const double qd = num * (prsq[i] * rt);
-                                const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
-                                pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
+                                if constexpr (kExactNoRcp) {
+                                    // the same test without a quotient: q > thr <=> num > thr * t for t > 0 (minima: -q > thr
+                                    // <=> num < -thr * t); a flat window (t == 0) scores the rules' constant, 0 or 1
+                                    const double tt = psq[i] * T.templ_norm;
+                                    const double thr_lo = EXT ? T.ext_thr_lo : p.cand_thr_lo;
+                                    const bool over = METHOD == MTM_TM_SQDIFF_NORMED ? num < -thr_lo * tt : num > thr_lo * tt;
+                                    const bool flat_over = (METHOD == MTM_TM_SQDIFF_NORMED ? -1.0 : 0.0) > thr_lo;
+                                    pass = pass || (tt > 0.0 ? (over || fabs(num) >= 0.999999999 * tt) : flat_over);
+                                } else {
+                                    const double qd = num * (prsq[i] * rt);
+                                    const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
+                                    pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
+                                }
                             }
                             if (!pass) continue;
                         }
@@ -1651,6 +1664,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             else
                                 out[i] = finish_fast<METHOD, EXACT_DIV, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
                                                                             prsq[i], T);
+                            // (IEEE division: one quotient after the other - four interleaved division sequences need ~40
+                            // registers more than the epilogue has next to 128 accumulators, and spilled)
+                            if constexpr (EXACT_DIV && !MASKED) __builtin_amdgcn_sched_barrier(0);
                         }
                         if (!MASKED) {
                             const bool ones = T.all_ones != 0;

@@ -186,3 +186,42 @@ def test_template_records_memo_only_for_zero_copy_arrays():
     assert r3 is not r2
     assert (ctx._rec_keep[0][0] == 255).all()
     assert _lib._zero_copy(lt, [base, lt[1][0], lt[1][1]]) and not _lib._zero_copy(lt2, [copy1])
+
+
+def test_validated_list_memo_never_hides_a_change(mtm):
+    """Round 5: the per-template checks of a list are remembered by the identity of its tuples, the shapes of their arrays
+    and the image's shape (a loop over images passes the same tuples again and again).  Anything that could change the
+    outcome of the reference's checks (MTM/__init__.py:147-167) must still be seen: another tuple in the list, a list
+    that grew, an array reshaped in place, a smaller image, a searchBox."""
+    image = load_coins()
+    small, big = coin_templates(image)
+    lt = [("small", small), ("big", big)]
+    v = mtm._validate_search
+    assert v(lt, image, float("inf"), None)[1:] == (0, 0)
+    assert mtm._list_memo is not None and mtm._list_memo.matches(lt) and mtm._list_memo.matches(list(lt))
+    v(lt, image, float("inf"), None)                                  # remembered: nothing to see, nothing raised
+    # a template that does not fit any more: same list object, one tuple replaced
+    lt[0] = ("tooLarge", np.pad(image, 1))
+    _raises("too_large", lambda: v(lt, image, float("inf"), None))
+    lt[0] = ("small", small)
+    v(lt, image, float("inf"), None)
+    # the same tuples against a smaller image / a searchBox
+    with pytest.raises(ValueError, match="is larger than image"):
+        v(lt, image[:50, :50], float("inf"), None)
+    _raises("searchbox_small", lambda: v(lt, image, float("inf"), (0, 0, 20, 20)))
+    # not a tuple, appended to a remembered list
+    lt.append(small)
+    _raises("not_tuple", lambda: v(lt, image, float("inf"), None))
+    lt.pop()
+    # an array reshaped IN PLACE (same object, same buffer): one row of 1558 pixels now, wider than the image
+    t = np.ascontiguousarray(small)
+    lt2 = [("tooLarge", t)]
+    v(lt2, image, float("inf"), None)
+    t.shape = (1, t.size)
+    _raises("too_large", lambda: v(lt2, image, float("inf"), None))
+    # labels follow the list, not the memo of another one
+    raw = np.zeros(2, dtype=mtm._lib.HIT_DTYPE)
+    raw["templ_idx"] = [0, 1]
+    assert [h[0] for h in mtm._to_hit_list(raw, lt, 0, 0)] == ["small", "big"]
+    other = [("a", small), ("b", big)]
+    assert [h[0] for h in mtm._to_hit_list(raw, other, 0, 0)] == ["a", "b"]
