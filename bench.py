@@ -375,9 +375,15 @@ def main():
         def call(lt=units):
             return MTM.matchTemplates(lt, img, method=method, score_threshold=thr, maxOverlap=0.25)
     else:
+        from MTM.distributed import _u8_units
+        sub_units = _u8_units(sub, img, method) if exchange_kind == "rccl" else None
+
         def call(lt=None):
             # the same call with the units sharded over the ranks: this rank's templates + the image go to its GPU,
-            # hit records are exchanged (RCCL all-gather), every rank runs the global NMS
+            # hit records are exchanged (RCCL all-gather), every rank runs the global NMS - one native call per step
+            # (mtm_find_matches_image_sharded_nms); over the control-plane fallback: step by step from here
+            if sub_units is not None:
+                return MTM._to_hit_list(ctx.search_sharded_nms(sub_units, img, method, thr, 0.25, -1, gidx), units, 0, 0)
             raw = MTM._raw_matches(sub, img, method, inf, thr, context=ctx).copy()
             raw["templ_idx"] = gidx[raw["templ_idx"]]
             return merge_and_nms(exchange.allgather(raw), units, method, inf, thr, 0.25)

@@ -250,6 +250,17 @@ int mtm_find_matches_image_nms(mtm_ctx* ctx, const void* px, int rows, int cols,
                                int64_t row_stride_bytes, double score_threshold, double max_overlap, int64_t n_object,
                                mtm_hit* out, int64_t capacity, int64_t* n_out);
 
+/* One step of the process-per-GPU form in one native call (round 5): search this rank's shard of the caller's template
+ * list (the context's current templates; global_idx[i] = list position of local template i), exchange the ranks' hit
+ * lists through the context's communicator (mtm_comm_init; without one, or with one rank: no exchange), merge them in
+ * template order and run MTM's non-maxima suppression - every rank returns the same kept hits, best first.  The
+ * reference's fan-in of per-template results (MTM/__init__.py:173-177) + MTM/NMS.py:53-84 across processes.  A rank
+ * without units passes n_local_templ = 0 (px may be NULL) and still takes part in the collective. */
+int mtm_find_matches_image_sharded_nms(mtm_ctx* ctx, const void* px, int rows, int cols, int chans, int dtype,
+                                       int64_t row_stride_bytes, double score_threshold, double max_overlap,
+                                       int64_t n_object, int method, const int32_t* global_idx, int n_local_templ,
+                                       mtm_hit* out, int64_t capacity, int64_t* n_out);
+
 /* Stream form of mtm_find_matches ("thousands of images", reference
  * tutorials/Tutorial3-SpeedingUp.ipynb:564: same templates, one image after the other): returns the
  * hits of the CURRENT image exactly like mtm_find_matches and makes `next_px` the current image for

@@ -85,6 +85,10 @@ SYMBOLS = {
     "mtm_find_matches_image_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int64,
                                                   ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
+    "mtm_find_matches_image_sharded_nms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                          ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                          ctypes.c_void_p, ctypes.c_int64, _P(ctypes.c_int64)]),
     "mtm_find_matches_next": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                              ctypes.c_int64, _P(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
@@ -425,6 +429,32 @@ class Context(_RecordMemo):
             out = np.empty(cap, dtype=HIT_DTYPE)
             rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
         check(rc, "mtm_find_matches_image_nms")
+        return out[:n.value]
+
+    def search_sharded_nms(self, templates, image, method, score_threshold, max_overlap, n_object, global_idx):
+        """This rank's step of a sharded matchTemplates in one native call (mtm_find_matches_image_sharded_nms): search
+        `templates` (this rank's shard; global_idx = their positions in the whole list), all-gather the ranks' hits over
+        the context's communicator, merge, suppress.  Collective: every rank calls it; every rank gets the same list."""
+        gidx = np.ascontiguousarray(global_idx, dtype=np.int32)
+        n_t = len(templates)
+        if n_t:
+            self.set_templates(templates, method)
+            a, ptr, stride = _pixel_rows(image)
+            chans = 1 if a.ndim == 2 else a.shape[2]
+            shape, code = a.shape, _dtype_code(a)
+        else:
+            ptr, stride, chans, shape, code = None, 0, 1, (0, 0), MTM_U8
+        cap = 4096
+        out = np.empty(cap, dtype=HIT_DTYPE)
+        n = ctypes.c_int64(0)
+        rc = self._lib.mtm_find_matches_image_sharded_nms(self._h, ptr, shape[0], shape[1], chans, code, stride,
+                                                          float(score_threshold), float(max_overlap), int(n_object),
+                                                          int(method), gidx.ctypes.data, n_t, out.ctypes.data, cap, ctypes.byref(n))
+        if rc == E_OVERFLOW:
+            cap = int(n.value)
+            out = np.empty(cap, dtype=HIT_DTYPE)
+            rc = self._lib.mtm_last_hits(self._h, out.ctypes.data, cap, ctypes.byref(n))
+        check(rc, "mtm_find_matches_image_sharded_nms")
         return out[:n.value]
 
     def find_matches_async(self, mode, score_threshold):

@@ -238,6 +238,31 @@ def merge_and_nms(raw_all: np.ndarray, listTemplates, method, N_object, score_th
     return _to_hit_list(kept, listTemplates, xOffset, yOffset)
 
 
+def _u8_units(sub, image, method):
+    """[(template, mask or None)] if every template of `sub` takes the 8-bit path of MTM._raw_matches against `image`
+    (uint8, same number of dimensions and channels, masks only where the method uses them and only well-formed ones),
+    else None - then the general per-template pixel policy applies and the caller takes the step-by-step route."""
+    if image.dtype != np.uint8 or image.ndim not in (2, 3):
+        return None
+    ichans = image.shape[2] if image.ndim == 3 else 1
+    if ichans > 4:
+        return None
+    units = []
+    for t in sub:
+        a = t[1]
+        if a.dtype != np.uint8 or a.ndim != image.ndim or (a.ndim == 3 and a.shape[2] != ichans):
+            return None
+        mask = None
+        if len(t) >= 3:
+            if method not in (0, 3):
+                return None                 # (the reference warns about the ignored mask: the general route does)
+            mask = t[2]
+            if not (mask.shape == a.shape and mask.dtype == np.uint8):
+                return None
+        units.append((a, mask))
+    return units
+
+
 def matchTemplates_sharded(listTemplates, image, exchange: HitExchange, method=5, N_object=float("inf"),
                            score_threshold=0.5, maxOverlap=0.25, searchBox=None, find_local=None):
     """matchTemplates with the units sharded over exchange.world_size ranks.  Collective: every rank
@@ -250,6 +275,18 @@ def matchTemplates_sharded(listTemplates, image, exchange: HitExchange, method=5
     costs = [unit_cost(t[1], image.shape, len(t) >= 3 and method in (0, 3)) for t in listTemplates]
     mine = shard_units(costs, exchange.world_size)[exchange.rank]
     sub = [listTemplates[i] for i in mine]
+    # 8-bit inputs over the RCCL exchange: search, index remap, all-gather, merge and NMS in ONE native call
+    # (mtm_find_matches_image_sharded_nms, round 5) - the same collective, the same selection
+    if find_local is None and exchange.backend == "rccl" and exchange.ctx is not None and N_object != 1:
+        units = _u8_units(sub, image, method)
+        if units is not None:
+            n_obj = -1 if N_object == float("inf") else int(N_object)
+            with exchange.ctx.lock:
+                raw = exchange.ctx.search_sharded_nms(units, image, method, score_threshold, maxOverlap, n_obj, mine)
+            if method == 0:
+                raise ValueError("The method TM_SQDIFF is not supported. Use TM_SQDIFF_NORMED instead.")
+            from . import _to_hit_list
+            return _to_hit_list(raw, listTemplates, xOffset, yOffset)
     if find_local is not None:
         raw = find_local(sub, image)
     elif sub:

@@ -911,6 +911,70 @@ int mtm_find_matches_image_nms(mtm_ctx* c, const void* px, int rows, int cols, i
     return rc;
 }
 
+// One step of the process-per-GPU form in ONE native call (round 5): this rank's shard is searched, its hits get their list
+// positions in the caller's whole template list (global_idx), the ranks' lists are exchanged (mtm_comm_allgather_hits: the
+// context's communicator; none / one rank: no exchange), merged in template order and suppressed - every rank returns
+// the same kept hits.  What MTM.distributed.matchTemplates_sharded did in four steps from Python (search, remap,
+// all-gather, mtm_nms) with the reference's fan-in (MTM/__init__.py:173-177) and MTM/NMS.py:53-84 behind it.
+int mtm_find_matches_image_sharded_nms(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes,
+                                       double score_threshold, double max_overlap, int64_t n_object, int method,
+                                       const int32_t* global_idx, int n_local_templ, mtm_hit* out, int64_t capacity,
+                                       int64_t* n_out) {
+    if (!c || !n_out || capacity < 0 || (capacity > 0 && !out) || n_local_templ < 0 || (n_local_templ > 0 && !global_idx)) {
+        set_error("mtm_find_matches_image_sharded_nms: bad arguments");
+        return MTM_E_INVALID;
+    }
+    std::vector<mtm_hit> local;
+    if (n_local_templ > 0) {                    // (a rank without units still takes part in the exchange)
+        if ((int)c->templs.size() != n_local_templ || c->method != method) {
+            set_error("mtm_find_matches_image_sharded_nms: global_idx / method do not match the context's template set");
+            return MTM_E_INVALID;
+        }
+        host_trace(c, 0);
+        MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image_sharded_nms"));
+        const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
+        int64_t n = 0;
+        int rc = find_matches_impl(c, MTM_PEAKS_LOCAL, score_threshold, nullptr, 0, &n, nullptr, &up);
+        if (rc != MTM_OK && rc != MTM_E_OVERFLOW) return rc;
+        local = c->last_hits;                   // (find_matches_impl keeps the whole list there whatever the capacity)
+        for (mtm_hit& h : local) h.templ_idx = global_idx[h.templ_idx];
+    }
+    std::vector<mtm_hit> all;
+    if (c->comm && c->n_ranks > 1) {
+        std::vector<int64_t> counts((size_t)c->n_ranks, 0);
+        int64_t n_all = 0;
+        all.resize(std::max<size_t>(4096, local.size() * (size_t)c->n_ranks));
+        int rc = mtm_comm_allgather_hits(c, local.data(), (int64_t)local.size(), all.data(), (int64_t)all.size(), counts.data(), &n_all);
+        if (rc == MTM_E_OVERFLOW) {             // (a local matter: the gathered slots are still in the staging area)
+            all.resize((size_t)n_all);
+            rc = mtm_comm_last_gather(c, all.data(), n_all, counts.data(), &n_all);
+        }
+        if (rc != MTM_OK) return rc;
+        all.resize((size_t)n_all);
+    } else {
+        all.swap(local);
+    }
+    std::stable_sort(all.begin(), all.end(), [](const mtm_hit& a, const mtm_hit& b) { return a.templ_idx < b.templ_idx; });
+    const bool ascending = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED;
+    if (all.size() > 1) {                       // (MTM/NMS.py:53-55: a list of one hit is returned as it is)
+        const float thr_s = (float)(ascending ? (1.0 - score_threshold) : score_threshold);
+        std::vector<int32_t> keep;
+        nms_select(all.data(), (int64_t)all.size(), ascending ? 1 : 0, thr_s, (float)max_overlap, keep);
+        std::vector<mtm_hit> kept(keep.size());
+        for (size_t i = 0; i < keep.size(); ++i) kept[i] = all[(size_t)keep[i]];
+        all.swap(kept);
+    }
+    if (n_object >= 0 && (int64_t)all.size() > n_object) all.resize((size_t)n_object);
+    *n_out = (int64_t)all.size();
+    c->last_hits.swap(all);
+    if ((int64_t)c->last_hits.size() > capacity) {
+        set_error("mtm_find_matches_image_sharded_nms: output capacity too small (fetch the result with mtm_last_hits)");
+        return MTM_E_OVERFLOW;
+    }
+    if (!c->last_hits.empty()) std::memcpy(out, c->last_hits.data(), sizeof(mtm_hit) * c->last_hits.size());
+    return MTM_OK;
+}
+
 int mtm_find_matches_next(mtm_ctx* c, int mode, double score_threshold, mtm_hit* out, int64_t capacity,
                           int64_t* n_out, const void* next_px, int rows, int cols, int chans, int dtype,
                           int64_t row_stride_bytes) {

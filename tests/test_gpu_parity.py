@@ -2728,3 +2728,42 @@ def test_float32_adversarial_lists_equal_the_float64_kernels():
     finally:
         fast.close()
         exact.close()
+
+
+@pytest.mark.gpu
+def test_sharded_step_in_one_native_call(mtm):
+    """mtm_find_matches_image_sharded_nms (round 5): this rank's shard searched, its hits renumbered to the caller's list,
+    exchanged, merged and suppressed in one native call.  On a one-GPU box: without a communicator and with a communicator
+    of one rank (the RCCL all-gather end to end) a "shard" that is the whole list in a permuted order returns exactly what
+    MTM.matchTemplates returns for the list in its own order - maxima and minima methods, finite N_object, masks; a rank
+    without units takes part with an empty list.  Reference: MTM/__init__.py:173-177, :289-296, MTM/NMS.py:53-84."""
+    from MTM import _lib
+    from MTM.distributed import _u8_units
+    img, units, _ = synth.make_workload(seed=61, image_hw=(420, 640), n_base=7, templ=32, rotations=2, noisy_per_unit=2)
+    perm = [5, 0, 13, 2, 9, 1, 7, 3, 11, 4, 6, 8, 10, 12]           # local template i is list position perm[i]
+    assert sorted(perm) == list(range(len(units)))
+    sub = [units[g] for g in perm]
+    ctx = _lib.Context(0)
+    try:
+        for with_comm in (False, True):
+            if with_comm:
+                ctx.comm_init(_lib.comm_unique_id(), 1, 0)
+            for method, thr, ov, nobj in ((5, 0.5, 0.25, -1), (5, 0.5, 0.0, 5), (1, 0.3, 0.4, -1), (3, 0.8, 0.25, -1)):
+                exp = mtm.matchTemplates(units, img, method=method, score_threshold=thr, maxOverlap=ov,
+                                         N_object=float("inf") if nobj < 0 else nobj)
+                raw = ctx.search_sharded_nms(_u8_units(sub, img, method), img, method, thr, ov, nobj, perm)
+                got = mtm._to_hit_list(raw, units, 0, 0)
+                assert len(got) == len(exp) > 0, (with_comm, method, len(got), len(exp))
+                assert [(h[0], h[1]) for h in got] == [(h[0], h[1]) for h in exp], (with_comm, method)
+                assert all(np.float32(a[2]) == np.float32(b[2]) for a, b in zip(got, exp)), (with_comm, method)
+        # masked units through the same call
+        mimg, munits, _ = synth.make_workload(seed=62, image_hw=(400, 520), n_base=2, templ=32, scales=(24, 40), masked=True)
+        order = list(range(len(munits)))[::-1]
+        exp = mtm.matchTemplates(munits, mimg, method=3, score_threshold=0.9, maxOverlap=0.25)
+        raw = ctx.search_sharded_nms(_u8_units([munits[g] for g in order], mimg, 3), mimg, 3, 0.9, 0.25, -1, order)
+        got = mtm._to_hit_list(raw, munits, 0, 0)
+        assert [(h[0], h[1]) for h in got] == [(h[0], h[1]) for h in exp] and len(got) > 0
+        # a rank without units: nothing to search, an empty contribution to the exchange
+        assert len(ctx.search_sharded_nms([], None, 5, 0.5, 0.25, -1, [])) == 0
+    finally:
+        ctx.close()
