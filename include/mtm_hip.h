@@ -86,8 +86,8 @@ extern "C" {
                                    0: always materialise the maps.  Results are identical either way. */
 #define MTM_OPT_F32_MFMA 7      /* float32 images (every non-uint8, non-uint16 input: MTM/__init__.py:71-74), unmasked
                                    templates; the normalised methods, and the raw-sum methods for the global extremum
-                                   (N_object == 1: listed by rigorous per-pixel error bounds, re-scored exactly; raw sums
-                                   with a threshold, and their maps, always take the float64 kernel).
+                                   and for local extrema against a threshold (listed by rigorous per-pixel error bounds
+                                   of the sum, re-scored exactly; the raw sums' maps always take the float64 kernel).
                                    1 (default): scores on the bf16 matrix cores (within ~1e-5 of cv2's float64 result)
                                    as a SCREEN - every output whose exact score COULD be a peak, the global extremum or
                                    pass the threshold is re-scored with the float64 arithmetic of the exact kernel.

@@ -141,7 +141,11 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         // raw sums (TM_SQDIFF / TM_CCORR / TM_CCOEFF): only the refined global extremum runs on the matrix cores - maps and
         // thresholds on unnormalised sums have no error the bf16 pieces could promise (an exact copy is TM_SQDIFF 0)
         const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
-        if (any_bf16 && raw_m && (mode != MTM_PEAKS_GLOBAL || c->f32_mfma != 1)) {
+        // ... except, round 5, local extrema against a threshold while the kernel's candidate list is available: every output
+        // whose upper bound (score + E, E in the sum's own units) passes the threshold is listed and re-scored exactly -
+        // route 1 only; maps, the map scan and every overflow keep the float64 kernel
+        c->raw_rig_now = any_bf16 && all_bf16 && raw_m && mode == MTM_PEAKS_LOCAL && c->f32_mfma == 1 && c->f32_rig && fused;
+        if (any_bf16 && raw_m && (mode != MTM_PEAKS_GLOBAL || c->f32_mfma != 1) && !c->raw_rig_now) {
             c->f32_exact_now = true;
         } else if (any_bf16 && c->f32_mfma == 1) {
             if (all_bf16) c->refine_now = true;
@@ -657,13 +661,18 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 c->hits_only_now = false;
                 c->timing.ncc_launches = 0;
             c->timing.sq_launches = 0;
-                if (!pp_mode) {
+                if (!pp_mode && !c->raw_rig_now) {
                     c->fuse_backoff = c->backoff_len;
                     c->backoff_len = std::min(2 * c->backoff_len, 1024);
                     pp_mode = true;
                     c->refine_scan_now = true;
                     HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
                 } else {
+                    if (c->raw_rig_now) {           // raw sums have no map-scan route: the next calls start on the float64 kernel
+                        c->fuse_backoff = c->backoff_len;
+                        c->backoff_len = std::min(2 * c->backoff_len, 1024);
+                        c->raw_rig_now = false;
+                    }
                     pp_mode = false;
                     use_fused = false;
                     c->refine_now = c->refine_scan_now = false;

@@ -74,7 +74,10 @@ __device__ __forceinline__ float bf_finish_r(int method, double corr, const doub
         *exact_out = true;
         return 1.0f;
     }
-    if (method == MTM_TM_CCORR) return (float)corr;
+    if (method == MTM_TM_CCORR) {
+        *r_out = corr;
+        return (float)corr;
+    }
     const int num_type = (method == MTM_TM_CCORR_NORMED) ? 0
                        : (method == MTM_TM_CCOEFF || method == MTM_TM_CCOEFF_NORMED) ? 1 : 2;
     const bool normed = (method == MTM_TM_SQDIFF_NORMED) || (method == MTM_TM_CCORR_NORMED) ||
@@ -88,6 +91,7 @@ __device__ __forceinline__ float bf_finish_r(int method, double corr, const doub
         num = sum2 - 2.0 * num + T.templ_sum2;
         num = fmax(num, 0.0);
     }
+    if (!normed) *r_out = num;                  // raw sums: the value itself (the bound is in its units)
     if (normed) {
         const double tt = sq * T.templ_norm;
         const double an = fabs(num);
@@ -177,7 +181,12 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             k.templ_norm = T.templ_norm;
             k.templ_sum2 = T.templ_sum2;
             k.t2c = T.centred_sum2 * 1.000001;        // (a float64 variance times the area: its own rounding covered)
-            k.bfac = T.templ_norm > 0.0 ? (p.method == MTM_TM_SQDIFF_NORMED ? 2.0 : 1.0) * sqrt(k.t2c) / T.templ_norm * 1.000001 : 0.0;
+            {
+                const bool nrm = p.method == MTM_TM_SQDIFF_NORMED || p.method == MTM_TM_CCORR_NORMED || p.method == MTM_TM_CCOEFF_NORMED;
+                const double esc = (p.method == MTM_TM_SQDIFF_NORMED || p.method == MTM_TM_SQDIFF) ? 2.0 : 1.0;
+                k.bfac = nrm ? (T.templ_norm > 0.0 ? esc * sqrt(k.t2c) / T.templ_norm * 1.000001 : 0.0)
+                             : esc * sqrt(k.t2c) * 1.000001;            // raw sums (rig == 2): the bound in the sum's own units
+            }
             k.map_off = T.map_off;
             k.map_pitch = T.map_pitch;
             k.all_ones = T.all_ones;
@@ -296,7 +305,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const bool lane_on = y < p.oh && xq < p.ow;
     const int method = p.method;
     const bool normed = method == MTM_TM_SQDIFF_NORMED || method == MTM_TM_CCORR_NORMED || method == MTM_TM_CCOEFF_NORMED;
-    const bool rig = p.rig != 0 && normed;      // listing decisions by the per-output error bound (Bf16Params::rig)
+    // listing decisions by the per-output error bound (Bf16Params::rig): 1 = normalised methods (bound of the ratio),
+    // 2 = raw sums with a threshold (bound of the sum itself: eps sqrt(sum (I - mu)^2 sum (T - mean)^2), twice for TM_SQDIFF)
+    const bool rig_n = p.rig == 1 && normed, rig_r = p.rig == 2 && !normed;
+    const bool rig = rig_n || rig_r;
     const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED || (p.ext_on && p.ext_raw) || rig;
     // (the two halves of a lane's eight pixels as a generic lambda over a compile-time constant: every accumulator index
     // below must be one, or the accumulators leave the register file)
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     }
                 // (+ the cancellation in s2c itself: three terms of the size of s2 and area mu^2)
                 s2c = fmax(s2c, 0.0) * 1.000001 + 1e-12 * (fabs(s2[i]) + area * (double)s_mu[0] * (double)s_mu[0]);
-                bp[i] = sq[i] > 0.0 ? (double)p.rig_eps * sqrt(s2c) / sq[i] : 0.0;
+                bp[i] = rig_r ? (double)p.rig_eps * sqrt(s2c) : sq[i] > 0.0 ? (double)p.rig_eps * sqrt(s2c) / sq[i] : 0.0;
             }
         }
 #pragma unroll
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     Mv[i] = ex ? 0.0 : bp[i] * T.bfac + 3e-7 * fmax(1.0, fabs(r));
                 }
                 const int xb = xq + 4 * half;
-                if (rig && p.rig_flag != nullptr) {
+                if (rig_n && p.rig_flag != nullptr) {
                     // map mode: the scan that follows works with tolerances of rig_cap - an output that could pass the
                     // threshold with a larger bound than that takes the call to the float64 kernel
                     bool wide = false;
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     if (wide) *p.rig_flag = 1u;
                 }
                 float key_v[4] = {out[0], out[1], out[2], out[3]};      // what the published key is built from
-                if (p.ext_on && p.ext_raw && rig) {
+                if (p.ext_on && p.ext_raw && rig_n) {
                     // normalised methods, refined: bounds of the exact QUALITY instead of scores.  Maxima: the exact score is
                     // sat(r) <= min(r, 1), and 0 where |r| >= 1.125; minima (TM_SQDIFF_NORMED): -clamp(r, 0, 1), monotone.
 #pragma unroll

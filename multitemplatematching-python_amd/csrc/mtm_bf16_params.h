@@ -60,7 +60,8 @@ struct Bf16Params {
     // 1 + A (window mean - mu)^2 / (A var): a low-contrast window beside a brightness step - where the tile constant mu is
     // far from the window's own mean - gets the large margin it needs, a textured one ~rig_eps.  An output is listed
     // (candidate list, running best) whenever its UPPER bound passes; exact re-scoring decides.
-    int rig;                 // 1: listing by that bound (cand_thr / the running best are then compared WITHOUT a margin)
+    int rig;                 // 1: listing by that bound (cand_thr / the running best are then compared WITHOUT a margin);
+                             // 2: the raw-sum methods with a threshold - the bound of the sum itself (round 4's E, above)
     float rig_eps;
     int list_all;            // the threshold lies beyond the score range's clamp value on the far side (maxima: < 0, minima:
                              // > 1): a saturated exact score passes whatever the approximate one says - list everything

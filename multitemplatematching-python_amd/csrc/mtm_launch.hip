@@ -819,6 +819,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 p.rig_flag = reinterpret_cast<unsigned int*>(c->cands.as<uint8_t>() + 8);
             }
         }
+        if (c->refine_now && raw_m && c->raw_rig_now && !c->ext_now && only_li < 0) {
+            // raw sums with a threshold (round 5): everything whose UPPER bound passes is listed and re-scored exactly
+            p.rig = 2;
+            p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb);
+            p.rig_thr = c->rig_thr;
+            p.list_all = 0;
+        }
         if (c->ext_now && only_li < 0) {                  // fused global extremum (find_matches_impl checked the classes)
             p.ext_on = 1;
             p.ext_best = c->counters.as<unsigned long long>();

@@ -1018,11 +1018,12 @@ def test_float32_hit_lists_are_the_float64_kernels(coins):
                         assert np.array_equal(got[f], ref[f]), (name, method, cap, f, fast.timing()["f32_route"])
                     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (name, method, cap)
         assert routes == {1, 2, 3}, routes          # every way of refining has been exercised
-        # raw sums with thresholds, and their maps, stay on the float64 kernel (no error the bf16 pieces could promise there)
+        # raw sums with thresholds: listed by the bound of the sum and re-scored (round 5; route 3 while a back-off lasts -
+        # test_float32_raw_sums_with_thresholds_equal_the_float64_kernels); their maps stay on the float64 kernel
         name, im, lt = cases[0]
         fast.set_option(_lib.OPT_HIT_CAPACITY, 1 << 18)
         got = fast.search([(t, None) for t in lt[:4]], im, 4, _lib.PEAKS_LOCAL, 1e6)
-        assert fast.timing()["f32_route"] == 3
+        assert fast.timing()["f32_route"] in (1, 3)
         ref = exact.search([(t, None) for t in lt[:4]], im, 4, _lib.PEAKS_LOCAL, 1e6)
         assert got.tobytes() == ref.tobytes()
         shape = (im.shape[0] - lt[0].shape[0] + 1, im.shape[1] - lt[0].shape[1] + 1)
@@ -2724,6 +2725,54 @@ def test_float32_adversarial_lists_equal_the_float64_kernels():
                 for f in ("templ_idx", "x", "y"):
                     assert np.array_equal(got[f], ref[f]), (seed, method, f, fast.timing()["f32_route"])
                 assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (seed, method)
+        assert 1 in routes, routes
+    finally:
+        fast.close()
+        exact.close()
+
+
+@pytest.mark.gpu
+def test_float32_raw_sums_with_thresholds_equal_the_float64_kernels():
+    """Raw-sum methods (TM_SQDIFF 0, TM_CCORR 2, TM_CCOEFF 4) on float32 images with a threshold, local extrema: the kernel
+    lists every output whose upper bound (score + E, E = eps sqrt(sum (I - mu)^2 sum (T - mean)^2), twice that for TM_SQDIFF)
+    passes the threshold and the float64 re-scoring decides - the records must be the float64 kernel's, bit for bit, for
+    thresholds on either side of true peak scores; a threshold that lists more than the list holds ends on the float64
+    kernel (route 3) with the same records.  Reference: MTM/__init__.py:71-74 (cv2.matchTemplate), :45-52."""
+    if not default_routes():
+        pytest.skip("asserts the default float32 routes")
+    from MTM import _lib
+    fast, exact = _lib.Context(0), _lib.Context(0)
+    exact.set_option(_lib.OPT_F32_MFMA, 0)
+    routes = set()
+    try:
+        for seed, (lo, hi, noise) in enumerate(((0.0, 1.0, 2e-3), (0.0, 255.0, 0.5), (100.0, 101.0, 1e-2))):
+            im = _step_image(seed + 11, lo=lo, hi=hi, noise=noise)
+            cx = im.shape[1] // 2
+            lt = [np.ascontiguousarray(im[100:132, cx - 20:cx + 20]), np.ascontiguousarray(im[45:77, 30:70]),
+                  np.ascontiguousarray(im[20:52, cx + 60:cx + 100])]
+            templs = [(t, None) for t in lt]
+            for method in (0, 2, 4):
+                # a threshold every window passes: peaks of the whole map by the float64 kernel, then thresholds between them
+                everything = -3.0e38 if method != 0 else 3.0e38
+                ref0 = exact.search(templs, im, method, _lib.PEAKS_LOCAL, everything)
+                sc = np.sort(np.unique(ref0["score"].astype(np.float64)))
+                if method != 0:
+                    sc = sc[::-1]
+                picks = [float(s) for s in sc[:: max(1, len(sc) // 5)][:5]]
+                thrs = []
+                for s in picks:
+                    d = max(abs(s), 1.0) * 2e-6
+                    thrs += [s - d, s + d, float(np.nextafter(np.float32(s), np.float32(0)))]
+                for thr in thrs:
+                    ref = exact.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
+                    got = fast.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
+                    tm = fast.timing()
+                    routes.add(tm["f32_route"])
+                    assert tm["f32_route"] in (1, 3), tm
+                    assert len(got) == len(ref), (seed, method, thr, tm["f32_route"], len(got), len(ref))
+                    for f in ("templ_idx", "x", "y", "w", "h"):
+                        assert np.array_equal(got[f], ref[f]), (seed, method, thr, tm["f32_route"], f)
+                    assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (seed, method, thr)
         assert 1 in routes, routes
     finally:
         fast.close()
