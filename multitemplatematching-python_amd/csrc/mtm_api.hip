@@ -82,6 +82,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     const float thr = (float)score_threshold;
     c->timing = mtm_timing{};
     c->maps_valid = false;
+    c->seg_skip_used = false;
 
     // fused peak candidates: only when every class runs the MFMA kernel - and not while the maps of this context are
     // known to be dense (the last attempts overflowed the candidate list: smooth images at a low threshold), where the
@@ -615,7 +616,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                     hipLaunchKernelGGL(peaks_sparse_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
                                        c->td.as<TemplDev>(), c->tlist.as<int>() + c->list2d_off, mode_min ? 1 : 0, thr,
                                        c->opt_border, hits_t, cap_t, counts_t, flags, c->seg_flags.as<uint8_t>(),
-                                       c->flag_tstride, c->flag_rstride);
+                                       c->flag_tstride, c->flag_rstride, c->seg_skip_used ? 1 : 0);
                     hipLaunchKernelGGL(compact_hits_kernel, dim3((unsigned)n_lists), dim3(256), 0, c->stream, hits_t, cap_t, counts_t,
                                        (int)n_lists, dhits, (unsigned long long)c->hit_cap, counter);
                     // a suppression request: its device share follows at once (it reads the list's length on the device)
@@ -729,7 +730,15 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             use_fused = false;
             // (the per-segment lists of the flagged route are bounded in total: if growing did not help, the full scan with
             // its single list takes over - the maps are complete)
-            if (c->sparse_now && attempt >= 1) c->sparse_now = false;
+            if (c->sparse_now && attempt >= 1) {
+                c->sparse_now = false;
+                if (c->seg_skip_used) {         // (round 5: ... unless the score pass left the unflagged segments out - once more, in full)
+                    c->timing.ncc_launches = 0;
+                    c->timing.sq_launches = 0;
+                    MTMC(run_score_all(c));
+                    HIPC(hipEventRecord(c->ev[1], c->stream));
+                }
+            }
         }
         if (n2d == 0) {
             HIPC(hipEventRecord(c->ev[2], c->stream));
@@ -808,7 +817,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     c->nms_sure = 0;
     c->timing.hits_only = c->sparse_now ? 2 : c->hits_only_now ? 1 : 0;
     c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
-    c->maps_valid = !c->hits_only_now && !c->ext_now;
+    c->maps_valid = !c->hits_only_now && !c->ext_now && !c->seg_skip_used;
     c->refine_now = c->refine_scan_now = c->f32_exact_now = false;      // states of this call only
     c->sparse_now = false;
     *n_out = (int64_t)hits.size();

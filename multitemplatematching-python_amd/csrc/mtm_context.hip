@@ -269,6 +269,7 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     if (const char* v = std::getenv("MTM_FUSE_LAYOUT")) c->fuse_layout = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_ALIGN")) c->band_align = std::atoi(v);
     if (const char* v = std::getenv("MTM_SINGLE_BAND")) c->single_band = std::atoi(v);
+    if (const char* v = std::getenv("MTM_SEG_SKIP")) c->seg_skip = std::atoi(v);
     if (const char* v = std::getenv("MTM_EAGER_COPY_STREAM")) c->eager_copy_stream = std::atoi(v);
     if (const char* v = std::getenv("MTM_ZERO_IN_STATS")) c->zero_in_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_MIN_FILL")) c->band_min_fill = std::atof(v);

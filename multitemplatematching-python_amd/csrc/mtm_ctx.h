@@ -228,6 +228,8 @@ struct mtm_ctx {
                                             // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are
     int f32_rig = 1;                        // MTM_F32_RIG: the refined routes list by the rigorous per-output error bound of the bf16
                                             // scores (Bf16Params::rig); 0 = round 3's empirical margins (kRefineThrMargin / kRefineNbrTol)
+    int seg_skip = 1;                       // MTM_SEG_SKIP: dense route - outputs that cannot pass the threshold are not finished (MfmaParams::seg_skip)
+    bool seg_skip_used = false;             // this call: some map holds such placeholders (the maps are not published)
     bool raw_rig_now = false;               // this call: a raw-sum method with a threshold, listed by the bound of the sum (route 1 only)
     float rig_thr = 0.0f;                   // the exact quality threshold of the call (the lists' own cand_thr carries a margin in map mode)
     float scan_thr = 0.0f;                  // map mode: the threshold of refine_scan_kernel (rig_thr lowered by rig_cap)

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void peaks_sparse_kernel(const float* __restri
                                                            mtm_hit* __restrict__ hits_t, unsigned long long cap_t,
                                                            unsigned long long* __restrict__ counts_t,
                                                            int* __restrict__ nontrivial, const uint8_t* __restrict__ seg_flags,
-                                                           int flag_tstride, int flag_rstride) {
+                                                           int flag_tstride, int flag_rstride, int holes) {
     __shared__ mtm_hit stage[4][kPkStage];
     const int t = tlist[blockIdx.z];
     const TemplDev T = td[t];
@@ -164,14 +164,40 @@ __global__ __launch_bounds__(256) void peaks_sparse_kernel(const float* __restri
         h[3] = fmaxf(fmaxf(v[2], v[3]), hr);
     };
     int nontriv = 0;
+    // holes (MfmaParams::seg_skip, round 5): only flagged segments - and segments in which some output came close to the
+    // threshold - were written at all; what an unflagged segment holds is stale memory.  Its outputs are all at or below
+    // the threshold, so as NEIGHBOURS of a flagged segment's pixels they count as "below": never read.
+    const float below_raw = mode_min ? INFINITY : -INFINITY;
+    const int n_sx = (T.ow + kPkCols - 1) / kPkCols;
+    auto fetch = [&](int y) {
+        if (!holes || y < 0 || y >= T.oh) return peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y, xb, lane, padr);
+        const uint8_t* fr = seg_flags + (size_t)t * flag_tstride + (size_t)y * flag_rstride;
+        PeakRow r;
+        if (fr[sx] != 0) {
+            r = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y, xb, lane, padr);
+        } else {
+            r.q = make_float4(below_raw, below_raw, below_raw, below_raw);
+            r.el = r.er = padr;
+            // (columns beyond the map keep the pad value, as peaks_fetch_row leaves them)
+            if (xb >= T.ow) r.q.x = padr;
+            if (xb + 1 >= T.ow) r.q.y = padr;
+            if (xb + 2 >= T.ow) r.q.z = padr;
+            if (xb + 3 >= T.ow) r.q.w = padr;
+            if (lane == 0 && xb - 1 >= 0) r.el = m[(size_t)y * T.map_pitch + xb - 1];
+            if (lane == 63 && xb + 4 < T.ow) r.er = m[(size_t)y * T.map_pitch + xb + 4];
+        }
+        if (lane == 0 && sx > 0 && fr[sx - 1] == 0) r.el = below_raw;
+        if (lane == 63 && sx + 1 < n_sx && fr[sx + 1] == 0 && xb + 4 < T.ow) r.er = below_raw;
+        return r;
+    };
     PeakRow na{}, nb{}, nc{};                             // the rows of the next flagged row, requested one iteration ahead
     int y_next = -1;
     if (todo) {
         y_next = y0 + (int)__builtin_ctzll(todo);
         todo &= todo - 1;
-        na = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next - 1, xb, lane, padr);
-        nb = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next, xb, lane, padr);
-        nc = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next + 1, xb, lane, padr);
+        na = fetch(y_next - 1);
+        nb = fetch(y_next);
+        nc = fetch(y_next + 1);
     }
     while (y_next >= 0) {                                 // wave-uniform
         const int y = y_next;
@@ -180,9 +206,9 @@ __global__ __launch_bounds__(256) void peaks_sparse_kernel(const float* __restri
         if (todo) {
             y_next = y0 + (int)__builtin_ctzll(todo);
             todo &= todo - 1;
-            na = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next - 1, xb, lane, padr);
-            nb = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next, xb, lane, padr);
-            nc = peaks_fetch_row(m, T.map_pitch, T.oh, T.ow, y_next + 1, xb, lane, padr);
+            na = fetch(y_next - 1);
+            nb = fetch(y_next);
+            nc = fetch(y_next + 1);
         }
         float va[4], vb[4], vc[4], hl, hr, hm_a[4], hm_b[4], hm_c[4];
         peaks_finish_row(ra, lane, mode_min != 0, va, hl, hr);

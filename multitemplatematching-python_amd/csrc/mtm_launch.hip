@@ -562,6 +562,9 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.seg_flags = c->seg_flags.as<uint8_t>();
             p.flag_tstride = c->flag_tstride;
             p.flag_rstride = c->flag_rstride;
+            const bool normed_m = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED || c->method == MTM_TM_CCOEFF_NORMED;
+            p.seg_skip = (c->seg_skip && !sc.masked && normed_m) ? 1 : 0;
+            c->seg_skip_used = c->seg_skip_used || p.seg_skip != 0;
         }
         p.cand_cap = (unsigned long long)c->hit_cap;
         p.cand_counter = c->cands.as<unsigned long long>();

@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // hold a candidate skips the transposition and the per-output normalisation below.
         if constexpr (CH == 1 && ((!MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) ||
                                   (MASKED && METHOD == MTM_TM_CCORR_NORMED))) {
-            if (p.hits_only && p.screen_l1 && st.blk != nullptr && (EXT || p.cand_thr_lo >= 0.0)) {
+            if ((p.hits_only || (!MASKED && !EXT && p.seg_skip)) && p.screen_l1 && st.blk != nullptr && (EXT || p.cand_thr_lo >= 0.0)) {
                 bool pass1 = false;
                 const int bj = min((x0 >> 4) + j, st.blk_pitch - 1);
 #pragma unroll
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const MfTemplConst T = tcl[t];
                         const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
                         const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
-                        if (kNormed && p.hits_only) {
+                        if (kNormed && (p.hits_only || (!MASKED && !EXT && p.seg_skip))) {
                             bool pass = T.all_ones != 0;
                             const double rt = T.rtempl_norm;
 #pragma unroll
@@ -1160,7 +1160,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
                                 pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
                             }
-                            if (!pass) continue;
+                            if (!p.hits_only) {          // seg_skip (see the plain tiling's epilogue)
+                                if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+                                if (!pass) {
+                                    const float below = METHOD == MTM_TM_SQDIFF_NORMED ? INFINITY : -INFINITY;
+                                    const float sent[4] = {below, below, below, below};
+                                    store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, sent);
+                                    continue;
+                                }
+                            } else if (!pass) {
+                                continue;
+                            }
                         }
                         float out[4];
 #pragma unroll
@@ -1404,7 +1414,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         if constexpr (CH == 1 && !MASKED && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
             // (quotients <= -1 saturate to -1 or 0, which can only be candidates below a negative threshold:
             // such calls skip the screen instead of tracking the minima as well)
-            if (p.hits_only && (EXT || p.cand_thr_lo >= 0.0)) {
+            if ((p.hits_only || (!EXT && p.seg_skip)) && (EXT || p.cand_thr_lo >= 0.0)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* sw0 = smem + p.st_off + wave * (R2 ? MB * 4 * 1024 : mf_stat_bytes_per_wave(1));
                 bool pass1 = false;
@@ -1624,7 +1634,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const int li = tg * kTG + lt0 + s8;
                         if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;   // wave-uniform
                         const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
-                        if (kNormed && p.hits_only) {
+                        if (kNormed && (p.hits_only || (!MASKED && !EXT && p.seg_skip))) {
                             // Nothing is stored in this mode, so only outputs that can reach the
                             // threshold need the full normalisation: q is the float64 quotient of the
                             // reciprocal path (within 2 ulp(double) of num / t), compared with a
@@ -1654,7 +1664,20 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                     pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
                                 }
                             }
-                            if (!pass) continue;
+                            if (!p.hits_only) {
+                                // seg_skip: a row segment none of whose outputs can pass stays unwritten and unflagged (the peak
+                                // pass reads flagged segments only and takes their unflagged neighbours as "below the
+                                // threshold"); in a segment that is written, outputs that cannot pass get exactly that value
+                                if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
+                                if (!pass) {
+                                    const float below = METHOD == MTM_TM_SQDIFF_NORMED ? INFINITY : -INFINITY;
+                                    const float sent[4] = {below, below, below, below};
+                                    store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, sent);
+                                    continue;
+                                }
+                            } else if (!pass) {
+                                continue;
+                            }
                         }
                         float out[4];
 #pragma unroll

@@ -128,7 +128,10 @@ struct MfmaParams {
     // flag_base = template index * flag_tstride.  nullptr: off
     uint8_t* seg_flags;
     int flag_tstride, flag_rstride;
-    int cand_rowmax_unused_;
+    // Round 5: with the segment flags on (dense images, maps not published), unmasked normalised classes finish only the
+    // outputs that can pass the threshold (the hits-only pre-test) and store -inf (minima: +inf) for the others: a value that
+    // is below the threshold can neither be a peak nor beat one, whatever it is exactly
+    int seg_skip;
     double sq_k;             // 257 * 128 * sum(M)
     float* clk_out;          // non-null: the work-group in the middle of the grid stores the shader clock it ran at, in
                              // MHz (s_memtime ticks - shader cycles - per s_memrealtime tick of the 100 MHz reference)

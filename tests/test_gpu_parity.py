@@ -730,7 +730,7 @@ def test_banded_call_with_float64_classes_on_two_lanes(mtm, monkeypatch):
 @pytest.mark.parametrize("env", ["MTM_KERNEL=dot4", "MTM_ROW_MUX=0", "MTM_HITS_ONLY=0", "MTM_MASKSQ_FUSED=0", "MTM_RM_EDGES=0",
                                  "MTM_MFMA_PERSISTENT=2", "MTM_MFMA_R2=0", "MTM_SCREEN_L1=0", "MTM_CLASS_LANES=1",
                                  # round 5: what the fixed-cost work replaced, each still selectable
-                                 "MTM_FUSE_LAYOUT=0", "MTM_CAND_PINNED=0", "MTM_ZERO_IN_STATS=0", "MTM_SINGLE_BAND=0", "MTM_BAND_ALIGN=0",
+                                 "MTM_FUSE_LAYOUT=0", "MTM_CAND_PINNED=0", "MTM_ZERO_IN_STATS=0", "MTM_SINGLE_BAND=0", "MTM_BAND_ALIGN=0", "MTM_SEG_SKIP=0",
                                  "MTM_EXACT_DIV=0"])
 def test_production_reachable_routes_give_the_default_lists(mtm, env, monkeypatch):
     """Every switch that selects a kernel or route a production call can also reach by itself (the VALU kernel for shapes

@@ -176,6 +176,21 @@ def run():
             if d:
                 vs_exact_diffs += 1
                 print("seed %d: DIFFERS FROM THE FLOAT64 KERNEL %s" % (seed, d), flush=True)
+        if verdict.startswith("REAL score") or verdict.startswith("REAL unmatched"):
+            # the same call once more: a list that changes between two identical calls is a race or a read of memory the
+            # library never wrote, not an arithmetic difference - say so, with the templates concerned
+            try:
+                again = MTM.findMatches(lt, img, **kw)
+                ga = {(h[0], tuple(h[1])): float(h[2]) for h in again}
+                g1 = {(h[0], tuple(h[1])): float(h[2]) for h in got}
+                if ga != g1:
+                    names = sorted({k[0] for k in set(ga.items()) ^ set(g1.items())})
+                    from MTM import _lib as _l
+                    verdict += " | NOT REPRODUCIBLE: the same call again differs in %d records (templates %s); timing %s" % (
+                        len(set(ga.items()) ^ set(g1.items())), names[:8],
+                        {k: v for k, v in _l.default_context().timing().items() if k in ("kernel_used", "hits_only", "f32_route", "ncc_launches")})
+            except Exception as ex:                                # noqa: BLE001
+                verdict += " | rerun raised %r" % (ex,)
         if verdict.startswith("REAL"):
             real += 1
         elif verdict:
