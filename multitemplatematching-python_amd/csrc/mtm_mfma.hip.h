@@ -1299,9 +1299,16 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // the window statistics of this lane's four outputs - behind the screen: 40 registers that would otherwise be
         // live across it next to the 192 accumulator registers (they went to scratch memory in every work item: 63 MB of
         // HBM writes per 4K launch), and plane reads that the waves the screen sends away never need
+        // Round 5: NO divergent region from here to the stores.  With 192 accumulator registers live the compiler spills
+        // some of them around this code; a spill placed inside `if (lane_on)` saves the active lanes only, and the lanes
+        // that later WRITE those accumulators into the transposition buffer (q == stage) are not the lanes of the pixels -
+        // in a row segment that is only partly inside the map they reloaded stale scratch memory: pixels 4..6 of every
+        // 16-pixel block of the last segment wrong for the templates of stages 1..3, whenever the scratch backing store
+        // held another launch's data (profiles/r05_flake/diag.txt).  Lanes outside the map now compute on clamped
+        // coordinates like everyone else; only the stores and the candidate list look at lane_on.
         double us1[4] = {0.0, 0.0, 0.0, 0.0}, up1[4], usum2[4] = {0.0, 0.0, 0.0, 0.0}, usq[4] = {0.0, 0.0, 0.0, 0.0}, ursq[4];
-        if (lane_on) {
-            const size_t sidx = (size_t)y * st.pitch + xq;       // pitch is a multiple of 4: the 4 values exist
+        {
+            const size_t sidx = (size_t)min(y, p.oh - 1) * st.pitch + min(xq, st.pitch - 4);       // pitch is a multiple of 4: the 4 values exist
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const double2 a = *reinterpret_cast<const double2*>(st.t[0] + sidx + 2 * hh);
@@ -1351,7 +1358,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (lane_on) {
+            {
 #pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
                     const int lt = 4 * stage + e, li = tg * 16 + lt;
@@ -1376,13 +1383,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                     }
                     if constexpr (EXT) {
-                        ext_update(out, y, T.ext_hi, &ext_slot[lt]);
+                        if (lane_on) ext_update(out, y, T.ext_hi, &ext_slot[lt]);
                     } else if (p.cand_on) {
                         const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                         const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                        if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, y);
+                        if (lane_on && (p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, y);
                     }
-                    if (!p.hits_only) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
+                    if (lane_on && !p.hits_only) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

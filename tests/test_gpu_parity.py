@@ -2773,7 +2773,7 @@ def test_float32_raw_sums_with_thresholds_equal_the_float64_kernels():
                     for f in ("templ_idx", "x", "y", "w", "h"):
                         assert np.array_equal(got[f], ref[f]), (seed, method, thr, tm["f32_route"], f)
                     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (seed, method, thr)
-        assert 1 in routes, routes
+        assert 1 in routes or os.environ.get("MTM_F32_RIG") == "0", routes     # (without the bound: float64 kernel only)
     finally:
         fast.close()
         exact.close()
