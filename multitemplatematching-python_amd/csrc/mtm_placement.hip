@@ -173,10 +173,10 @@ bool mfma16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
            (long long)sc.w * sc.h <= 131071;
 }
 
-// float32 image + float32 templates, no mask: two bfloat16 pieces per value on the bf16 matrix cores - for the
-// NORMALISED methods, whose outputs are O(1) and stay within ~1e-5 of the float64 result.  The raw sums (TM_SQDIFF,
-// TM_CCORR, TM_CCOEFF) are as accurate relative to the sums they are built from (~1e-7), but they can cancel to
-// values far smaller than those sums (an exact copy: SQDIFF = 0), where no relative bound holds: float64 kernel.
+// float32 image + float32 templates, no mask: bfloat16 pieces on the bf16 matrix cores.  The normalised methods' outputs
+// are O(1) and stay within ~1e-5 of the float64 result; the raw sums (TM_SQDIFF, TM_CCORR, TM_CCOEFF) can cancel to values
+// far smaller than the sums they are built from (an exact copy: SQDIFF = 0), so no RELATIVE margin holds for them - their
+// lists are decided by an absolute per-output bound and exact re-scoring (mtm_api.hip), their maps by the float64 kernel.
 bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
     // All six methods (round 4).  The raw-sum methods only take this kernel for the refined global extremum
     // (N_object == 1; mtm_api.hip decides per call) - everything else they do runs the float64 kernel, for which a
