@@ -1299,13 +1299,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // the window statistics of this lane's four outputs - behind the screen: 40 registers that would otherwise be
         // live across it next to the 192 accumulator registers (they went to scratch memory in every work item: 63 MB of
         // HBM writes per 4K launch), and plane reads that the waves the screen sends away never need
-        // Round 5: NO divergent region from here to the stores.  With 192 accumulator registers live the compiler spills
-        // some of them around this code; a spill placed inside `if (lane_on)` saves the active lanes only, and the lanes
-        // that later WRITE those accumulators into the transposition buffer (q == stage) are not the lanes of the pixels -
-        // in a row segment that is only partly inside the map they reloaded stale scratch memory: pixels 4..6 of every
-        // 16-pixel block of the last segment wrong for the templates of stages 1..3, whenever the scratch backing store
-        // held another launch's data (profiles/r05_flake/diag.txt).  Lanes outside the map now compute on clamped
-        // coordinates like everyone else; only the stores and the candidate list look at lane_on.
+        // Round 5: NO divergent region from here to the stores.  With `if (lane_on)` around the statistics loads and the
+        // normalisation this epilogue returned wrong scores in row segments that are only partly inside the map: pixels
+        // 4..6 of every 16-pixel block, templates of stages 1..3, depending on what earlier launches of the process had
+        // done (profiles/r05_flake/diag.txt).  The lanes that WRITE the accumulators into the transposition
+        // buffer (q == stage) are not the lanes of the pixels, 192 accumulator registers are live and ~300 bytes of them
+        // spill: a spill / reload pair under two different execution masks is the suspected mechanism.  Lanes outside the
+        // map now compute on clamped coordinates like everyone else; only the stores and the candidate list look at lane_on.
         double us1[4] = {0.0, 0.0, 0.0, 0.0}, up1[4], usum2[4] = {0.0, 0.0, 0.0, 0.0}, usq[4] = {0.0, 0.0, 0.0, 0.0}, ursq[4];
         {
             const size_t sidx = (size_t)min(y, p.oh - 1) * st.pitch + min(xq, st.pitch - 4);       // pitch is a multiple of 4: the 4 values exist
