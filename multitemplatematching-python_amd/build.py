@@ -30,8 +30,11 @@ HEADERS = ["mtm_ctx.h", "mtm_k_image.hip.h", "mtm_k_stats.hip.h", "mtm_k_score.h
            "mtm_bf16.hip.h", "mtm_bf16_params.h", "mtm_refine.hip.h", "mtm_mfma_step_asm.inc", "mtm_kernels.h", "mtm_internal.h",
            "mtm_k_nms.hip.h", "mtm_nms_core.h",
            os.path.join("..", "..", "include", "mtm_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default"]
+# -save-temps=obj: the device assembly of every unit stays next to its object (csrc/build/*-gfx950.s) - what
+# tools/spill_exec_scan.py and tests/test_abi_cpu.py::test_no_spill_ahead_of_an_exec_restore read (this compiler
+# can place register spills ahead of a join block's exec restore; the build is checked for it)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-save-temps=obj",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-fvisibility=default", "-Wno-unused-command-line-argument"]
 LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl", "-pthread"]
 
 
@@ -82,6 +85,12 @@ def _compile(src, force, verbose):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    # of -save-temps' by-products only the device assembly is kept (preprocessed sources and bitcode are ~10 MB per unit)
+    stem = os.path.splitext(src)[0]
+    for f in os.listdir(OBJ):
+        if f.startswith(stem + "-") or f.startswith(stem + ".hip-"):
+            if not f.endswith("-gfx950.s"):
+                os.remove(os.path.join(OBJ, f))
     with open(stamp, "w") as f:
         f.write(dig)
     return obj

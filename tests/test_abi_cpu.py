@@ -135,3 +135,45 @@ def test_score_kernel_does_not_spill_accumulators():
     two_row = [k for k in ks if re.search(r"ncc_mfma_kernelILi2ELi[2-5]ELb0ELb0ELb0ELi1ELb0ELb1ELb0E", k["name"])]
     assert len(two_row) == 4 and all(k["scratch"] == 0 for k in two_row), [k for k in two_row if k["scratch"]]
     assert all(k["vgpr"] <= 256 for k in ks)
+
+
+def _spill_exec_scan():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("spill_exec_scan", os.path.join(ROOT, "tools", "spill_exec_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_no_spill_ahead_of_an_exec_restore():
+    """The code-generation defect behind round 5's state-dependent uint16 scores (profiles/r06_flake/): this
+    compiler can place the register allocator's spill stores at the top of a join block AHEAD of the `s_or_b64 exec` that
+    re-opens the execution mask, so only the lanes of the divergent region that just ended save their register - and
+    every lane reloads it.  The build keeps the device assembly of every unit (-save-temps); no kernel of the library may
+    contain that placement, whatever the source looks like."""
+    import build as mtm_build
+    mtm_build.build()
+    scan = _spill_exec_scan()
+    files, hits = scan.scan_all()
+    assert len(files) >= 11, files                     # every .hip unit left its assembly behind
+    names = " ".join(os.path.basename(f) for f in files)
+    for unit in ("mtm_mfma_plain", "mtm_mfma_rows", "mtm_mfma_rm", "mtm_mfma_ext", "mtm_mfma_kp", "mtm_bf16", "mtm_api", "mtm_launch"):
+        assert unit + "-hip-amdgcn-amd-amdhsa-gfx950.s" in names, unit
+    assert not hits, hits[:3]
+
+
+def test_spill_scan_sees_the_round5_defect(tmp_path):
+    """The detector itself, pinned on the block that produced the wrong scores (the uint16 reciprocal packed-K kernel of
+    commit 960e744 + profiles/r05_flake/detector_build.patch; excerpt committed under profiles/r06_flake/) and on its
+    correctly ordered sibling (the IEEE-division instantiation of the same build)."""
+    scan = _spill_exec_scan()
+    bad = open(os.path.join(ROOT, "profiles", "r06_flake", "failing_kernel_excerpt.s")).read()
+    good = open(os.path.join(ROOT, "profiles", "r06_flake", "exact_div_sibling_excerpt.s")).read()
+    for name, text, expect in (("bad.s", bad, 1), ("good.s", good, 0)):
+        p = tmp_path / name
+        p.write_text("_ZN3mtm15ncc_mfma_kernelTEST:\n" + text + "\n.Lfunc_end0:\n")
+        found = scan.scan(str(p))
+        assert len(found) == expect, (name, found)
+    (_, _, restore, offenders), = scan.scan(str(tmp_path / "bad.s"))
+    assert restore.startswith("s_or_b64 exec, exec")
+    assert sum("scratch_store_dwordx4" in t for _, t in offenders) == 3      # the three accumulator vectors (pixels 4..6)
