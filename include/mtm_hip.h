@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 6
+#define MTM_ABI_VERSION 7
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -165,6 +165,17 @@ const char* mtm_last_error(void);
 int         mtm_ctx_create(mtm_ctx** out, int device_id);
 void        mtm_ctx_destroy(mtm_ctx* ctx);
 int         mtm_set_option(mtm_ctx* ctx, int option, int64_t value);
+int         mtm_get_option(mtm_ctx* ctx, int option, int64_t* value);     /* the current value of an MTM_OPT_* option */
+/* Test support (ABI 7; nothing of the reference's interface corresponds to it).  The reference's functions are pure
+ * functions of their arguments (MTM/__init__.py:92, :238-241); a kernel that reads memory it did not write in this call -
+ * register-spill slots, LDS, a recycled work buffer - breaks that silently, depending on what earlier launches of the
+ * process left behind (round 5's uint16 finding).  This call leaves a byte pattern (0xFF: NaN as float32 /
+ * float64; 0x7F: huge finite values) in the places such a read would hit: every wave slot's scratch memory, every CU's
+ * LDS, and the context's per-call work buffers.  tests/test_gpu_parity.py runs it ahead of every parity test. */
+#define MTM_POISON_SCRATCH 1
+#define MTM_POISON_LDS     2
+#define MTM_POISON_ARENAS  4
+int         mtm_debug_poison(mtm_ctx* ctx, int pattern_byte, int what);
 /* Page-locked host memory for pixel buffers (optional).  The reference's caller hands over whatever numpy holds
  * (MTM/__init__.py:247 `image`) - pageable memory, which the runtime stages through its own pinned buffers while the
  * upload call blocks.  An image kept in memory from mtm_host_alloc crosses PCIe as a plain DMA transfer behind the call

@@ -9,6 +9,7 @@ import ctypes
 import struct
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -22,10 +23,12 @@ PEAKS_LOCAL, PEAKS_GLOBAL = 0, 1
 BORDER_CONSTANT, BORDER_NEAREST = 0, 1
 KERNEL_AUTO, KERNEL_NAIVE, KERNEL_DOT4, KERNEL_MFMA = 0, 1, 2, 3
 OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY, OPT_F32_MFMA = 1, 2, 3, 4, 5, 6, 7
+ALL_OPTIONS = (OPT_KERNEL, OPT_PEAK_BORDER, OPT_HIT_CAPACITY, OPT_DOT4_VARIANT, OPT_EXACT_DIV, OPT_HITS_ONLY, OPT_F32_MFMA)
+POISON_SCRATCH, POISON_LDS, POISON_ARENAS = 1, 2, 4
 E_OVERFLOW = -5
 E_HIP = -2
 COMM_ID_BYTES = 128
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class MtmTempl(ctypes.Structure):
@@ -69,6 +72,8 @@ SYMBOLS = {
     "mtm_ctx_create": (ctypes.c_int, [_P(ctypes.c_void_p), ctypes.c_int]),
     "mtm_ctx_destroy": (None, [ctypes.c_void_p]),
     "mtm_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "mtm_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _P(ctypes.c_int64)]),
+    "mtm_debug_poison": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "mtm_set_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "mtm_set_image_downscaled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -302,6 +307,13 @@ class _RecordMemo:
         return self._rec
 
 
+_LIVE = weakref.WeakSet()          # contexts that exist right now (test support: live_contexts)
+
+
+def live_contexts():
+    return [c for c in list(_LIVE) if c._h]
+
+
 class Context(_RecordMemo):
     """One GPU context (single caller: guarded by a lock)."""
 
@@ -320,6 +332,7 @@ class Context(_RecordMemo):
         self.lock = threading.RLock()
         self._keep = []
         self._rec_key, self._rec, self._rec_keep = None, None, None
+        _LIVE.add(self)
         k = os.environ.get("MTM_KERNEL")
         if k:
             self.set_option(OPT_KERNEL, {"auto": 0, "naive": 1, "dot4": 2, "mfma": 3}[k.lower()])
@@ -328,6 +341,7 @@ class Context(_RecordMemo):
             self.set_option(OPT_PEAK_BORDER, {"constant": 0, "nearest": 1}[b.lower()])
 
     def close(self):
+        _LIVE.discard(self)
         if self._h:
             self._lib.mtm_ctx_destroy(self._h)
             self._h = None
@@ -340,6 +354,21 @@ class Context(_RecordMemo):
 
     def set_option(self, opt, value):
         check(self._lib.mtm_set_option(self._h, int(opt), int(value)), "mtm_set_option")
+
+    def get_option(self, opt):
+        v = ctypes.c_int64(0)
+        check(self._lib.mtm_get_option(self._h, int(opt), ctypes.byref(v)), "mtm_get_option")
+        return int(v.value)
+
+    def options(self):
+        """{option: value} of every MTM_OPT_* option (what a fresh context starts with is `DEFAULT_OPTIONS` after the
+        environment switches have been applied: compare with Context(...).options())."""
+        return {o: self.get_option(o) for o in ALL_OPTIONS}
+
+    def debug_poison(self, pattern=0xFF, what=7):
+        """Test support (mtm_debug_poison): a byte pattern into every wave slot's scratch memory (1), every CU's LDS (2) and
+        the context's per-call work buffers (4) - memory no result may depend on."""
+        check(self._lib.mtm_debug_poison(self._h, int(pattern), int(what)), "mtm_debug_poison")
 
     def set_image(self, image, downscale=1):
         """Upload the search image; `downscale` > 1 area-averages it by that integer factor on the

@@ -423,6 +423,84 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
     return MTM_E_INVALID;
 }
 
+int mtm_get_option(mtm_ctx* c, int option, int64_t* value) {
+    if (!c || !value) return MTM_E_INVALID;
+    switch (option) {
+        case MTM_OPT_KERNEL: *value = c->opt_kernel; return MTM_OK;
+        case MTM_OPT_PEAK_BORDER: *value = c->opt_border; return MTM_OK;
+        case MTM_OPT_HIT_CAPACITY: *value = c->hit_cap; return MTM_OK;
+        case MTM_OPT_EXACT_DIV: *value = c->exact_div; return MTM_OK;
+        case MTM_OPT_HITS_ONLY: *value = c->hits_only; return MTM_OK;
+        case MTM_OPT_F32_MFMA: *value = c->f32_mfma; return MTM_OK;
+        case MTM_OPT_DOT4_VARIANT: *value = c->dot_variant; return MTM_OK;
+        default: break;
+    }
+    set_error("mtm_get_option: bad option");
+    return MTM_E_INVALID;
+}
+
+// ---- test support: memory a kernel must not depend on, filled with a pattern (mtm_debug_poison) -------------------------
+// Per-lane private memory: 160 dwords through a volatile pointer (a real scratch array, larger than any product kernel's
+// spill area), held while the wave sleeps so that the launch occupies every wave slot of the chip at once - scratch is
+// handed out per wave SLOT, a kernel that reloads a slot it has not stored sees what the previous tenant left there.
+__global__ __launch_bounds__(256) void poison_scratch_kernel(uint32_t pat, int sleeps, uint32_t* sink) {
+    uint32_t buf[160];
+    volatile uint32_t* vb = buf;
+    for (int i = 0; i < 160; ++i) vb[i] = pat;
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    uint32_t acc = 0;
+    for (int i = 0; i < 160; ++i) acc += vb[(i * 7 + (int)threadIdx.x) % 160] != pat;
+    if (acc) atomicAdd(sink, acc);                  // (never: keeps the array alive)
+}
+// LDS: 40 KiB per work-group, four of them fill a CU's 160 KiB while they sleep side by side
+constexpr int kPoisonLdsBytes = 40 * 1024;
+__global__ __launch_bounds__(256) void poison_lds_kernel(uint32_t pat, int sleeps, uint32_t* sink) {
+    __shared__ uint32_t lds[kPoisonLdsBytes / 4];
+    for (int i = threadIdx.x; i < kPoisonLdsBytes / 4; i += 256) lds[i] = pat;
+    __syncthreads();
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    if (lds[(threadIdx.x * 13) % (kPoisonLdsBytes / 4)] != pat) atomicAdd(sink, 1u);
+}
+
+int mtm_debug_poison(mtm_ctx* c, int pattern_byte, int what) {
+    if (!c) return MTM_E_INVALID;
+    MTM_NOT_IN_FLIGHT(c, "mtm_debug_poison");
+    HIPC(hipSetDevice(c->device));
+    const uint32_t b = (uint32_t)(pattern_byte & 0xFF), pat = b | (b << 8) | (b << 16) | (b << 24);
+    if (c->n_cus == 0) {
+        hipDeviceProp_t prop;
+        HIPC(hipGetDeviceProperties(&prop, c->device));
+        c->n_cus = prop.multiProcessorCount;
+    }
+    MTMC(c->sched.ensure(sizeof(unsigned int) * (1 + 4096 + 8 * 32)));
+    uint32_t* sink = c->sched.as<uint32_t>() + 4096;        // (a word no launch reads before clearing the block)
+    // ~8128 cycles per s_sleep(127): a few tens of microseconds per work-group, every slot taken several times over
+    if (what & MTM_POISON_SCRATCH)
+        hipLaunchKernelGGL(poison_scratch_kernel, dim3(c->n_cus * 8 * 3), dim3(256), 0, c->stream, pat, 4, sink);
+    if (what & MTM_POISON_LDS)
+        hipLaunchKernelGGL(poison_lds_kernel, dim3(c->n_cus * 4 * 3), dim3(256), 0, c->stream, pat, 4, sink);
+    if (what & MTM_POISON_ARENAS) {
+        // buffers a call writes before it reads them: window statistics (planes, reciprocals, block ranges, row sums),
+        // raw partial maps, the score maps, the byte planes of I^2 - of the context and of every class lane.  Buffers with
+        // an invariant kept between calls (image padding, candidate header, hash tables, flags, packs) are left alone.
+        auto fill = [&](mtm_ctx::DevBuf& d) -> int {
+            if (d.p && d.cap) HIPC(hipMemsetAsync(d.p, (int)b, d.cap, c->stream));
+            return MTM_OK;
+        };
+        for (mtm_ctx::DevBuf* d : {&c->stats, &c->stats_rsq, &c->stats_blk, &c->hs1, &c->hs2, &c->raw16, &c->slab_raw,
+                                   &c->stats_hi, &c->maps, &c->sq_planes})
+            MTMC(fill(*d));
+        for (auto& ln : c->lanes)
+            for (mtm_ctx::DevBuf* d : {&ln.stats, &ln.stats_rsq, &ln.stats_blk, &ln.hs1, &ln.hs2, &ln.raw16, &ln.slab_raw, &ln.stats_hi})
+                MTMC(fill(*d));
+        c->maps_valid = false;
+        c->sq_valid = false;
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
 int mtm_set_image_downscaled(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
                              int64_t row_stride_bytes, int factor) {
     if (!c) {

@@ -33,6 +33,13 @@
 namespace mtm {
 
 __device__ __forceinline__ int mf_epi_rot(int j) { return 4 * ((j >> 1) & 3); }
+// A launch parameter read where it is used: as a plain `p.x` the compiler evaluates the test once ahead of the item loop and,
+// out of scalar registers there, parks the boolean in a VECTOR register across the K loop - i.e. in scratch memory (one dword
+// per lane stored per work-group, reloaded per work item, in the headline instantiation).
+__device__ __forceinline__ int mf_opaque_sgpr(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
 // finish_unmasked on values already in registers (same arithmetic, same order).  METHOD >= 0 fixes
 // the matching method at compile time: the per-output code is then branch-free apart from the
 // data-dependent normalisation cases (the runtime-method version spends most of its time in
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
                 int loff = 0;
                 v4i qx, qy, qx2, qy2, a0, a1, a2 = v4i{0, 0, 0, 0}, a3 = v4i{0, 0, 0, 0};
-                if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+                if (mf_opaque_sgpr(p.hits_only)) __builtin_amdgcn_s_setprio(3);
 #define MTM_R3_LOAD(QA, QB, A)                                              \
                 QA = *reinterpret_cast<const v4i*>(lbase + loff);           \
                 QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);      \
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
                 int loff = 0;
                 v4i qx, qy, qx2, qy2, aA, aB, aC = r2_prev;
-                if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+                if (mf_opaque_sgpr(p.hits_only)) __builtin_amdgcn_s_setprio(3);
 #define MTM_R2_LOAD(QA, QB, A)                                              \
                 QA = *reinterpret_cast<const v4i*>(lbase + loff);           \
                 QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);      \
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);                      \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                           \
                 A[mb] = *reinterpret_cast<const v4i*>(aptr + mb * p.group_bytes);
-            if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+            if (mf_opaque_sgpr(p.hits_only)) __builtin_amdgcn_s_setprio(3);
             MTM_KP_LOAD(qa0, qb0, a0)            // step 0
             int ks = 0;
             for (; ks + 2 <= nsteps; ks += 2) {
@@ -723,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
             // hits-only launches: the MFMA main loop outranks the (short) epilogue of the co-resident work-group
             // (-0.9 % kernel time; with the maps written the long epilogue is the one that must not starve: +1 %)
-            if (p.hits_only) __builtin_amdgcn_s_setprio(3);
+            if (mf_opaque_sgpr(p.hits_only)) __builtin_amdgcn_s_setprio(3);
             MTM_MF_LOAD(qa0, qb0, a0)            // step 0
             int ks = 0;
             for (; ks + 2 <= nsteps; ks += 2) {
@@ -903,17 +910,16 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 }
         }
     };
-    auto emit = [&](const float (&out)[4], int li) { emit_at(out, li, y); };
     // global extremum (EXT): the lane's best key not below the template's running best goes to the wave's
     // LDS slot (cv2.minMaxLoc: the first index wins ties, NaN never wins)
-    auto ext_update = [&](const float (&out)[4], int yrow, uint32_t best_hi, unsigned long long* slot) {
+    auto ext_update = [&](const float (&out)[4], int yrow, uint32_t best_hi, unsigned long long* slot, bool on = true) {
         unsigned long long bestk = 0ull;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = out[i];
             const uint32_t o = mf_float_order(v);
             const uint32_t hiw = p.cand_min ? ~o : o;
-            if (xq + i < p.ow && v == v && hiw >= best_hi) {
+            if (on && xq + i < p.ow && v == v && hiw >= best_hi) {
                 const unsigned long long key = ((unsigned long long)hiw << 32) |
                                                (unsigned long long)(0xFFFFFFFFu - (uint32_t)(yrow * p.ow + xq + i));
                 bestk = key > bestk ? key : bestk;
@@ -936,7 +942,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         // (template i % nt, output row mb R + i / nt) to raw_out + t * raw_map + row * raw_pitch
         __syncthreads();
         const int R = p.rm_R, ntm = p.rm_nt - 1, lg = p.rm_log2nt;
-        const bool col_on = xq < p.ow;
         if (p.sq_fused) {
             // ---- sum I^2 M, finished here (round 4; round 3: two raw launches + masksq_combine_kernel): the accumulator
             // holds 256 a_h + a_l, c2 = that + 257 * 128 * sum(M) (p.sq_k; the mask operand is not biased) goes to the
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 if ((q >> 1) == round) put(acc[mb]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (col_on) {
+                {   // (the only divergent code between the transposition stages are the stores themselves)
 #pragma unroll 1
                     for (int s8 = 0; s8 < 8; ++s8) {
                         const int i = 8 * round + s8;
@@ -1090,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 if ((q >> 1) == round) put(acc[mb]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (col_on) {
+                {   // (no divergent region: lanes right of the map compute on the clamped column xs - see the plain tiling)
                     int cur_rho = -1;
                     double ps1[4][CH], pp1[4] = {0, 0, 0, 0}, psum2[4] = {0, 0, 0, 0}, psq[4] = {0, 0, 0, 0},
                            prsq[4] = {0, 0, 0, 0};
@@ -1146,7 +1151,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const MfTemplConst T = tcl[t];
                         const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
                         const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
-                        if (kNormed && (p.hits_only || (!MASKED && !EXT && p.seg_skip))) {
+                        bool wanted = col_on;          // (see the plain tiling's epilogue)
+                        const bool pretest = kNormed && (p.hits_only || (!MASKED && !EXT && p.seg_skip));
+                        if (pretest) {
                             bool pass = T.all_ones != 0;
                             const double rt = T.rtempl_norm;
 #pragma unroll
@@ -1160,17 +1167,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 const double quality = METHOD == MTM_TM_SQDIFF_NORMED ? -qd : qd;
                                 pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
                             }
-                            if (!p.hits_only) {          // seg_skip (see the plain tiling's epilogue)
-                                if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
-                                if (!pass) {
-                                    const float below = METHOD == MTM_TM_SQDIFF_NORMED ? INFINITY : -INFINITY;
-                                    const float sent[4] = {below, below, below, below};
-                                    store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, sent);
-                                    continue;
-                                }
-                            } else if (!pass) {
-                                continue;
-                            }
+                            wanted = wanted && pass;
+                            if (__builtin_amdgcn_ballot_w64(wanted) == 0ull) continue;       // wave-uniform
                         }
                         float out[4];
 #pragma unroll
@@ -1182,20 +1180,23 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const bool ones = !MASKED && T.all_ones != 0;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) out[k] = ones ? 1.0f : out[k];
+                        if (pretest && !p.hits_only) {          // seg_skip (see the plain tiling's epilogue)
+                            const float below = METHOD == MTM_TM_SQDIFF_NORMED ? INFINITY : -INFINITY;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) out[k] = wanted ? out[k] : below;
+                        }
+                        const float hi4 = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                        const float lo4 = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                        const bool above = wanted && (p.cand_min ? -lo4 : hi4) > p.cand_thr;
                         if constexpr (EXT) {
-                            ext_update(out, yy, T.ext_hi, &ext_slot[t]);
+                            ext_update(out, yy, T.ext_hi, &ext_slot[t], wanted);
                         } else if (p.cand_on) {
-                            const unsigned allow = 15u;
-                            const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
-                            const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, t, yy, allow);
+                            if (__builtin_amdgcn_ballot_w64(above) != 0ull) emit_at(out, t, yy, above ? 15u : 0u);
                         }
                         if (!p.hits_only) {
-                            store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, out);
+                            if (col_on) store4(maps + T.map_off + (size_t)yy * T.map_pitch + xq, out);
                             if constexpr (!EXT) if (p.seg_flags != nullptr) {      // segment flags (see the plain tiling's epilogue)
-                                const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
-                                const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                                if (__builtin_amdgcn_ballot_w64((p.cand_min ? -lo : hi) > p.cand_thr) != 0ull)
+                                if (__builtin_amdgcn_ballot_w64(above) != 0ull)
                                     p.seg_flags[(size_t)T.flag_base + (size_t)yy * p.flag_rstride + (x0 >> 8)] = 1;
                             }
                         }
@@ -1220,20 +1221,20 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 if ((q >> 1) == round) put(acc[mb]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (lane_on) {
+                {   // (the only divergent code between the transposition stages are the stores themselves)
 #pragma unroll
                     for (int s8 = 0; s8 < 8; ++s8) {
                         const int li = tg * MB * 16 + mb * 16 + 8 * round + s8;
                         if (li >= p.n_list) break;                          // wave-uniform
                         const v4i a4 = *reinterpret_cast<const v4i*>(&epi[s8 * kMfEpiPitch + rd_off]);
                         int* orow = p.raw_out + (size_t)li * p.raw_map + (size_t)y * p.raw_pitch + xq;
-                        if (xq + 3 < p.ow) {
+                        if (lane_on && xq + 3 < p.ow) {
                             *reinterpret_cast<v4i*>(orow) = a4;
                         } else {
                             const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                if (xq + i < p.ow) orow[i] = a32[i];
+                                if (lane_on && xq + i < p.ow) orow[i] = a32[i];
                         }
                     }
                 }
@@ -1383,11 +1384,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                     }
                     if constexpr (EXT) {
-                        if (lane_on) ext_update(out, y, T.ext_hi, &ext_slot[lt]);
+                        ext_update(out, y, T.ext_hi, &ext_slot[lt], lane_on);
                     } else if (p.cand_on) {
                         const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
                         const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                        if (lane_on && (p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, y);
+                        const bool above = lane_on && (p.cand_min ? -lo : hi) > p.cand_thr;
+                        if (__builtin_amdgcn_ballot_w64(above) != 0ull) emit_at(out, li, y, above ? 15u : 0u);     // wave-uniform entry
                     }
                     if (lane_on && !p.hits_only) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
                 }
@@ -1614,6 +1616,13 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         const bool col_on = xq < p.ow;
         unsigned long long* ext_slot = reinterpret_cast<unsigned long long*>(smem + p.ext_off) + wave * 32;
         if (EXT && lane < 32) ext_slot[lane] = 0ull;   // ordered before the first update by the fences below
+        // Round 6: NO divergent region between put() and the stores, and no ballot / continue under a divergent mask.  Lanes
+        // outside the map run the same code on clamped coordinates (the statistics above are loaded that way); `lane_on` only
+        // gates what leaves the lane - stores, candidate records, extremum keys, segment flags.  Why: the lanes that WRITE the
+        // transposition buffer (put) are not the lanes of the pixels, so every lane's accumulators must survive whatever the
+        // epilogue does, and this toolchain has placed accumulator spills ahead of the exec restore of an `if (lane_on)`
+        // region (profiles/r06_flake/: the lanes outside the map then reload other launches' scratch memory).
+        // tools/spill_exec_scan.py checks every build for that placement; this form keeps the opportunity for it small.
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int yrow = y + (R2 ? mb : 0);
@@ -1624,29 +1633,31 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 if ((q >> 1) == round) put(acc[mb]);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // LDS writes above, reads below
                 __builtin_amdgcn_wave_barrier();
-                if (lane_on) {
+                {
                     const int lt0 = (R2 ? 0 : mb * 16) + 8 * round;       // template inside this work item
-                    MfTemplConst Tn = tcl[lt0];
                     v4i an = *reinterpret_cast<const v4i*>(&epi[rd_off]);
-#pragma unroll 2
+#pragma unroll 1
                     for (int s8 = 0; s8 < 8; ++s8) {
                         // template = 4*q_src + e with q_src = 2*round + (s8 >> 2), e = s8 & 3
                         // (C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + reg)
-                        const MfTemplConst T = Tn;
+                        // (round 6: the constants are read where they are used - a second MfTemplConst in flight, requested one
+                        // template ahead, cost ~20 registers next to the 128 accumulators and was what spilled)
+                        const MfTemplConst& T = tcl[lt0 + s8];
                         const v4i a4 = an;
-                        if (s8 < 7) {
-                            Tn = tcl[lt0 + s8 + 1];
-                            an = *reinterpret_cast<const v4i*>(&epi[(s8 + 1) * kMfEpiPitch + rd_off]);
-                        }
+                        if (s8 < 7) an = *reinterpret_cast<const v4i*>(&epi[(s8 + 1) * kMfEpiPitch + rd_off]);
                         const int li = tg * kTG + lt0 + s8;
                         if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;   // wave-uniform
                         const int a32[4] = {a4.x, a4.y, a4.z, a4.w};
-                        if (kNormed && (p.hits_only || (!MASKED && !EXT && p.seg_skip))) {
-                            // Nothing is stored in this mode, so only outputs that can reach the
-                            // threshold need the full normalisation: q is the float64 quotient of the
-                            // reciprocal path (within 2 ulp(double) of num / t), compared with a
-                            // threshold lowered by 8 float32 ulps.  |q| >= 1 (saturation cases) and
-                            // constant templates always take the exact path below.
+                        // wanted: this lane's four outputs may leave it (inside the map; behind the pre-test: can pass)
+                        bool wanted = lane_on;
+                        constexpr bool kPreTest = kNormed;
+                        const bool pretest = kPreTest && (p.hits_only || (!MASKED && !EXT && p.seg_skip));
+                        if (pretest) {
+                            // Only outputs that can reach the threshold need the full normalisation (hits-only: nothing
+                            // is stored; seg_skip: a value certainly below the threshold needs no value): q is the
+                            // float64 quotient of the reciprocal path (within 2 ulp(double) of num / t), compared with a
+                            // threshold lowered by 8 float32 ulps.  |q| >= 1 (saturation cases) and constant templates
+                            // always take the exact path below.
                             bool pass = T.all_ones != 0;
                             const double rt = T.rtempl_norm;
                             constexpr bool kExactNoRcp = EXACT_DIV && !MASKED;
@@ -1671,20 +1682,11 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                     pass = pass || quality > (EXT ? T.ext_thr_lo : p.cand_thr_lo) || fabs(qd) >= 0.999999999;
                                 }
                             }
-                            if (!p.hits_only) {
-                                // seg_skip: a row segment none of whose outputs can pass stays unwritten and unflagged (the peak
-                                // pass reads flagged segments only and takes their unflagged neighbours as "below the
-                                // threshold"); in a segment that is written, outputs that cannot pass get exactly that value
-                                if (__builtin_amdgcn_ballot_w64(pass) == 0ull) continue;
-                                if (!pass) {
-                                    const float below = METHOD == MTM_TM_SQDIFF_NORMED ? INFINITY : -INFINITY;
-                                    const float sent[4] = {below, below, below, below};
-                                    store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, sent);
-                                    continue;
-                                }
-                            } else if (!pass) {
-                                continue;
-                            }
+                            wanted = wanted && pass;
+                            // hits-only: nothing to do for a (template, segment) without a possible candidate.  seg_skip: such
+                            // a row segment stays unwritten and unflagged (the peak pass reads flagged segments only and takes
+                            // their unflagged neighbours as "below the threshold").  Wave-uniform either way.
+                            if (__builtin_amdgcn_ballot_w64(wanted) == 0ull) continue;
                         }
                         float out[4];
 #pragma unroll
@@ -1703,23 +1705,27 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                             for (int i = 0; i < 4; ++i) out[i] = ones ? 1.0f : out[i];
                         }
+                        if (pretest && !p.hits_only) {
+                            // seg_skip: in a segment that is written, outputs that cannot pass get "below the threshold"
+                            const float below = METHOD == MTM_TM_SQDIFF_NORMED ? INFINITY : -INFINITY;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) out[i] = wanted ? out[i] : below;
+                        }
+                        // does one of the four reach the threshold?  (emit_at() repeats the exact per-pixel test)
+                        const float hi4 = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
+                        const float lo4 = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
+                        const bool above = wanted && (p.cand_min ? -lo4 : hi4) > p.cand_thr;
                         if constexpr (EXT) {
-                            ext_update(out, yrow, T.ext_hi, &ext_slot[lt0 + s8]);
+                            ext_update(out, yrow, T.ext_hi, &ext_slot[lt0 + s8], wanted);
                         } else if (p.cand_on) {
-                            // cheap any-of-4 test; emit_at() repeats the exact per-pixel test (rare)
-                            const unsigned allow = 15u;
-                            const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
-                            const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                            if ((p.cand_min ? -lo : hi) > p.cand_thr) emit_at(out, li, yrow, allow);
+                            if (__builtin_amdgcn_ballot_w64(above) != 0ull) emit_at(out, li, yrow, above ? 15u : 0u);
                         }
                         if (!p.hits_only) {
-                            store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, out);
+                            if (lane_on) store4(maps + T.map_off + (size_t)yrow * T.map_pitch + xq, out);
                             if constexpr (!EXT) if (p.seg_flags != nullptr) {
                                 // segment flags (dense images): the peak pass only visits row segments in which some output
                                 // passes the threshold
-                                const float hi = fmaxf(fmaxf(out[0], out[1]), fmaxf(out[2], out[3]));
-                                const float lo = fminf(fminf(out[0], out[1]), fminf(out[2], out[3]));
-                                if (__builtin_amdgcn_ballot_w64((p.cand_min ? -lo : hi) > p.cand_thr) != 0ull)
+                                if (__builtin_amdgcn_ballot_w64(above) != 0ull)
                                     p.seg_flags[(size_t)T.flag_base + (size_t)yrow * p.flag_rstride + (x0 >> 8)] = 1;
                             }
                         }
@@ -1746,7 +1752,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (y < p.oh && xq < p.ow) {
+            {   // (no divergent region: lanes outside the map compute on clamped coordinates - see the single-channel path)
+                const bool lane_on = y < p.oh && xq < p.ow;
 #pragma unroll 1
                 for (int s8 = 0; s8 < 8; ++s8) {
                     const int lt = mb * 16 + 8 * round + s8;
@@ -1760,7 +1767,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int x = min(xq + i, p.ow - 1);
-                        const size_t sidx = (size_t)y * st.pitch + x;
+                        const size_t sidx = (size_t)min(y, p.oh - 1) * st.pitch + x;
                         double tv[kMaxChans] = {0.0, 0.0, 0.0, 0.0};
                         double s1 = 0.0;
 #pragma unroll
@@ -1772,8 +1779,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         const double corr = ((double)a32[i] + 128.0 * s1) + T.mfma_k;
                         out[i] = finish_vals<-1>(p.method, corr, tv, st.sum2[sidx], st.sq[sidx], T, p.chans);
                     }
-                    if (p.cand_on) emit(out, li);
-                    store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
+                    if (p.cand_on) emit_at(out, li, y, lane_on ? 15u : 0u);
+                    if (lane_on) store4(maps + T.map_off + (size_t)y * T.map_pitch + xq, out);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

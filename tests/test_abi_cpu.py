@@ -31,7 +31,7 @@ def test_header_symbols_exported(lib):
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().mtm_abi_version() == lib.ABI_VERSION == 6
+    assert lib.load().mtm_abi_version() == lib.ABI_VERSION == 7
 
 
 def test_struct_layout(lib):
@@ -131,9 +131,10 @@ def test_score_kernel_does_not_spill_accumulators():
     worst = max((k for k in ks if not three_row(k)), key=lambda k: k["scratch"])
     assert worst["scratch"] <= 200, worst
     assert all(k["scratch"] <= 640 for k in ks if three_row(k))
-    # <2, method, exact = false, false, false, 1, ext = false, R2 = true, false>: the default two-row instantiations
-    two_row = [k for k in ks if re.search(r"ncc_mfma_kernelILi2ELi[2-5]ELb0ELb0ELb0ELi1ELb0ELb1ELb0E", k["name"])]
-    assert len(two_row) == 4 and all(k["scratch"] == 0 for k in two_row), [k for k in two_row if k["scratch"]]
+    # <2, method, exact, false, false, 1, ext, R2 = true, false>: the two-row instantiations - IEEE division (the default
+    # since round 5) and reciprocal, with and without the fused extremum; the headline kernel is <2, 5, true, ..., false, true>
+    two_row = [k for k in ks if re.search(r"ncc_mfma_kernelILi2ELi[2-5]ELb[01]ELb0ELb0ELi1ELb[01]ELb1ELb0E", k["name"])]
+    assert len(two_row) == 16 and all(k["scratch"] == 0 for k in two_row), [k for k in two_row if k["scratch"]]
     assert all(k["vgpr"] <= 256 for k in ks)
 
 

@@ -63,8 +63,23 @@ def map_close(got, exp, tol=1e-4):
 
 
 def set_exact(ctx, on):
-    """MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-identical to the other kernels)."""
+    """MTM_OPT_EXACT_DIV: IEEE division in the MFMA epilogue (bit-identical to the other kernels; the library's default
+    since round 5), 0 = the correctly rounded reciprocals of rounds 1-4."""
     ctx.set_option(5, 1 if on else 0)
+
+
+def restore_exact(ctx):
+    """Back to what a fresh context starts with (conftest.fresh_options: the shipped default, 1, unless an environment
+    switch of tools/alt_modes.sh says otherwise).  Round 5's suite restored `False` here and so ran everything behind
+    test_guards in the reciprocal mode - the mode that no longer ships as the default."""
+    from conftest import fresh_options
+    ctx.set_option(5, fresh_options()[5])
+
+
+def restore_options(ctx):
+    from conftest import fresh_options
+    for opt, value in fresh_options().items():
+        ctx.set_option(opt, value)
 
 
 def ulp_close(a, b, tol=1.2e-7):
@@ -181,12 +196,12 @@ def test_guards(mtm):
     ctx = mtm._lib.default_context()
     for m in (1, 3, 5):
         exp = O.compute_score_map(t2, img, m)
-        set_exact(ctx, True)
+        assert np.array_equal(mtm.computeScoreMap(t2, img, m), exp), m         # the default (IEEE division): bit-identical
+        set_exact(ctx, False)                                                  # the reciprocal epilogue of rounds 1-4
         try:
-            assert np.array_equal(mtm.computeScoreMap(t2, img, m), exp), m     # exact mode: bit-identical
+            got = mtm.computeScoreMap(t2, img, m)
         finally:
-            set_exact(ctx, False)
-        got = mtm.computeScoreMap(t2, img, m)
+            restore_exact(ctx)
         ulp_close(got, exp)
         special = (exp == 0.0) | (np.abs(exp) == 1.0)               # flat windows, saturation branches
         assert np.array_equal(got[special], exp[special]), m
@@ -211,6 +226,7 @@ def test_dot4_variants_agree(mtm, ctx):
             for i in range(len(units)):
                 assert np.array_equal(ctx.score_map(i, shape), base[i]), (v, i)
         set_kernel(ctx, "mfma")
+        set_exact(ctx, False)
         hits = ctx.find_matches(0, 0.5)
         assert len(hits) == 4 * len(units) and ctx.timing()["kernel_used"] == 3
         for i in range(len(units)):
@@ -218,10 +234,9 @@ def test_dot4_variants_agree(mtm, ctx):
         set_exact(ctx, True)
         for i in range(len(units)):
             assert np.array_equal(ctx.score_map(i, shape), base[i]), ("mfma exact", i)
-        set_exact(ctx, False)
     finally:
         ctx.set_option(4, 0)
-        set_exact(ctx, False)
+        restore_exact(ctx)
         set_kernel(ctx, "auto")
 
 
@@ -253,7 +268,7 @@ def test_mfma_template_groups(mtm, ctx, n_templ, side, method):
                     else:
                         assert np.array_equal(a, b), (kernel, i)
         finally:
-            set_exact(ctx, False)
+            restore_exact(ctx)
             set_kernel(ctx, "auto")
     assert len(res["naive"]) >= n_templ
     assert res["mfma_exact"] == res["naive"] and res["dot4"] == res["naive"]
@@ -1328,7 +1343,7 @@ def test_masked_integer_path(mtm, ctx, method):
                 hits = ctx.find_matches(0, 0.97 if method in (1, 3) else 1e9)
                 assert ctx.timing()["kernel_used"] == 3       # the integer path really ran
         finally:
-            set_exact(ctx, False)
+            restore_exact(ctx)
             set_kernel(ctx, "auto")
     for k, i in enumerate((0, 1, 7, 18)):
         exp = O.match_template(img, templs[i][0], method, mask=templs[i][1])
@@ -1457,20 +1472,22 @@ def test_hits_only_equals_map_mode(mtm, ctx, coins):
                     assert canon(res[0]) == canon(res[1]), (method, thr, exact, border)
         # hits-only results against the oracle directly (dense: thousands of candidates)
         ctx.set_option(6, 1)
-        set_exact(ctx, 0)
         ctx.set_option(2, 1)
         lt = [("small", small), ("big", big)]
-        for method, thr in ((5, 0.05), (3, 0.6), (1, 0.9)):
-            got = mtm.findMatches(lt, coins, method=method, score_threshold=thr)
-            exp = O.find_matches(lt, coins, method=method, score_threshold=thr)
-            assert len(got) == len(exp) and len(got) > 50
-            assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+        for exact in (1, 0):                    # the shipped default (IEEE division) and the reciprocal epilogue
+            set_exact(ctx, exact)
+            for method, thr in ((5, 0.05), (3, 0.6), (1, 0.9)):
+                got = mtm.findMatches(lt, coins, method=method, score_threshold=thr)
+                exp = O.find_matches(lt, coins, method=method, score_threshold=thr)
+                assert len(got) == len(exp) and len(got) > 50, (exact, method)
+                assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+        restore_exact(ctx)
         # the timing record says which mode ran
         ctx.set_option(6, 1)
         mtm.findMatches(lt, coins)
     finally:
         set_kernel(ctx, "auto")
-        set_exact(ctx, 0)
+        restore_exact(ctx)
         ctx.set_option(2, 1)
         ctx.set_option(6, 1)
 
@@ -2507,8 +2524,8 @@ def test_rgb_lean_path(mtm, ctx):
                         assert np.array_equal(got, exp), (method, exact, name, float(np.abs(got - exp).max()))
                     else:
                         ulp_close(got, exp)
-        set_exact(ctx, 0)
-        for method, thr in ((5, 0.5), (3, 0.85), (1, 0.3)):
+        for exact, (method, thr) in [(e, mt) for e in (1, 0) for mt in ((5, 0.5), (3, 0.85), (1, 0.3))]:
+            set_exact(ctx, exact)
             res = []
             for honly in (0, 1):
                 ctx.set_option(6, honly)
@@ -2528,7 +2545,7 @@ def test_rgb_lean_path(mtm, ctx):
             assert_hits_equal(one[1], hits_json(O.find_matches(lt, img, method=method, N_object=1)), tol=1e-6)
     finally:
         set_kernel(ctx, "auto")
-        set_exact(ctx, 0)
+        restore_exact(ctx)
         ctx.set_option(6, 1)
 
 
