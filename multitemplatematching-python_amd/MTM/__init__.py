@@ -152,9 +152,15 @@ class _ListMemo:
     label column of the hit list.  One immutable snapshot, replaced as a whole: safe to read without a lock."""
     __slots__ = ("items", "shapes", "ishape", "units_pack", "labels")
 
+    @staticmethod
+    def _geometry(items):
+        """Everything about a tuple's arrays that can change IN PLACE and matters to the checks and to the records built
+        from them: shape and dtype of the template, shape and dtype of its mask (`arr.shape = ...`, `arr.dtype = ...`)."""
+        return [(t[1].shape, t[1].dtype, (t[2].shape, t[2].dtype) if len(t) > 2 and t[2] is not None else None) for t in items]
+
     def __init__(self, listTemplates, ishape):
         self.items = tuple(listTemplates)            # (keeps the tuples alive: an id cannot be recycled)
-        self.shapes = [t[1].shape for t in self.items]
+        self.shapes = self._geometry(self.items)
         self.ishape = ishape
         self.units_pack = None                       # (key, units, ignored masks): ONE attribute, replaced as a whole
         self.labels = None
@@ -162,7 +168,7 @@ class _ListMemo:
     def matches(self, listTemplates):
         it = self.items
         return len(listTemplates) == len(it) and all(map(_is, listTemplates, it)) and \
-            [t[1].shape for t in listTemplates] == self.shapes
+            self._geometry(listTemplates) == self.shapes
 
 
 _list_memo = None

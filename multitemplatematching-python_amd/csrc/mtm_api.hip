@@ -735,6 +735,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 if (c->seg_skip_used) {         // (round 5: ... unless the score pass left the unflagged segments out - once more, in full)
                     c->timing.ncc_launches = 0;
                     c->timing.sq_launches = 0;
+                    c->seg_skip_used = false;   // (the re-run writes every output: the maps are complete and may be published)
                     MTMC(run_score_all(c));
                     HIPC(hipEventRecord(c->ev[1], c->stream));
                 }
@@ -820,6 +821,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     c->maps_valid = !c->hits_only_now && !c->ext_now && !c->seg_skip_used;
     c->refine_now = c->refine_scan_now = c->f32_exact_now = false;      // states of this call only
     c->sparse_now = false;
+    c->raw_rig_now = false;
+    c->zero_pending = false;
     *n_out = (int64_t)hits.size();
     c->last_hits.swap(hits);
     if ((int64_t)c->last_hits.size() > capacity) {
@@ -942,34 +945,63 @@ int mtm_find_matches_image_sharded_nms(mtm_ctx* c, const void* px, int rows, int
         set_error("mtm_find_matches_image_sharded_nms: bad arguments");
         return MTM_E_INVALID;
     }
+    // This is a COLLECTIVE: whatever goes wrong on this rank before the exchange (arguments that differ per rank, a bad
+    // image, a HIP error in the search) must not keep it away from the all-gather - the other ranks would wait in it without
+    // a time-out of their own.  A failing rank joins with zero hits and its error code in the slot header; every rank then
+    // returns an error (this one its own, the others MTM_E_COMM naming the rank) instead of a list with hits missing.
     std::vector<mtm_hit> local;
+    int local_rc = MTM_OK;
+    std::string local_msg;
     if (n_local_templ > 0) {                    // (a rank without units still takes part in the exchange)
         if ((int)c->templs.size() != n_local_templ || c->method != method) {
             set_error("mtm_find_matches_image_sharded_nms: global_idx / method do not match the context's template set");
-            return MTM_E_INVALID;
+            local_rc = MTM_E_INVALID;
         }
         host_trace(c, 0);
-        MTMC(check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image_sharded_nms"));
-        const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
-        int64_t n = 0;
-        int rc = find_matches_impl(c, MTM_PEAKS_LOCAL, score_threshold, nullptr, 0, &n, nullptr, &up);
-        if (rc != MTM_OK && rc != MTM_E_OVERFLOW) return rc;
-        local = c->last_hits;                   // (find_matches_impl keeps the whole list there whatever the capacity)
-        for (mtm_hit& h : local) h.templ_idx = global_idx[h.templ_idx];
+        if (local_rc == MTM_OK)
+            local_rc = check_image_args(px, rows, cols, chans, dtype, row_stride_bytes, "mtm_find_matches_image_sharded_nms");
+        if (local_rc == MTM_OK) {
+            const ImageArgs up{px, rows, cols, chans, dtype, row_stride_bytes};
+            int64_t n = 0;
+            const int rc = find_matches_impl(c, MTM_PEAKS_LOCAL, score_threshold, nullptr, 0, &n, nullptr, &up);
+            if (rc != MTM_OK && rc != MTM_E_OVERFLOW) local_rc = rc;
+        }
+        if (local_rc == MTM_OK) {
+            local = c->last_hits;               // (find_matches_impl keeps the whole list there whatever the capacity)
+            for (mtm_hit& h : local) h.templ_idx = global_idx[h.templ_idx];
+        } else {
+            local_msg = mtm_last_error();
+        }
     }
     std::vector<mtm_hit> all;
     if (c->comm && c->n_ranks > 1) {
         std::vector<int64_t> counts((size_t)c->n_ranks, 0);
+        std::vector<int32_t> flags;
         int64_t n_all = 0;
         all.resize(std::max<size_t>(4096, local.size() * (size_t)c->n_ranks));
-        int rc = mtm_comm_allgather_hits(c, local.data(), (int64_t)local.size(), all.data(), (int64_t)all.size(), counts.data(), &n_all);
+        int rc = comm_allgather_hits_flagged(c, local.data(), (int64_t)local.size(), (int32_t)local_rc, all.data(), (int64_t)all.size(),
+                                             counts.data(), &n_all, &flags);
         if (rc == MTM_E_OVERFLOW) {             // (a local matter: the gathered slots are still in the staging area)
             all.resize((size_t)n_all);
             rc = mtm_comm_last_gather(c, all.data(), n_all, counts.data(), &n_all);
         }
+        if (local_rc != MTM_OK) {               // this rank's own failure: its message, its code (the exchange has been served)
+            set_error(local_msg);
+            return local_rc;
+        }
         if (rc != MTM_OK) return rc;
+        for (size_t r = 0; r < flags.size(); ++r)
+            if (flags[r] != 0) {
+                set_error("mtm_find_matches_image_sharded_nms: rank " + std::to_string(r) + " failed its local search (code " +
+                          std::to_string(flags[r]) + "); no list is returned");
+                return MTM_E_COMM;
+            }
         all.resize((size_t)n_all);
     } else {
+        if (local_rc != MTM_OK) {
+            set_error(local_msg);
+            return local_rc;
+        }
         all.swap(local);
     }
     std::stable_sort(all.begin(), all.end(), [](const mtm_hit& a, const mtm_hit& b) { return a.templ_idx < b.templ_idx; });

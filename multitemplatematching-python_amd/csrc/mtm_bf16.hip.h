@@ -331,15 +331,16 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             const double area = (double)p.h * (double)p.w;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                double s2c = s2[i];
+                double s2c = s2[i], mu2 = 0.0;
 #pragma unroll
                 for (int cc = 0; cc < kMaxChans; ++cc)
                     if (cc < p.chans) {
                         const double m = (double)s_mu[cc];
                         s2c += m * (area * m - 2.0 * ts[i][cc]);
+                        mu2 += m * m;
                     }
-                // (+ the cancellation in s2c itself: three terms of the size of s2 and area mu^2)
-                s2c = fmax(s2c, 0.0) * 1.000001 + 1e-12 * (fabs(s2[i]) + area * (double)s_mu[0] * (double)s_mu[0]);
+                // (+ the cancellation in s2c itself: three terms of the size of s2 and area mu^2, summed over the channels)
+                s2c = fmax(s2c, 0.0) * 1.000001 + 1e-12 * (fabs(s2[i]) + area * mu2);
                 bp[i] = rig_r ? (double)p.rig_eps * sqrt(s2c) : sq[i] > 0.0 ? (double)p.rig_eps * sqrt(s2c) / sq[i] : 0.0;
             }
         }

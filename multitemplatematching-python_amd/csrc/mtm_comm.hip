@@ -92,8 +92,15 @@ int mtm_comm_init(mtm_ctx* c, const void* id, int n_ranks, int rank) {
     return MTM_OK;
 }
 
-int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, mtm_hit* out,
-                            int64_t capacity, int64_t* counts_out, int64_t* n_out) {
+}  // extern "C"
+
+namespace mtmi {
+// The exchange itself.  `my_flag` travels in the spare bytes of this rank's slot header and comes back for every rank in
+// `flags_out` (n_ranks entries): a rank whose LOCAL step failed still takes part - with zero records and its error code -
+// so that the others neither hang in the collective nor return a list with that rank's hits silently missing
+// (mtm_find_matches_image_sharded_nms; advisor finding of round 5).
+int comm_allgather_hits_flagged(mtm_ctx* c, const mtm_hit* local, int64_t n_local, int32_t my_flag, mtm_hit* out,
+                                int64_t capacity, int64_t* counts_out, int64_t* n_out, std::vector<int32_t>* flags_out) {
     if (!c || !c->comm || n_local < 0 || (n_local > 0 && !local) || !counts_out || !n_out) {
         set_error("mtm_comm_allgather_hits: bad arguments or communicator not initialised");
         return MTM_E_INVALID;
@@ -101,6 +108,7 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
     MTM_NOT_IN_FLIGHT(c, "mtm_comm_allgather_hits");
     HIPC(hipSetDevice(c->device));
     const int R = c->n_ranks;
+    if (flags_out) flags_out->assign((size_t)R, 0);
     // One all-gather of fixed-size slots: [count (16-byte header) | slot_hits records].  Every rank
     // sees every count; only if some rank produced more than kSlotHits hits is a second all-gather
     // issued with slots of the (globally known) maximum count.  The usual case is ONE collective of
@@ -130,6 +138,7 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
         std::memset(mine, 0, 16);
         const long long cnt = n_local;
         std::memcpy(mine, &cnt, sizeof(cnt));
+        std::memcpy(mine + 8, &my_flag, sizeof(my_flag));
         if (n_local > 0) std::memcpy(mine + 16, local, mine_bytes - 16);
         HIPC(hipMemcpyAsync(c->comm_send.p, mine, mine_bytes, hipMemcpyHostToDevice, c->stream));
         NCCLC(g_rccl.AllGather(c->comm_send.p, c->comm_recv.p, slot, ncclInt8, c->comm, c->stream));
@@ -164,6 +173,7 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
         for (int r = 0; r < R; ++r) {
             std::memcpy(&counts[r], all + slot * r, sizeof(long long));
             mx = std::max(mx, counts[r]);
+            if (flags_out) std::memcpy(&(*flags_out)[(size_t)r], all + slot * r + 8, sizeof(int32_t));
         }
         long long want = 512;
         while (want < 2 * mx) want <<= 1;
@@ -178,6 +188,23 @@ int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, m
     // the pinned staging area and mtm_comm_last_gather() delivers them - the exchange is NEVER repeated (the
     // other ranks, whose buffers were large enough, have already moved on).
     return mtm_comm_last_gather(c, out, capacity, counts_out, n_out);
+}
+}  // namespace mtmi
+
+extern "C" {
+
+int mtm_comm_allgather_hits(mtm_ctx* c, const mtm_hit* local, int64_t n_local, mtm_hit* out,
+                            int64_t capacity, int64_t* counts_out, int64_t* n_out) {
+    std::vector<int32_t> flags;
+    const int rc = mtmi::comm_allgather_hits_flagged(c, local, n_local, 0, out, capacity, counts_out, n_out, &flags);
+    if (rc != MTM_OK && rc != MTM_E_OVERFLOW) return rc;
+    for (size_t r = 0; r < flags.size(); ++r)
+        if (flags[r] != 0) {            // (a rank inside mtm_find_matches_image_sharded_nms whose local search failed)
+            set_error("mtm_comm_allgather_hits: rank " + std::to_string(r) + " reported a failed local step (code " +
+                      std::to_string(flags[r]) + "); its hits are missing from the gathered list");
+            return MTM_E_COMM;
+        }
+    return rc;
 }
 
 int mtm_comm_last_gather(mtm_ctx* c, mtm_hit* out, int64_t capacity, int64_t* counts_out, int64_t* n_out) {

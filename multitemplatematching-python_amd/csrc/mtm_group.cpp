@@ -60,14 +60,15 @@ struct mtm_group {
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
     unsigned long long generation = 0;
-    int pending = 0;
     bool stop = false;
     // Round 5: the same hand-off through atomics the workers and the caller SPIN on before they sleep on the condition
     // variables (a wake-up through the futex is 20-50 us, twice per search and on the critical path of every device)
     std::atomic<unsigned long long> gen_a{0};
     std::atomic<int> pending_a{0};
     std::atomic<bool> stop_a{false};
-    long long spin_us = 300;                    // MTM_GROUP_SPIN_US: how long a worker polls for the next job before it sleeps
+    long long spin_us = 300;                    // MTM_GROUP_SPIN_US: how long a worker polls for the next job before it sleeps; the
+                                                // caller polls for the searches' end for at most 1 ms.  0 = no polling at all:
+                                                // the setting for shared / CPU-constrained hosts (N + 1 busy cores otherwise)
     Job job;
     std::vector<mtm_hit> last_hits;
     // hit exchange
@@ -136,6 +137,10 @@ void run_job(mtm_group* g, Worker& w) {
 inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield" ::: "memory");
+#else
+    std::this_thread::yield();
 #endif
 }
 
@@ -166,7 +171,6 @@ void worker_main(mtm_group* g, int wi) {
         run_job(g, g->workers[(size_t)wi]);
         if (g->pending_a.fetch_sub(1, std::memory_order_acq_rel) == 1) {
             std::lock_guard<std::mutex> lk(g->mu);      // (the caller may be asleep on cv_done)
-            g->pending = 0;
             g->cv_done.notify_one();
         }
     }
@@ -347,7 +351,6 @@ static int group_search(mtm_group* g, const mtm_templ* templs, int n_templ, int 
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->job = Job{method, mode, score_threshold, px, rows, cols, chans, dtype, row_stride_bytes};
-        g->pending = nd;
         g->pending_a.store(nd, std::memory_order_release);
         ++g->generation;
         g->gen_a.store(g->generation, std::memory_order_release);
@@ -365,7 +368,8 @@ static int group_search(mtm_group* g, const mtm_templ* templs, int n_templ, int 
             }
             cpu_relax();
             if ((i & 255) == 255 &&
-                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 20 * g->spin_us)
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >
+                    std::min<long long>(20 * g->spin_us, 1000))
                 break;
         }
         if (!done) {

@@ -147,7 +147,10 @@ def test_uint16_whole_maps_on_partly_filled_last_segments(lib, method, exact):
                 t = units[idx][0]
                 shape = (H - t.shape[0] + 1, W - t.shape[1] + 1)
                 got = ctx.last_score_map(idx, shape)
-                exp = O.match_template(f32, t.astype(np.float32), method)
+                # (corr="direct": sums of integer-valued float64 products below 2^53 are exact - the oracle's FFT route for
+                # float32 input, which is what the reference turns uint16 into, carries ~1e-13 of noise: one last float32 bit
+                # in half a million pixels)
+                exp = O.match_template(f32, t.astype(np.float32), method, corr="direct")
                 if exact:
                     same = got == exp
                 else:

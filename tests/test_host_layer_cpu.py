@@ -219,6 +219,20 @@ def test_validated_list_memo_never_hides_a_change(mtm):
     v(lt2, image, float("inf"), None)
     t.shape = (1, t.size)
     _raises("too_large", lambda: v(lt2, image, float("inf"), None))
+    # dtype of a template / shape or dtype of a MASK changed in place: the records built for the old geometry must not be reused
+    t8, m8 = np.ascontiguousarray(small), np.full(small.shape, 255, np.uint8)
+    lt3 = [("m", t8, m8)]
+    v(lt3, image, float("inf"), None)
+    assert mtm._list_memo.matches(lt3)
+    m8.dtype = np.int8
+    assert not mtm._list_memo.matches(lt3)
+    m8.dtype = np.uint8
+    assert mtm._list_memo.matches(lt3)
+    m8.shape = (1, m8.size)
+    assert not mtm._list_memo.matches(lt3)
+    m8.shape = small.shape
+    t8.dtype = np.int8
+    assert not mtm._list_memo.matches(lt3)
     # labels follow the list, not the memo of another one
     raw = np.zeros(2, dtype=mtm._lib.HIT_DTYPE)
     raw["templ_idx"] = [0, 1]
