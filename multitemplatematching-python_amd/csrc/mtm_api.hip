@@ -87,7 +87,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // fused peak candidates: only when every class runs the MFMA kernel - and not while the maps of this context are
     // known to be dense (the last attempts overflowed the candidate list: smooth images at a low threshold), where the
     // full peak pass over the maps is the cheaper route
-    bool fused = mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0;
+    bool fused = mode == MTM_PEAKS_LOCAL && n > 0;
     if (fused && c->fuse_backoff > 0) {
         --c->fuse_backoff;
         fused = false;
@@ -98,7 +98,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // the flagged segments, from the hits-only screens: no faster - on such images the screens pass nearly everywhere.
     // uint8 classes on the lean 1- / 3-channel MFMA epilogue, every map 2-D.
     c->sparse_now = false;
-    if (mode == MTM_PEAKS_LOCAL && c->fuse_peaks && n > 0 && !fused && c->sparse_maps && c->hits_only &&
+    if (mode == MTM_PEAKS_LOCAL && n > 0 && !fused && c->sparse_maps && c->hits_only &&
         c->dtype == MTM_U8 && (c->chans == 1 || c->chans == 3) && (int)c->list2d.size() == n) {
         bool ok = true;
         int max_oh = 0, max_nseg = 0;
@@ -145,7 +145,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         // ... except, round 5, local extrema against a threshold while the kernel's candidate list is available: every output
         // whose upper bound (score + E, E in the sum's own units) passes the threshold is listed and re-scored exactly -
         // route 1 only; maps, the map scan and every overflow keep the float64 kernel
-        c->raw_rig_now = any_bf16 && all_bf16 && raw_m && mode == MTM_PEAKS_LOCAL && c->f32_mfma == 1 && c->f32_rig && fused;
+        c->raw_rig_now = any_bf16 && all_bf16 && raw_m && mode == MTM_PEAKS_LOCAL && c->f32_mfma == 1 && fused;
         if (any_bf16 && raw_m && (mode != MTM_PEAKS_GLOBAL || c->f32_mfma != 1) && !c->raw_rig_now) {
             c->f32_exact_now = true;
         } else if (any_bf16 && c->f32_mfma == 1) {
@@ -158,7 +158,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // (plain, two-row, row-multiplexed or in slabs - there in slab_combine_kernel; binary masks with the reciprocal
     // normalisation), the uint16 byte-plane kernel
     // or the float32 kernel; same switch as the hits-only mode (MTM_OPT_HITS_ONLY)
-    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && c->fuse_peaks && n > 0 && (c->chans == 1 || c->chans == 3) &&
+    if (mode == MTM_PEAKS_GLOBAL && c->hits_only && n > 0 && (c->chans == 1 || c->chans == 3) &&
         !c->f32_exact_now) {
         bool ok = true;
         for (const SizeClass& sc : c->classes)
@@ -200,7 +200,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         float eps = 0.0f;
         for (const SizeClass& sc : c->classes)
             if (resolved_kernel(c, sc) == MTM_KERNEL_MFMA_F32) eps = std::max(eps, bf16_rig_eps(c->chans, sc.h, bf16_nkb(sc.w)));
-        c->rig_cap = c->f32_rig ? std::max(kRefineThrMargin, 4.0f * eps) : kRefineThrMargin;
+        c->rig_cap = std::max(kRefineThrMargin, 4.0f * eps);
         c->scan_thr = tq - c->rig_cap * std::max(1.0f, std::fabs(tq));
     }
     if (pp_mode) {
@@ -215,7 +215,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         // the counter is normally cleared right after the previous call fetched it (off the critical path); round 5: a banded
         // uint8 call lets its first statistics launch do it (zero_pending; run_score_banded) - no fill command at all
         c->zero_pending = false;
-        if (banded && c->zero_in_stats && c->dtype == MTM_U8) c->zero_pending = true;
+        if (banded && c->dtype == MTM_U8) c->zero_pending = true;
         else if (c->cands.p != c->cands_zeroed) HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
         c->cands_zeroed = nullptr;
         c->cand_on = true;
@@ -506,8 +506,8 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             std::memcpy(&c->timing.sclk_mhz, land + 8, sizeof(float));
             if (ncand <= nfetch) {
                 // everything needed is on the host: clear the counter for the next call while this one finishes
-                // (unless this context's calls clear it in their own first kernel: zero_in_stats)
-                if (!(c->zero_in_stats && S.banded_u8) && hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess)
+                // (unless this context's calls clear it in their own first kernel: banded uint8 calls)
+                if (!S.banded_u8 && hipMemsetAsync(c->cands.p, 0, 16, c->stream) == hipSuccess)
                     c->cands_zeroed = c->cands.p;
                 const mtm_hit* cd = reinterpret_cast<const mtm_hit*>(land + 16);
                 // open-addressing table over the candidates (key -> index), kept in the context between calls
@@ -621,7 +621,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                                        (int)n_lists, dhits, (unsigned long long)c->hit_cap, counter);
                     // a suppression request: its device share follows at once (it reads the list's length on the device)
                     dnms = DeviceNms{};
-                    if (c->nms_req.on && c->nms_device && c->nms_req.max_overlap >= 0.0)
+                    if (c->nms_req.on && c->nms_req.max_overlap >= 0.0)
                         MTMC(queue_device_nms(c, dhits, counter, mode_min, &dnms));
                 } else
                     hipLaunchKernelGGL(peaks_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(),
@@ -640,7 +640,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             std::memcpy(tflags.data(), host_buf.data() + 3 * sizeof(count), sizeof(int) * n);
             unsigned int rig_wide = 0;
             if (use_fused) std::memcpy(&rig_wide, host_buf.data() + 2 * sizeof(count), sizeof(rig_wide));
-            if (pp_mode && c->refine_now && c->f32_rig && rig_wide != 0) {
+            if (pp_mode && c->refine_now && rig_wide != 0) {
                 // float32 map mode: some output that could pass the threshold has an error bound beyond what the scan's
                 // tolerances cover (a low-contrast window beside a brightness step) - the float64 kernel decides
                 c->cand_on = false;

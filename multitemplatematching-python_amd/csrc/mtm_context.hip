@@ -267,43 +267,22 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     }
     if (const char* v = std::getenv("MTM_CAND_PINNED")) c->cand_pinned = std::atoi(v);
     if (const char* v = std::getenv("MTM_FUSE_LAYOUT")) c->fuse_layout = std::atoi(v);
-    if (const char* v = std::getenv("MTM_BAND_ALIGN")) c->band_align = std::atoi(v);
-    if (const char* v = std::getenv("MTM_SINGLE_BAND")) c->single_band = std::atoi(v);
     if (const char* v = std::getenv("MTM_SEG_SKIP")) c->seg_skip = std::atoi(v);
-    if (const char* v = std::getenv("MTM_EAGER_COPY_STREAM")) c->eager_copy_stream = std::atoi(v);
-    if (const char* v = std::getenv("MTM_ZERO_IN_STATS")) c->zero_in_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_BAND_MIN_FILL")) c->band_min_fill = std::atof(v);
-    if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v);
+    if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
+    if (const char* v = std::getenv("MTM_ROW_MUX")) c->row_mux = std::atoi(v);
+    if (const char* v = std::getenv("MTM_FUSE_STATS")) c->fuse_stats = std::atoi(v);
+    if (const char* v = std::getenv("MTM_MFMA_R2")) c->mfma_r2 = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_F32_MFMA")) c->f32_mfma = std::atoi(v);
-    if (const char* v = std::getenv("MTM_F32_RIG")) c->f32_rig = std::atoi(v);
-    if (const char* v = std::getenv("MTM_KPACK")) c->kpack = std::atoi(v);
     if (const char* v = std::getenv("MTM_MASKSQ_FUSED")) c->masksq_fused = std::atoi(v);
-    if (const char* v = std::getenv("MTM_RM_EDGES")) c->rm_edges = std::atoi(v);
-    if (const char* v = std::getenv("MTM_CAND_STAGE")) c->cand_stage = std::atoi(v);
     if (const char* v = std::getenv("MTM_SPARSE_MAPS")) c->sparse_maps = std::atoi(v);
-    if (const char* v = std::getenv("MTM_NMS_DEVICE")) c->nms_device = std::atoi(v);
-    if (const char* v = std::getenv("MTM_NMS_DEVICE_MIN")) c->nms_device_min = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("MTM_NMS_DEVICE_MIN")) c->nms_device_min = std::atoll(v) < 0 ? (1ll << 60) : std::max(1, std::atoi(v));   // < 0: never
     if (const char* v = std::getenv("MTM_SCREEN_L1")) c->screen_l1 = std::atoi(v);
     if (const char* v = std::getenv("MTM_HOST_TRACE")) c->host_trace = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_CLASS_LANES")) c->class_lanes = std::max(1, std::min(8, std::atoi(v)));
-    if (const char* v = std::getenv("MTM_SLAB_STREAMS")) c->slab_concurrency = std::max(1, std::min(8, std::atoi(v)));
     if (const char* v = std::getenv("MTM_COMM_TIMEOUT_S")) c->comm_timeout_s = std::atof(v);
-    if (const char* v = std::getenv("MTM_SLAB_MFMA")) c->slab_mfma = std::atoi(v);
-    if (const char* v = std::getenv("MTM_SLAB_CW")) c->slab_cw = std::atoi(v);
-    if (const char* v = std::getenv("MTM_SLAB_MERGE")) c->slab_merge = std::atoi(v);
-    if (const char* v = std::getenv("MTM_TEMPL_ON_DEVICE")) c->templ_on_device = std::atoi(v);
-    if (const char* v = std::getenv("MTM_FUSE_PEAKS")) c->fuse_peaks = std::atoi(v);
     if (const char* v = std::getenv("MTM_HITS_ONLY")) c->hits_only = std::atoi(v);
-    if (const char* v = std::getenv("MTM_ROW_MUX")) c->row_mux = std::atoi(v);
-    if (const char* v = std::getenv("MTM_FUSE_STATS")) c->fuse_stats = std::atoi(v);
     if (const char* v = std::getenv("MTM_EXACT_DIV")) c->exact_div = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MFMA_PERSISTENT")) c->mfma_persistent = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MFMA_STAGGER")) c->mfma_stagger = std::atoi(v);
-    if (const char* v = std::getenv("MTM_MFMA_PER_CU")) c->mfma_per_cu = std::atoi(v);
-    if (const char* v = std::getenv("MTM_DOT4_VARIANT")) {
-        const int k = std::atoi(v);
-        if (dot_variant_ok(k)) c->dot_variant = k;
-    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -312,9 +291,9 @@ int mtm_ctx_create(mtm_ctx** out, int device_id) {
     // in creation order; created lazily by the first banded call it came AFTER the streams RCCL makes for a communicator
     // (mtm_group_comm_init) and shared a hardware queue with them - the band's statistics launch then started 67 us
     // after its copy ended instead of 8, every call (profiles/r05c: group + RCCL 1.04 ms against 0.87 with the host merge).
-    if (c->eager_copy_stream && ensure_copy_stream(c) != MTM_OK) c->copy_stream = nullptr;
+    if (ensure_copy_stream(c) != MTM_OK) c->copy_stream = nullptr;
     // (the first side lane of multi-class calls likewise: third in the rotation, a hardware queue of its own)
-    if (c->eager_copy_stream && c->class_lanes > 1) (void)ensure_lanes(c, 1);
+    if (c->class_lanes > 1) (void)ensure_lanes(c, 1);
     *out = c;
     return MTM_OK;
 }

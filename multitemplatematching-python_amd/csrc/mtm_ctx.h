@@ -127,7 +127,7 @@ struct SizeClass {
     bool mfma_ok = false;       // packed for ncc_mfma_kernel
     bool masked_int = false;    // masked class on the integer path: binary uint8 mask shared by all members
     unsigned long long mask_hash = 0;
-    long long mask_pack_off = -1;   // dot4 pack of the mask bytes (0xFF / 0) in the pack arena
+    long long mask_pack_off = -1;   // dot4 pack of the mask bytes (0xFF / 0) in the pack arena (MTM_ROW_MUX=0 / MTM_FUSE_STATS=0 only)
     long long apack_off = 0;    // byte offset of this class's A packs in the apack arena
     long long group_bytes = 0;
 };
@@ -168,16 +168,10 @@ struct mtm_ctx {
                                 // landing buffer itself (MfmaParams::cand_pin) - no fetch kernel behind the score launch (0: round 4)
     bool cand_pin_now = false;  // ... in the launches being queued
     size_t cand_pin_n = 0;
-    int eager_copy_stream = 1;  // MTM_EAGER_COPY_STREAM: the copy-side stream is created with the context (0: by the first banded call)
-    int single_band = 1;        // MTM_SINGLE_BAND: one-class uint8 calls below the banding size take the banded path as one band
     bool single_band_now = false;
-    int band_align = 1;         // MTM_BAND_ALIGN: upload bands end where their score launch is a whole number of work-group generations
-    int zero_in_stats = 1;      // MTM_ZERO_IN_STATS: a banded uint8 call clears the candidate header in its first statistics launch
     bool zero_pending = false;  // ... and has not done so yet
     int fuse_layout = 1;        // MTM_FUSE_LAYOUT: banded uploads convert a band's rows inside its statistics launch (0: planarize kernel)
     int lay_r0 = 0, lay_r1 = 0; // ... the rows the statistics launch being queued converts (run_score_banded -> launch_stats)
-    int cand_stage = 1;         // MTM_CAND_STAGE: peak candidates of a wave collected in LDS, one atomic per wave and work item (0: one per emission)
-    int rm_edges = 1;           // MTM_RM_EDGES: one-group K steps where a row-multiplexed wave's other group has no template row (0: off)
     int masksq_fused = 1;       // MTM_MASKSQ_FUSED: sum I^2 M of a masked class as ONE launch over both byte planes of I^2 that
                                 // writes the sum2 plane itself (0: round 3's two raw launches + masksq_combine_kernel)
 
@@ -207,7 +201,6 @@ struct mtm_ctx {
     } nms_req;
     long long nms_raw_count = -1;           // >= 0: the device pruned this call's peak list; the count before that
     long long nms_sure = 0;                 // ... and its first nms_sure hits are kept for certain (the neighbourhoods' best)
-    int nms_device = 1;
     long long nms_device_min = 4096;        // fewer peaks than this: the host is as fast
     DevBuf nms_buf;
     // segment flags (MTM_SPARSE_MAPS, default 1): the route of a call on dense maps (candidate list overflowed recently)
@@ -222,12 +215,9 @@ struct mtm_ctx {
     // statistics of the rows that became computable); the score kernel of a band waits for its event
     hipStream_t stats_stream = nullptr;     // non-null while a banded call queues its statistics launches
     int screen_l1 = 1;                      // MTM_SCREEN_L1: the hits-only screen starts with the per-lane bound (0: round 2's screen alone)
-    int kpack = 1;                          // MTM_KPACK: packed K for template widths that are not multiples of 64
     int f32_mfma = 1;                       // MTM_F32_MFMA / MTM_OPT_F32_MFMA: unmasked float32 classes on the bf16 matrix cores:
                                             // 0 = float64 kernel, 1 = bf16 screen + exact float64 re-scoring of everything
                                             // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are
-    int f32_rig = 1;                        // MTM_F32_RIG: the refined routes list by the rigorous per-output error bound of the bf16
-                                            // scores (Bf16Params::rig); 0 = round 3's empirical margins (kRefineThrMargin / kRefineNbrTol)
     int seg_skip = 1;                       // MTM_SEG_SKIP: dense route - outputs that cannot pass the threshold are not finished (MfmaParams::seg_skip)
     bool seg_skip_used = false;             // this call: some map holds such placeholders (the maps are not published)
     bool raw_rig_now = false;               // this call: a raw-sum method with a threshold, listed by the bound of the sum (route 1 only)
@@ -238,8 +228,9 @@ struct mtm_ctx {
     bool refine_now = false;                // bf16 classes of this call are refined
     bool refine_scan_now = false;           // ... by map scan + ring re-scoring (maps in memory) instead of kernel candidates
     bool f32_exact_now = false;             // bf16 classes run the float64 kernel in this call (refinement lists overflowed)
-    int mfma_r2 = 1;                        // MTM_MFMA_R2: 1 = two-row variant of the MFMA kernel where it applies, 3 = three rows, 0 = off
-    int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing)
+    int templ_on_device = 1;                // MTM_TEMPL_ON_DEVICE: uint8 template sets live on the device (views + device packing); 0 = packed on
+                                            // the host (the independent restatement test_template_sets_on_device compares with)
+    int mfma_r2 = 1;                        // MTM_MFMA_R2: 1 = two-row variant of the MFMA kernel where it applies, 0 = off
     // lanes of a multi-class call: size classes are independent (their own statistics, launches, scratch); consecutive
     // classes go to alternating lanes - a stream plus the per-class scratch buffers - so that the statistics / combine
     // kernels and the tail of one class run under the score kernel of the next.  Lane 0 is the context's own stream and
@@ -264,7 +255,6 @@ struct mtm_ctx {
     std::vector<hipStream_t> slab_streams;
     std::vector<hipEvent_t> slab_done;
     hipEvent_t slab_fork = nullptr;
-    int slab_concurrency = 8;               // MTM_SLAB_STREAMS (1: one after another on the main stream)
     std::vector<hipEvent_t> band_ev;
     int banded_cls = -1;                    // the size class a banded call runs under the upload (banded_ok)
     std::vector<double> upload_bands{0.25, 1.0};   // cumulative row fractions (MTM_UPLOAD_BANDS)
@@ -274,8 +264,6 @@ struct mtm_ctx {
     long long trace_n[24] = {0};
     long long trace_calls = 0;
     double trace_t0 = 0.0;
-    double band_min_fill = 1.0;                     // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work
-                                                    // items fill the resident work-group slots this many times (banded_ok)
 
     // templates
     bool have_templ = false;
@@ -293,9 +281,6 @@ struct mtm_ctx {
     std::vector<uint8_t> tstage;                    // host image of the source arena's prefix (set_templates_device)
     bool stage_pending = false;                     // copies from tstage / usrc_host may be in flight on `stream`
     bool place_pending = false;                     // copies from td_host / tlist_host may be in flight on `stream`
-    int slab_merge = 1;                             // MTM_SLAB_MERGE: equal-shaped slabs of a class in one launch (launch_ncc)
-    int slab_cw = 0;                                // MTM_SLAB_CW: 64 / 128 = fixed slab width for <= 16 templates (0: chosen per shape)
-    int slab_mfma = 1;                              // MTM_SLAB_MFMA: large templates as slabs on the MFMA kernel
     DevBuf slab_raw;                                // raw int32 maps of the slabs
     DevBuf tsrc, usrc_dev, tsums_dev, tgather;      // template source arena, unit views, source sums, gather scratch
     DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq, stats_blk;
@@ -310,15 +295,17 @@ struct mtm_ctx {
     // candidates the list is the cheaper way, and that is where it overflows.
     int64_t hit_cap = 1 << 18;
     int dot_variant = 0;
-    int fuse_stats = 1;        // MTM_FUSE_STATS: single-kernel window statistics (uint8, one channel)
+    int fuse_stats = 1;        // MTM_FUSE_STATS: single-kernel window statistics (0 = the two-pass kernels, which large windows and float32
+                               // images use anyway: test_uint16_fused_window_statistics_bit_for_bit compares the two)
+    int row_mux = 1;           // MTM_ROW_MUX: row-multiplexed MFMA tiling for classes of <= 16 templates (0 = the plain tiling:
+                               // test_fused_global_extremum runs both)
+    double band_min_fill = 1.0;   // MTM_BAND_MIN_FILL: a band is only worth a launch of its own if its work items fill the resident
+                               // work-group slots this many times (0 lets the band tests use small images)
     int n_cus = 0;
-    std::map<std::pair<const void*, size_t>, int> occupancy_cache;
-    int fuse_peaks = 1;        // MTM_FUSE_PEAKS: candidates from the MFMA epilogue + verify kernel
     // candidate emission of the current launch sequence (set by mtm_find_matches)
     bool cand_on = false;
     bool cand_min = false;
     float cand_thr = 0.f;
-    int row_mux = 1;           // MTM_ROW_MUX: row-multiplexed MFMA mode for classes of <= 16 templates
     int hits_only = 1;         // MTM_OPT_HITS_ONLY: mtm_find_matches does not materialise the score maps when
                                // every class runs the single-channel MFMA kernel (candidates + hash verify)
     int backoff_len = 16;      // length of the next back-off period: doubles with every overflow in a row (<= 1024), reset by a
@@ -333,9 +320,6 @@ struct mtm_ctx {
     int exact_div = 1;         // MTM_OPT_EXACT_DIV: 1 (default since round 5) = IEEE division in the MFMA epilogue, bit-identical to the
                                // oracle; 0 = correctly rounded reciprocals (<= 1 ulp(float32) on ~1e-8 of the outputs); 2 = strict: also
                                // the fused extremum of masked classes (reciprocal-only kernels) goes through maps + extremum_kernel
-    int mfma_persistent = 0;   // 1: persistent grid + atomic work counter (measured slightly slower)
-    int mfma_stagger = -1;     // < 0: automatic
-    int mfma_per_cu = 2;
     int auto_kernel = MTM_KERNEL_MFMA;   // what MTM_KERNEL_AUTO resolves to for uint8 classes (dot4 when not eligible)
 
     mtm_timing timing{};

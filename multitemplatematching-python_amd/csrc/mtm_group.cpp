@@ -75,8 +75,7 @@ struct mtm_group {
     int exchange = MTM_GROUP_EXCHANGE_HOST;     // what the next search uses
     int exchange_used = MTM_GROUP_EXCHANGE_HOST;   // what the last search used
     bool comm_ready = false;
-    // shared page-locked staging of the image (MTM_GROUP_STAGE=0: every worker uploads the caller's buffer itself)
-    bool stage_on = true;
+    // shared page-locked staging of the image (small images and failed allocations: every worker uploads the caller's buffer)
     void* pin = nullptr;
     size_t pin_cap = 0;
     size_t row_bytes = 0;                       // bytes of one image row in the staging buffer (tight)
@@ -203,7 +202,6 @@ int mtm_group_create(mtm_group** out, const int* device_ids, int n_devices) {
             return rc;
         }
     }
-    if (const char* v = std::getenv("MTM_GROUP_STAGE")) g->stage_on = std::atoi(v) != 0;
     if (const char* v = std::getenv("MTM_GROUP_SPIN_US")) g->spin_us = std::atoll(v);
     for (int i = 0; i < n_devices; ++i) g->workers[(size_t)i].th = std::thread(worker_main, g, i);
     *out = g;
@@ -338,7 +336,7 @@ static int group_search(mtm_group* g, const mtm_templ* templs, int n_templ, int 
     {
         const size_t esz = dtype == MTM_U8 ? 1 : dtype == MTM_U16 ? 2 : 4;
         const size_t row_bytes = (size_t)cols * (size_t)chans * esz, need = row_bytes * (size_t)rows;
-        g->staged_job = g->stage_on && nd > 1 && need >= ((size_t)1 << 20) && row_stride_bytes >= (int64_t)row_bytes;
+        g->staged_job = nd > 1 && need >= ((size_t)1 << 20) && row_stride_bytes >= (int64_t)row_bytes;
         if (g->staged_job && g->pin_cap < need) {
             if (g->pin) mtm_host_free(g->pin);
             g->pin = mtm_host_alloc(need);

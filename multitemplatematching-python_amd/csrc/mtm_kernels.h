@@ -8,7 +8,7 @@ constexpr int kMaxChans = 4;
 
 // float32 refinement (mtm_refine.hip.h): margins of the bf16 screen around the exact decisions
 constexpr float kRefineThrMargin = 1e-4f;   // candidates: approximate quality > threshold - margin * max(1, |threshold|)
-constexpr float kRefineNbrTol = 5e-5f;      // potential peaks of a map scan: approximate value >= 3x3 maximum - tolerance
+constexpr int kSlabStreams = 8;             // side streams of a slab class whose launches cannot fill the chip one at a time
 
 // Padding of the planar device image so that tile staging never needs bounds checks:
 // every kernel may read up to kPadCols bytes right of / kPadRows rows below the image.

@@ -237,7 +237,6 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         p.cpr_dstep = 256 % p.cpr;
         p.cpr_magic = 65536 / p.cpr + 1;
         p.group_bytes = -(long long)16 * p.nb * 1024;
-        p.rm_edges = c->rm_edges;
         p.only_li = -1;
         p.raw_map = raw_map;
         p.raw_pitch = map_pitch;
@@ -247,8 +246,6 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         p.tc_off = (int)lds_main;
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
         const size_t lds = (size_t)p.st_off;
-        constexpr int kSchedWords = 1 + 4096 + 8 * 32;      // item counter, per-CU arrivals, per-XCD item counters
-        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.mask_rm_off + (long long)16 * p.nb * 1024;
         const int grid = ((p.n_work + 7) / 8) * 8;
         const double km257 = 257.0 * 128.0 * sc.mask_ones;      // the mask operand is not biased
@@ -270,15 +267,13 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
             p.sq_k = km257;
             st.sum2 = sum2;             // (the kernel's output planes travel in the plane table)
             hipLaunchKernelGGL(mfma_raw_fn(true, false), dim3(grid), dim3(256), lds, c->stream, p,
-                               c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>(),
-                               c->sched.as<unsigned int>());
+                               c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>());
         } else {
             for (int x = 0; x < 2; ++x) {
                 p.img = c->sq_planes.as<uint8_t>() + (size_t)x * plane_bytes;
                 p.raw_out = c->raw16.as<int>() + (size_t)x * raw_map;
                 hipLaunchKernelGGL(mfma_raw_fn(true, false), dim3(grid), dim3(256), lds, c->stream, p,
-                                   c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>(),
-                                   c->sched.as<unsigned int>());
+                                   c->td.as<TemplDev>(), c->tlist.as<int>(), ap, st, c->maps.as<float>());
             }
             hipLaunchKernelGGL(masksq_combine_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, c->raw16.as<int>(),
                                c->raw16.as<int>() + raw_map, map_pitch, sum2, st.pitch, km257, oh, ow,
@@ -372,8 +367,6 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const long long raw_map = (long long)oh * map_pitch;
         const int S = (int)sc.slabs.size();
         MTMC(c->slab_raw.ensure(sizeof(int) * (size_t)S * n_all * (size_t)raw_map));
-        constexpr int kSchedWords = 1 + 4096 + 8 * 32;      // item counter, per-CU arrivals, per-XCD item counters
-        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
         const bool rmr = sc.slab_R > 0;
         // The slabs' launches are independent.  One of them is (output rows / 8R) x (columns / 256) work items - 91 for the
         // reference's own benchmark shape (2048^2 image, one 414 x 400 template: four slabs), against 512 resident
@@ -385,13 +378,13 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             const long long items = (long long)((ow + kMfSeg - 1) / kMfSeg) * ((oh + rows_per_item - 1) / rows_per_item) *
                                     (rmr ? 1 : (n_all + 31) / 32);
             const int cus = c->n_cus > 0 ? c->n_cus : 256;
-            if (items < 4LL * cus) n_side = (int)std::min<long long>(std::min(S, c->slab_concurrency), (4LL * cus + items - 1) / items);
+            if (items < 4LL * cus) n_side = (int)std::min<long long>(std::min(S, kSlabStreams), (4LL * cus + items - 1) / items);
         }
         // MTM_SLAB_MERGE (default 1): slabs of equal height and block count go out as ONE launch (MfmaParams::n_slab) - the
         // hardware fills the chip from one grid and back-fills as work-groups finish, where several launches on several
         // streams share four hardware queues (the fourth of four side-by-side slab launches started when the first had
         // ended: profiles/r04_r04v_slab) - on one side stream, so that the statistics pass still runs under it.
-        bool merged = rmr && S > 1 && c->slab_merge;
+        bool merged = rmr && S > 1;
         for (int k = 1; k < S && merged; ++k) {
             const SizeClass::Slab &a = sc.slabs[0], &b = sc.slabs[(size_t)k];
             merged = (b.r1 - b.r0) == (a.r1 - a.r0) && (b.c1 - b.c0 + 63) / 64 == (a.c1 - a.c0 + 63) / 64 &&
@@ -448,8 +441,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 p.nyb = (oh + 8 * R - 1) / (8 * R);
                 p.ntg = 1;
                 p.group_bytes = -(long long)R * p.nb * 1024;
-                p.rm_edges = c->rm_edges;
-                tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * R;
+                        tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * R;
             } else {
                 p.nyb = (oh + kMfRows - 1) / kMfRows;
                 p.ntg = (n_all + 31) / 32;
@@ -480,7 +472,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             // the fork and the join, not the launch)
             if (merged && slab_s != ncc_s) HIPC(hipEventRecord(evp.first, slab_s));
             hipLaunchKernelGGL(mfma_raw_fn(rmr, false), dim3(grid), dim3(256), lds, slab_s, p, td,
-                               c->tlist.as<int>() + sc.tlist_off, ap, st, maps, c->sched.as<unsigned int>());
+                               c->tlist.as<int>() + sc.tlist_off, ap, st, maps);
             if (merged && slab_s != ncc_s) {
                 HIPC(hipEventRecord(evp.second, slab_s));
                 ev_own = true;
@@ -590,8 +582,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.rm_steps = h + 2 * sc.rm_R - 1;
             p.rm_cstride = class_rm_pack_bytes(sc);
             p.rm_rsq = c->stats_rsq.as<double>();
-            p.rm_edges = c->rm_edges;
-            p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
+                p.nyb = (oh + 8 * sc.rm_R - 1) / (8 * sc.rm_R);
             p.ntg = 1;
             tile_rows = std::min(p.rm_steps, kMfChunkH) + (kMfRows - 1) * 2 * sc.rm_R;
         }
@@ -615,7 +606,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.cand_on = 1;
             p.hits_only = 1;
         }
-        if (p.cand_on && !ext && c->cand_stage) {             // wave-private candidate staging (see emit_at)
+        if (p.cand_on && !ext) {             // wave-private candidate staging (see emit_at)
             lds = (lds + 15) & ~(size_t)15;
             p.cs_off = (int)lds;
             lds += (size_t)kMfRows * kMfCandStageBytes;
@@ -651,35 +642,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             set_error("internal: no ncc_mfma_kernel instantiation for this class");
             return MTM_E_STATE;
         }
-        // persistent launch: as many work-groups as stay co-resident; items via an atomic counter
-        constexpr int kSchedWords = 1 + 4096 + 8 * 32;      // item counter, per-CU arrivals, per-XCD item counters
-        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
-        p.persistent = c->mfma_persistent;
-        int grid_launch = grid;
-        if (p.persistent) {
-            // residency query, cached per (kernel, LDS size): both calls are slow on the host
-            int per_cu = 0;
-            const auto key = std::make_pair(reinterpret_cast<const void*>(fn), lds);
-            auto it = c->occupancy_cache.find(key);
-            if (it == c->occupancy_cache.end()) {
-                HIPC(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds));
-                it = c->occupancy_cache.emplace(key, per_cu).first;
-            }
-            per_cu = it->second;
-            if (c->n_cus == 0) {
-                hipDeviceProp_t prop;
-                HIPC(hipGetDeviceProperties(&prop, c->device));
-                c->n_cus = prop.multiProcessorCount;
-            }
-            per_cu = std::max(1, std::min(per_cu, c->mfma_per_cu));
-            grid_launch = std::min(p.n_work, per_cu * c->n_cus);
-            // one main loop is chans*h*nb*16*MB MFMAs of 16 cycles; s_sleep(127) is ~8128 cycles
-            const double main_cycles = (double)c->chans * h * p.nb * 16.0 * mb * 16.0;
-            p.stagger_sleeps = c->mfma_stagger >= 0 ? c->mfma_stagger : (int)(0.75 * main_cycles / 8128.0 + 0.5);
-            HIPC(hipMemsetAsync(c->sched.p, 0, sizeof(unsigned int) * kSchedWords, c->stream));
-        }
-        hipLaunchKernelGGL(fn, dim3(grid_launch), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps,
-                           c->sched.as<unsigned int>());
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps);
         c->timing.kernel_used = MTM_KERNEL_MFMA;
     } else if (kernel == MTM_KERNEL_MFMA16) {
         // uint16: ONE launch over the image's two byte planes (the "channels" of the launch) x [T_hi | T_lo] of 16 templates
@@ -721,8 +684,6 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.st_off = (int)((lds_main + sizeof(MfTemplConst) * 32 + kMfItemBytes + 15) & ~(size_t)15);
         size_t lds = (size_t)p.st_off;                          // (no statistics prefetch: the epilogue reads them from memory)
         const int grid = ((p.n_work + 7) / 8) * 8;
-        constexpr int kSchedWords = 1 + 4096 + 8 * 32;      // item counter, per-CU arrivals, per-XCD item counters
-        MTMC(c->sched.ensure(sizeof(unsigned int) * kSchedWords));
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * 2 * sc.group_bytes;
         const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16;
         p.img = c->slot[c->cur].u8b.as<uint8_t>();             // plane 0: high bytes, plane 1: low bytes
@@ -757,7 +718,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
             p.cand_on = 1;
             p.hits_only = 1;
         }
-        if (p.cand_on && !ext && c->cand_stage) {
+        if (p.cand_on && !ext) {
             lds = (lds + 15) & ~(size_t)15;
             p.cs_off = (int)lds;
             lds += (size_t)kMfRows * kMfCandStageBytes;
@@ -767,8 +728,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         sel16.kp = sc.kp_nseg > 0;
         sel16.ext = ext;
         sel16.exact_div = c->exact_div != 0;
-        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps,
-                           c->sched.as<unsigned int>());
+        hipLaunchKernelGGL(mfma_kernel(sel16), dim3(grid), dim3(256), lds, ncc_s, p, td, tl_k, ap, st, maps);
         c->timing.kernel_used = MTM_KERNEL_MFMA16;
     } else if (kernel == MTM_KERNEL_MFMA_F32 && !c->f32_exact_now) {
         const int n_all = (int)sc.members.size();
@@ -811,7 +771,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
         const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
-        if (c->refine_now && !raw_m && c->f32_rig && only_li < 0) {
+        if (c->refine_now && !raw_m && only_li < 0) {
             // Round 5: the listing decisions of the refined routes by the rigorous per-output bound (Bf16Params::rig)
             p.rig = 1;
             p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb);
@@ -954,7 +914,7 @@ int launch_refine_scan(mtm_ctx* c, const SizeClass& sc) {
     const dim3 grd((ow + kPkCols - 1) / kPkCols, (oh + 4 * kPkRows - 1) / (4 * kPkRows), (unsigned)sc.members.size());
     hipLaunchKernelGGL(refine_scan_kernel, grd, dim3(256), 0, c->stream, c->maps.as<float>(), c->td.as<TemplDev>(),
                        c->tlist.as<int>() + sc.tlist_off, c->cand_min ? 1 : 0, c->scan_thr,
-                       c->f32_rig ? 2.0f * c->rig_cap : kRefineNbrTol, c->opt_border,
+                       2.0f * c->rig_cap, c->opt_border,
                        reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16),
                        (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256), c->cands.as<unsigned long long>());
     HIPC(hipGetLastError());
@@ -978,7 +938,6 @@ struct LaneScope {
         std::swap(c->slab_raw, L->slab_raw);
         std::swap(c->stats_hi, L->stats_hi);
         std::swap(c->mask_td, L->mask_td);          // (the scratch template record of the dot4 sum I^2 M pass)
-        std::swap(c->sched, L->sched);              // (item counters of persistent / staggered launches)
         std::swap(c->slab_streams, L->slab_streams);    // (side streams + fork / join events of a slab class)
         std::swap(c->slab_done, L->slab_done);
         std::swap(c->slab_fork, L->slab_fork);
@@ -1059,7 +1018,7 @@ static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
         // slabs: the raw launches read no statistics (slab_combine_kernel does) - their side streams fork HERE, ahead of
         // the statistics pass, which then runs under them (2048^2 x 414x400: hsum + vsum took 0.25 of the call's 1.16 ms)
         c->slab_fork_early = false;
-        if (!sc.slabs.empty() && c->slab_concurrency > 1 && resolved_kernel(c, sc) == MTM_KERNEL_MFMA) {
+        if (!sc.slabs.empty() && resolved_kernel(c, sc) == MTM_KERNEL_MFMA) {
             if (!c->slab_fork) HIPC(hipEventCreateWithFlags(&c->slab_fork, hipEventDisableTiming));
             HIPC(hipEventRecord(c->slab_fork, c->stream));
             c->slab_fork_early = true;
@@ -1152,7 +1111,7 @@ bool banded_ok(mtm_ctx* c, const ImageArgs& a) {
         }
     }
     c->single_band_now = false;
-    if (c->banded_cls < 0 && c->single_band && c->classes.size() == 1 && a.dtype == MTM_U8) {
+    if (c->banded_cls < 0 && c->classes.size() == 1 && a.dtype == MTM_U8) {
         // Round 5: a call too small to be worth two score launches (1080p x 8 templates) still takes the banded path's
         // kernels, as ONE band - layout conversion inside the statistics launch, the candidate header cleared there: two
         // launches and a fill command fewer than the plain upload path
@@ -1224,7 +1183,7 @@ int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
     // per launch.  (A part-filled last generation runs as long as a full one; on some boxes a first band of 0.25 of the
     // rows - 3.46 generations at 4K x 32 templates - cost 11 us of kernel time against 0.28 = 3.93, profiles/r05b.)
     double gen_blocks = 0.0;                // output row blocks per generation
-    if (c->band_align) {
+    {
         const int ow = a.cols - sc.w + 1, n = (int)sc.members.size();
         const int tg = u16 ? (n + 15) / 16 : sc.rm_R > 0 ? 1 : (n + (sc.r2 ? 16 : 32) - 1) / (sc.r2 ? 16 : 32);
         const int per_block = ((ow + kMfSeg - 1) / kMfSeg) * tg;

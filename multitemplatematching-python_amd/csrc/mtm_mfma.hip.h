@@ -160,7 +160,7 @@ __device__ __forceinline__ float finish_rt(int method, double corr, double s1, d
 
 // Masked templates (OpenCV's matchTemplateMask, binary uint8 mask, reference MTM/__init__.py:78,:216):
 // c1 = sum I*(T*M) comes from the MFMA accumulator exactly like an unmasked correlation (the packed
-// template is T*M), c2 = sum I^2*M from the MASKSQ dot4 pass.  No guards, as in OpenCV: 0/0 is NaN.
+// template is T*M), c2 = sum I^2*M from the class's raw row-multiplexed pass (MfmaParams::sq_fused; MTM_ROW_MUX=0: the MASKSQ dot4 pass).  No guards, as in OpenCV: 0/0 is NaN.
 template <int METHOD, bool EXACT_DIV>
 __device__ __forceinline__ float finish_lean_masked(int a32, double p1, double c2, double rsqrt_c2,
                                                     const MfTemplConst& T) {
@@ -261,8 +261,7 @@ template <int MB, int METHOD, bool EXACT_DIV, bool MASKED = false, bool RM = fal
 __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack,
-                                                          StatPlanes st, float* __restrict__ maps,
-                                                          unsigned int* __restrict__ sched) {
+                                                          StatPlanes st, float* __restrict__ maps) {
     constexpr bool C1 = METHOD >= 0;         // compile-time method: CH (1 or 3) channels, lean epilogue
     static_assert(CH == 1 || !MASKED, "multi-channel: unmasked paths only");
     static_assert(!EXT || (METHOD >= 0 && METHOD != kMfRaw), "fused extremum: compile-time-method paths");
@@ -270,29 +269,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
     // packed K is a compile-time variant (its own instantiations): two K loops in one kernel - a run-time choice -
     // push the register allocator of the 256-VGPR kernel into spilling accumulators
     static_assert(!KP || (!R2 && METHOD >= 0 && (METHOD != kMfRaw || !RM)), "packed K");
-    static_assert(!R2 || ((MB == 2 || MB == 3) && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two- / three-row variant");
-    static_assert(MB <= 2 || R2, "three MFMA groups: the three-row variant only");
+    // (a three-row form of this variant - 192 accumulators, 48 MFMAs per step - shipped as an opt-in through round 5: 3 % fewer
+    // cycles, 2.4 % less clock, no gain, and the only uint8 instantiations with hundreds of bytes of spills; removed in round 6)
+    static_assert(!R2 || (MB == 2 && METHOD >= 2 && METHOD <= 5 && !MASKED && !RM && CH == 1), "two-row variant");
+    static_assert(MB <= 2, "at most two MFMA groups per wave");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    // ---- scheduling.  Persistent mode: the grid is the number of co-resident work-groups and
-    // items are pulled from an atomic counter (sched[0]).  The MFMA main loop and the float64
-    // epilogue of an item use different pipes; two work-groups that share a CU overlap them only
-    // if they are out of phase, so the second work-group to arrive on a CU (per-CU arrival counter
-    // sched[1 + cu]) sleeps for about one main loop before its first item.  Placement only
-    // affects speed, never results.
+    // One work item per work-group; the block index orders the items so that the rows of the image an XCD reads stay in
+    // its own L2 (block b runs on XCD b % 8: XCD x works through the contiguous item range [x per_xcd, (x + 1) per_xcd)).
+    // (Rounds 2-5 also carried a persistent form - a grid of co-resident work-groups drawing items from atomic counters,
+    // with and without a start stagger, per chip and per XCD: measured several times, never faster, removed in round 6.)
     int* s_item = reinterpret_cast<int*>(smem + p.tc_off + 32 * (int)sizeof(MfTemplConst));
-    if (p.persistent) {
-        if (threadIdx.x == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
-            const unsigned cu = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
-            int late = (int)(atomicAdd(&sched[1 + cu], 1u) & 1u);
-            s_item[1] = late;
-        }
-        __syncthreads();
-        if (s_item[1])
-            for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // effective shader clock under this very load (the chip clocks to its power budget: MFMA-dense code runs well
     // below the 2.4 GHz the peak figures assume)
     // (the two start values wait in LDS: kept in registers they were live across the whole kernel and the compiler
@@ -304,46 +291,8 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         clk0[1] = __builtin_amdgcn_s_memrealtime();
     }
     const int per_xcd = (p.n_work + 7) >> 3;
-    // persistent == 2: items are drawn per XCD (one counter per XCD, a cache line apart, behind the per-CU arrival
-    // counters): XCD x works through the contiguous item range [x per_xcd, (x + 1) per_xcd) - the order the
-    // non-persistent launch gives it through its block index, which keeps the rows of the image an XCD reads in its own
-    // L2 - and takes from the other XCDs' ranges once its own is used up.  The draw for the NEXT item is issued when the
-    // K loop ends, so that its round trip runs under the epilogue.
-    auto xcd_counter = [&](unsigned x) { return &sched[1 + 4096 + 32 * x]; };
-    auto xcd_count = [&](unsigned x) { return min(per_xcd, max(0, p.n_work - (int)x * per_xcd)); };
-    unsigned next_draw = 0xFFFFFFFFu;           // thread 0: the own-XCD draw issued behind the previous item's K loop
-    for (int iter = 0;; ++iter) {
-    int wid;
-    if (p.persistent == 2) {
-        __syncthreads();                       // previous item fully done (s_item / LDS reuse)
-        if (threadIdx.x == 0) {
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
-            unsigned k = next_draw != 0xFFFFFFFFu ? next_draw : atomicAdd(xcd_counter(xcc), 1u);
-            int w = p.n_work;
-            if ((int)k < xcd_count(xcc)) {
-                w = (int)xcc * per_xcd + (int)k;
-            } else {
-                for (unsigned d = 1; d < 8 && w == p.n_work; ++d) {
-                    const unsigned x2 = (xcc + d) & 7u;
-                    if (xcd_count(x2) == 0) continue;
-                    k = atomicAdd(xcd_counter(x2), 1u);
-                    if ((int)k < xcd_count(x2)) w = (int)x2 * per_xcd + (int)k;
-                }
-            }
-            s_item[0] = w;
-        }
-        __syncthreads();
-        wid = s_item[0];
-    } else if (p.persistent) {
-        __syncthreads();                       // previous item fully done (s_item / LDS reuse)
-        if (threadIdx.x == 0) s_item[0] = (int)atomicAdd(&sched[0], 1u);
-        __syncthreads();
-        wid = s_item[0];
-    } else {
-        if (iter > 0) break;
-        wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    }
-    next_draw = 0xFFFFFFFFu;               // (a constant again until the K loop has ended: nothing lives across the loop)
+    do {        // (a scope to leave: `continue` / `break` below = this wave is done with the item)
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (wid >= p.n_work) break;
     if (!EXT && METHOD != kMfRaw && p.hits_only) {
         // hits-only launch whose candidate list overflowed: the call will be repeated with the maps in memory
@@ -439,6 +388,27 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     k.ext_thr_lo = ql - 1e-6 * fmax(1.0, fabs(ql));
                 }
             }
+            tcl[tid_i] = k;
+        } else if (!RM) {
+            // Beyond the list (zero-padded A rows): constants with which no screen can pass and nothing is read uninitialised -
+            // the bound acc + K + ... is hugely negative whatever the statistics are, the running best is out of reach.  The
+            // screens then need no per-lane "is this template in the list" test (three vector registers of indices that lived
+            // across them next to 128 accumulators, one of them in scratch memory); the epilogue's own loops stop at n_list.
+            MfTemplConst k;
+#pragma unroll
+            for (int cc = 0; cc < kMaxChans; ++cc) k.mean[cc] = 0.0, k.m128[cc] = 0.0;
+            k.templ_norm = 1.0;
+            k.templ_sum2 = 0.0;
+            k.mfma_k = -1e300;
+            k.rtempl_norm = 0.0;
+            k.tms = 1.0;
+            k.rsqrt_tms = 0.0;
+            k.map_off = 0;
+            k.map_pitch = 0;
+            k.all_ones = 0;
+            k.ext_thr_lo = 1e300;
+            k.ext_hi = 0xFFFFFFFFu;
+            k.flag_base = 0;
             tcl[tid_i] = k;
         }
     }
@@ -545,47 +515,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
-            if constexpr (R2 && MB == 3) {
-                // ---- K loop of the three-row variant: MFMA group g is output row y + g, whose template row at image row
-                // r is r - y - g - the operand group 0 used g steps earlier.  A operands rotate through four register
-                // sets (this step's, the two before it, the one being loaded), B operands alternate between two: the body
-                // is unrolled four times.  One LDS tile holds all h + 2 steps (the launcher only picks this variant for
-                // h + 2 <= kMfChunkR2), so no operand has to be carried from one chunk to the next.
-                const uint8_t* aptr = apack_g + (size_t)cy0 * 1024;
-                const uint8_t* lbase = smem + wave * wave_rows * p.lds_pitch + (j + q) * 16;
-                int loff = 0;
-                v4i qx, qy, qx2, qy2, a0, a1, a2 = v4i{0, 0, 0, 0}, a3 = v4i{0, 0, 0, 0};
-                if (mf_opaque_sgpr(p.hits_only)) __builtin_amdgcn_s_setprio(3);
-#define MTM_R3_LOAD(QA, QB, A)                                              \
-                QA = *reinterpret_cast<const v4i*>(lbase + loff);           \
-                QB = *reinterpret_cast<const v4i*>(lbase + loff + 16);      \
-                A = *reinterpret_cast<const v4i*>(aptr);
-#define MTM_R3_STEP(QA, QB, ACUR, AP1, AP2, QA2, QB2, ANEXT)                \
-                {                                                           \
-                    aptr += 1024;                                           \
-                    loff += p.lds_pitch;                                    \
-                    MTM_R3_LOAD(QA2, QB2, ANEXT)                            \
-                    __builtin_amdgcn_sched_barrier(0);                      \
-                    const v4i ar_[3] = {ACUR, AP1, AP2};                    \
-                    mfma_step<3>(acc, QA, QB, ar_);                         \
-                    __builtin_amdgcn_sched_barrier(0);                      \
-                }
-                MTM_R3_LOAD(qx, qy, a0)           // step 0; a3 / a2 = the (zero) operands of the two steps before it
-                int ks = 0;
-                for (; ks + 4 <= ch; ks += 4) {
-                    MTM_R3_STEP(qx, qy, a0, a3, a2, qx2, qy2, a1)
-                    MTM_R3_STEP(qx2, qy2, a1, a0, a3, qx, qy, a2)
-                    MTM_R3_STEP(qx, qy, a2, a1, a0, qx2, qy2, a3)
-                    MTM_R3_STEP(qx2, qy2, a3, a2, a1, qx, qy, a0)
-                }
-                if (ks < ch) { MTM_R3_STEP(qx, qy, a0, a3, a2, qx2, qy2, a1) }
-                if (ks + 1 < ch) { MTM_R3_STEP(qx2, qy2, a1, a0, a3, qx, qy, a2) }
-                if (ks + 2 < ch) { MTM_R3_STEP(qx, qy, a2, a1, a0, qx2, qy2, a3) }
-#undef MTM_R3_LOAD
-#undef MTM_R3_STEP
-                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-                __builtin_amdgcn_s_setprio(0);
-            } else if constexpr (R2) {
+            if constexpr (R2) {
                 // ---- K loop of the two-row variant (nb == 1: one step per image row).  B operands alternate between
                 // two register sets, A operands rotate through three (this step's, the previous step's - the second
                 // row's operand - and the one being loaded), so the body is unrolled six times; every request runs
@@ -720,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
             const int edge_lo = RM ? p.rm_R : 0, edge_hi = RM ? p.h + p.rm_R - 1 : 0x7fffffff;
 #define MTM_MF_STEP(QA, QB, A, K)                                                       \
             if constexpr (kRmEdges) {                                                   \
-                const int mode_ = !p.rm_edges ? 0 : srow < edge_lo ? 1 : srow >= edge_hi ? 2 : 0; \
+                const int mode_ = srow < edge_lo ? 1 : srow >= edge_hi ? 2 : 0; \
                 mfma_step2_rm(acc, QA, QB, A, __builtin_amdgcn_readfirstlane(mode_));   \
                 const bool last_ = sblk + 1 == p.nb;                                    \
                 srow += last_ ? 1 : 0;                                                  \
@@ -761,8 +691,6 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
 
-    if (p.persistent == 2 && threadIdx.x == 0)
-        next_draw = atomicAdd(xcd_counter(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u), 1u);
     // ---- epilogue: per wave, 8 templates at a time through LDS ([8 templates][pixel] int32).
     // A lane owns 4 consecutive pixels: their statistics are loaded ONCE into registers (they do
     // not depend on the template), per-template constants come from LDS, every (lane, template)
@@ -927,8 +855,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
         if (bestk) atomicMax(slot, bestk);
     };
+    const bool full4 = xq + 3 < p.ow;         // (a lane mask in scalar registers: as `xq + 3` recomputed per store it cost a vector register)
     auto store4 = [&](float* orow, const float (&out)[4]) {
-        if (xq + 3 < p.ow) {
+        if (full4) {
             *reinterpret_cast<float4*>(orow) = make_float4(out[0], out[1], out[2], out[3]);
         } else {
 #pragma unroll
@@ -994,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            continue;           // next work item (the loop's tail has no work-group barrier)
+            continue;           // done (nothing behind the scope needs a work-group barrier)
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -1488,13 +1417,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int lt = (R2 ? 0 : 16 * mb) + 4 * q + e;
-                            const bool live = tg * kTG + lt < p.n_list;     // beyond the list: zero-padded A rows
-                            const MfTemplConst& T = tcl[lt];
+                            const MfTemplConst& T = tcl[lt];        // (beyond the list: constants that cannot pass, see above)
                             const double m = METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0;
                             const double thr_lo_e = EXT ? T.ext_thr_lo : p.cand_thr_lo;
                             const double hi = EXT ? fmin(thr_lo_e, 0.999999) - 1e-6 : p.screen_hi;
                             const double bound = ((double)amax[e] + T.mfma_k) + fmax(m * s1lo[r], m * s1hi[r]);
-                            pass1 = pass1 || (live && (T.all_ones != 0 || thr_lo_e < 0.0 || bound > hi * T.templ_norm * sq_eff));
+                            pass1 = pass1 || T.all_ones != 0 || thr_lo_e < 0.0 || bound > hi * T.templ_norm * sq_eff;
                         }
                     }
                 } else {
@@ -1514,11 +1442,10 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int lt = (R2 ? 0 : 16 * mb) + 4 * q + e;
-                        const bool live = tg * kTG + lt < p.n_list;     // beyond the list: zero-padded A rows
                         const MfTemplConst& T = tcl[lt];
-                        kk[e] = live ? T.mfma_k : 0.0;
-                        mm[e] = live ? (METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0) : 0.0;
-                        pass = pass || (live && T.all_ones != 0);
+                        kk[e] = T.mfma_k;
+                        mm[e] = METHOD == MTM_TM_CCOEFF_NORMED ? T.m128[0] : 128.0;
+                        pass = pass || T.all_ones != 0;
                         umax[e] = -INFINITY;
                     }
 #pragma unroll
@@ -1549,19 +1476,21 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                 umax[e] = fmax(umax[e], u);
                             }
                         }
+                        // (level 2 is the rare path: one group of statistics in flight at a time - with all sixteen loads of a
+                        // row hoisted to the top the allocator ran out of registers next to the 128 accumulators)
+                        if constexpr (R2) __builtin_amdgcn_sched_barrier(0);
                     }
                     // quotient q = u / templ_norm: candidate if q > threshold; q >= 1 saturates (above any
                     // threshold < 1, tested anyway)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int lt = (R2 ? 0 : 16 * mb) + 4 * q + e;
-                        const bool live = tg * kTG + lt < p.n_list;
                         const double tn = tcl[lt].templ_norm;
                         // extremum mode: the template's own running best is the threshold (negative or none
                         // yet: no screen for this template)
                         const double thr_lo_e = EXT ? tcl[lt].ext_thr_lo : p.cand_thr_lo;
                         const double hi = EXT ? fmin(thr_lo_e, 0.999999) - 1e-6 : p.screen_hi;
-                        pass = pass || (live && (thr_lo_e < 0.0 || umax[e] > hi * tn));
+                        pass = pass || thr_lo_e < 0.0 || umax[e] > hi * tn;
                     }
                 }
                 wave_has_work = __builtin_amdgcn_ballot_w64(pass) != 0ull;
@@ -1803,7 +1732,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
         }
     }
     }   // epilogue scope
-    }   // work-item loop
+    } while (false);   // work item
     if (p.clk_out != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) {
         const unsigned long long* clk0 = reinterpret_cast<const unsigned long long*>(s_item + 4);
         const unsigned long long dt = __builtin_readcyclecounter() - clk0[0], dr = __builtin_amdgcn_s_memrealtime() - clk0[1];

@@ -63,10 +63,7 @@ struct MfmaParams {
     int only_li;             // >= 0: store only the template at this list position (mtm_score_map)
     int tc_off;              // byte offset in LDS of the per-template constants (after tile/epilogue)
     int st_off;              // byte offset in LDS of the prefetched window statistics (4 waves)
-    int persistent;          // 1: work items are pulled from *work_counter (grid = resident blocks)
-    int stagger_sleeps;      // s_sleep(127) count of the second block on a CU before its first item
-    int stagger_first_unused_;
-    int stagger_mode_unused_;
+    int pad0_[4];
     mtm_hit* cand_hits;
     unsigned long long* cand_counter;
     unsigned long long cand_cap;
@@ -120,7 +117,7 @@ struct MfmaParams {
     // c2 = acc + sq_k as float64 into st.sum2 plus its 16-pixel block minima into st.blk (no raw maps, no combine kernel).
     int cs_off;              // byte offset in LDS of the candidate staging buffers (4 waves x kMfCandStageBytes); 0 = none
     int sq_fused;
-    int rm_edges;            // row-multiplexed tilings: 1 = the edge steps (one group's A operand all zero) run the one-group step
+    int pad_rm_edges_;
     // segment flags (dense images, maps in memory, the lean single- / three-channel epilogue): when one of the 256 outputs
     // of a wave's row of a template passes the candidate test, the byte
     // seg_flags[flag_base(template) + row * flag_rstride + segment] is set - the peak pass visits only those row segments
@@ -164,7 +161,7 @@ struct MfTemplConst {
 };
 
 // One instantiation of ncc_mfma_kernel (defined in the mtm_mfma_*.hip units).
-using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*, unsigned int*);
+using MfmaFn = void (*)(MfmaParams, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*);
 
 // Template arguments of ncc_mfma_kernel as run-time values.
 struct MfmaSel {

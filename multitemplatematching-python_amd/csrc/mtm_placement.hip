@@ -40,7 +40,7 @@ void pack_template_dot4(const HostTempl& t, uint8_t* out) {
 // templates beyond the list are 0 (the signed zero), so they add nothing.
 std::vector<SizeClass::Slab> slab_layout(const mtm_ctx* c, const SizeClass& sc) {
     std::vector<SizeClass::Slab> out;
-    if (!c->slab_mfma || sc.masked || !sc.all_u8 || c->dtype != MTM_U8) return out;
+    if (sc.masked || !sc.all_u8 || c->dtype != MTM_U8) return out;
     for (int m : sc.members)
         if (!c->templs[(size_t)m].on_device) return out;
     auto layout = [&](int cw) {
@@ -59,8 +59,7 @@ std::vector<SizeClass::Slab> slab_layout(const mtm_ctx* c, const SizeClass& sc) 
     // items - 91 of 128 output rows x 256 columns for 2048^2 x 414x400 - whose waves cannot be split: with 128-tap slabs
     // that shape is 1.24 waves' worth of work per SIMD and the launches take as long as the SIMDs that got two.  Half as
     // wide slabs are twice as many waves of half the length (and more raw planes for slab_combine_kernel to add): the
-    // width whose greedy schedule over the CUs ends first is taken (MTM_SLAB_CW: fixed width).
-    if (c->slab_cw == 64 || c->slab_cw == 128) return layout(c->slab_cw);
+    // width whose greedy schedule over the CUs ends first is taken.
     std::vector<SizeClass::Slab> best = layout(128);
     if (!c->have_image || c->rows < sc.h || c->cols < sc.w) return best;
     const int oh = c->rows - sc.h + 1, ow = c->cols - sc.w + 1;
@@ -459,16 +458,6 @@ int place_templates(mtm_ctx* c) {
         }
         sc.r2 = (c->mfma_r2 && class_kernel[k] == MTM_KERNEL_MFMA && sc.rm_R == 0 && sc.slabs.empty() && n_cls > 16 &&
                  sc.w <= 64 && c->chans == 1 && !sc.masked && c->method >= MTM_TM_CCORR && c->fuse_stats) ? 2 : 0;
-        // MTM_MFMA_R2=3: three rows per wave where they fit - one LDS tile for all h + 2 steps, and two work-groups per CU
-        // (<= 80 KB each, the fused extremum's keys included).  48 MFMAs then share the operand shifts of a step instead of
-        // 32: +5 % on the K step in isolation (tools/ubench/step3), 3 % fewer cycles in the kernel - and 0.5 % less time,
-        // because the chip is at its power budget on random operands and answers with a 2.4 % lower clock
-        // (tools/ubench/power: the pure MFMA stream itself runs at 2.0 instead of 2.4 GHz on such data); its larger work
-        // items also quantise worse on the short launches of a banded upload.  Not the default.
-        if (sc.r2 && c->mfma_r2 == 3 && sc.h + 2 <= kMfChunkR2) {
-            const size_t lds3 = mfma_lds_bytes(sc.h + 2 + (kMfRows - 1) * 3, (sc.w + 63) / 64, (size_t)kMfRows * 2 * 1024 + 1024);
-            if (lds3 <= 80 * 1024) sc.r2 = 3;
-        }
         // packed K: uint8 classes (one channel, masked or not; RGB) on the plain or row-multiplexed tiling whose width
         // leaves part of the last 64-tap block empty.  Replaces the two-row variant where both apply (that one saves template loads,
         // this one whole MFMA steps).
@@ -477,7 +466,7 @@ int place_templates(mtm_ctx* c) {
             const int nseg = (sc.w + 15) / 16;
             const bool normed = c->method == MTM_TM_SQDIFF_NORMED || c->method == MTM_TM_CCORR_NORMED ||
                                 c->method == MTM_TM_CCOEFF_NORMED;       // the instantiated variants (ncc_mfma_kernel<.., KP>)
-            if (c->kpack && class_kernel[k] == MTM_KERNEL_MFMA && sc.slabs.empty() && nseg % 4 != 0 && normed &&
+            if (class_kernel[k] == MTM_KERNEL_MFMA && sc.slabs.empty() && nseg % 4 != 0 && normed &&
                 (c->chans == 1 || (c->chans == 3 && !sc.masked)) && (!sc.masked || c->method != MTM_TM_CCOEFF_NORMED)) {
                 sc.kp_nseg = nseg;
                 sc.r2 = false;
@@ -632,7 +621,7 @@ int place_templates(mtm_ctx* c) {
         if (class_kernel[k] != MTM_KERNEL_MFMA16) continue;
         {   // packed K for the two byte-plane passes (widths that are not multiples of 64), as for uint8 classes
             const int nseg = (sc.w + 15) / 16;
-            sc.kp_nseg = (c->kpack && nseg % 4 != 0) ? nseg : 0;
+            sc.kp_nseg = (nseg % 4 != 0) ? nseg : 0;
         }
         sc.group_bytes = sc.kp_nseg ? (long long)kp_blocks(sc.h, sc.kp_nseg) * 1024 : mfma_group_bytes(sc.h, sc.w, 1);
         sc.apack_off = (long long)a_off;
