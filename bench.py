@@ -732,6 +732,12 @@ def main():
                                          "frac": round(fl / I8_MFMA_PEAK_TOPS, 4),
                                          "frac_of_power_limited_ceiling": round(fl / I8_MFMA_RANDOM_OPERANDS_TOPS, 4),
                                          "sclk_mhz_in_kernel": ri.get("sclk_mhz_in_kernel")}
+            # what the band split of the upload costs the score kernel itself (two launch heads and tails, the copy / layout /
+            # statistics kernels running beside launch 1): part of `ms_per_step - kernel_ms_per_step` would otherwise hide here
+            if roof.get("launches_per_step", 1) > 1:
+                roof["band_split_overhead_ms"] = round(roof["kernel_ms_per_step"] - ri["kernel_ms_per_launch"], 4)
+                roof["fixed_cost_ms"] = round(out["ms_per_step"] - roof["kernel_ms_per_step"], 4)
+                roof["fixed_cost_incl_band_split_ms"] = round(out["ms_per_step"] - ri["kernel_ms_per_launch"], 4)
         if not args.no_cpu_baseline and world == 1 and not group_n:
             out["cpu_baseline"] = cpu_baseline(img, units, method, thr, args.cpu_sample_templates)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
