@@ -153,7 +153,9 @@ typedef struct mtm_timing {
                             banded call overlapped; what a profiler's per-launch average times the count gives) */
     int32_t f32_route;   /* float32 images on the bf16 matrix cores (MTM_OPT_F32_MFMA = 1), how the exact decisions were
                             reached: 0 not such a call, 1 kernel candidates re-scored, 2 map scan + neighbourhoods
-                            re-scored, 3 the float64 kernel after all (lists overflowed, or classes it has to run anyway) */
+                            re-scored, 3 the float64 kernel after all (lists overflowed, or classes it has to run anyway), 4 (round 6)
+                            templates with masks: two raw bf16 correlations as a screen, every output that could pass the threshold
+                            re-scored with the float64 kernel's own chains, "below" placeholders elsewhere (maps not published) */
     int32_t sq_launches; /* masked classes on the matrix cores: launches of the sum I^2 M pass (one per masked class) ... */
     float   masked_stat_ms; /* ... and the time they took (sum of the passes' own event pairs; 0 without masked classes) */
 } mtm_timing;

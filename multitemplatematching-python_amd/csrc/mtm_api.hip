@@ -83,6 +83,11 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     c->timing = mtm_timing{};
     c->maps_valid = false;
     c->seg_skip_used = false;
+    // masked float32 classes: the bf16 screen needs the threshold (local extrema only; mtm_score_map and N_object == 1 keep
+    // the float64 kernel).  What the peak pass compares with: the float32 threshold, on float32 scores.
+    c->mbf_used = false;
+    c->mbf_thr_on = mode == MTM_PEAKS_LOCAL && n > 0 && c->f32_mfma == 1;
+    c->mbf_thr = thr;
 
     // fused peak candidates: only when every class runs the MFMA kernel - and not while the maps of this context are
     // known to be dense (the last attempts overflowed the candidate list: smooth images at a low threshold), where the
@@ -817,8 +822,9 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
     c->nms_raw_count = -1;
     c->nms_sure = 0;
     c->timing.hits_only = c->sparse_now ? 2 : c->hits_only_now ? 1 : 0;
-    c->timing.f32_route = c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
-    c->maps_valid = !c->hits_only_now && !c->ext_now && !c->seg_skip_used;
+    c->timing.f32_route = c->mbf_used ? 4 : c->f32_exact_now ? 3 : !c->refine_now ? 0 : (c->refine_scan_now ? 2 : 1);
+    c->maps_valid = !c->hits_only_now && !c->ext_now && !c->seg_skip_used && !c->mbf_used;
+    c->mbf_thr_on = false;
     c->refine_now = c->refine_scan_now = c->f32_exact_now = false;      // states of this call only
     c->sparse_now = false;
     c->raw_rig_now = false;

@@ -210,7 +210,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             const int sc = min(x0 + (lane & 7) * (p.lds_cols - 1) / 7, p.cols - 1);
             float v = plane[(size_t)sr * p.pitch + sc];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0) s_mu[c] = v * (1.0f / 64.0f);          // (one slot per channel: the epilogue's error bound reads them back)
+            if (lane == 0) {
+                s_mu[c] = v * (1.0f / 64.0f);      // (one slot per channel: the epilogue's error bound reads them back)
+                if (p.mu_out != nullptr && tg == 0 && c == 0) p.mu_out[(size_t)yb * p.nseg + seg] = v * (1.0f / 64.0f);
+            }
         }
         __syncthreads();
         const float mu = s_mu[c];

@@ -70,6 +70,10 @@ struct Bf16Params {
     float rig_cap;
     float rig_thr;           // the exact quality threshold (score_threshold, negated for minima)
     unsigned int* rig_flag;
+    // Round 6 (masked float32 templates, mtm_maskf32.hip.h): the constant a work item subtracted from its tile, per (row
+    // block, segment) - mu_out[yb * nseg + seg], single-channel launches - so that a later pass can restate this launch's
+    // error bound eps * sqrt(sum (I - mu)^2 ...) with the very constant that was used.  nullptr: not wanted
+    float* mu_out;
 };
 
 // Per-template constants of a work item, staged in LDS once (the epilogue reads them as LDS broadcasts).

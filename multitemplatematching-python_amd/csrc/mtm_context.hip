@@ -155,6 +155,7 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
 
 void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype) {
     c->sq_valid = false;
+    c->f32_sq_valid = false;
     if (rows != c->rows || cols != c->cols || chans != c->chans || dtype != c->dtype) c->placed = false;
     c->rows = rows;
     c->cols = cols;
@@ -317,7 +318,8 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
-    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw, &c->seg_flags, &c->hits_t, &c->nms_buf}) b->release();
+    for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw, &c->seg_flags, &c->hits_t, &c->nms_buf, &c->td_u, &c->td_v,
+                      &c->mbf_maps, &c->f32_sq, &c->mbf_stats, &c->mbf_mu, &c->mbf_list}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->stats_blk, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})
@@ -467,13 +469,14 @@ int mtm_debug_poison(mtm_ctx* c, int pattern_byte, int what) {
             return MTM_OK;
         };
         for (mtm_ctx::DevBuf* d : {&c->stats, &c->stats_rsq, &c->stats_blk, &c->hs1, &c->hs2, &c->raw16, &c->slab_raw,
-                                   &c->stats_hi, &c->maps, &c->sq_planes})
+                                   &c->stats_hi, &c->maps, &c->sq_planes, &c->mbf_maps, &c->f32_sq, &c->mbf_stats, &c->mbf_mu})
             MTMC(fill(*d));
         for (auto& ln : c->lanes)
             for (mtm_ctx::DevBuf* d : {&ln.stats, &ln.stats_rsq, &ln.stats_blk, &ln.hs1, &ln.hs2, &ln.raw16, &ln.slab_raw, &ln.stats_hi})
                 MTMC(fill(*d));
         c->maps_valid = false;
         c->sq_valid = false;
+        c->f32_sq_valid = false;
     }
     HIPC(hipStreamSynchronize(c->stream));
     HIPC(hipGetLastError());

@@ -128,6 +128,10 @@ struct SizeClass {
     bool masked_int = false;    // masked class on the integer path: binary uint8 mask shared by all members
     unsigned long long mask_hash = 0;
     long long mask_pack_off = -1;   // dot4 pack of the mask bytes (0xFF / 0) in the pack arena (MTM_ROW_MUX=0 / MTM_FUSE_STATS=0 only)
+    // float32 class with masks on the bf16 matrix cores as a screen (mtm_maskf32.hip.h, round 6): bf16 packs of U = T M^2 and
+    // V = M^2 in the apack arena (the class itself stays a float64-kernel class: weights, fallback, exact re-scoring)
+    bool mask_bf16 = false;
+    long long mbf_off_u = -1, mbf_off_v = -1, mbf_group_bytes = 0;
     long long apack_off = 0;    // byte offset of this class's A packs in the apack arena
     long long group_bytes = 0;
 };
@@ -282,6 +286,13 @@ struct mtm_ctx {
     bool stage_pending = false;                     // copies from tstage / usrc_host may be in flight on `stream`
     bool place_pending = false;                     // copies from td_host / tlist_host may be in flight on `stream`
     DevBuf slab_raw;                                // raw int32 maps of the slabs
+    // masked float32 classes screened on the bf16 matrix cores: the U / V template tables, the approximate c1 / c2 maps,
+    // J = I^2, the window sums of I and J, the launches' tile constants, the list of outputs to re-score exactly
+    DevBuf td_u, td_v, mbf_maps, f32_sq, mbf_stats, mbf_mu, mbf_list;
+    bool mbf_thr_on = false;                        // this call: local extrema against mbf_thr (find_matches_impl)
+    float mbf_thr = 0.0f;
+    bool mbf_used = false;                          // this call: some class's maps hold "below the threshold" placeholders
+    bool f32_sq_valid = false;                      // f32_sq holds the square of the current float32 plane
     DevBuf tsrc, usrc_dev, tsums_dev, tgather;      // template source arena, unit views, source sums, gather scratch
     DevBuf td, tlist, weights, packs, apacks, maps, hs1, hs2, stats, hits, counters, sched, cands, mask_td, chash, raw16, stats_hi, tsum, stats_rsq, stats_blk;
 

@@ -7,6 +7,7 @@ using namespace mtmi;
 #include "mtm_k_stats.hip.h"
 #include "mtm_k_score.hip.h"
 #include "mtm_refine.hip.h"
+#include "mtm_maskf32.hip.h"
 
 namespace {
 
@@ -323,6 +324,146 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         HIPC(hipGetLastError());
     }
     *out = st;
+    return MTM_OK;
+}
+
+// Masked float32 class on the bf16 matrix cores (mtm_maskf32.hip.h): J = I^2 and the window sums of I and J, two raw
+// launches of ncc_bf16_kernel (I x U = T M^2, J x V = M^2) into scratch maps, the combine pass (placeholders + the list of
+// outputs that could pass the threshold), exact re-scoring of the list into the score maps.  *done = false: the list
+// overflowed (a threshold that passes nearly everything) - the caller runs the float64 kernel.
+static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool* done) {
+    *done = false;
+    const int h = sc.h, w = sc.w, oh = c->rows - h + 1, ow = c->cols - w + 1, n_all = (int)sc.members.size();
+    const ImageDev img = image_dev(c);
+    const size_t plane_floats = (size_t)img.f32_plane;
+    MTMC(c->f32_sq.ensure(sizeof(float) * plane_floats));
+    if (!c->f32_sq_valid) {
+        hipLaunchKernelGGL(square_f32_kernel, dim3((unsigned)((plane_floats / 4 + 255) / 256)), dim3(256), 0, c->stream, img.f32,
+                           c->f32_sq.as<float>(), plane_floats / 4);
+        c->f32_sq_valid = true;
+    }
+    // window sums (float64): S1, S2 of I and of J - the two-pass kernels of the float32 statistics, on both planes
+    const int st_pitch = (int)round_up((size_t)ow, 4);
+    const size_t st_plane = (size_t)st_pitch * oh;
+    MTMC(c->mbf_stats.ensure(sizeof(double) * 4 * st_plane));
+    double* s1i = c->mbf_stats.as<double>();
+    double* s2i = s1i + st_plane;
+    double* s1j = s2i + st_plane;
+    double* s2j = s1j + st_plane;
+    {
+        const int hs_pitch = (int)round_up((size_t)ow, 4);
+        const size_t hs_plane = (size_t)hs_pitch * c->rows;
+        MTMC(c->hs1.ensure(sizeof(double) * hs_plane));
+        MTMC(c->hs2.ensure(sizeof(double) * hs_plane));
+        const dim3 g1((ow + 256 * kHsumSeg - 1) / (256 * kHsumSeg), c->rows, 1);
+        const dim3 g2((ow + 255) / 256, (oh + kVsumBand - 1) / kVsumBand);
+        for (int pl = 0; pl < 2; ++pl) {
+            const float* src = pl == 0 ? img.f32 : c->f32_sq.as<float>();
+            hipLaunchKernelGGL((hsum_kernel<double>), g1, dim3(256), 0, c->stream, src, img.f32_pitch, img.f32_plane, c->rows, w, ow,
+                               c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, (long long)hs_plane);
+            hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream, c->hs1.as<double>(),
+                               c->hs2.as<double>(), hs_pitch, (long long)hs_plane, 1, h, oh, ow, 1.0 / ((double)h * w), 0, 0, 1,
+                               pl == 0 ? s1i : s1j, (double*)nullptr, (double*)nullptr, (double*)nullptr, pl == 0 ? s2i : s2j,
+                               (double*)nullptr, st_pitch);
+        }
+    }
+    // the two raw launches
+    MTMC(c->mbf_maps.ensure(sizeof(float) * 2 * std::max<size_t>(4, c->maps_floats)));
+    const int mb = n_all > 16 ? 2 : 1;
+    Bf16Params p{};
+    p.pitch = img.f32_pitch;
+    p.plane = img.f32_plane;
+    p.chans = 1;
+    p.rows = c->rows;
+    p.cols = c->cols;
+    p.h = h;
+    p.w = w;
+    p.oh = oh;
+    p.ow = ow;
+    p.nkb = bf16_nkb(w);
+    p.chunk_h = p.nkb <= 2 ? 64 : 32;
+    p.lds_cols = kBfSeg + 32 * p.nkb;
+    p.n_list = n_all;
+    p.nseg = (ow + kBfSeg - 1) / kBfSeg;
+    p.nyb = (oh + kBfRows - 1) / kBfRows;
+    p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
+    p.method = MTM_TM_CCORR;                                    // raw sums: acc + centre * S1
+    p.group_bytes = sc.mbf_group_bytes;
+    p.piece_bytes = sc.mbf_group_bytes * mfma_groups_alloc(n_all);
+    p.only_li = -1;
+    p.n_work = p.nseg * p.nyb * p.ntg;
+    const size_t n_tiles = (size_t)p.nseg * p.nyb;
+    MTMC(c->mbf_mu.ensure(sizeof(float) * 2 * n_tiles));
+    const size_t lds = bf16_lds_bytes(p.chunk_h, p.lds_cols);
+    const int grid = ((p.n_work + 7) / 8) * 8;
+    const int* tl_k = c->tlist.as<int>() + sc.tlist_off;
+    StatPlanes st{};
+    st.pitch = st_pitch;
+    for (int pl = 0; pl < 2; ++pl) {
+        p.img = pl == 0 ? img.f32 : c->f32_sq.as<float>();
+        p.mu_out = c->mbf_mu.as<float>() + (size_t)pl * n_tiles;
+        st.t[0] = pl == 0 ? s1i : s1j;
+        st.sum2 = pl == 0 ? s2i : s2j;
+        st.sq = st.sum2;                                        // (not read by a raw-sum launch)
+        const uint8_t* ap = c->apacks.as<uint8_t>() + (pl == 0 ? sc.mbf_off_u : sc.mbf_off_v);
+        const TemplDev* tdp = (pl == 0 ? c->td_u : c->td_v).as<TemplDev>();
+        hipLaunchKernelGGL(bf16_kernel(mb), dim3(grid), dim3(256), lds, c->stream, p, tdp, tl_k, ap, st, c->mbf_maps.as<float>());
+    }
+    // combine: placeholders into the score maps, the rest listed
+    const unsigned long long cap = (unsigned long long)std::min<int64_t>(std::max<int64_t>(c->hit_cap, 1 << 18), 4096LL * 256);
+    MTMC(c->mbf_list.ensure(16 + sizeof(mtm_hit) * (size_t)cap));
+    HIPC(hipMemsetAsync(c->mbf_list.p, 0, 16, c->stream));
+    MaskF32Params q{};
+    q.m1 = q.m2 = c->mbf_maps.as<float>();
+    q.td = c->td.as<TemplDev>();
+    q.td_u = c->td_u.as<TemplDev>();
+    q.td_v = c->td_v.as<TemplDev>();
+    q.tlist = tl_k;
+    q.s1i = s1i;
+    q.s2i = s2i;
+    q.s1j = s1j;
+    q.s2j = s2j;
+    q.st_pitch = st_pitch;
+    q.mu_i = c->mbf_mu.as<float>();
+    q.mu_j = c->mbf_mu.as<float>() + n_tiles;
+    q.nseg = p.nseg;
+    q.method = c->method;
+    q.mode_min = c->method == MTM_TM_SQDIFF ? 1 : 0;
+    q.thr = c->mbf_thr;
+    q.eps = bf16_rig_eps(1, h, p.nkb);
+    q.h = h;
+    q.w = w;
+    q.oh = oh;
+    q.ow = ow;
+    q.maps = maps;
+    q.list = reinterpret_cast<mtm_hit*>(c->mbf_list.as<uint8_t>() + 16);
+    q.counter = c->mbf_list.as<unsigned long long>();
+    q.cap = cap;
+    hipLaunchKernelGGL(maskf32_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q);
+    HIPC(hipGetLastError());
+    // how many?  (one small read-back: this path is milliseconds long, and an overflowing list changes the route)
+    unsigned long long count = 0;
+    HIPC(hipMemcpyAsync(&count, c->mbf_list.p, sizeof(count), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (count > cap) return MTM_OK;                             // *done stays false: float64 kernel
+    if (count > 0) {
+        RefineParams r{};
+        r.img = img;
+        r.td = c->td.as<TemplDev>();
+        r.weights = c->weights.as<double>();
+        r.method = c->method;
+        r.cls = c->td_host[(size_t)sc.members[0]].cls;
+        r.ring = 0;
+        r.list = q.list;
+        r.count = q.counter;
+        r.cap = cap;
+        r.maps = maps;
+        const unsigned rgrid = (unsigned)std::min<unsigned long long>(count, 16384ull);
+        hipLaunchKernelGGL(refine_rescore_masked_kernel, dim3(rgrid), dim3(64), 0, c->stream, r);
+        HIPC(hipGetLastError());
+    }
+    c->mbf_used = true;
+    *done = true;
     return MTM_OK;
 }
 
@@ -839,7 +980,15 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int ntx = (ow + kF64BX - 1) / kF64BX, nty = (oh + kF64BY - 1) / kF64BY;
         const dim3 grd(ntx * nty, n_list);
         MTMC(ensure_f32_plane(c));
-        if (sc.masked)
+        // masked float32 class, local extrema against a threshold: two raw launches of the bf16 kernel as a screen + exact
+        // re-scoring of everything that could pass (mtm_maskf32.hip.h); the float64 kernel only if that list overflows
+        bool screened = false;
+        if (sc.masked && sc.mask_bf16 && c->mbf_thr_on && only_li < 0 && n_list == (int)sc.members.size() && kernel == MTM_KERNEL_AUTO)
+            MTMC(launch_masked_bf16(c, sc, maps, &screened));
+        if (screened) {
+            c->timing.kernel_used = MTM_KERNEL_MFMA_F32;
+            c->timing.f32_route = 4;
+        } else if (sc.masked)
             hipLaunchKernelGGL(ncc_f64_kernel<true>, grd, dim3(256), 0, c->stream, img, td, tl,
                                c->weights.as<double>(), st, c->method, maps, ntx);
         else
@@ -971,7 +1120,9 @@ static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
     // re-scoring kernels walk the candidate list of the class that just ran.
     int n_lanes = 1;
     const size_t n_todo = c->classes.size() - (skip >= 0 ? 1 : 0);
-    if (c->classes.size() > 1 && n_todo > 0 && c->class_lanes > 1 && !c->refine_now && !c->refine_scan_now && !c->f32_exact_now)
+    bool mbf_any = false;                  // (masked float32 classes screened on the bf16 cores share their scratch buffers)
+    for (const SizeClass& sc : c->classes) mbf_any = mbf_any || (sc.mask_bf16 && c->mbf_thr_on);
+    if (c->classes.size() > 1 && n_todo > 0 && c->class_lanes > 1 && !c->refine_now && !c->refine_scan_now && !c->f32_exact_now && !mbf_any)
         n_lanes = (int)std::min<size_t>(skip >= 0 ? n_todo + 1 : n_todo, (size_t)c->class_lanes);
     if (n_lanes > 1) {
         MTMC(ensure_lanes(c, n_lanes - 1));

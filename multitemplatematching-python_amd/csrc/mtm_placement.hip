@@ -184,13 +184,21 @@ bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
     return c->f32_mfma && c->dtype == MTM_F32 && sc.all_f32 && !sc.masked && sc.w <= kBfMaxW &&
            c->rows > sc.h && c->cols > sc.w;
 }
+// float32 class with masks (float weights or binary), one channel, TM_SQDIFF / TM_CCORR_NORMED - the methods the reference
+// lets masks through for (MTM/__init__.py:78): two raw bf16 correlations as a screen + exact re-scoring (mtm_maskf32.hip.h)
+bool masked_bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
+    return c->f32_mfma == 1 && c->dtype == MTM_F32 && sc.all_f32 && sc.masked && c->chans == 1 && sc.w <= kBfMaxW &&
+           c->rows > sc.h && c->cols > sc.w && (c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR_NORMED);
+}
 inline int bf16_nkb(int w) { return (w + 31) / 32; }
 long long bf16_group_bytes(int h, int w, int chans) { return (long long)chans * h * bf16_nkb(w) * 1024; }
 
 // A packs of a float32 class for ncc_bf16_kernel: [piece 0 | piece 1][group of 16][ch][dy][32-tap block][lane = 16 q + i]
 // [8 bf16]: lane (i, q) holds taps 32 kb + 8 q .. + 7 of template i, centred by its channel mean and split
 // v = v0 + v1 (bfloat16, round to nearest even).  centre[] receives the means (TemplDev::centre).
-void pack_class_bf16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, std::vector<TemplDev>& td_host) {
+// `which`: 0 = the template's pixels; 1 = U = T M^2, 2 = V = M^2 (masked classes, single channel: mtm_maskf32.hip.h) - then
+// td_host is the U / V copy of the table: centre and centred_sum2 of the packed values go there
+void pack_class_bf16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, std::vector<TemplDev>& td_host, int which = 0) {
     const int h = sc.h, w = sc.w, nkb = bf16_nkb(w), chans = c->chans;
     const long long gb = bf16_group_bytes(h, w, chans);
     const int groups = mfma_groups_alloc((int)sc.members.size());
@@ -207,14 +215,22 @@ void pack_class_bf16(const mtm_ctx* c, const SizeClass& sc, uint8_t* out, std::v
         uint8_t* g = out + (li / 16) * gb;
         const int i = (int)(li % 16);
         const size_t plane = (size_t)h * w;
+        auto val = [&](size_t k) {
+            if (which == 0) return t.px[k];
+            const double m2 = t.mask[k] * t.mask[k];
+            return which == 1 ? t.px[k] * m2 : m2;
+        };
+        if (which) d.centred_sum2 = 0.0;
         for (int ch = 0; ch < chans; ++ch) {
             double mean = 0.0;
-            for (size_t k = 0; k < plane; ++k) mean += t.px[ch * plane + k];
+            for (size_t k = 0; k < plane; ++k) mean += val(ch * plane + k);
             mean /= (double)plane;
             d.centre[ch] = mean;
+            if (which)
+                for (size_t k = 0; k < plane; ++k) d.centred_sum2 += (val(ch * plane + k) - mean) * (val(ch * plane + k) - mean);
             for (int dy = 0; dy < h; ++dy)
                 for (int dx = 0; dx < w; ++dx) {
-                    const float v = (float)(t.px[ch * plane + (size_t)dy * w + dx] - mean);
+                    const float v = (float)(val(ch * plane + (size_t)dy * w + dx) - mean);
                     const uint16_t v0 = rne(v);
                     const uint16_t v1 = rne(v - bf16_to_float(v0));
                     const int kb = dx / 32, q = (dx % 32) / 8, e = dx % 8;
@@ -614,6 +630,20 @@ int place_templates(mtm_ctx* c) {
         sc.apack_off = (long long)a_off;
         a_off += (size_t)(2 * sc.group_bytes * mfma_groups_alloc((int)sc.members.size()));
     }
+    bool any_mbf = false;
+    for (size_t k = 0; k < classes.size(); ++k) {
+        SizeClass& sc = classes[k];
+        sc.mask_bf16 = class_kernel[k] == MTM_KERNEL_AUTO && masked_bf16_class_ok(c, sc);      // (AUTO: the float64 kernel)
+        sc.mbf_off_u = sc.mbf_off_v = -1;
+        if (!sc.mask_bf16) continue;
+        any_mbf = true;
+        sc.mbf_group_bytes = bf16_group_bytes(sc.h, sc.w, 1);
+        const size_t set_bytes = (size_t)(2 * sc.mbf_group_bytes * mfma_groups_alloc((int)sc.members.size()));
+        sc.mbf_off_u = (long long)a_off;
+        a_off += set_bytes;
+        sc.mbf_off_v = (long long)a_off;
+        a_off += set_bytes;
+    }
     size_t ts_off = 0;
     for (size_t k = 0; k < classes.size(); ++k) {
         SizeClass& sc = classes[k];
@@ -640,7 +670,26 @@ int place_templates(mtm_ctx* c) {
         dev_pack[k] = all_dev ? 1 : 0;
         any_host_pack = any_host_pack || !all_dev;
     }
+    any_host_pack = any_host_pack || any_mbf;
     std::vector<uint8_t> apacks(any_host_pack ? a_off : 0);
+    // masked float32 classes: the U = T M^2 / V = M^2 packs and their copies of the template table (centre, centred
+    // energy, and where the approximate c1 / c2 maps go: the real maps' layout, twice, in a scratch arena of their own)
+    std::vector<TemplDev> td_u, td_v;
+    if (any_mbf) {
+        td_u = td_host;
+        td_v = td_host;
+        for (size_t k = 0; k < classes.size(); ++k) {
+            if (!classes[k].mask_bf16) continue;
+            SizeClass u = classes[k];
+            u.group_bytes = classes[k].mbf_group_bytes;
+            pack_class_bf16(c, u, apacks.data() + classes[k].mbf_off_u, td_u, 1);
+            pack_class_bf16(c, u, apacks.data() + classes[k].mbf_off_v, td_v, 2);
+            for (int m : classes[k].members) {
+                td_u[(size_t)m].all_ones = td_v[(size_t)m].all_ones = 0;
+                td_v[(size_t)m].map_off += (long long)map_off;       // second half of the scratch arena
+            }
+        }
+    }
     std::vector<double> tsums(ts_off);
     for (size_t k = 0; k < classes.size(); ++k) {
         if (dev_pack[k]) continue;
@@ -714,6 +763,12 @@ int place_templates(mtm_ctx* c) {
                             hipMemcpyHostToDevice, c->stream));
     if (w_off) HIPC(hipMemcpyAsync(c->weights.p, wts.data(), sizeof(double) * w_off, hipMemcpyHostToDevice, c->stream));
     if (p_off) HIPC(hipMemcpyAsync(c->packs.p, packs.data(), p_off, hipMemcpyHostToDevice, c->stream));
+    if (any_mbf) {
+        MTMC(c->td_u.ensure(sizeof(TemplDev) * n));
+        MTMC(c->td_v.ensure(sizeof(TemplDev) * n));
+        HIPC(hipMemcpyAsync(c->td_u.p, td_u.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipMemcpyAsync(c->td_v.p, td_v.data(), sizeof(TemplDev) * n, hipMemcpyHostToDevice, c->stream));
+    }
     MTMC(c->tsum.ensure(sizeof(double) * std::max<size_t>(2, ts_off)));
     if (ts_off) HIPC(hipMemcpyAsync(c->tsum.p, tsums.data(), sizeof(double) * ts_off, hipMemcpyHostToDevice, c->stream));
     // device-side packing: gathers the A operands straight from the unit views (the template list is in place)
@@ -721,7 +776,7 @@ int place_templates(mtm_ctx* c) {
         if (dev_pack[k]) MTMC(pack_class_on_device(c, classes[k]));
     // host staging vectors go out of scope; the tables that stay in the context (td_host, tlist_host) need no wait
     // (set_templates_device)
-    const bool local_sources = any_host_pack || w_off || p_off || ts_off || units_all.size() > c->usrc_units;
+    const bool local_sources = any_host_pack || any_mbf || w_off || p_off || ts_off || units_all.size() > c->usrc_units;
     if (local_sources) HIPC(hipStreamSynchronize(c->stream));
     c->place_pending = !local_sources;
     drain.armed = false;

@@ -2836,3 +2836,112 @@ def test_sharded_step_in_one_native_call(mtm):
         assert len(ctx.search_sharded_nms([], None, 5, 0.5, 0.25, -1, [])) == 0
     finally:
         ctx.close()
+
+
+# ---- round 6: float32 templates WITH masks on the bf16 matrix cores (mtm_maskf32.hip.h) -----------------------------------
+def _mf32_disc(h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    return ((((yy - h / 2 + 0.5) / (h / 2)) ** 2 + ((xx - w / 2 + 0.5) / (w / 2)) ** 2) <= 1.0).astype(np.float32)
+
+
+def _mf32_case(rng, H, W, h, w, n, kind, scale):
+    img = (rng.random((H, W)).astype(np.float32) * scale).astype(np.float32)
+    if kind == "step":                      # low-contrast windows beside a brightness step: where the bound has to be wide
+        img[:, W // 2:] += np.float32(scale)
+        img[:, :W // 2] *= np.float32(0.01)
+    units = []
+    for i in range(n):
+        y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+        t = img[y:y + h, x:x + w].copy()
+        if i % 3 == 1:
+            t = (t + rng.normal(0, 0.05 * scale, t.shape)).astype(np.float32)
+        m = _mf32_disc(h, w) if i % 2 == 0 else rng.random((h, w)).astype(np.float32)      # binary and weight masks
+        units.append((t, m))
+    return img, units
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(150, 333, 24, 40, 5, "noise", 1.0), (150, 333, 20, 70, 20, "noise", 255.0),
+                                  (300, 420, 33, 17, 7, "step", 1.0), (260, 610, 64, 64, 37, "noise", 65535.0),
+                                  (200, 300, 9, 130, 3, "step", 100.0)], ids=lambda g: "%dx%d_%dx%d_n%d_%s" % g[:6])
+def test_float32_masked_templates_equal_the_float64_kernels(geom):
+    """Masked float32 templates (float weights or binary masks; everything that is not uint8 / uint8 reaches cv2 as float32:
+    MTM/__init__.py:71-88, :212-219) with a threshold: two raw launches of the bf16 kernel + a rigorous bound screen the
+    outputs, what could pass is re-scored with the float64 kernel's own chains (f32_route 4).  The records must be the
+    float64 kernel's, bit for bit, in order - for both methods masks are allowed with, thresholds far from and within one
+    float32 ulp of true peak scores, lists that overflow the screen's capacity (the float64 kernel takes over)."""
+    from MTM import _lib
+    rng = np.random.default_rng(11)
+    H, W, h, w, n, kind, scale = geom
+    img, units = _mf32_case(rng, H, W, h, w, n, kind, scale)
+    fast, exact = _lib.Context(0), _lib.Context(0)
+    exact.set_option(_lib.OPT_F32_MFMA, 0)
+    try:
+        for method in (3, 0):
+            if method == 3:
+                thrs = [0.9, 0.5, 0.999]
+            else:
+                base = float((units[0][0].astype(np.float64) * units[0][1]).var() * h * w)
+                thrs = [1e-3 * base + 1e-6, 0.3 * base]
+            ref = exact.search(units, img, method, _lib.PEAKS_LOCAL, thrs[0]).copy()
+            # thresholds a float32 ulp on either side of true peak scores
+            for s in sorted(set(float(v) for v in ref["score"]))[:3]:
+                thrs += [float(np.nextafter(np.float32(s), np.float32(-np.inf))), float(np.nextafter(np.float32(s), np.float32(np.inf)))]
+            routes = set()
+            for thr in thrs:
+                for pattern in (0xFF, 0x7F):
+                    fast.debug_poison(pattern, 7)
+                    a = fast.search(units, img, method, _lib.PEAKS_LOCAL, thr).copy()
+                    routes.add(fast.timing()["f32_route"])
+                    b = exact.search(units, img, method, _lib.PEAKS_LOCAL, thr).copy()
+                    assert exact.timing()["f32_route"] == 0
+                    assert a.tobytes() == b.tobytes(), (geom, method, thr, len(a), len(b))
+            if default_routes():
+                assert 4 in routes, (geom, method, routes)         # the screen really ran (an overflowing list may add route 0 / 3)
+        # the routes that must NOT take the screen: one score map, the global extremum - and they agree with the float64 kernel
+        for c_ in (fast, exact):
+            c_.set_image(img)
+            c_.set_templates(units, 3)
+        shape = (H - h + 1, W - w + 1)
+        assert np.array_equal(fast.score_map(0, shape), exact.score_map(0, shape), equal_nan=True)
+        a = fast.search(units, img, 3, _lib.PEAKS_GLOBAL, 0.0)
+        assert fast.timing()["f32_route"] != 4
+        assert a.tobytes() == exact.search(units, img, 3, _lib.PEAKS_GLOBAL, 0.0).tobytes()
+        # the maps of a screened call hold placeholders: not published
+        fast.search(units, img, 3, _lib.PEAKS_LOCAL, 0.9)
+        if fast.timing()["f32_route"] == 4:
+            with pytest.raises(_lib.MtmError):
+                fast.last_score_map(0, shape)
+    finally:
+        fast.close()
+        exact.close()
+
+
+@pytest.mark.gpu
+def test_float32_masked_through_the_module_api_against_the_oracle(mtm):
+    """The same route through MTM.matchTemplates / findMatches - uint16 pixels with a uint16 mask (what the reference casts to
+    float32, mask included: MTM/__init__.py:71-74, :81-88), a float32 image with a float32 weight mask, and a call that mixes
+    masked and unmasked templates - against the oracle: same boxes, scores to 1e-5."""
+    rng = np.random.default_rng(23)
+    img16 = rng.integers(0, 65536, (180, 260), dtype=np.uint16)
+    m16 = (_mf32_disc(30, 44) * 65535).astype(np.uint16)
+    lt16 = [("a%d" % i, img16[y:y + 30, x:x + 44].copy(), m16) for i, (y, x) in enumerate([(10, 20), (100, 150), (60, 200)])]
+    got = mtm.findMatches(lt16, img16, method=3, score_threshold=0.9)
+    exp = O.find_matches([(n, t.astype(np.float32), m.astype(np.float32)) for n, t, m in lt16], img16.astype(np.float32),
+                         method=3, score_threshold=0.9)
+    assert len(got) == len(exp) >= 3, (len(got), len(exp))
+    assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+    imgf = rng.random((200, 310)).astype(np.float32)
+    wm = rng.random((25, 37)).astype(np.float32)
+    ltf = [("w%d" % i, imgf[y:y + 25, x:x + 37].copy(), wm) for i, (y, x) in enumerate([(5, 9), (120, 200), (77, 33), (150, 260)])]
+    ltf.append(("plain", imgf[40:40 + 25, 100:100 + 37].copy()))             # no mask: the call mixes both kinds
+    got = mtm.matchTemplates(ltf, imgf, method=3, score_threshold=0.95, maxOverlap=0.2)
+    exp = O.match_templates(ltf, imgf, method=3, score_threshold=0.95, maxOverlap=0.2)
+    assert len(got) == len(exp) >= 5
+    assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+    # TM_SQDIFF (minima below the threshold, raw units): noisy copies, so that the scores are sums and not cancellation noise
+    lts = [(n, (t + rng.normal(0, 0.05, t.shape)).astype(np.float32), m) for n, t, m in ltf[:4]]
+    got = mtm.findMatches(lts, imgf, method=0, score_threshold=3.0)
+    exp = O.find_matches(lts, imgf, method=0, score_threshold=3.0)
+    assert len(got) == len(exp) >= 4, (len(got), len(exp))
+    assert_hits_equal(canon(got), canon(exp), tol=1e-5)
