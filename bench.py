@@ -320,12 +320,32 @@ def main():
                                               "rccl all-gather inside ncclGroupStart/End (one process, ncclCommInitAll)"
                                               if group_exchange == "rccl" else "host merge (one process, mtm_group)")
     comm_ranks = 1
+
+    class _ControlPlaneStore:
+        """The RCCL unique id travels over the gloo group that exists anyway (the package's own TcpStore would listen on a
+        second port, MASTER_PORT + 1 - one more thing that can be taken on a shared node)."""
+        def broadcast(self, payload=None):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+    rccl_error = None
     try:
-        exchange = HitExchange("rccl", rank, world, context=ctx) if not group_n else None     # unique id through the package's TCP store
+        exchange = (HitExchange("rccl", rank, world, context=ctx, store=_ControlPlaneStore() if world > 1 else None)
+                    if not group_n else None)
         if world > 1:
             comm_ranks = int(getattr(ctx, "n_ranks", 1))           # ranks of the RCCL communicator that was created
     except Exception as e:  # noqa: BLE001 - keep the job alive: same records over gloo instead of RCCL
-        sys.stderr.write("[bench] RCCL hit exchange unavailable (%s); falling back to gloo\n" % e)
+        rccl_error = e
+    if world > 1:
+        # every rank takes the same exchange: one that failed to join the communicator would otherwise wait in a gloo
+        # all-gather while the others wait in RCCL's
+        flags = [None] * world
+        dist.all_gather_object(flags, rccl_error is None)
+        if rccl_error is None and not all(flags):
+            rccl_error = RuntimeError("rank(s) %s could not join the communicator" % [i for i, ok in enumerate(flags) if not ok])
+    if rccl_error is not None:
+        sys.stderr.write("[bench] RCCL hit exchange unavailable (%s); falling back to gloo\n" % rccl_error)
 
         def gloo_allgather(payload):
             parts = [None] * world

@@ -86,7 +86,8 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // masked float32 classes: the bf16 screen needs the threshold (local extrema only; mtm_score_map and N_object == 1 keep
     // the float64 kernel).  What the peak pass compares with: the float32 threshold, on float32 scores.
     c->mbf_used = false;
-    c->mbf_thr_on = mode == MTM_PEAKS_LOCAL && n > 0 && c->f32_mfma == 1;
+    c->mbf_thr_on = (mode == MTM_PEAKS_LOCAL || mode == MTM_PEAKS_GLOBAL) && n > 0 && c->f32_mfma == 1;
+    c->mbf_global = mode == MTM_PEAKS_GLOBAL;
     c->mbf_thr = thr;
 
     // fused peak candidates: only when every class runs the MFMA kernel - and not while the maps of this context are

@@ -319,7 +319,7 @@ void mtm_ctx_destroy(mtm_ctx* c) {
     for (auto& sl : c->slot)
         for (DevBuf* b : {&sl.raw, &sl.u8, &sl.u8b, &sl.f32}) b->release();
     for (DevBuf* b : {&c->tsrc, &c->usrc_dev, &c->tsums_dev, &c->tgather, &c->slab_raw, &c->seg_flags, &c->hits_t, &c->nms_buf, &c->td_u, &c->td_v,
-                      &c->mbf_maps, &c->f32_sq, &c->mbf_stats, &c->mbf_mu, &c->mbf_list}) b->release();
+                      &c->mbf_maps, &c->f32_sq, &c->mbf_stats, &c->mbf_mu, &c->mbf_list, &c->mbf_best}) b->release();
     for (DevBuf* b : {&c->td, &c->tlist, &c->weights, &c->packs, &c->apacks, &c->maps, &c->hs1, &c->hs2, &c->stats, &c->hits,
                       &c->counters, &c->sched, &c->cands, &c->mask_td, &c->chash, &c->raw16, &c->stats_hi, &c->tsum, &c->stats_rsq, &c->stats_blk, &c->sq_planes, &c->comm_send,
                       &c->comm_recv})

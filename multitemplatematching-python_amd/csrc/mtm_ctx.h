@@ -288,8 +288,9 @@ struct mtm_ctx {
     DevBuf slab_raw;                                // raw int32 maps of the slabs
     // masked float32 classes screened on the bf16 matrix cores: the U / V template tables, the approximate c1 / c2 maps,
     // J = I^2, the window sums of I and J, the launches' tile constants, the list of outputs to re-score exactly
-    DevBuf td_u, td_v, mbf_maps, f32_sq, mbf_stats, mbf_mu, mbf_list;
-    bool mbf_thr_on = false;                        // this call: local extrema against mbf_thr (find_matches_impl)
+    DevBuf td_u, td_v, mbf_maps, f32_sq, mbf_stats, mbf_mu, mbf_list, mbf_best;
+    bool mbf_thr_on = false;                        // this call: local extrema against mbf_thr, or (mbf_global) N_object == 1 (find_matches_impl)
+    bool mbf_global = false;
     float mbf_thr = 0.0f;
     bool mbf_used = false;                          // this call: some class's maps hold "below the threshold" placeholders
     bool f32_sq_valid = false;                      // f32_sq holds the square of the current float32 plane

@@ -439,7 +439,17 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
     q.list = reinterpret_cast<mtm_hit*>(c->mbf_list.as<uint8_t>() + 16);
     q.counter = c->mbf_list.as<unsigned long long>();
     q.cap = cap;
-    hipLaunchKernelGGL(maskf32_combine_kernel, dim3((ow + 255) / 256, oh, n_all), dim3(256), 0, c->stream, q);
+    if (c->mbf_global) {
+        // N_object == 1: the templates' best lower bounds first (ordered-float keys behind the list's header + records), then
+        // everything that reaches them
+        MTMC(c->mbf_best.ensure(sizeof(unsigned int) * c->templs.size()));
+        HIPC(hipMemsetAsync(c->mbf_best.p, 0, sizeof(unsigned int) * c->templs.size(), c->stream));
+        hipLaunchKernelGGL(maskf32_best_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, q, n_all, c->mbf_best.as<unsigned int>());
+        hipLaunchKernelGGL(maskf32_list_best_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, q, n_all,
+                           c->mbf_best.as<unsigned int>());
+    } else {
+        hipLaunchKernelGGL(maskf32_combine_kernel, dim3((ow + 255) / 256, oh), dim3(256), 0, c->stream, q, n_all);
+    }
     HIPC(hipGetLastError());
     // how many?  (one small read-back: this path is milliseconds long, and an overflowing list changes the route)
     unsigned long long count = 0;

@@ -16,8 +16,10 @@
 //   * every other output is listed and refine_rescore_masked_kernel replaces it by ncc_f64_kernel<true>'s own value -
 //     same FMA chains, same order, bit for bit.
 // The peak pass then runs on a map that equals the float64 kernel's wherever that matters: identical hit lists by
-// construction.  The maps are not publishable (mtm_last_score_map refuses); mtm_score_map and N_object == 1 keep the
-// float64 kernel.  A list that overflows sends the class to the float64 kernel for this call.
+// construction.  N_object == 1 (cv2.minMaxLoc) works the same way with the templates' own best LOWER bound in the place of the
+// threshold (two passes: maskf32_best_kernel, maskf32_list_best_kernel) - the exact extremum and every exact tie with it are
+// re-scored, the extremum search over the maps does the rest.  The maps are not publishable (mtm_last_score_map refuses);
+// mtm_score_map keeps the float64 kernel.  A list that overflows sends the class to the float64 kernel for this call.
 #pragma once
 #include "mtm_device_util.hip.h"
 #include "mtm_refine.hip.h"
@@ -54,60 +56,148 @@ struct MaskF32Params {
     unsigned long long cap;
 };
 
-__global__ __launch_bounds__(256) void maskf32_combine_kernel(MaskF32Params p) {
-    const int t = p.tlist[blockIdx.z];
-    const TemplDev T = p.td[t];
+// What the bounds need of the PIXEL (template-independent): sum (I - mu_I)^2 and sum (J - mu_J)^2 with their own cancellation
+// covered, as in ncc_bf16_kernel's epilogue.  One thread owns a pixel and walks the class's templates: the four statistics
+// planes are read once per pixel, not once per (pixel, template) - 10 GB of traffic at 4K x 32 otherwise.
+struct MaskF32Pixel {
+    double si, sj;
+};
+__device__ __forceinline__ MaskF32Pixel maskf32_pixel(const MaskF32Params& p, int x, int y) {
+    const size_t sidx = (size_t)y * p.st_pitch + x;
+    const size_t tile = (size_t)(y / kBfRows) * p.nseg + x / kBfSeg;
+    const double mi = (double)p.mu_i[tile], mj = (double)p.mu_j[tile];
+    const double area = (double)p.h * (double)p.w;
+    const double s2i = p.s2i[sidx], s2j = p.s2j[sidx];
+    double si = s2i + mi * (area * mi - 2.0 * p.s1i[sidx]);
+    double sj = s2j + mj * (area * mj - 2.0 * p.s1j[sidx]);
+    MaskF32Pixel o;
+    o.si = fmax(si, 0.0) * 1.000001 + 1e-12 * (fabs(s2i) + area * mi * mi);
+    o.sj = fmax(sj, 0.0) * 1.000001 + 1e-12 * (fabs(s2j) + area * mj * mj);
+    return o;
+}
+// Bounds of the QUALITY (the score; minima: minus the score) of output (x, y) of template t from the two approximate sums:
+// *lb <= exact quality <= *ub for finite inputs (+-inf where a bound does not exist: c2 - E2 <= 0, tms <= 0).
+__device__ __forceinline__ void maskf32_bounds(const MaskF32Params& p, int t, const TemplDev& T, const MaskF32Pixel& px, int x, int y,
+                                               float* approx, double* lb, double* ub) {
+    const TemplDev& U = p.td_u[t];
+    const TemplDev& V = p.td_v[t];
+    const double c1 = (double)p.m1[U.map_off + (size_t)y * U.map_pitch + x];
+    const double c2 = (double)p.m2[V.map_off + (size_t)y * V.map_pitch + x];
+    const double e1 = (double)p.eps * sqrt(px.si * U.centred_sum2) * 1.000002 + 3e-7 * fabs(c1) + 1e-30;
+    const double e2 = (double)p.eps * sqrt(px.sj * V.centred_sum2) * 1.000002 + 6e-7 * fabs(c2) + 1e-30;
+    const double tms = T.templ2_mask2_sum;
+    if (p.method == MTM_TM_SQDIFF) {
+        // minima: quality = -score, score = -2 c1 + c2 + tms
+        const double s = -2.0 * c1 + c2 + tms;
+        const double slack = (2.0 * e1 + e2) + 4e-7 * (2.0 * fabs(c1) + fabs(c2) + fabs(tms));
+        *ub = -(s - slack);
+        *lb = -(s + slack);
+        *approx = (float)s;
+        return;
+    }
+    // TM_CCORR_NORMED: c1 / sqrt(tms c2), no guards (0 / 0 is NaN, as in OpenCV)
+    const double num_hi = c1 + e1, num_lo = c1 - e1;
+    const double c2_lo = c2 - e2, c2_hi = c2 + e2;
+    if (!(tms > 0.0)) {
+        *ub = INFINITY;
+        *lb = -INFINITY;
+    } else {
+        if (num_hi <= 0.0) *ub = c2_hi > 0.0 ? num_hi / sqrt(tms * c2_hi) : 0.0;
+        else *ub = c2_lo > 0.0 ? num_hi / sqrt(tms * c2_lo) : INFINITY;
+        if (num_lo >= 0.0) *lb = c2_hi > 0.0 ? num_lo / sqrt(tms * c2_hi) : 0.0;
+        else *lb = c2_lo > 0.0 ? num_lo / sqrt(tms * c2_lo) : -INFINITY;
+        *ub += 4e-7 * fmax(1.0, fabs(*ub));          // (the float32 rounding of the exact score)
+        *lb -= 4e-7 * fmax(1.0, fabs(*lb));
+    }
+    *approx = (float)(c1 / sqrt(tms * fmax(c2, 1e-300)));
+}
+
+// Local extrema against a threshold: "below" placeholders where the upper bound stays below it, the rest listed.
+// Grid: (ceil(ow / 256), oh); every thread walks the n_list templates of the class for its pixel.
+__global__ __launch_bounds__(256) void maskf32_combine_kernel(MaskF32Params p, int n_list) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     const bool on = x < p.ow && y < p.oh;
-    bool list_it = false;
-    float approx = 0.0f;
-    if (on) {
-        const TemplDev& U = p.td_u[t];
-        const TemplDev& V = p.td_v[t];
-        const double c1 = (double)p.m1[U.map_off + (size_t)y * U.map_pitch + x];
-        const double c2 = (double)p.m2[V.map_off + (size_t)y * V.map_pitch + x];
-        const size_t sidx = (size_t)y * p.st_pitch + x;
-        const size_t tile = (size_t)(y / kBfRows) * p.nseg + x / kBfSeg;
-        const double mi = (double)p.mu_i[tile], mj = (double)p.mu_j[tile];
-        const double area = (double)p.h * (double)p.w;
-        // sum (I - mu)^2 = S2 - 2 mu S1 + A mu^2 (+ its own cancellation), as in ncc_bf16_kernel's epilogue
-        const double s2i = p.s2i[sidx], s2j = p.s2j[sidx];
-        double si = s2i + mi * (area * mi - 2.0 * p.s1i[sidx]);
-        double sj = s2j + mj * (area * mj - 2.0 * p.s1j[sidx]);
-        si = fmax(si, 0.0) * 1.000001 + 1e-12 * (fabs(s2i) + area * mi * mi);
-        sj = fmax(sj, 0.0) * 1.000001 + 1e-12 * (fabs(s2j) + area * mj * mj);
-        const double e1 = (double)p.eps * sqrt(si * U.centred_sum2) * 1.000002 + 3e-7 * fabs(c1) + 1e-30;
-        const double e2 = (double)p.eps * sqrt(sj * V.centred_sum2) * 1.000002 + 6e-7 * fabs(c2) + 1e-30;
-        const double tms = T.templ2_mask2_sum;
-        const double thr = (double)p.thr;
-        if (p.method == MTM_TM_SQDIFF) {
-            // minima: listed unless even the LOWER bound of the score stays above the threshold
-            const double s = -2.0 * c1 + c2 + tms;
-            const double lo = s - (2.0 * e1 + e2) - 4e-7 * (2.0 * fabs(c1) + fabs(c2) + fabs(tms));
-            list_it = !(lo > thr);
-            approx = (float)s;
-        } else {
-            // TM_CCORR_NORMED: c1 / sqrt(tms c2), no guards (0 / 0 is NaN, as in OpenCV)
-            const double num_hi = c1 + e1;
-            const double c2_lo = c2 - e2, c2_hi = c2 + e2;
-            double ub;
-            if (!(tms > 0.0)) ub = INFINITY;
-            else if (num_hi <= 0.0) ub = c2_hi > 0.0 ? num_hi / sqrt(tms * c2_hi) : 0.0;
-            else ub = c2_lo > 0.0 ? num_hi / sqrt(tms * c2_lo) : INFINITY;
-            list_it = !(ub + 4e-7 * fmax(1.0, fabs(ub)) < thr);
-            approx = (float)(c1 / sqrt(tms * fmax(c2, 1e-300)));
+    const MaskF32Pixel px = maskf32_pixel(p, min(x, p.ow - 1), min(y, p.oh - 1));
+    // quality threshold: the score threshold for maxima, minus it for minima (a hit needs quality > threshold in float32)
+    const double thr_q = p.mode_min ? -(double)p.thr : (double)p.thr;
+    for (int li = 0; li < n_list; ++li) {
+        const int t = p.tlist[li];
+        const TemplDev& T = p.td[t];
+        bool list_it = false;
+        float approx = 0.0f;
+        if (on) {
+            double lb, ub;
+            maskf32_bounds(p, t, T, px, x, y, &approx, &lb, &ub);
+            list_it = !(ub < thr_q);         // (inputs that are not finite: the comparison is false - listed, the exact chain decides)
+            if (!list_it) p.maps[T.map_off + (size_t)y * T.map_pitch + x] = p.mode_min ? INFINITY : -INFINITY;
         }
-        // (inputs that are not finite: every comparison above is false - listed, the exact chain decides)
-        if (!list_it) p.maps[T.map_off + (size_t)y * T.map_pitch + x] = p.mode_min ? INFINITY : -INFINITY;
+        mtm_hit rec;
+        rec.templ_idx = t;
+        rec.x = x;
+        rec.y = y;
+        rec.w = p.w;
+        rec.h = p.h;
+        rec.score = approx;
+        cand_append(on && list_it, p.counter, p.cap, p.list, rec);
     }
-    mtm_hit rec;
-    rec.templ_idx = t;
-    rec.x = x;
-    rec.y = y;
-    rec.w = p.w;
-    rec.h = p.h;
-    rec.score = approx;
-    cand_append(on && list_it, p.counter, p.cap, p.list, rec);
+}
+
+// N_object == 1 (cv2.minMaxLoc), pass 1: the best LOWER bound of the quality per template (`best[t]`: an ordered-float key,
+// atomicMax; NaN never takes part), and every output's UPPER bound parked in its score-map slot (rounded up).
+__global__ __launch_bounds__(256) void maskf32_best_kernel(MaskF32Params p, int n_list, unsigned int* __restrict__ best) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const bool on = x < p.ow && y < p.oh;
+    const MaskF32Pixel px = maskf32_pixel(p, min(x, p.ow - 1), min(y, p.oh - 1));
+    for (int li = 0; li < n_list; ++li) {
+        const int t = p.tlist[li];
+        const TemplDev& T = p.td[t];
+        uint32_t key = 0u;
+        if (on) {
+            float approx;
+            double lb, ub;
+            maskf32_bounds(p, t, T, px, x, y, &approx, &lb, &ub);
+            float ubf = (float)ub;
+            if ((double)ubf < ub) ubf = nextafterf(ubf, INFINITY);
+            if (!(ub == ub)) ubf = INFINITY;                      // not finite: to be re-scored whatever the others say
+            p.maps[T.map_off + (size_t)y * T.map_pitch + x] = ubf;
+            float lbf = (float)lb;
+            if ((double)lbf > lb) lbf = nextafterf(lbf, -INFINITY);
+            if (lb == lb) key = mf_float_order(lbf);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_down((int)key, off);
+            key = other > key ? other : key;
+        }
+        if ((threadIdx.x & 63) == 0 && key) atomicMax(&best[t], key);
+    }
+}
+// ... pass 2: every output whose upper bound reaches its template's best lower bound is listed (the exact extremum and
+// every exact tie with it are among them), the others get the placeholder no extremum search can pick.
+__global__ __launch_bounds__(256) void maskf32_list_best_kernel(MaskF32Params p, int n_list, const unsigned int* __restrict__ best) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const bool on = x < p.ow && y < p.oh;
+    for (int li = 0; li < n_list; ++li) {
+        const int t = p.tlist[li];
+        const TemplDev& T = p.td[t];
+        bool list_it = false;
+        if (on) {
+            float* slot = p.maps + T.map_off + (size_t)y * T.map_pitch + x;
+            const float ub = *slot;
+            const uint32_t bk = best[t];
+            const float lb_best = bk ? mf_order_float(bk) : -INFINITY;
+            list_it = !(ub < lb_best);
+            if (!list_it) *slot = p.mode_min ? INFINITY : -INFINITY;
+        }
+        mtm_hit rec;
+        rec.templ_idx = t;
+        rec.x = x;
+        rec.y = y;
+        rec.w = p.w;
+        rec.h = p.h;
+        rec.score = 0.0f;
+        cand_append(on && list_it, p.counter, p.cap, p.list, rec);
+    }
 }
 
 // refine_rescore_kernel for masked templates: the two FMA chains of ncc_f64_kernel<true> - c1 over K1 = T M^2, c2 over

@@ -10,6 +10,8 @@ as tests of the driver's suite: image width 333, so that the last segments hold 
 in both normalisation modes, hit lists of the hits-only route against map mode; and the memory the kernels must not depend on
 is poisoned ahead of every call (conftest's fixture does it ahead of every test, these tests repeat it with both patterns).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -142,7 +144,8 @@ def test_uint16_whole_maps_on_partly_filled_last_segments(lib, method, exact):
         for pattern in (0xFF, 0x7F):
             ctx.debug_poison(pattern, 7)
             ref = ctx.search(units, img, method, lib.PEAKS_LOCAL, thr).copy()
-            assert ctx.timing()["kernel_used"] == 4            # MTM_KERNEL_MFMA16
+            if not os.environ.get("MTM_KERNEL"):               # (tools/alt_modes.sh forces the VALU kernels through it)
+                assert ctx.timing()["kernel_used"] == 4        # MTM_KERNEL_MFMA16
             for idx in (0, 4, 12, 13, 20, 36, 37, 41, 50, 54, 55, 59, 67, n - 1):
                 t = units[idx][0]
                 shape = (H - t.shape[0] + 1, W - t.shape[1] + 1)

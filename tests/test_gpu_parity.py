@@ -50,7 +50,21 @@ def hits_of(oracle_hits):
 
 
 def set_kernel(ctx, name):
-    ctx.set_option(1, KERNELS[name])
+    """"auto" = what a fresh context starts with: the library's choice - or the kernel tools/alt_modes.sh forces through
+    MTM_KERNEL for this run of the suite (the tests' `finally: set_kernel(ctx, "auto")` must put THAT back)."""
+    if name == "auto":
+        from conftest import fresh_options
+        ctx.set_option(1, fresh_options()[1])
+    else:
+        ctx.set_option(1, KERNELS[name])
+
+
+def restore_hits_only(ctx):
+    """What a fresh context starts with (1 - or the 0 of tools/alt_modes.sh's MTM_HITS_ONLY=0 run); setting the option also
+    clears the dense-map back-off."""
+    from conftest import fresh_options
+    from MTM import _lib
+    ctx.set_option(_lib.OPT_HITS_ONLY, fresh_options()[_lib.OPT_HITS_ONLY])
 
 
 def map_close(got, exp, tol=1e-4):
@@ -485,7 +499,7 @@ def _batched_maps(mtm, ctx, units, img, method, thr, picks):
                 t = units[i][1]
                 maps[i] = ctx.last_score_map(i, (img.shape[0] - t.shape[0] + 1, img.shape[1] - t.shape[1] + 1))
         finally:
-            ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+            restore_hits_only(ctx)
     return raw, maps
 
 
@@ -1241,7 +1255,7 @@ def test_large_templates_as_slabs_on_mfma(mtm, ctx):
                 via_maps = mtm.findMatches(lt, im, method=method, N_object=1)
                 assert ctx.timing()["hits_only"] == 0
             finally:
-                ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+                restore_hits_only(ctx)
             assert fused == via_maps and len(fused) == len(lt), method
             if method != 2:
                 exp1 = O.find_matches(lt, im, method=method, N_object=1)
@@ -1251,7 +1265,7 @@ def test_large_templates_as_slabs_on_mfma(mtm, ctx):
     try:
         a = mtm.findMatches(cases[1][0], img, score_threshold=0.4)
     finally:
-        ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+        restore_hits_only(ctx)
     assert a == mtm.findMatches(cases[1][0], img, score_threshold=0.4)
 
 
@@ -1952,7 +1966,7 @@ def test_fused_global_extremum_masked(mtm, ctx, coins):
                     res.append(mtm.findMatches(lt, coins, method=method, N_object=1))
                     res.append(ctx.timing()["hits_only"])
                 finally:
-                    ctx.set_option(_lib.OPT_HITS_ONLY, 1)
+                    restore_hits_only(ctx)
             assert res[0] == res[2] and len(res[0]) == len(lt), (method, len(lt))
             if not any(os.environ.get(k) for k in ("MTM_EXACT_DIV", "MTM_KERNEL", "MTM_HITS_ONLY")):
                 assert res[1] == 1 and res[3] == 0            # fused route really ran
@@ -2598,7 +2612,7 @@ def test_4k_photograph_default_mode_hit_lists(mtm):
     exp9 = O.find_matches(lt, img, method=5, score_threshold=0.9)
     assert len(got) == len(exp9) >= 4
     assert_hits_equal(hits_json(got), hits_json(exp9), tol=1e-6, ordered=False)
-    MTM._lib.default_context().set_option(MTM._lib.OPT_HITS_ONLY, 1)      # clears the back-off for the tests that follow
+    restore_hits_only(MTM._lib.default_context())      # clears the back-off for the tests that follow
 
 
 # ---- round 5: the float32 route's listing decisions rest on a per-output error bound, not on empirical margins ----------
@@ -2898,15 +2912,28 @@ def test_float32_masked_templates_equal_the_float64_kernels(geom):
                     assert a.tobytes() == b.tobytes(), (geom, method, thr, len(a), len(b))
             if default_routes():
                 assert 4 in routes, (geom, method, routes)         # the screen really ran (an overflowing list may add route 0 / 3)
-        # the routes that must NOT take the screen: one score map, the global extremum - and they agree with the float64 kernel
+        # N_object == 1 (cv2.minMaxLoc): the same screen with the templates' own best lower bound as the threshold - exact
+        # extremum, first occurrence among exact ties (the image holds exact copies of some templates twice)
+        img2 = img.copy()
+        t0 = units[0][0]
+        if W - w > 2 * w and H - h > 1:
+            img2[1:1 + h, 1:1 + w] = t0
+            img2[1:1 + h, W - w - 1:W - 1] = t0
+        for method in (3, 0):
+            for pattern in (0xFF, 0x7F):
+                fast.debug_poison(pattern, 7)
+                a = fast.search(units, img2, method, _lib.PEAKS_GLOBAL, 0.0).copy()
+                route = fast.timing()["f32_route"]
+                b = exact.search(units, img2, method, _lib.PEAKS_GLOBAL, 0.0).copy()
+                assert a.tobytes() == b.tobytes() and len(a) == n, (geom, method, len(a), len(b))
+                if default_routes():
+                    assert route == 4, (geom, method, route)
+        # the route that must NOT take the screen: one published score map - and it agrees with the float64 kernel
         for c_ in (fast, exact):
             c_.set_image(img)
             c_.set_templates(units, 3)
         shape = (H - h + 1, W - w + 1)
         assert np.array_equal(fast.score_map(0, shape), exact.score_map(0, shape), equal_nan=True)
-        a = fast.search(units, img, 3, _lib.PEAKS_GLOBAL, 0.0)
-        assert fast.timing()["f32_route"] != 4
-        assert a.tobytes() == exact.search(units, img, 3, _lib.PEAKS_GLOBAL, 0.0).tobytes()
         # the maps of a screened call hold placeholders: not published
         fast.search(units, img, 3, _lib.PEAKS_LOCAL, 0.9)
         if fast.timing()["f32_route"] == 4:
@@ -2938,7 +2965,9 @@ def test_float32_masked_through_the_module_api_against_the_oracle(mtm):
     got = mtm.matchTemplates(ltf, imgf, method=3, score_threshold=0.95, maxOverlap=0.2)
     exp = O.match_templates(ltf, imgf, method=3, score_threshold=0.95, maxOverlap=0.2)
     assert len(got) == len(exp) >= 5
-    assert_hits_equal(canon(got), canon(exp), tol=1e-5)
+    # (five exact copies: every score is 1 to within the tolerance, so the order by score is not defined - MTM_F32_MFMA=2
+    # publishes the bf16 kernel's 0.99999994 for the unmasked one; compared by label and box)
+    assert_hits_equal(canon(got), canon(exp), tol=1e-5, ordered=False)
     # TM_SQDIFF (minima below the threshold, raw units): noisy copies, so that the scores are sums and not cancellation noise
     lts = [(n, (t + rng.normal(0, 0.05, t.shape)).astype(np.float32), m) for n, t, m in ltf[:4]]
     got = mtm.findMatches(lts, imgf, method=0, score_threshold=3.0)

@@ -55,6 +55,13 @@ for (H, W, h, w, n, kind, scale) in [(150, 333, 24, 40, 5, "noise", 1.0), (150, 
             print("%-5s %4dx%-4d %3dx%-3d n=%2d m%d thr %-10.4g: %5d records, %s  (route %s kernel %s)" % (
                 kind, H, W, h, w, n, method, thr, len(b), "identical" if same else "DIFFERENT (%d vs %d)" % (len(a), len(b)),
                 ta["f32_route"], ta["kernel_used"]), flush=True)
+            if thr == thrs[0]:                       # N_object == 1: the screen with the templates' own best lower bound
+                a = fast.search(units, img, method, _lib.PEAKS_GLOBAL, 0.0).copy()
+                ta = fast.timing()
+                b = exact.search(units, img, method, _lib.PEAKS_GLOBAL, 0.0).copy()
+                same = a.tobytes() == b.tobytes()
+                bad += 0 if same else 1
+                print("      N_object == 1 m%d: %d records, %s (route %s)" % (method, len(b), "identical" if same else "DIFFERENT", ta["f32_route"]), flush=True)
 print("cases with different records:", bad)
 # timing: 4K x 32 templates 64x64, disc masks, TM_CCORR_NORMED
 H, W = 2160, 3840
@@ -72,3 +79,9 @@ for name, ctx in (("bf16 screen + exact re-scoring", fast), ("float64 kernel", e
         r = run(ctx, img, units, 3, 0.9)
         ts.append(time.perf_counter() - t0)
     print("4K x 32 masked float32, TM_CCORR_NORMED: %-32s %.2f ms per call, %d records, route %s" % (name, 1e3 * float(np.median(ts)), len(r), ctx.timing()["f32_route"]), flush=True)
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        r = ctx.search(units, img, 3, _lib.PEAKS_GLOBAL, 0.0)
+        ts.append(time.perf_counter() - t0)
+    print("    ... N_object == 1: %.2f ms per call, route %s" % (1e3 * float(np.median(ts[1:])), ctx.timing()["f32_route"]), flush=True)
