@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 7
+#define MTM_ABI_VERSION 8
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -96,11 +96,19 @@ extern "C" {
                                    templ_norm), large where it has to be (a low-contrast window beside a much brighter
                                    region) and ~5e-5 on textured windows (one hardware assumption, stated in
                                    bf16_rig_eps and measured by tests/test_gpu_parity.py::test_float32_error_bound_holds);
-                                   mtm_find_matches then returns the exact kernel's hit lists.  MTM_F32_RIG=0: the
-                                   empirical margins of rounds 3-4 (1e-4 / 5e-5).  Score maps read back with mtm_score_map
-                                   keep the ~1e-5 tolerance;
+                                   mtm_find_matches then returns the exact kernel's hit lists.  Round 6: where only a list
+                                   leaves the kernel (hits-only mode: local extrema against a threshold, the global
+                                   extremum, templates with masks) the screen first runs with ONE bfloat16 piece product
+                                   instead of three - a third of the matrix-core work, eps ~2^-7 instead of ~2^-15, the
+                                   same bound and the same exact re-scoring, so the same lists; a list that overflows
+                                   repeats the launch with three products and the next calls start there
+                                   (mtm_timing.f32_pieces says which ran).  Score maps read back with mtm_score_map keep
+                                   the ~1e-5 tolerance (three products, always);
                                    0: the float64 kernel for everything (10x slower, maps exact to rounding);
-                                   2: bf16 scores as they are, no re-scoring.  Environment: MTM_F32_MFMA. */
+                                   2: bf16 scores as they are, no re-scoring;
+                                   3: as 1 without the one-product tier;
+                                   4: diagnostic - as 2 with one piece product (the screen's raw scores: what the tests
+                                   measure its bound on; never a result).  Environment: MTM_F32_MFMA. */
 
 /* error codes */
 #define MTM_OK            0
@@ -158,6 +166,10 @@ typedef struct mtm_timing {
                             re-scored with the float64 kernel's own chains, "below" placeholders elsewhere (maps not published) */
     int32_t sq_launches; /* masked classes on the matrix cores: launches of the sum I^2 M pass (one per masked class) ... */
     float   masked_stat_ms; /* ... and the time they took (sum of the passes' own event pairs; 0 without masked classes) */
+    int32_t f32_pieces;  /* (ABI 8) float32 images: bfloat16 piece products of the last matrix-core launch - 3 (scores to ~1e-5), or 1:
+                            the one-product screen of the hits-only refined routes (f32_route 1 and 4; listing by a bound of
+                            2^-7 of the norms' product, exact re-scoring decides; an overflowing list repeats the launch with 3);
+                            0: no such launch */
 } mtm_timing;
 
 /* ---- device / context ------------------------------------------------------------------- */

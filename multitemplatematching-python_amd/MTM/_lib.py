@@ -28,7 +28,7 @@ POISON_SCRATCH, POISON_LDS, POISON_ARENAS = 1, 2, 4
 E_OVERFLOW = -5
 E_HIP = -2
 COMM_ID_BYTES = 128
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class MtmTempl(ctypes.Structure):
@@ -49,7 +49,8 @@ class MtmTiming(ctypes.Structure):
                 ("ncc_launches", ctypes.c_int32), ("kernel_used", ctypes.c_int32),
                 ("n_hits", ctypes.c_int64), ("hits_only", ctypes.c_int32), ("sclk_mhz", ctypes.c_float),
                 ("ncc_sum_ms", ctypes.c_float), ("f32_route", ctypes.c_int32),
-                ("sq_launches", ctypes.c_int32), ("masked_stat_ms", ctypes.c_float)]
+                ("sq_launches", ctypes.c_int32), ("masked_stat_ms", ctypes.c_float),
+                ("f32_pieces", ctypes.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("templ_idx", "<i4"), ("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),

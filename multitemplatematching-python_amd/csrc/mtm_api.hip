@@ -86,7 +86,7 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
     // masked float32 classes: the bf16 screen needs the threshold (local extrema only; mtm_score_map and N_object == 1 keep
     // the float64 kernel).  What the peak pass compares with: the float32 threshold, on float32 scores.
     c->mbf_used = false;
-    c->mbf_thr_on = (mode == MTM_PEAKS_LOCAL || mode == MTM_PEAKS_GLOBAL) && n > 0 && c->f32_mfma == 1;
+    c->mbf_thr_on = (mode == MTM_PEAKS_LOCAL || mode == MTM_PEAKS_GLOBAL) && n > 0 && f32_refined(c);
     c->mbf_global = mode == MTM_PEAKS_GLOBAL;
     c->mbf_thr = thr;
 
@@ -151,10 +151,10 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
         // ... except, round 5, local extrema against a threshold while the kernel's candidate list is available: every output
         // whose upper bound (score + E, E in the sum's own units) passes the threshold is listed and re-scored exactly -
         // route 1 only; maps, the map scan and every overflow keep the float64 kernel
-        c->raw_rig_now = any_bf16 && all_bf16 && raw_m && mode == MTM_PEAKS_LOCAL && c->f32_mfma == 1 && fused;
-        if (any_bf16 && raw_m && (mode != MTM_PEAKS_GLOBAL || c->f32_mfma != 1) && !c->raw_rig_now) {
+        c->raw_rig_now = any_bf16 && all_bf16 && raw_m && mode == MTM_PEAKS_LOCAL && f32_refined(c) && fused;
+        if (any_bf16 && raw_m && (mode != MTM_PEAKS_GLOBAL || !f32_refined(c)) && !c->raw_rig_now) {
             c->f32_exact_now = true;
-        } else if (any_bf16 && c->f32_mfma == 1) {
+        } else if (any_bf16 && f32_refined(c)) {
             if (all_bf16) c->refine_now = true;
             else c->f32_exact_now = true;
         }
@@ -272,6 +272,13 @@ int fm_begin(mtm_ctx* c, int mode, double score_threshold, NextImage* next, FmSt
             c->cand_pin_now = true;
             c->cand_pin_n = nfetch_w;
         }
+    }
+    // float32: the hits-only refined routes (kernel candidates re-scored; the fused extremum by bounds) and the masked
+    // classes' screen start with ONE piece product (mtm_ctx::bf16_np_now) unless a recent call overflowed its list that way
+    c->bf16_np_now = 3;
+    if (c->dtype == MTM_F32 && c->f32_mfma == 1) {
+        if (c->np1_backoff > 0) --c->np1_backoff;
+        else c->bf16_np_now = 1;
     }
     host_trace(c, 3);
     // start of the GPU time of the call (timing.total_ms).  Banded: recorded by run_score_banded once the first band's
@@ -420,7 +427,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
 
     if (mode == MTM_PEAKS_GLOBAL) {
         std::vector<unsigned long long> best(2 * (size_t)std::max(1, n));
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
             if (!c->ext_now) {
                 MTMC(c->counters.ensure(sizeof(unsigned long long) * 2 * std::max(1, n)));
                 HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
@@ -439,7 +446,24 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
             if (refined)
                 HIPC(hipMemcpyAsync(&nlisted, c->cands.p, sizeof(nlisted), hipMemcpyDeviceToHost, c->stream));
             HIPC(hipStreamSynchronize(c->stream));
-            if (!refined || (int64_t)nlisted <= cand_cap) break;
+            if (!refined || (int64_t)nlisted <= cand_cap) {
+                if (refined && c->bf16_np_now == 1) c->np1_backoff_len = 16;
+                break;
+            }
+            if (c->bf16_np_now == 1) {
+                // the one-product screen's bounds let more outputs reach their template's best than the list holds: the
+                // same route with three piece products (and the next calls start there)
+                c->bf16_np_now = 3;
+                c->np1_backoff = c->np1_backoff_len;
+                c->np1_backoff_len = std::min(2 * c->np1_backoff_len, 1024);
+                c->timing.ncc_launches = 0;
+                c->timing.sq_launches = 0;
+                HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * std::max(1, n), c->stream));
+                HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+                MTMC(run_score_all(c));
+                HIPC(hipEventRecord(c->ev[1], c->stream));
+                continue;
+            }
             // float32 refinement: more outputs within the margin of their template's best than the list holds (near-flat
             // maps) - the float64 kernel decides, on maps in memory
             c->refine_now = false;
@@ -565,6 +589,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 }
                 count = hits.size();
                 verified_on_host = true;
+                if (c->refine_now && c->bf16_np_now == 1) c->np1_backoff_len = 16;
             }
         }
         if (!verified_on_host && c->hits_only_now)
@@ -661,6 +686,24 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 HIPC(hipEventRecord(c->ev[1], c->stream));
                 continue;
             }
+            if (use_fused && !pp_mode && (int64_t)ncand > cand_cap && c->refine_now && c->bf16_np_now == 1) {
+                // float32 refinement, the ONE-PRODUCT screen listed more than the list holds: the same route with three piece
+                // products - bounds 2^8 times tighter - before anything slower is tried (and the next calls start there)
+                c->bf16_np_now = 3;
+                c->np1_backoff = c->np1_backoff_len;
+                c->np1_backoff_len = std::min(2 * c->np1_backoff_len, 1024);
+                c->timing.ncc_launches = 0;
+                c->timing.sq_launches = 0;
+                HIPC(hipMemsetAsync(c->cands.p, 0, 16, c->stream));
+                if (c->hits_only_now)
+                    HIPC(hipMemsetAsync(c->chash.p, 0, ((size_t)hash_mask + 1) * sizeof(unsigned long long), c->stream));
+                c->cand_on = true;
+                const int rc_np = run_score_all(c);
+                c->cand_on = false;
+                MTMC(rc_np);
+                HIPC(hipEventRecord(c->ev[1], c->stream));
+                continue;
+            }
             if (use_fused && (int64_t)ncand > cand_cap && c->refine_now) {
                 // float32 refinement, list overflowed.  Kernel candidates (everything above the threshold): take the
                 // potential peaks of a map scan instead - far fewer.  Those too (plateau-rich maps): the float64 kernel.
@@ -708,6 +751,7 @@ int fm_end(mtm_ctx* c, const FmState& S, mtm_hit* out, int64_t capacity, int64_t
                 continue;
             }
             if (use_fused && !pp_mode) c->backoff_len = 16;     // the candidates fitted
+            if (use_fused && !pp_mode && c->refine_now && c->bf16_np_now == 1) c->np1_backoff_len = 16;
             if ((int64_t)count <= c->hit_cap) {
                 // thousands of peaks and a suppression request: decide on the device, fetch the kept ones
                 if (dnms.queued && c->sparse_now && !use_fused && (long long)count >= c->nms_device_min && count <= dnms.n_max) {

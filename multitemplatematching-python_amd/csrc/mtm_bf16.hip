@@ -3,6 +3,9 @@
 
 namespace mtm {
 
-Bf16Fn bf16_kernel(int mb) { return mb == 2 ? (Bf16Fn)ncc_bf16_kernel<2> : mb == 1 ? (Bf16Fn)ncc_bf16_kernel<1> : nullptr; }
+Bf16Fn bf16_kernel(int mb, int np) {
+    if (np == 1) return mb == 2 ? (Bf16Fn)ncc_bf16_kernel<2, 1> : mb == 1 ? (Bf16Fn)ncc_bf16_kernel<1, 1> : nullptr;
+    return mb == 2 ? (Bf16Fn)ncc_bf16_kernel<2, 3> : mb == 1 ? (Bf16Fn)ncc_bf16_kernel<1, 3> : nullptr;
+}
 
 }  // namespace mtm

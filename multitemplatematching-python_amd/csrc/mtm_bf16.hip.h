@@ -105,9 +105,19 @@ __device__ __forceinline__ float bf_finish_r(int method, double corr, const doub
     return (float)num;
 }
 
-// One K step: 32 taps x 8 phases x MB template groups x 3 piece products.  h0/h1 (l0/l1): the lane's two aligned
-// 16-byte chunks of the first (second) piece plane; a0 / a1: the packed template pieces.
-template <int MB>
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+template <int N, class F>
+__device__ __forceinline__ void bf_static_for(F& f) {
+    if constexpr (N > 0) {
+        bf_static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// One K step: 32 taps x 8 phases x MB template groups x NP piece products (3: I0 T0 + I0 T1 + I1 T0; 1: I0 T0 alone - the
+// one-product screen of round 6, below).  h0/h1 (l0/l1): the lane's two aligned 16-byte chunks of the first (second) piece
+// plane; a0 / a1: the packed template pieces.
+template <int MB, int NP>
 __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const v4i_b h1, const v4i_b l0, const v4i_b l1,
                                         const v4i_b (&a0)[MB], const v4i_b (&a1)[MB]) {
     const int W[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -116,25 +126,35 @@ __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
         EW[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)W[m + 1], (uint32_t)W[m], 2);
-        EV[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)V[m + 1], (uint32_t)V[m], 2);
+        if constexpr (NP == 3) EV[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)V[m + 1], (uint32_t)V[m], 2);
     }
 #pragma unroll
     for (int ph = 0; ph < 8; ++ph) {
         const int k = ph >> 1;
         const v4i_b bh = (ph & 1) ? v4i_b{EW[k], EW[k + 1], EW[k + 2], EW[k + 3]} : v4i_b{W[k], W[k + 1], W[k + 2], W[k + 3]};
-        const v4i_b bl = (ph & 1) ? v4i_b{EV[k], EV[k + 1], EV[k + 2], EV[k + 3]} : v4i_b{V[k], V[k + 1], V[k + 2], V[k + 3]};
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             v4f a = acc[mb][ph];
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bl), a, 0, 0, 0);
+            if constexpr (NP == 3) {
+                const v4i_b bl = (ph & 1) ? v4i_b{EV[k], EV[k + 1], EV[k + 2], EV[k + 3]} : v4i_b{V[k], V[k + 1], V[k + 2], V[k + 3]};
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bl), a, 0, 0, 0);
+            }
             acc[mb][ph] = a;
         }
     }
 }
 
-template <int MB>
+// NP = 1 (round 6): the ONE-PRODUCT SCREEN.  Only the leading bfloat16 piece of both operands is correlated - a third of
+// the matrix-core work, half of the LDS and template traffic - and the result is good to ~2^-7 of
+// sqrt(sum (I - mu)^2 sum (T - mean)^2) instead of ~2^-15 (bf16_rig_eps).  That is useless as a score and entirely sufficient
+// as a screen: the refined hits-only routes (Bf16Params::rig / ext_raw) list every output whose UPPER bound passes the
+// threshold (or reaches the running best) and the float64 chain decides on those, so a wider bound only lengthens the
+// list - on images whose maps are sparse above the threshold by a few records.  The host launches this instantiation only
+// where nothing but the list leaves the kernel (hits-only; maps are never written from it) and falls back to NP = 3 when
+// the list overflows (mtm_api.hip).
+template <int MB, int NP>
 __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
                                                           const uint8_t* __restrict__ apack, StatPlanes st,
@@ -248,9 +268,11 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                         if (rr[u] >= trows) break;
                         const float a = v[u].x - mu, b = v[u].y - mu;
                         const uint32_t a0 = bf16_rne(a), b0 = bf16_rne(b);
-                        const uint32_t a1 = bf16_rne(a - bf16_to_float(a0)), b1 = bf16_rne(b - bf16_to_float(b0));
                         *reinterpret_cast<uint32_t*>(thi + (size_t)rr[u] * row_bytes + 4 * cc[u]) = a0 | (b0 << 16);
-                        *reinterpret_cast<uint32_t*>(tlo + (size_t)rr[u] * row_bytes + 4 * cc[u]) = a1 | (b1 << 16);
+                        if constexpr (NP == 3) {
+                            const uint32_t a1 = bf16_rne(a - bf16_to_float(a0)), b1 = bf16_rne(b - bf16_to_float(b0));
+                            *reinterpret_cast<uint32_t*>(tlo + (size_t)rr[u] * row_bytes + 4 * cc[u]) = a1 | (b1 << 16);
+                        }
                     }
                 }
             }
@@ -265,14 +287,22 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             int loff = wave * row_bytes + (j + q) * 16;
             int kb_i = 0;
             v4i_b hA0, hA1, lA0, lA1, hB0, hB1, lB0, lB1, aA0[MB], aA1[MB], aB0[MB], aB1[MB];
+            if constexpr (NP != 3) {            // (never loaded, never multiplied: defined values for the compiler's sake)
+                lA0 = lA1 = lB0 = lB1 = v4i_b{0, 0, 0, 0};
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) aA1[mb] = aB1[mb] = v4i_b{0, 0, 0, 0};
+            }
 #define MTM_BF_LOAD(H0, H1, L0, L1, A0, A1)                                                    \
             H0 = *reinterpret_cast<const v4i_b*>(thi + loff);                                  \
             H1 = *reinterpret_cast<const v4i_b*>(thi + loff + 16);                             \
-            L0 = *reinterpret_cast<const v4i_b*>(tlo + loff);                                  \
-            L1 = *reinterpret_cast<const v4i_b*>(tlo + loff + 16);                             \
+            if constexpr (NP == 3) {                                                           \
+                L0 = *reinterpret_cast<const v4i_b*>(tlo + loff);                              \
+                L1 = *reinterpret_cast<const v4i_b*>(tlo + loff + 16);                         \
+            }                                                                                  \
             _Pragma("unroll") for (int mb = 0; mb < MB; ++mb) {                                \
                 A0[mb] = *reinterpret_cast<const v4i_b*>(aptr + mb * p.group_bytes);           \
-                A1[mb] = *reinterpret_cast<const v4i_b*>(aptr + p.piece_bytes + mb * p.group_bytes); \
+                if constexpr (NP == 3)                                                         \
+                    A1[mb] = *reinterpret_cast<const v4i_b*>(aptr + p.piece_bytes + mb * p.group_bytes); \
             }
 #define MTM_BF_ADVANCE()                                        \
             {                                                   \
@@ -287,15 +317,15 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 MTM_BF_ADVANCE()
                 MTM_BF_LOAD(hB0, hB1, lB0, lB1, aB0, aB1)
                 __builtin_amdgcn_sched_barrier(0);
-                bf_step<MB>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
+                bf_step<MB, NP>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
                 __builtin_amdgcn_sched_barrier(0);
                 MTM_BF_ADVANCE()
                 MTM_BF_LOAD(hA0, hA1, lA0, lA1, aA0, aA1)
                 __builtin_amdgcn_sched_barrier(0);
-                bf_step<MB>(acc, hB0, hB1, lB0, lB1, aB0, aB1);
+                bf_step<MB, NP>(acc, hB0, hB1, lB0, lB1, aB0, aB1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ks < nsteps) bf_step<MB>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
+            if (ks < nsteps) bf_step<MB, NP>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
 #undef MTM_BF_LOAD
 #undef MTM_BF_ADVANCE
         }
@@ -313,6 +343,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const bool rig_n = p.rig == 1 && normed, rig_r = p.rig == 2 && !normed;
     const bool rig = rig_n || rig_r;
     const bool need_sum2 = method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED || (p.ext_on && p.ext_raw) || rig;
+    // the quotient-free listing screen of the hits-only route (epilogue_half)
+    const bool fast_screen = rig_n && p.cand_on && !p.ext_on && p.hits_only && p.rig_flag == nullptr;
+    const double fs_thr = (double)p.rig_thr;
+    const double fs_d = p.cand_min ? 2.4e-6 + 1e-9 : 6e-7 * fmax(1.0, fabs(fs_thr)) + 1e-9;
     // (the two halves of a lane's eight pixels as a generic lambda over a compile-time constant: every accumulator index
     // below must be one, or the accumulators leave the register file)
     auto epilogue_half = [&](auto half_c) {
@@ -347,13 +381,49 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 bp[i] = rig_r ? (double)p.rig_eps * sqrt(s2c) : sq[i] > 0.0 ? (double)p.rig_eps * sqrt(s2c) / sq[i] : 0.0;
             }
         }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
+        // one template of the lane (group mb, accumulator element e) - instantiated 4 MB times by bf_static_for: as a
+        // `#pragma unroll` loop the body grew past the unroller's size limit in round 6, the loop stayed a loop and the
+        // accumulators it indexes went to scratch memory
+        auto one_template = [&](auto idx_c) {
+            constexpr int mb = decltype(idx_c)::value / 4, e = decltype(idx_c)::value % 4;
+            {
                 const int lt = mb * 16 + 4 * q + e, li = tg * MB * 16 + lt;
-                if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) continue;
+                if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) return;
                 const BfTemplConst& T = tcl[lt];
+                bool skip = false;
+                if (fast_screen) {
+                    // Hits-only listing by the bound (normalised methods): most outputs are nowhere near the threshold, and
+                    // the listing test  r + M > thr  (r = num / t) is  num > (thr - B - d) t  without the quotient - B the
+                    // output's bound, d twice the rounding allowance 3e-7 max(1, |r|) of the exact test below at the largest
+                    // |r| that reaches this branch (|r| <= max(1, |thr|); minima: r <= 4), which also dwarfs the float64
+                    // roundings of this restatement.  An output outside [-1, thr) (minima: (.., 4]), a flat window, a constant
+                    // template or anything that is not finite takes the exact test.  Lanes whose four outputs all fail
+                    // leave here: three float64 multiplications and two comparisons per output instead of a division
+                    // sequence, the saturation analysis and the bound arithmetic - a third of this kernel's time once the K
+                    // loop runs one piece product.
+                    bool anyp = p.list_all != 0 || T.all_ones != 0;
+                    const double tn = T.templ_norm;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double num = (double)acc[mb][4 * half + i][e];
+#pragma unroll
+                        for (int cc = 0; cc < kMaxChans; ++cc)
+                            if (cc < p.chans) num += T.centre[cc] * ts[i][cc];
+                        if (method == MTM_TM_CCOEFF_NORMED) {
+#pragma unroll
+                            for (int cc = 0; cc < kMaxChans; ++cc)
+                                if (cc < p.chans) num -= ts[i][cc] * T.mean[cc];
+                        } else if (method == MTM_TM_SQDIFF_NORMED) {
+                            num = fmax(s2[i] - 2.0 * num + T.templ_sum2, 0.0);
+                        }
+                        const double tt = sq[i] * tn, B = bp[i] * T.bfac;
+                        const bool pp = p.cand_min ? (num < (B - fs_thr + fs_d) * tt || num > 4.0 * tt)
+                                                   : (num > (fs_thr - B - fs_d) * tt || num < -tt);
+                        anyp = anyp || !(tt > 0.0) || pp;
+                    }
+                    skip = !anyp;
+                }
+                if (!skip) {
                 float out[4];
                 double qv[4], Mv[4];        // rig: quality before the saturation rules, bound of its error
 #pragma unroll
@@ -488,8 +558,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                             if (xb + i < p.ow) orow[i] = out[i];
                     }
                 }
+                }   // !skip
             }
-        }
+        };
+        bf_static_for<4 * MB>(one_template);
     };
     if (lane_on) {
         epilogue_half(std::integral_constant<int, 0>{});

@@ -101,8 +101,9 @@ __host__ __device__ inline size_t bf16_lds_bytes(int chunk_h, int lds_cols) {
            (size_t)kBfRows * 32 * sizeof(unsigned long long);
 }
 
-// ncc_bf16_kernel<MB> (defined in mtm_bf16.hip), MB = 1 or 2 groups of 16 templates per wave
+// ncc_bf16_kernel<MB, NP> (defined in mtm_bf16.hip), MB = 1 or 2 groups of 16 templates per wave, NP = 3 piece products
+// (scores to ~1e-5) or 1 (the one-product screen of the hits-only refined routes)
 using Bf16Fn = void (*)(Bf16Params, const TemplDev*, const int*, const uint8_t*, StatPlanes, float*);
-Bf16Fn bf16_kernel(int mb);
+Bf16Fn bf16_kernel(int mb, int np);
 
 }  // namespace mtm

@@ -388,11 +388,15 @@ int mtm_set_option(mtm_ctx* c, int option, int64_t value) {
             c->hits_only = value ? 1 : 0;
             c->fuse_backoff = 0;
             c->backoff_len = 16;
+            c->np1_backoff = 0;
+            c->np1_backoff_len = 16;
             return MTM_OK;
         case MTM_OPT_F32_MFMA:
-            if (value < 0 || value > 2) break;
+            if (value < 0 || value > 4) break;
             if ((c->f32_mfma != 0) != (value != 0)) c->placed = false;     // the packs follow the kernel
             c->f32_mfma = (int)value;
+            c->np1_backoff = 0;
+            c->np1_backoff_len = 16;
             return MTM_OK;
         case MTM_OPT_DOT4_VARIANT:
             if (!dot_variant_ok(value)) break;

@@ -221,7 +221,15 @@ struct mtm_ctx {
     int screen_l1 = 1;                      // MTM_SCREEN_L1: the hits-only screen starts with the per-lane bound (0: round 2's screen alone)
     int f32_mfma = 1;                       // MTM_F32_MFMA / MTM_OPT_F32_MFMA: unmasked float32 classes on the bf16 matrix cores:
                                             // 0 = float64 kernel, 1 = bf16 screen + exact float64 re-scoring of everything
-                                            // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are
+                                            // that could be a peak (hit lists of the float64 kernel), 2 = bf16 scores as they are,
+                                            // 3 = as 1 without the one-product tier (every screen with three piece products),
+                                            // 4 = (diagnostic) as 2 with ONE piece product: the screen's raw scores, what
+                                            // tests/test_gpu_parity.py measures its bound on - never a result
+    // Round 6: the hits-only refined routes screen with ONE piece product first (ncc_bf16_kernel<MB, 1>, a third of the
+    // matrix-core work, bound 2^-7 instead of 2^-15 of the norms' product); a list that overflows repeats the launch with
+    // three products, and the next np1_backoff calls start there
+    int bf16_np_now = 3;                    // this call's piece products of the hits-only screens (fm_begin)
+    int np1_backoff = 0, np1_backoff_len = 16;
     int seg_skip = 1;                       // MTM_SEG_SKIP: dense route - outputs that cannot pass the threshold are not finished (MfmaParams::seg_skip)
     bool seg_skip_used = false;             // this call: some map holds such placeholders (the maps are not published)
     bool raw_rig_now = false;               // this call: a raw-sum method with a threshold, listed by the bound of the sum (route 1 only)
@@ -435,8 +443,21 @@ struct SlotGeom {
 // Round 6 (advisor): the whole is doubled.  The "two roundings per MFMA" is an assumption about undocumented hardware; the
 // measured worst case is 0.16 of the undoubled bound, so the factor costs a few more exact re-scores and buys a guarantee that
 // survives an ASIC or compiler whose accumulation is a little worse than assumed.
-inline float bf16_rig_eps(int chans, int h, int nkb) {
+// (Round 6, second look at the first term: bfloat16 carries 8 significant bits, unit roundoff 2^-8, so two pieces represent a
+// float to 2^-16 and the three neglected terms - I's residual, T's residual, I1 T1 - are 3 * 2^-16 = 4.6e-5 of |I||T| per tap,
+// not the "3 * 2^-18" the 2^-15 above was written for; the doubled total, 6.1e-5 + ..., still covers it.)
+// np == 1 (the one-product screen, ncc_bf16_kernel<MB, 1>): only I0 T0 is summed.  |I T - I0 T0| <= |I - I0||T| + |I0||T - T0|
+// <= (2^-8 + 2^-8 (1 + 2^-8)) |I||T| = 2^-7 (1 + 2^-9) |I||T| per tap, Cauchy-Schwarz over the taps; ONE MFMA per 32-tap block,
+// two roundings each, doubled like the rest for the undocumented accumulation.
+inline bool f32_refined(const mtm_ctx* c) { return c->f32_mfma == 1 || c->f32_mfma == 3; }
+inline float bf16_rig_eps(int chans, int h, int nkb, int np = 3) {
+    if (np == 1) return (float)(0.0078125 * 1.002 + 2.0 * (2.0 * 1.0 * (double)chans * h * nkb * 5.97e-8));
     return (float)(2.0 * (3.0518e-5 + 2.0 * 3.0 * (double)chans * h * nkb * 5.97e-8));
+}
+// ... and what the refined raw-sum extremum (Bf16Params::ext_eps) works with
+inline float bf16_ext_eps(int chans, int h, int nkb, int np = 3) {
+    if (np == 1) return bf16_rig_eps(chans, h, nkb, 1);
+    return (float)(3.0518e-5 + 3.0 * (double)chans * h * nkb * 5.97e-8);
 }
 
 // ---- mtm_context.hip

@@ -399,6 +399,13 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
     const int* tl_k = c->tlist.as<int>() + sc.tlist_off;
     StatPlanes st{};
     st.pitch = st_pitch;
+    const unsigned long long cap = (unsigned long long)std::min<int64_t>(std::max<int64_t>(c->hit_cap, 1 << 18), 4096LL * 256);
+    MTMC(c->mbf_list.ensure(16 + sizeof(mtm_hit) * (size_t)cap));
+    MaskF32Params q{};
+    unsigned long long count = 0;
+    // Round 6: ONE piece product first (ncc_bf16_kernel<MB, 1>: bounds 2^-7 instead of 2^-15 of the norms' products - the
+    // combine pass states them with the eps of the launch that ran); a list that overflows repeats the screen with three
+    for (int np = c->bf16_np_now == 1 ? 1 : 3;; np = 3) {
     for (int pl = 0; pl < 2; ++pl) {
         p.img = pl == 0 ? img.f32 : c->f32_sq.as<float>();
         p.mu_out = c->mbf_mu.as<float>() + (size_t)pl * n_tiles;
@@ -407,13 +414,12 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
         st.sq = st.sum2;                                        // (not read by a raw-sum launch)
         const uint8_t* ap = c->apacks.as<uint8_t>() + (pl == 0 ? sc.mbf_off_u : sc.mbf_off_v);
         const TemplDev* tdp = (pl == 0 ? c->td_u : c->td_v).as<TemplDev>();
-        hipLaunchKernelGGL(bf16_kernel(mb), dim3(grid), dim3(256), lds, c->stream, p, tdp, tl_k, ap, st, c->mbf_maps.as<float>());
+        hipLaunchKernelGGL(bf16_kernel(mb, np), dim3(grid), dim3(256), lds, c->stream, p, tdp, tl_k, ap, st, c->mbf_maps.as<float>());
     }
+    c->timing.f32_pieces = np;
     // combine: placeholders into the score maps, the rest listed
-    const unsigned long long cap = (unsigned long long)std::min<int64_t>(std::max<int64_t>(c->hit_cap, 1 << 18), 4096LL * 256);
-    MTMC(c->mbf_list.ensure(16 + sizeof(mtm_hit) * (size_t)cap));
     HIPC(hipMemsetAsync(c->mbf_list.p, 0, 16, c->stream));
-    MaskF32Params q{};
+    q = MaskF32Params{};
     q.m1 = q.m2 = c->mbf_maps.as<float>();
     q.td = c->td.as<TemplDev>();
     q.td_u = c->td_u.as<TemplDev>();
@@ -430,7 +436,7 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
     q.method = c->method;
     q.mode_min = c->method == MTM_TM_SQDIFF ? 1 : 0;
     q.thr = c->mbf_thr;
-    q.eps = bf16_rig_eps(1, h, p.nkb);
+    q.eps = bf16_rig_eps(1, h, p.nkb, np);
     q.h = h;
     q.w = w;
     q.oh = oh;
@@ -452,10 +458,17 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
     }
     HIPC(hipGetLastError());
     // how many?  (one small read-back: this path is milliseconds long, and an overflowing list changes the route)
-    unsigned long long count = 0;
     HIPC(hipMemcpyAsync(&count, c->mbf_list.p, sizeof(count), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    if (count > cap) return MTM_OK;                             // *done stays false: float64 kernel
+    if (count <= cap) {
+        if (np == 1) c->np1_backoff_len = 16;
+        break;
+    }
+    if (np == 3) return MTM_OK;                                 // *done stays false: float64 kernel
+    c->bf16_np_now = 3;                                         // (this call's other classes and the next calls start with three)
+    c->np1_backoff = c->np1_backoff_len;
+    c->np1_backoff_len = std::min(2 * c->np1_backoff_len, 1024);
+    }
     if (count > 0) {
         RefineParams r{};
         r.img = img;
@@ -922,10 +935,16 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.cand_hits = reinterpret_cast<mtm_hit*>(c->cands.as<uint8_t>() + 16);
         p.hits_only = (p.cand_on && c->hits_only_now) ? 1 : 0;
         const bool raw_m = c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR || c->method == MTM_TM_CCOEFF;
+        // piece products of this launch: one where only a list leaves the kernel and every listing decision rests on a
+        // bound that knows it (below: rig 1 / 2, the refined extremum by bounds); three everywhere else
+        int np = 3;
+        if (c->bf16_np_now == 1 && c->refine_now && only_li < 0 && (p.hits_only || c->ext_now) &&
+            (!raw_m || c->ext_now || c->raw_rig_now))
+            np = 1;
         if (c->refine_now && !raw_m && only_li < 0) {
             // Round 5: the listing decisions of the refined routes by the rigorous per-output bound (Bf16Params::rig)
             p.rig = 1;
-            p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb);
+            p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb, np);
             p.rig_thr = c->rig_thr;
             p.list_all = c->cand_min ? (c->rig_thr < -1.0f ? 1 : 0) : (c->rig_thr < 0.0f ? 1 : 0);
             if (c->refine_scan_now) {           // map mode: the scan's tolerances hold while no bound exceeds the cap
@@ -936,7 +955,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         if (c->refine_now && raw_m && c->raw_rig_now && !c->ext_now && only_li < 0) {
             // raw sums with a threshold (round 5): everything whose UPPER bound passes is listed and re-scored exactly
             p.rig = 2;
-            p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb);
+            p.rig_eps = bf16_rig_eps(c->chans, h, p.nkb, np);
             p.rig_thr = c->rig_thr;
             p.list_all = 0;
         }
@@ -950,7 +969,7 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
                 // rigorous bounds instead of a relative margin (Bf16Params::ext_raw): 2^-15 for the dropped piece products
                 // and the two 16-bit representations, 2^-24 per float32 accumulation (three MFMAs per 32-tap block)
                 p.ext_raw = 1;
-                p.ext_eps = (float)(3.0518e-5 + 3.0 * (double)c->chans * h * p.nkb * 5.97e-8);
+                p.ext_eps = bf16_ext_eps(c->chans, h, p.nkb, np);
             } else if (p.rig) {
                 p.ext_raw = 1;                              // (bounds of the quality instead of scores: the rig branch of the epilogue)
                 p.list_all = 0;
@@ -960,8 +979,14 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         const int grid = ((p.n_work + 7) / 8) * 8;
         const uint8_t* ap = c->apacks.as<uint8_t>() + sc.apack_off + (long long)tg0 * mb * sc.group_bytes;
         const int* tl_k = c->tlist.as<int>() + sc.tlist_off + tg0 * 16 * mb;
-        hipLaunchKernelGGL(bf16_kernel(mb), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
+        // (a launch that is neither listing by a bound nor the bound-keeping extremum must not run the screen: its scores
+        // would be taken at face value)
+        if (np == 1 && !(p.rig != 0 || (p.ext_on && p.ext_raw))) np = 3;
+        if (np == 1 && !p.hits_only) np = 3;
+        if (c->f32_mfma == 4) np = 1;               // (diagnostic: the screen's scores as they are)
+        hipLaunchKernelGGL(bf16_kernel(mb, np), dim3(grid), dim3(256), lds, c->stream, p, td, tl_k, ap, st, maps);
         c->timing.kernel_used = MTM_KERNEL_MFMA_F32;
+        c->timing.f32_pieces = np;
     } else if (kernel == MTM_KERNEL_DOT4) {
         const bool wide = (double)c->chans * w * h * 65025.0 >= 4294967296.0;
         const DotVariant& v = kDotVariants[wide ? kDotWideVariant : c->dot_variant];

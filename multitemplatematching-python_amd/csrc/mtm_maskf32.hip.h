@@ -169,7 +169,10 @@ __global__ __launch_bounds__(256) void maskf32_best_kernel(MaskF32Params p, int 
             const uint32_t other = (uint32_t)__shfl_down((int)key, off);
             key = other > key ? other : key;
         }
-        if ((threadIdx.x & 63) == 0 && key) atomicMax(&best[t], key);
+        // (a plain look first: 4 M waves x 32 templates of atomics on 32 addresses cost 25 ms at 4K x 32 - same-address
+        // atomics serialise at ~9 ns apiece -, and hardly any wave improves on what is already there)
+        if ((threadIdx.x & 63) == 0 && key && key > __hip_atomic_load(&best[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&best[t], key);
     }
 }
 // ... pass 2: every output whose upper bound reaches its template's best lower bound is listed (the exact extremum and

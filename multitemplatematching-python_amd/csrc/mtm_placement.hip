@@ -187,7 +187,7 @@ bool bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
 // float32 class with masks (float weights or binary), one channel, TM_SQDIFF / TM_CCORR_NORMED - the methods the reference
 // lets masks through for (MTM/__init__.py:78): two raw bf16 correlations as a screen + exact re-scoring (mtm_maskf32.hip.h)
 bool masked_bf16_class_ok(const mtm_ctx* c, const SizeClass& sc) {
-    return c->f32_mfma == 1 && c->dtype == MTM_F32 && sc.all_f32 && sc.masked && c->chans == 1 && sc.w <= kBfMaxW &&
+    return f32_refined(c) && c->dtype == MTM_F32 && sc.all_f32 && sc.masked && c->chans == 1 && sc.w <= kBfMaxW &&
            c->rows > sc.h && c->cols > sc.w && (c->method == MTM_TM_SQDIFF || c->method == MTM_TM_CCORR_NORMED);
 }
 inline int bf16_nkb(int w) { return (w + 31) / 32; }

@@ -1013,7 +1013,7 @@ def test_float32_hit_lists_are_the_float64_kernels(coins):
               np.ascontiguousarray(im[150:190, 40:64])] + \
              [np.ascontiguousarray(im[10 * k:10 * k + 24, 16 * k:16 * k + 24]) for k in range(18)]   # a 21-template class
         cases.append((name, im, lt))
-    routes = set()
+    routes, pieces = set(), set()
     try:
         for name, im, lt in cases:
             templs = [(t, None) for t in lt]
@@ -1027,6 +1027,7 @@ def test_float32_hit_lists_are_the_float64_kernels(coins):
                         got = fast.search(templs, im, method, _lib.PEAKS_LOCAL, thr)
                         tm = fast.timing()
                         routes.add(tm["f32_route"])
+                        pieces.add((tm["f32_route"], honly, tm["f32_pieces"]))
                         assert tm["f32_route"] in (1, 2, 3), tm
                         assert len(got) == len(ref), (name, method, thr, cap, honly, tm["f32_route"], len(got), len(ref))
                         for f in ("templ_idx", "x", "y", "w", "h"):
@@ -1050,6 +1051,10 @@ def test_float32_hit_lists_are_the_float64_kernels(coins):
                         assert np.array_equal(got[f], ref[f]), (name, method, cap, f, fast.timing()["f32_route"])
                     assert np.array_equal(got["score"].view(np.uint32), ref["score"].view(np.uint32)), (name, method, cap)
         assert routes == {1, 2, 3}, routes          # every way of refining has been exercised
+        # round 6: the hits-only candidate route starts with the one-product screen (and only it: maps in memory are the
+        # three-product kernel's); overflowing lists went through the three-product launch on their way to the scan
+        assert (1, 1, 1) in pieces and not any(hon == 0 and pc == 1 for _, hon, pc in pieces), sorted(pieces)
+        assert any(pc == 3 and hon == 1 for _, hon, pc in pieces), sorted(pieces)
         # raw sums with thresholds: listed by the bound of the sum and re-scored (round 5; route 3 while a back-off lasts -
         # test_float32_raw_sums_with_thresholds_equal_the_float64_kernels); their maps stay on the float64 kernel
         name, im, lt = cases[0]
@@ -2616,7 +2621,7 @@ def test_4k_photograph_default_mode_hit_lists(mtm):
 
 
 # ---- round 5: the float32 route's listing decisions rest on a per-output error bound, not on empirical margins ----------
-def _bf16_bound_map(img, templ, method):
+def _bf16_bound_map(img, templ, method, pieces=3):
     """numpy restatement of Bf16Params::rig's bound M(x, y) for a single-channel float32 image and one template:
     rig_eps * sqrt(sum (I - mu)^2) / sq * (escale * sqrt(sum (T - mean)^2) / templ_norm), with mu the constant the
     bf16 kernel's work item (128 columns x 4 rows of outputs) subtracts: the mean of an 8 x 8 sample grid over its patch."""
@@ -2629,6 +2634,8 @@ def _bf16_bound_map(img, templ, method):
     nkb = (w + 31) // 32
     lds_cols = 128 + 32 * nkb
     eps = 3.0518e-5 + 2.0 * 3.0 * h * nkb * 5.97e-8
+    if pieces == 1:         # the one-product screen (bf16_rig_eps(.., np = 1), the accumulation term not doubled)
+        eps = 2.0 ** -7 * (1.0 + 2.0 ** -9) + 2.0 * 1.0 * h * nkb * 5.97e-8
     c1 = np.zeros((rows + 1, cols + 1))
     c1[1:, 1:] = I.cumsum(0).cumsum(1)
     c2 = np.zeros((rows + 1, cols + 1))
@@ -2670,14 +2677,17 @@ def _step_image(seed, shape=(300, 420), lo=0.0, hi=1.0, noise=2e-3):
 
 
 @pytest.mark.gpu
-def test_float32_error_bound_holds():
+@pytest.mark.parametrize("pieces", [3, 1])
+def test_float32_error_bound_holds(pieces):
     """|bf16 kernel score - float64 kernel score| <= M at every output, M the bound the refined routes list by
     (Bf16Params::rig): on the adversarial geometry (low-contrast windows beside a brightness step, templates cut across
     the step) and on random data, for the three normalised methods.  Also reports how tight the bound is.
+    pieces = 1: the one-product screen of the hits-only routes (round 6; MTM_OPT_F32_MFMA = 4 publishes its raw scores for
+    this test alone) against ITS bound, 2^-7 (1 + 2^-9) of the norms' product + the accumulation.
     Reference: MTM/__init__.py:71-74 (everything not uint8 is matched as float32)."""
     from MTM import _lib
     fast, exact = _lib.Context(0), _lib.Context(0)
-    fast.set_option(_lib.OPT_F32_MFMA, 2)           # the bf16 scores as they are
+    fast.set_option(_lib.OPT_F32_MFMA, 2 if pieces == 3 else 4)           # the bf16 scores as they are
     exact.set_option(_lib.OPT_F32_MFMA, 0)
     rng = np.random.default_rng(5)
     step = _step_image(1)
@@ -2698,13 +2708,14 @@ def test_float32_error_bound_holds():
                         ctx.set_templates([(t, None)], method)
                         maps.append(ctx.score_map(0, shape).astype(np.float64))
                     assert fast.timing()["kernel_used"] == 5 and exact.timing()["kernel_used"] == 0
-                    M, live = _bf16_bound_map(im, t, method)
+                    assert fast.timing()["f32_pieces"] == pieces
+                    M, live = _bf16_bound_map(im, t, method, pieces)
                     unsat = live & (np.abs(maps[1]) < 1.0) & (np.abs(maps[0]) < 1.0)
                     d = np.abs(maps[0] - maps[1])
                     assert (d[unsat] <= M[unsat]).all(), (name, method, t.shape, float((d[unsat] / M[unsat]).max()))
                     if unsat.any():
                         worst = max(worst, float((d[unsat] / M[unsat]).max()))
-        print("float32 bound: worst |error| / bound = %.3f" % worst)
+        print("float32 bound, %d piece product(s): worst |error| / bound = %.3f" % (pieces, worst))
         assert worst <= 1.0
     finally:
         fast.close()
@@ -2762,6 +2773,63 @@ def test_float32_adversarial_lists_equal_the_float64_kernels():
         assert 1 in routes, routes
     finally:
         fast.close()
+        exact.close()
+
+
+@pytest.mark.gpu
+def test_float32_one_product_screen_and_its_fallback():
+    """Round 6: the hits-only refined routes screen with ONE bfloat16 piece product first (mtm_timing.f32_pieces = 1; bound
+    2^-7 of the norms' product instead of 2^-15) - the records must stay the float64 kernel's.  On noise, with a threshold
+    two standard deviations up the score distribution, the one-product screen lists a multiple of what the three-product
+    screen lists: walking the list capacity down finds capacities the first overflows and the second fits - the launch is
+    then repeated with three products (f32_pieces = 3, still route 1), and the calls after it start there until the
+    back-off ends.  MTM_OPT_F32_MFMA = 3 never takes the tier.  Reference: MTM/__init__.py:71-74, :45-52."""
+    if not default_routes():
+        pytest.skip("asserts the default float32 routes")
+    from MTM import _lib
+    fast, three, exact = _lib.Context(0), _lib.Context(0), _lib.Context(0)
+    exact.set_option(_lib.OPT_F32_MFMA, 0)
+    three.set_option(_lib.OPT_F32_MFMA, 3)
+    rng = np.random.default_rng(77)
+    im = rng.normal(50.0, 9.0, (260, 400)).astype(np.float32)
+    lt = [(np.ascontiguousarray(im[y:y + 24, x:x + 24]), None) for y, x in ((10, 20), (120, 300), (200, 77))]
+    seen = set()
+    try:
+        for method, thr in ((5, 0.085), (3, 0.9712), (1, 0.0576)):
+            ref = exact.search(lt, im, method, _lib.PEAKS_LOCAL, thr).copy()
+            assert len(ref) >= 3
+            for cap in (1 << 18, 40000, 20000, 10000, 5000, 2500):
+                for ctx in (fast, three):
+                    ctx.set_option(_lib.OPT_HIT_CAPACITY, cap)
+                    ctx.set_option(_lib.OPT_HITS_ONLY, 1)          # (also ends a back-off)
+                    got = ctx.search(lt, im, method, _lib.PEAKS_LOCAL, thr)
+                    tm = ctx.timing()
+                    assert got.tobytes() == ref.tobytes(), (method, cap, tm["f32_route"], tm["f32_pieces"], len(got), len(ref))
+                    if ctx is three:
+                        assert tm["f32_pieces"] in (0, 3), tm
+                    else:
+                        seen.add((method, cap, tm["f32_route"], tm["f32_pieces"]))
+                        if tm["f32_route"] == 1 and tm["f32_pieces"] == 3:
+                            # the screen overflowed in this call: the next call starts with three products (back-off) ...
+                            again = fast.search(lt, im, method, _lib.PEAKS_LOCAL, thr)
+                            assert again.tobytes() == ref.tobytes() and fast.timing()["f32_pieces"] == 3
+        print("one-product tier:", sorted(seen))
+        assert any(r == 1 and pc == 1 for _, _, r, pc in seen), sorted(seen)            # the tier ran and sufficed
+        assert any(r == 1 and pc == 3 for _, _, r, pc in seen), sorted(seen)            # ... overflowed, three products sufficed
+        # N_object == 1 by bounds: the screen's wider bounds list more outputs around each template's best - same records
+        for method in (5, 3, 1, 0, 2, 4):
+            ref = exact.search(lt, im, method, _lib.PEAKS_GLOBAL, 0.0).copy()
+            for cap in (1 << 18, 256):
+                fast.set_option(_lib.OPT_HIT_CAPACITY, cap)
+                fast.set_option(_lib.OPT_HITS_ONLY, 1)
+                got = fast.search(lt, im, method, _lib.PEAKS_GLOBAL, 0.0)
+                tm = fast.timing()
+                assert got.tobytes() == ref.tobytes(), (method, cap, tm["f32_route"], tm["f32_pieces"])
+                if cap == 1 << 18:
+                    assert tm["f32_route"] == 1 and tm["f32_pieces"] == 1, (method, tm)
+    finally:
+        fast.close()
+        three.close()
         exact.close()
 
 
