@@ -120,30 +120,39 @@ __device__ __forceinline__ void bf_static_for(F& f) {
 template <int MB, int NP>
 __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const v4i_b h1, const v4i_b l0, const v4i_b l1,
                                         const v4i_b (&a0)[MB], const v4i_b (&a1)[MB]) {
-    const int W[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    const int V[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-    int EW[7], EV[7];
+    // (round 6: the lane's 32 bytes of a piece plane as ONE eight-register value and the phases' operands as sub-ranges of it
+    // - built from eight scalars, every window that straddles the two loads cost the compiler four register copies: 16 of
+    // the 27 vector instructions of a one-product step were moves)
+    typedef int v8i_b __attribute__((ext_vector_type(8)));
+    const v8i_b W = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8i_b V = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    v8i_b EW = W, EV = V;
 #pragma unroll
     for (int m = 0; m < 7; ++m) {
         EW[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)W[m + 1], (uint32_t)W[m], 2);
         if constexpr (NP == 3) EV[m] = (int)__builtin_amdgcn_alignbyte((uint32_t)V[m + 1], (uint32_t)V[m], 2);
     }
-#pragma unroll
-    for (int ph = 0; ph < 8; ++ph) {
-        const int k = ph >> 1;
-        const v4i_b bh = (ph & 1) ? v4i_b{EW[k], EW[k + 1], EW[k + 2], EW[k + 3]} : v4i_b{W[k], W[k + 1], W[k + 2], W[k + 3]};
+    auto window = [](const v8i_b& x, auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        return __builtin_shufflevector(x, x, k, k + 1, k + 2, k + 3);
+    };
+    auto phase = [&](auto ph_c) {
+        constexpr int ph = decltype(ph_c)::value;
+        constexpr int k = ph >> 1;
+        const v4i_b bh = (ph & 1) ? window(EW, std::integral_constant<int, k>{}) : window(W, std::integral_constant<int, k>{});
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             v4f a = acc[mb][ph];
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
             if constexpr (NP == 3) {
-                const v4i_b bl = (ph & 1) ? v4i_b{EV[k], EV[k + 1], EV[k + 2], EV[k + 3]} : v4i_b{V[k], V[k + 1], V[k + 2], V[k + 3]};
+                const v4i_b bl = (ph & 1) ? window(EV, std::integral_constant<int, k>{}) : window(V, std::integral_constant<int, k>{});
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a1[mb]), __builtin_bit_cast(v8bf, bh), a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a0[mb]), __builtin_bit_cast(v8bf, bl), a, 0, 0, 0);
             }
             acc[mb][ph] = a;
         }
-    }
+    };
+    bf_static_for<8>(phase);
 }
 
 // NP = 1 (round 6): the ONE-PRODUCT SCREEN.  Only the leading bfloat16 piece of both operands is correlated - a third of
@@ -170,6 +179,10 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const int seg = rest % p.nseg, yb = rest / p.nseg;
     const int x0 = seg * kBfSeg, y0 = yb * kBfRows;
 
+    // (Round 6 measured a phase offset between the two work-groups of a CU - the one in the odd wave slot of the first
+    // generation sleeping half a tile period, so that one wave of a SIMD multiplies while the other normalises: 2.03-2.05
+    // against 1.95-1.96 ms at 4K x 32, one piece product, alternating on one box; removed.  The same start stagger had been
+    // measured on ncc_mfma_kernel in rounds 3 and 4 with the same result.)
     v4f acc[MB][8];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -243,16 +256,17 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
             const float* grow = plane + (size_t)(y0 + cy0) * p.pitch + x0;
             __syncthreads();                    // previous tile fully consumed
             // stage: two adjacent pixels per thread and step -> one dword per piece plane; (row, pair) advance
-            // without divisions, four requests in flight per thread
+            // without divisions, eight requests in flight per thread
             {
                 const int pairs = p.lds_cols >> 1;
                 const int rstep = 256 / pairs, cstep = 256 - rstep * pairs;
                 int r = threadIdx.x / pairs, cp = threadIdx.x - r * pairs;
                 while (r < trows) {
-                    float2 v[4];
-                    int rr[4], cc[4];
+                    constexpr int kInFlight = 8;        // (round 6: 8 instead of 4 requests per thread - the tile is a chain of load latencies)
+                    float2 v[kInFlight];
+                    int rr[kInFlight], cc[kInFlight];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kInFlight; ++u) {
                         rr[u] = r;
                         cc[u] = cp;
                         if (r < trows) v[u] = *reinterpret_cast<const float2*>(grow + (size_t)r * p.pitch + 2 * cp);
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < kInFlight; ++u) {
                         if (rr[u] >= trows) break;
                         const float a = v[u].x - mu, b = v[u].y - mu;
                         const uint32_t a0 = bf16_rne(a), b0 = bf16_rne(b);
@@ -311,6 +325,84 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 loff += wrap_ ? row_adv : 64;                   \
                 kb_i = wrap_ ? 0 : kb_i + 1;                    \
             }
+            if constexpr (NP == 1) {
+                // One piece product: a step is 8 MB MFMAs, ~270 cycles of the matrix pipe (twice that while the SIMD's other
+                // wave is in its K loop too) - less than the latency of the packed template rows, which come from memory
+                // (L2) every step.  With the one-step look-ahead of the three-product loop the waves sat in s_waitcnt for a
+                // third of their lives (PMC, 4K x 32: SQ_WAIT_ANY 44 k of a wave's 134 k cycles, matrix pipe 49 % busy).
+                // Here the two register sets hold the template rows of kStage = 4 steps each: a stage's rows are requested
+                // while the previous stage multiplies, four steps ahead of their use; the image chunks from LDS stay one step
+                // ahead.  Requests beyond the chunk's last step repeat that step's address (nothing is read past the packs),
+                // steps beyond it are skipped (wave-uniform).  (A four-set rotation with single steps was tried first: the
+                // compiler re-rotated it into a one-step look-ahead with register copies.)
+                constexpr int kStage = 4;
+                const uint8_t* abase = aptr;
+                v4i_b sA[kStage][MB], sB[kStage][MB], hq0a, hq0b, hq1a, hq1b;
+                const v4i_b zero4 = v4i_b{0, 0, 0, 0};
+#define MTM_BF1_LDSTAGE(S, STEP0)                                                                           \
+                _Pragma("unroll") for (int i_ = 0; i_ < kStage; ++i_) {                                     \
+                    const uint8_t* ap_ = abase + (size_t)min((STEP0) + i_, nsteps - 1) * 1024;              \
+                    _Pragma("unroll") for (int mb = 0; mb < MB; ++mb)                                       \
+                        S[i_][mb] = *reinterpret_cast<const v4i_b*>(ap_ + mb * p.group_bytes);              \
+                }
+#define MTM_BF1_LDH(HA, HB)                                                                                 \
+                HA = *reinterpret_cast<const v4i_b*>(thi + loff);                                           \
+                HB = *reinterpret_cast<const v4i_b*>(thi + loff + 16);
+#define MTM_BF1_ADV()                                                                                       \
+                {                                                                                           \
+                    const bool wrap_ = kb_i + 1 == p.nkb;                                                   \
+                    loff += wrap_ ? row_adv : 64;                                                           \
+                    kb_i = wrap_ ? 0 : kb_i + 1;                                                            \
+                }
+                // the four steps of a stage: image chunks alternate between the two (hq*) sets, the next step's are
+                // requested before this step's MFMAs (one step past the chunk at its end: inside the LDS allocation)
+#define MTM_BF1_RUNSTAGE(S, STEP0)                                                                          \
+                {                                                                                           \
+                    const int left_ = nsteps - (STEP0);                                                     \
+                    MTM_BF1_ADV()                                                                           \
+                    MTM_BF1_LDH(hq1a, hq1b)                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                                      \
+                    bf_step<MB, 1>(acc, hq0a, hq0b, zero4, zero4, S[0], S[0]);                              \
+                    __builtin_amdgcn_sched_barrier(0);                                                      \
+                    if (left_ > 1) {                                                                        \
+                        MTM_BF1_ADV()                                                                       \
+                        MTM_BF1_LDH(hq0a, hq0b)                                                             \
+                        __builtin_amdgcn_sched_barrier(0);                                                  \
+                        bf_step<MB, 1>(acc, hq1a, hq1b, zero4, zero4, S[1], S[1]);                          \
+                        __builtin_amdgcn_sched_barrier(0);                                                  \
+                    }                                                                                       \
+                    if (left_ > 2) {                                                                        \
+                        MTM_BF1_ADV()                                                                       \
+                        MTM_BF1_LDH(hq1a, hq1b)                                                             \
+                        __builtin_amdgcn_sched_barrier(0);                                                  \
+                        bf_step<MB, 1>(acc, hq0a, hq0b, zero4, zero4, S[2], S[2]);                          \
+                        __builtin_amdgcn_sched_barrier(0);                                                  \
+                    }                                                                                       \
+                    if (left_ > 3) {                                                                        \
+                        MTM_BF1_ADV()                                                                       \
+                        MTM_BF1_LDH(hq0a, hq0b)                                                             \
+                        __builtin_amdgcn_sched_barrier(0);                                                  \
+                        bf_step<MB, 1>(acc, hq1a, hq1b, zero4, zero4, S[3], S[3]);                          \
+                        __builtin_amdgcn_sched_barrier(0);                                                  \
+                    }                                                                                       \
+                }
+                MTM_BF1_LDSTAGE(sA, 0)
+                MTM_BF1_LDH(hq0a, hq0b)
+                for (int ks = 0; ks < nsteps; ks += 2 * kStage) {
+                    MTM_BF1_LDSTAGE(sB, ks + kStage)
+                    __builtin_amdgcn_sched_barrier(0);
+                    MTM_BF1_RUNSTAGE(sA, ks)
+                    if (ks + kStage < nsteps) {
+                        MTM_BF1_LDSTAGE(sA, ks + 2 * kStage)
+                        __builtin_amdgcn_sched_barrier(0);
+                        MTM_BF1_RUNSTAGE(sB, ks + kStage)
+                    }
+                }
+#undef MTM_BF1_LDSTAGE
+#undef MTM_BF1_LDH
+#undef MTM_BF1_ADV
+#undef MTM_BF1_RUNSTAGE
+            } else {
             MTM_BF_LOAD(hA0, hA1, lA0, lA1, aA0, aA1)
             int ks = 0;
             for (; ks + 2 <= nsteps; ks += 2) {
@@ -326,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ks < nsteps) bf_step<MB, NP>(acc, hA0, hA1, lA0, lA1, aA0, aA1);
+            }   // NP == 3
 #undef MTM_BF_LOAD
 #undef MTM_BF_ADVANCE
         }
@@ -364,6 +457,8 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
         // rig: the pixel's share of the bound, rig_eps * sqrt(sum (I - mu)^2) / sq (0 where the window is flat: the
         // normalisation rules return a constant there)
         double bp[4] = {0.0, 0.0, 0.0, 0.0};
+        double fs_E[4] = {0.0, 0.0, 0.0, 0.0}, fs_P[4] = {0.0, 0.0, 0.0, 0.0};      // the quotient-free listing screen's per-pixel terms
+        bool fs_wide = false;
         if (rig) {
             const double area = (double)p.h * (double)p.w;
 #pragma unroll
@@ -378,7 +473,13 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                     }
                 // (+ the cancellation in s2c itself: three terms of the size of s2 and area mu^2, summed over the channels)
                 s2c = fmax(s2c, 0.0) * 1.000001 + 1e-12 * (fabs(s2[i]) + area * mu2);
-                bp[i] = rig_r ? (double)p.rig_eps * sqrt(s2c) : sq[i] > 0.0 ? (double)p.rig_eps * sqrt(s2c) / sq[i] : 0.0;
+                const double ee = (double)p.rig_eps * sqrt(s2c);
+                bp[i] = rig_r ? ee : sq[i] > 0.0 ? ee / sq[i] : 0.0;
+                if (fast_screen) {
+                    fs_E[i] = ee * 1.0000001;            // (never below bp sq as the exact test multiplies it out)
+                    fs_P[i] = (p.cand_min ? fs_d - fs_thr : fs_thr - fs_d) * sq[i];
+                    fs_wide = fs_wide || !(sq[i] > 0.0) || !(bp[i] <= 0.2);
+                }
             }
         }
         // one template of the lane (group mb, accumulator element e) - instantiated 4 MB times by bf_static_for: as a
@@ -393,33 +494,47 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 bool skip = false;
                 if (fast_screen) {
                     // Hits-only listing by the bound (normalised methods): most outputs are nowhere near the threshold, and
-                    // the listing test  r + M > thr  (r = num / t) is  num > (thr - B - d) t  without the quotient - B the
-                    // output's bound, d twice the rounding allowance 3e-7 max(1, |r|) of the exact test below at the largest
-                    // |r| that reaches this branch (|r| <= max(1, |thr|); minima: r <= 4), which also dwarfs the float64
-                    // roundings of this restatement.  An output outside [-1, thr) (minima: (.., 4]), a flat window, a constant
-                    // template or anything that is not finite takes the exact test.  Lanes whose four outputs all fail
-                    // leave here: three float64 multiplications and two comparisons per output instead of a division
-                    // sequence, the saturation analysis and the bound arithmetic - a third of this kernel's time once the K
-                    // loop runs one piece product.
-                    bool anyp = p.list_all != 0 || T.all_ones != 0;
-                    const double tn = T.templ_norm;
+                    // the listing test  r + B > thr  (r = num / t, t = sq tn, B = bp bfac the output's bound) is, multiplied
+                    // by t > 0,   num + G E > tn P   with G = bfac tn per template and E = eps sqrt(sum (I - mu)^2),
+                    // P = (thr - d) sq per pixel (fs_E, fs_P above; minima: num - G E < tn P, P = (-thr + d) sq): a
+                    // conversion, two multiply-adds, a multiplication and a comparison per output instead of a division
+                    // sequence, the saturation analysis and the bound arithmetic - with one piece product in the K loop the
+                    // exact form of this epilogue took as many cycles as the K loop itself (PMC: 2.1 G VALU-active against
+                    // 2.1 G MFMA-busy cycles per launch at 4K x 32).  d is twice the rounding allowance 3e-7 max(1, |r|) of
+                    // the exact test below wherever |r| can matter, which also dwarfs the float64 roundings of this
+                    // restatement: a pixel whose bound is wide (bp > 0.2: a low-contrast window beside a step - also every
+                    // flat window and anything not finite) sends all its outputs to the exact test (fs_wide), so here
+                    // B <= 0.41 and a failing output has r <= thr - d, |r| <= max(1, |thr|) or r < -1 where r + B + 3e-7 |r|
+                    // < 0 <= thr (negative thresholds list everything: list_all); minima: r >= 0, and r (1 - 3e-7) >=
+                    // B - thr by the same d.  Constant templates take the exact test as well.
+                    const double tn = T.templ_norm, G = T.bfac * tn;
+                    bool anyp = p.list_all != 0 || T.all_ones != 0 || !(tn > 0.0) || fs_wide;
+                    double cm[kMaxChans];
+#pragma unroll
+                    for (int cc = 0; cc < kMaxChans; ++cc)
+                        cm[cc] = method == MTM_TM_CCOEFF_NORMED ? T.centre[cc] - T.mean[cc] : T.centre[cc];
+                    const double ts2 = T.templ_sum2;
+                    // (the bound's sign folded into G: one fma and one comparison direction per output; the channel loop behind a
+                    // wave-uniform branch - as selects it was 44 v_cndmask per template)
+                    const double Gs = p.cand_min ? -G : G;
+                    double numv[4];
+                    if (p.chans == 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) numv[i] = fma(cm[0], ts[i][0], (double)acc[mb][4 * half + i][e]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            double num = (double)acc[mb][4 * half + i][e];
+                            for (int cc = 0; cc < p.chans; ++cc) num = fma(cm[cc], ts[i][cc], num);
+                            numv[i] = num;
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        double num = (double)acc[mb][4 * half + i][e];
-#pragma unroll
-                        for (int cc = 0; cc < kMaxChans; ++cc)
-                            if (cc < p.chans) num += T.centre[cc] * ts[i][cc];
-                        if (method == MTM_TM_CCOEFF_NORMED) {
-#pragma unroll
-                            for (int cc = 0; cc < kMaxChans; ++cc)
-                                if (cc < p.chans) num -= ts[i][cc] * T.mean[cc];
-                        } else if (method == MTM_TM_SQDIFF_NORMED) {
-                            num = fmax(s2[i] - 2.0 * num + T.templ_sum2, 0.0);
-                        }
-                        const double tt = sq[i] * tn, B = bp[i] * T.bfac;
-                        const bool pp = p.cand_min ? (num < (B - fs_thr + fs_d) * tt || num > 4.0 * tt)
-                                                   : (num > (fs_thr - B - fs_d) * tt || num < -tt);
-                        anyp = anyp || !(tt > 0.0) || pp;
+                        double num = numv[i];
+                        if (method == MTM_TM_SQDIFF_NORMED) num = fmax(fma(-2.0, num, s2[i] + ts2), 0.0);
+                        const double lhs = fma(Gs, fs_E[i], num), rhs = tn * fs_P[i];
+                        anyp = anyp || (p.cand_min ? lhs < rhs : lhs > rhs);
                     }
                     skip = !anyp;
                 }

@@ -1,6 +1,7 @@
 // Host-visible part of the float32 (bf16-piece) score-map kernel: tile constants, launch parameters, LDS size.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 

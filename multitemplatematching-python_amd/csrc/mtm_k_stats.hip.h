@@ -48,6 +48,52 @@ __global__ void hsum_kernel(const float* __restrict__ img, int pitch, long long 
     }
 }
 
+// hsum_kernel<double> with the row segment staged through LDS (round 6).  The generic kernel's threads start 16 floats = 64 B
+// apart, so every one of its loads touches 64 cache lines: 270 us for a 4K float32 plane, next to a 2 ms score kernel once the
+// float32 screen runs one piece product.  Here the work-group copies its stretch of the row into LDS with coalesced loads
+// and every thread then performs EXACTLY the generic kernel's operations in the generic kernel's order on it (the float64
+// sums depend on the order - the statistics planes are bit for bit what they were).  LDS index i -> i + i / 16: the threads'
+// stride of 16 floats would put all lanes of a wave on four banks.  Same grid as hsum_kernel (blockDim 256); needs
+// 4 * (256 * kHsumSeg + w + its padding) bytes of dynamic LDS; the launcher keeps the generic kernel for w > 1024.
+__host__ __device__ __forceinline__ int hsum_lds_idx(int i) { return i + (i >> 4); }
+inline size_t hsum_lds_bytes(int w) { return sizeof(float) * (size_t)(hsum_lds_idx(256 * kHsumSeg + w) + 2); }
+
+__global__ __launch_bounds__(256) void hsum_lds_kernel(const float* __restrict__ img, int pitch, long long plane, int rows,
+                                                       int w, int ow, double* __restrict__ hs1, double* __restrict__ hs2,
+                                                       int hs_pitch, long long hs_plane) {
+    extern __shared__ float hsum_row[];
+    const int xb = blockIdx.x * 256 * kHsumSeg;           // first output column of the work-group
+    const int y = blockIdx.y, c = blockIdx.z;
+    if (y >= rows) return;
+    const float* row = img + c * plane + (size_t)y * pitch + xb;
+    // outputs xb .. xb + n_out - 1 read row elements 0 .. n_out + w - 1 (the padded image keeps x + w readable, as in the
+    // generic kernel); clamp to the row pitch all the same
+    const int n_out = min(256 * kHsumSeg, ow - xb);
+    const int n_in = min(n_out + w, pitch - xb);
+    for (int i = threadIdx.x; i < n_in; i += 256) hsum_row[hsum_lds_idx(i)] = row[i];
+    __syncthreads();
+    const int x0 = threadIdx.x * kHsumSeg;
+    if (x0 >= n_out) return;
+    double s1 = 0, s2 = 0;
+    for (int dx = 0; dx < w; ++dx) {
+        const double v = (double)hsum_row[hsum_lds_idx(x0 + dx)];
+        s1 += v;
+        s2 += v * v;
+    }
+    double* o1 = hs1 + c * hs_plane + (size_t)y * hs_pitch + xb;
+    double* o2 = hs2 + c * hs_plane + (size_t)y * hs_pitch + xb;
+    for (int k = 0; k < kHsumSeg; ++k) {
+        const int x = x0 + k;
+        if (x >= n_out) break;
+        o1[x] = s1;
+        o2[x] = s2;
+        const double vn = (double)hsum_row[hsum_lds_idx(x + w)];
+        const double vo = (double)hsum_row[hsum_lds_idx(x)];
+        s1 += vn - vo;
+        s2 += vn * vn - vo * vo;
+    }
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave with DPP (no LDS, no ds_bpermute): the classic
 // row_shr 1/2/3, row_shr 4 (banks 1-3), row_shr 8 (banks 2-3), row_bcast 15 (rows 1,3), row_bcast 31
 // (rows 2,3) sequence.  Lanes without a source keep 0 (the `old` operand).

@@ -193,9 +193,14 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         }
     } else {
         MTMC(ensure_f32_plane(c));
-        hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
-                           img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
-                           hs_plane);
+        if (w <= 1024)      // (the same sums in the same order, the row staged through LDS: mtm_k_stats.hip.h)
+            hipLaunchKernelGGL(hsum_lds_kernel, g1, dim3(256), hsum_lds_bytes(w), c->stream, img.f32, img.f32_pitch,
+                               img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
+                               hs_plane);
+        else
+            hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
+                               img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
+                               hs_plane);
         hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
                            inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
@@ -359,8 +364,8 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
         const dim3 g2((ow + 255) / 256, (oh + kVsumBand - 1) / kVsumBand);
         for (int pl = 0; pl < 2; ++pl) {
             const float* src = pl == 0 ? img.f32 : c->f32_sq.as<float>();
-            hipLaunchKernelGGL((hsum_kernel<double>), g1, dim3(256), 0, c->stream, src, img.f32_pitch, img.f32_plane, c->rows, w, ow,
-                               c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, (long long)hs_plane);
+            hipLaunchKernelGGL(hsum_lds_kernel, g1, dim3(256), hsum_lds_bytes(w), c->stream, src, img.f32_pitch, img.f32_plane, c->rows,
+                               w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, (long long)hs_plane);
             hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream, c->hs1.as<double>(),
                                c->hs2.as<double>(), hs_pitch, (long long)hs_plane, 1, h, oh, ow, 1.0 / ((double)h * w), 0, 0, 1,
                                pl == 0 ? s1i : s1j, (double*)nullptr, (double*)nullptr, (double*)nullptr, pl == 0 ? s2i : s2j,
