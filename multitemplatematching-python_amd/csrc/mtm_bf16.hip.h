@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     if (wid >= p.n_work) return;
     const int tg = wid % p.ntg;
     const int rest = wid / p.ntg;
-    const int seg = rest % p.nseg, yb = rest / p.nseg;
+    const int seg = rest % p.nseg, yb = rest / p.nseg + p.yb0;
     const int x0 = seg * kBfSeg, y0 = yb * kBfRows;
 
     // (Round 6 measured a phase offset between the two work-groups of a CU - the one in the odd wave slot of the first

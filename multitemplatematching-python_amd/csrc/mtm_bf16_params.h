@@ -31,6 +31,7 @@ struct Bf16Params {
     int lds_cols;            // elements per tile row: 128 + 32 * nkb
     int n_list;
     int nseg, nyb, ntg, n_work;
+    int yb0;                 // first row block of this launch (banded float32 uploads, round 6: a launch per band of rows); nyb counts from it
     int method;
     long long group_bytes;   // bytes of one 16-template pack of ONE piece: chans * h * nkb * 1024
     long long piece_bytes;   // bytes between the T0 packs and the T1 packs

@@ -87,6 +87,19 @@ int upload_rows_u8c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src,
     return MTM_OK;
 }
 
+// Rows r0 .. r1 - 1 of a single-channel float32 image (round 6: banded float32 uploads): straight into the padded plane -
+// what planarize_f32_kernel makes of a one-channel image is a copy.
+int upload_rows_f32c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
+                      hipStream_t stream) {
+    const int nrows = r1 - r0;
+    if (nrows <= 0) return MTM_OK;
+    float* dst = sl.f32.as<float>() + (size_t)r0 * g.pitch;
+    HIPC(hipMemcpy2DAsync(dst, sizeof(float) * (size_t)g.pitch, (const uint8_t*)src + (size_t)r0 * src_stride, (size_t)src_stride,
+                          sizeof(float) * (size_t)g.cols, nrows, hipMemcpyHostToDevice, stream));
+    sl.f32_valid = true;
+    return MTM_OK;
+}
+
 // The same for rows r0 .. r1 - 1 of a single-channel uint16 image: the three byte planes and the float32 plane.
 int upload_rows_u16c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1,
                       hipStream_t stream, hipEvent_t copy_done, hipEvent_t before_kernels) {

@@ -473,6 +473,7 @@ int upload_image(mtm_ctx* c, mtm_ctx::ImageSlot& sl, const void* src, int64_t sr
 void adopt_image(mtm_ctx* c, int rows, int cols, int chans, int dtype);
 int check_image_args(const void* px, int rows, int cols, int chans, int dtype, int64_t row_stride_bytes, const char* who);
 int ensure_f32_plane(mtm_ctx* c);
+int upload_rows_f32c1(mtm_ctx::ImageSlot& sl, const SlotGeom& g, const void* src, int64_t src_stride, int r0, int r1, hipStream_t stream);
 int ensure_copy_stream(mtm_ctx* c);
 int ensure_lanes(mtm_ctx* c, int n);
 // ---- mtm_comm.hip

@@ -60,10 +60,10 @@ inline size_t hsum_lds_bytes(int w) { return sizeof(float) * (size_t)(hsum_lds_i
 
 __global__ __launch_bounds__(256) void hsum_lds_kernel(const float* __restrict__ img, int pitch, long long plane, int rows,
                                                        int w, int ow, double* __restrict__ hs1, double* __restrict__ hs2,
-                                                       int hs_pitch, long long hs_plane) {
+                                                       int hs_pitch, long long hs_plane, int y_off) {
     extern __shared__ float hsum_row[];
     const int xb = blockIdx.x * 256 * kHsumSeg;           // first output column of the work-group
-    const int y = blockIdx.y, c = blockIdx.z;
+    const int y = (int)blockIdx.y + y_off, c = blockIdx.z;      // y_off: banded uploads - the rows that have just arrived
     if (y >= rows) return;
     const float* row = img + c * plane + (size_t)y * pitch + xb;
     // outputs xb .. xb + n_out - 1 read row elements 0 .. n_out + w - 1 (the padded image keeps x + w readable, as in the
@@ -687,9 +687,9 @@ __global__ void vsum_stats_kernel(const AccT* __restrict__ hs1, const AccT* __re
                                   double inv_area, int num_type, int want_sq, int want_t,
                                   double* __restrict__ t0, double* __restrict__ t1,
                                   double* __restrict__ t2, double* __restrict__ t3,
-                                  double* __restrict__ sum2, double* __restrict__ sq, int pitch) {
+                                  double* __restrict__ sum2, double* __restrict__ sq, int pitch, int yb_off) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y0 = blockIdx.y * kVsumBand;
+    const int y0 = ((int)blockIdx.y + yb_off) * kVsumBand;      // yb_off: banded uploads (a band of kVsumBand rows restarts its column sums: whole bands only)
     if (x >= ow || y0 >= oh) return;
     double* tp[kMaxChans] = {t0, t1, t2, t3};
     SumT s1[kMaxChans], s2[kMaxChans];

@@ -171,7 +171,7 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
         hipLaunchKernelGGL((vsum_stats_kernel<uint32_t, unsigned long long>), g2, dim3(256), 0, c->stream,
                            c->hs1.as<uint32_t>(), c->hs2.as<uint32_t>(), hs_pitch, hs_plane, c->chans, h, oh,
                            ow, inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq,
-                           st.pitch);
+                           st.pitch, 0);
     } else if (c->dtype == MTM_U16 && c->chans == 1 && w <= 768 && (double)w * h * 65535.0 < 4294967296.0 && c->fuse_stats) {
         // single-channel uint16: the fused kernel over the two byte planes (the ones the MFMA kernel reads)
         const int owg = stats_u8_owg(w);
@@ -192,18 +192,29 @@ int launch_stats(mtm_ctx* c, const SizeClass& sc, StatPlanes* out, int sb0, int 
                                tp[0], sum2, sq, st.pitch, blk, st.blk_pitch, sb0);
         }
     } else {
-        MTMC(ensure_f32_plane(c));
-        if (w <= 1024)      // (the same sums in the same order, the row staged through LDS: mtm_k_stats.hip.h)
-            hipLaunchKernelGGL(hsum_lds_kernel, g1, dim3(256), hsum_lds_bytes(w), c->stream, img.f32, img.f32_pitch,
+        // Round 6, banded float32 uploads (run_score_banded): c->lay_r0 .. lay_r1 are the image rows that have just arrived
+        // (their horizontal sums), sb0 .. sb1 the output rows whose windows they complete, in blocks of kStatBand4 rows that
+        // make whole vsum bands (a band restarts its column sums: the planes are bit for bit those of one launch)
+        const bool part = c->lay_r1 > c->lay_r0 && w <= 1024;
+        const hipStream_t ss = c->stats_stream ? c->stats_stream : c->stream;
+        if (!part) MTMC(ensure_f32_plane(c));
+        if (w <= 1024) {    // (the same sums in the same order, the row staged through LDS: mtm_k_stats.hip.h)
+            const dim3 g1p(g1.x, part ? c->lay_r1 - c->lay_r0 : c->rows, c->chans);
+            hipLaunchKernelGGL(hsum_lds_kernel, g1p, dim3(256), hsum_lds_bytes(w), ss, img.f32, img.f32_pitch,
+                               img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
+                               hs_plane, part ? c->lay_r0 : 0);
+        } else
+            hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, ss, img.f32, img.f32_pitch,
                                img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
                                hs_plane);
-        else
-            hipLaunchKernelGGL(hsum_kernel<double>, g1, dim3(256), 0, c->stream, img.f32, img.f32_pitch,
-                               img.f32_plane, c->rows, w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch,
-                               hs_plane);
-        hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream,
-                           c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
-                           inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch);
+        const int o0 = part ? sb0 * kStatBand4 : 0, o1 = part && sb1 >= 0 ? std::min(oh, sb1 * kStatBand4) : oh;
+        if (o1 > o0) {
+            const dim3 g2p(g2.x, (o1 - o0 + kVsumBand - 1) / kVsumBand);
+            hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2p, dim3(256), 0, ss,
+                               c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, hs_plane, c->chans, h, oh, ow,
+                               inv_area, num_type, normed ? 1 : 0, want_t, tp[0], tp[1], tp[2], tp[3], sum2, sq, st.pitch,
+                               o0 / kVsumBand);
+        }
     }
     HIPC(hipGetLastError());
     for (int k = 0; k < kMaxChans; ++k) st.t[k] = tp[k];
@@ -365,11 +376,11 @@ static int launch_masked_bf16(mtm_ctx* c, const SizeClass& sc, float* maps, bool
         for (int pl = 0; pl < 2; ++pl) {
             const float* src = pl == 0 ? img.f32 : c->f32_sq.as<float>();
             hipLaunchKernelGGL(hsum_lds_kernel, g1, dim3(256), hsum_lds_bytes(w), c->stream, src, img.f32_pitch, img.f32_plane, c->rows,
-                               w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, (long long)hs_plane);
+                               w, ow, c->hs1.as<double>(), c->hs2.as<double>(), hs_pitch, (long long)hs_plane, 0);
             hipLaunchKernelGGL((vsum_stats_kernel<double, double>), g2, dim3(256), 0, c->stream, c->hs1.as<double>(),
                                c->hs2.as<double>(), hs_pitch, (long long)hs_plane, 1, h, oh, ow, 1.0 / ((double)h * w), 0, 0, 1,
                                pl == 0 ? s1i : s1j, (double*)nullptr, (double*)nullptr, (double*)nullptr, pl == 0 ? s2i : s2j,
-                               (double*)nullptr, st_pitch);
+                               (double*)nullptr, st_pitch, 0);
         }
     }
     // the two raw launches
@@ -919,6 +930,10 @@ int launch_ncc(mtm_ctx* c, const SizeClass& sc, int list_off, int n_list, const 
         p.n_list = n_all;
         p.nseg = (ow + kBfSeg - 1) / kBfSeg;
         p.nyb = (oh + kBfRows - 1) / kBfRows;
+        if (yb1 >= 0) {                             // a band of row blocks (run_score_banded, float32 uploads)
+            p.yb0 = yb0;
+            p.nyb = std::min(yb1, p.nyb) - yb0;
+        }
         p.ntg = (n_all + 16 * mb - 1) / (16 * mb);
         p.method = c->method;
         p.group_bytes = sc.group_bytes;
@@ -1097,6 +1112,18 @@ int launch_refine(mtm_ctx* c, const SizeClass& sc, const StatPlanes& st, bool ri
     return MTM_OK;
 }
 
+// refined global extremum: the keys the score kernel kept are approximate - rebuild them from the re-scored list
+static int launch_refine_extremum(mtm_ctx* c) {
+    const size_t n = c->templs.size();
+    HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * n, c->stream));
+    const unsigned long long cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
+    hipLaunchKernelGGL(refine_extremum_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream,
+                       reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16), c->cands.as<unsigned long long>(), cap,
+                       c->td.as<TemplDev>(), c->cand_min ? 1 : 0, c->counters.as<unsigned long long>());
+    HIPC(hipGetLastError());
+    return MTM_OK;
+}
+
 // the map scan of the refined route: potential peaks of class `sc` (approximate maps in memory) -> candidate buffer
 int launch_refine_scan(mtm_ctx* c, const SizeClass& sc) {
     const int oh = c->rows - sc.h + 1, ow = c->cols - sc.w + 1;
@@ -1231,16 +1258,7 @@ static int run_score_classes(mtm_ctx* c, int skip, hipEvent_t fork) {
         HIPC(hipEventRecord(c->lanes[(size_t)i].done, c->lanes[(size_t)i].stream));
         HIPC(hipStreamWaitEvent(c->stream, c->lanes[(size_t)i].done, 0));
     }
-    if (c->refine_now && !c->f32_exact_now && c->ext_now) {
-        // global extremum: the keys the score kernel kept are approximate - rebuild them from the re-scored list
-        const size_t n = c->templs.size();
-        HIPC(hipMemsetAsync(c->counters.p, 0, sizeof(unsigned long long) * 2 * n, c->stream));
-        const unsigned long long cap = (unsigned long long)std::min<int64_t>(c->hit_cap, 4096LL * 256);
-        hipLaunchKernelGGL(refine_extremum_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, c->stream,
-                           reinterpret_cast<const mtm_hit*>(c->cands.as<uint8_t>() + 16), c->cands.as<unsigned long long>(), cap,
-                           c->td.as<TemplDev>(), c->cand_min ? 1 : 0, c->counters.as<unsigned long long>());
-        HIPC(hipGetLastError());
-    }
+    if (c->refine_now && !c->f32_exact_now && c->ext_now) MTMC(launch_refine_extremum(c));
     return MTM_OK;
 }
 
@@ -1317,6 +1335,17 @@ bool banded_ok(mtm_ctx* c, const ImageArgs& a) {
 
 static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass& sc, double* work, bool any_fill) {
     const bool u16 = a.dtype == MTM_U16;
+    if (a.dtype == MTM_F32) {
+        // Round 6: single-channel float32 images whose one size class runs the bf16 kernel - 33 MB cross PCIe at 4K, 0.7 ms
+        // next to a 1.9 ms score launch since the one-product screen; two bands, the second under the first's score launch
+        if (any_fill || c->upload_bands.size() < 2 || a.chans != 1 || c->classes.size() != 1 || sc.masked || sc.w > 1024 ||
+            resolved_kernel(c, sc) != MTM_KERNEL_MFMA_F32)
+            return false;
+        const int oh = a.rows - sc.h + 1;
+        if (!((size_t)a.rows * a.cols >= ((size_t)1 << 20) && oh >= 8 * kVsumBand)) return false;
+        *work = (double)oh * (a.cols - sc.w + 1) * sc.h * sc.w * (double)sc.members.size();
+        return true;
+    }
     if (c->upload_bands.size() < 2 || (a.dtype != MTM_U8 && !u16) || a.chans != 1) return false;
     if (sc.masked || !c->fuse_stats || !sc.slabs.empty() || resolved_kernel(c, sc) != (u16 ? MTM_KERNEL_MFMA16 : MTM_KERNEL_MFMA))
         return false;
@@ -1342,7 +1371,72 @@ static bool class_bandable(const mtm_ctx* c, const ImageArgs& a, const SizeClass
 // conversion and the window statistics of the output rows that became computable; c->stream: the score kernel
 // over the row blocks whose statistics exist, behind the band's event.  With a pageable source every copy call
 // blocks the host while its rows are staged - the kernels queued before it run meanwhile.
+// ... of a float32 image (round 6): two bands; the first ends where ~30 % of the output rows are complete, at a whole number of
+// vsum bands (their column sums restart per band: the statistics planes are those of one launch) - the second band's 23 MB
+// cross PCIe under the first band's score launch.  The rows go straight into the padded float32 plane.
+static int run_score_banded_f32(mtm_ctx* c, const ImageArgs& a) {
+    const SizeClass& sc = c->classes[(size_t)c->banded_cls];
+    if (!c->hits_only_now) MTMC(ensure_maps(c));
+    MTMC(ensure_copy_stream(c));
+    mtm_ctx::ImageSlot& sl = c->slot[c->cur];
+    SlotGeom g{};
+    MTMC(prepare_slot(c, sl, a.rows, a.cols, 1, a.dtype, c->copy_stream, 1, &g));
+    while ((int)c->band_ev.size() < 2) {
+        hipEvent_t e;
+        HIPC(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->band_ev.push_back(e);
+    }
+    const hipStream_t bs0 = c->copy_stream;
+    if (c->f32_exact_now) {
+        // (this call's method / mode sends the class to the float64 kernel after all - decided behind the banding decision:
+        // the whole image in one piece, then the plain score pass)
+        MTMC(upload_rows_f32c1(sl, g, a.px, a.stride, 0, a.rows, bs0));
+        HIPC(hipEventRecord(c->band_ev[0], bs0));
+        HIPC(hipStreamWaitEvent(c->stream, c->band_ev[0], 0));
+        HIPC(hipEventRecord(c->ev[0], c->stream));
+        return run_score_all(c);
+    }
+    const int h = sc.h, oh = a.rows - h + 1;
+    const int nyb = (oh + kBfRows - 1) / kBfRows;
+    const double frac = std::min(0.6, std::max(0.1, c->upload_bands[0] + 0.05));
+    const int o_split = std::max(kVsumBand, ((int)(frac * oh) / kVsumBand) * kVsumBand);      // < oh: class_bandable asked for 8 bands
+    const hipStream_t bs = c->copy_stream;
+    StatPlanes st;
+    int r_done = 0;
+    for (int k = 0; k < 2; ++k) {
+        const bool last = k == 1;
+        const int r1 = last ? a.rows : o_split + h - 1;
+        MTMC(upload_rows_f32c1(sl, g, a.px, a.stride, r_done, r1, bs));
+        if (k == 0) HIPC(hipEventRecord(c->ev[0], c->stream));          // (see fm_begin)
+        c->lay_r0 = r_done;
+        c->lay_r1 = r1;
+        c->stats_stream = bs;
+        const int rc = launch_stats(c, sc, &st, last ? o_split / kStatBand4 : 0, last ? -1 : o_split / kStatBand4);
+        c->stats_stream = nullptr;
+        c->lay_r0 = c->lay_r1 = 0;
+        MTMC(rc);
+        r_done = r1;
+        HIPC(hipEventRecord(c->band_ev[(size_t)k], bs));
+        (void)hipStreamQuery(bs);
+        HIPC(hipStreamWaitEvent(c->stream, c->band_ev[(size_t)k], 0));
+        MTMC(launch_ncc(c, sc, sc.tlist_off, (int)sc.members.size(), st, -1, last ? o_split / kBfRows : 0, last ? nyb : o_split / kBfRows));
+        (void)hipStreamQuery(c->stream);
+    }
+    // what run_score_all does behind a bf16 class's launch: the exact re-scoring of what the screen listed
+    if (c->refine_now && !c->f32_exact_now) {
+        if (c->refine_scan_now) {
+            MTMC(launch_refine_scan(c, sc));
+            MTMC(launch_refine(c, sc, st, true, true));
+        } else {
+            MTMC(launch_refine(c, sc, st, false, !c->hits_only_now));
+        }
+        if (c->ext_now) MTMC(launch_refine_extremum(c));
+    }
+    return MTM_OK;
+}
+
 int run_score_banded(mtm_ctx* c, const ImageArgs& a) {
+    if (a.dtype == MTM_F32) return run_score_banded_f32(c, a);
     const SizeClass& sc = c->classes[(size_t)c->banded_cls];
     host_trace(c, 16);
     if (!c->hits_only_now) MTMC(ensure_maps(c));

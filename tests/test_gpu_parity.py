@@ -661,6 +661,7 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
         rgb_img, rgb_units, _ = synth.make_workload(seed=22, image_hw=(700, 1600), n_base=3, templ=24, channels=3)
         msk_img, msk_units, _ = synth.make_workload(seed=23, image_hw=(1050, 1100), n_base=2, templ=32, scales=(24, 40), masked=True)
         img16 = img.astype(np.uint16) * 200 + 7
+        imgf = img.astype(np.float32) * np.float32(0.37) + np.float32(3.0)
         cases = [
             (img, [(u[1], None) for u in units], 5, 0.5),                      # 20 templates: plain MFMA class, banded
             (img, [(u[1], None) for u in units[:5]], 5, 0.5),                  # row-multiplexed (nt = 8, R = 2)
@@ -673,6 +674,13 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
             # several classes, the heaviest of them banded, the others (a masked one among them) on the complete image
             (img, [(u[1], None) for u in units[:6]] + [(np.ascontiguousarray(units[8][1][:24, :28]), None)] +
                   [(np.ascontiguousarray(units[7][1][:28, :30]), (units[7][1][:28, :30] > 90).astype(np.uint8))], 3, 0.8),
+            # round 6: single-channel float32 images in two bands (bf16 kernel, one launch per band; the statistics of a band
+            # from the rows that have arrived) - the one-product screen, the three-product maps, and a raw-sum method whose
+            # maps send the call to the float64 kernel behind the banding decision
+            (imgf, [(u[1].astype(np.float32) * np.float32(0.37) + np.float32(3.0), None) for u in units], 5, 0.5),
+            (imgf, [(u[1].astype(np.float32) * np.float32(0.37) + np.float32(3.0), None) for u in units[:4]], 3, 0.97),
+            (imgf, [(u[1].astype(np.float32) * np.float32(0.37) + np.float32(3.0), None) for u in units[:4]], 1, 0.05),
+            (imgf, [(u[1].astype(np.float32) * np.float32(0.37) + np.float32(3.0), None) for u in units[:4]], 4, 1e5),
         ]
         for honly in (1, 0):
             fused.set_option(_lib.OPT_HITS_ONLY, honly)
@@ -695,6 +703,10 @@ def test_fused_image_call_equals_two_calls(mtm, bands, monkeypatch):
         if not any(os.environ.get(k) for k in ("MTM_FUSE_STATS", "MTM_KERNEL")):   # (tools/alt_modes.sh)
             assert (t["ncc_launches"] == 1) if bands == "1" else (2 <= t["ncc_launches"] <= len(bands.split(",")))
             assert 300.0 < t["sclk_mhz"] < 3500.0
+        if default_routes():        # the float32 call too: two launches of the bf16 kernel, the one-product screen in both
+            fused.search(cases[-4][1], imgf, 5, _lib.PEAKS_LOCAL, 0.5)
+            t = fused.timing()
+            assert t["kernel_used"] == 5 and t["ncc_launches"] == (1 if bands == "1" else 2) and t["f32_pieces"] == 1, t
         # a different image through the same fused context: nothing stale survives
         img2 = np.ascontiguousarray(img[::-1, ::-1])
         a = fused.search(cases[0][1], img2, 5, _lib.PEAKS_LOCAL, 0.5)
