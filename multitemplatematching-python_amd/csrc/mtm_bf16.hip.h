@@ -440,6 +440,25 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
     const bool fast_screen = rig_n && p.cand_on && !p.ext_on && p.hits_only && p.rig_flag == nullptr;
     const double fs_thr = (double)p.rig_thr;
     const double fs_d = p.cand_min ? 2.4e-6 + 1e-9 : 6e-7 * fmax(1.0, fabs(fs_thr)) + 1e-9;
+    // Round 6: the same screen for the refined global extremum of the maxima methods (N_object == 1: cv2.minMaxLoc).  An
+    // output matters only if its UPPER bound reaches its template's best LOWER bound; what other work items have published
+    // so far is read here, once per wave (the final best can only be higher), and an output whose bound stays below it by the
+    // screen's allowance is neither a key nor a listing - its accumulator registers are set to NaN, which the listing pass
+    // (list_half) never lists.  Templates without a published best, or with a negative one, are not screened.
+    const bool ext_fast = rig_n && p.ext_on && p.ext_raw && !p.cand_min && p.ext_margin > 0.0f;
+    double ext_thr[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ext_thr[mb][e] = -1.0;
+            const int lt = mb * 16 + 4 * q + e, li = tg * MB * 16 + lt;
+            if (ext_fast && li < p.n_list) {
+                const unsigned long long gk = __hip_atomic_load(&p.ext_best[2 * tlist[li] + p.cand_min], __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                if (gk) ext_thr[mb][e] = (double)mf_order_float((uint32_t)(gk >> 32));      // (maxima: the key holds the quality itself)
+            }
+        }
     // (the two halves of a lane's eight pixels as a generic lambda over a compile-time constant: every accumulator index
     // below must be one, or the accumulators leave the register file)
     auto epilogue_half = [&](auto half_c) {
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 s2c = fmax(s2c, 0.0) * 1.000001 + 1e-12 * (fabs(s2[i]) + area * mu2);
                 const double ee = (double)p.rig_eps * sqrt(s2c);
                 bp[i] = rig_r ? ee : sq[i] > 0.0 ? ee / sq[i] : 0.0;
-                if (fast_screen) {
+                if (fast_screen || ext_fast) {
                     fs_E[i] = ee * 1.0000001;            // (never below bp sq as the exact test multiplies it out)
                     fs_P[i] = (p.cand_min ? fs_d - fs_thr : fs_thr - fs_d) * sq[i];
                     fs_wide = fs_wide || !(sq[i] > 0.0) || !(bp[i] <= 0.2);
@@ -492,6 +511,31 @@ __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const Te
                 if (li >= p.n_list || (p.only_li >= 0 && li != p.only_li)) return;
                 const BfTemplConst& T = tcl[lt];
                 bool skip = false;
+                if (ext_fast && ext_thr[mb][e] >= 0.0 && !fs_wide && T.all_ones == 0 && T.templ_norm > 0.0) {
+                    // (the listing screen below with this template's published best as the threshold: an output with
+                    // r + B <= best - d has an upper bound below the best lower bound - by d, twice the exact path's rounding
+                    // allowance at |r| <= 1; r < -1: r + B + 3e-7 |r| < 0 <= best.  The exact extremum and every tie with it have
+                    // upper bounds >= their scores >= every lower bound: never screened.)
+                    const double tn = T.templ_norm, G = T.bfac * tn, tnthr = tn * (ext_thr[mb][e] - (6e-7 + 1e-9));
+                    const double cm0 = method == MTM_TM_CCOEFF_NORMED ? T.centre[0] - T.mean[0] : T.centre[0];
+                    bool anyp = false;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double num = (double)acc[mb][4 * half + i][e];
+                        if (p.chans == 1) {
+                            num = fma(cm0, ts[i][0], num);
+                        } else {
+                            for (int cc = 0; cc < p.chans; ++cc)
+                                num = fma(method == MTM_TM_CCOEFF_NORMED ? T.centre[cc] - T.mean[cc] : T.centre[cc], ts[i][cc], num);
+                        }
+                        anyp = anyp || fma(G, fs_E[i], num) > tnthr * sq[i];
+                    }
+                    if (!anyp) {
+                        skip = true;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[mb][4 * half + i][e] = __builtin_nanf("");
+                    }
+                }
                 if (fast_screen) {
                     // Hits-only listing by the bound (normalised methods): most outputs are nowhere near the threshold, and
                     // the listing test  r + B > thr  (r = num / t, t = sq tn, B = bp bfac the output's bound) is, multiplied
