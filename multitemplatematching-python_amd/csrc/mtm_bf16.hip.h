@@ -120,9 +120,11 @@ __device__ __forceinline__ void bf_static_for(F& f) {
 template <int MB, int NP>
 __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const v4i_b h1, const v4i_b l0, const v4i_b l1,
                                         const v4i_b (&a0)[MB], const v4i_b (&a1)[MB]) {
-    // (round 6: the lane's 32 bytes of a piece plane as ONE eight-register value and the phases' operands as sub-ranges of it
-    // - built from eight scalars, every window that straddles the two loads cost the compiler four register copies: 16 of
-    // the 27 vector instructions of a one-product step were moves)
+    // (round 6: the lane's 32 bytes of a piece plane as ONE eight-register value and the phases' operands as sub-ranges of
+    // it.  MFMA operand tuples start at even registers, so the odd-offset windows need copies: 16 of the 27 vector
+    // instructions of a one-product step are moves.  This form did NOT remove them - the compiler canonicalises the
+    // shuffles back into the per-element form and emits the same ISA; only a generated asm step as the int8 kernel's,
+    // which places the copies in the MFMAs' shadow, would.  Kept: it states what the operands are.)
     typedef int v8i_b __attribute__((ext_vector_type(8)));
     const v8i_b W = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
     const v8i_b V = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -161,8 +163,9 @@ __device__ __forceinline__ void bf_step(v4f (&acc)[MB][8], const v4i_b h0, const
 // as a screen: the refined hits-only routes (Bf16Params::rig / ext_raw) list every output whose UPPER bound passes the
 // threshold (or reaches the running best) and the float64 chain decides on those, so a wider bound only lengthens the
 // list - on images whose maps are sparse above the threshold by a few records.  The host launches this instantiation only
-// where nothing but the list leaves the kernel (hits-only; maps are never written from it) and falls back to NP = 3 when
-// the list overflows (mtm_api.hip).
+// where nothing but the list leaves the kernel (hits-only; PUBLISHED maps are never written from it - the masked classes'
+// raw launches write scratch maps that mtm_maskf32.hip.h bounds with this launch's eps) and falls back to NP = 3 when the
+// list overflows (mtm_api.hip).
 template <int MB, int NP>
 __global__ __launch_bounds__(256, 2) void ncc_bf16_kernel(Bf16Params p, const TemplDev* __restrict__ td,
                                                           const int* __restrict__ tlist,
