@@ -644,6 +644,27 @@ def main():
                 "slab_launch_ms": round(float(tml["ncc_kernel_ms"]), 4),
                 "value": round(2048 * 2048 / lm / 1e3, 1),
                 "note": "Mpx-corr/s of this shape (image pixels x 1 template per second); 7 slabs of 64 taps, one launch"}
+            # (f) the same workload as float32 pixels - what the reference turns every non-uint8 input into
+            # (MTM/__init__.py:71-74): bf16 matrix cores as a screen (round 6: one piece product where only a list leaves the
+            # kernel, two upload bands), exact float64 re-scoring of what the screen lists, the float64 kernel's records
+            fimg = img.astype(np.float32) * np.float32(0.731) + np.float32(3.25)
+            funits = [(u[0], u[1].astype(np.float32) * np.float32(0.731) + np.float32(3.25)) for u in units]
+            for _ in range(4):
+                hf = MTM.matchTemplates(funits, fimg, method=method, score_threshold=thr, maxOverlap=0.25)
+            st = []
+            for _ in range(12):
+                t1 = time.perf_counter()
+                hf = MTM.matchTemplates(funits, fimg, method=method, score_threshold=thr, maxOverlap=0.25)
+                st.append(time.perf_counter() - t1)
+            fm = float(np.median(st)) * 1e3
+            tmf = ctx.timing()
+            extras["float32_image"] = {
+                "median_ms_per_call": round(fm, 4), "value": rate(fm), "hits": len(hf),
+                "same_boxes_as_uint8": sorted((h[0], h[1]) for h in hf) == sorted((h[0], h[1]) for h in hits),
+                "gpu_ms": round(float(tmf["total_ms"]), 4), "bf16_kernel_ms": round(float(tmf["ncc_kernel_ms"]), 4),
+                "launches": int(tmf["ncc_launches"]), "f32_route": int(tmf["f32_route"]), "f32_pieces": int(tmf["f32_pieces"]),
+                "note": "float32 pixels and templates (an affine map of the uint8 workload), numpy arrays in -> hit list out; "
+                        "f32_route 1 = kernel candidates re-scored with the float64 chain, f32_pieces 1 = the one-product screen"}
         gc.enable()
 
     # sanity: the timed path found every planted template

@@ -97,6 +97,23 @@ __device__ __forceinline__ float finish_lean(int a32, double s1, double p1, doub
     return (an < tt) ? qf : ((an < tt * 1.125) ? satf : other);
 }
 
+// The float32 value of the IEEE quotient num / tt without the IEEE division sequence (round 6).  Only the float32
+// rounding of the float64 quotient leaves the kernel, so a float64 quotient that is a few ulp off gives the same
+// float unless it lies next to a float32 rounding boundary: q0 = num * rr with rr = RN(RN(1 / sq) * RN(1 / templ_norm))
+// carries four roundings, the reference RN(num / RN(sq * templ_norm)) two - they differ by <= 6 ulp(double).  A float32
+// rounding boundary is a double whose low 29 significand bits read 0x10000000; q0 within 32 ulp of one (6e-8 of the
+// outputs), or below 2^-120 where the float is denormal and rounds elsewhere, takes the division itself.  Zero, the
+// 0 * x of a flat window and the unused quotients of |num| >= tt are "far from a boundary" by the same integer test.
+__device__ __forceinline__ float quotient_as_float(double num, double tt, double rr) {
+    const double q0 = num * rr;
+    float qf = (float)q0;
+    const uint32_t lo = (uint32_t)__double2loint(q0), hi = (uint32_t)__double2hiint(q0);
+    const bool near_boundary = ((lo & 0x1fffffffu) - (0x10000000u - 32u)) <= 64u;
+    const bool tiny = ((hi & 0x7fffffffu) - 1u) < (0x38700000u - 1u);       // 0 < |q0| < 2^-120 (hi == 0: 0 or a double denormal -> +-0)
+    if (near_boundary || tiny) qf = (float)(num / tt);
+    return qf;
+}
+
 // finish_lean with the quotient computed unconditionally (the empty asm keeps the compiler from
 // sinking it into a divergent branch): straight-line code, the four pixels of a lane interleave.
 // Same operations in the same order as finish_lean: bit-identical results.
@@ -130,7 +147,7 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
     if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
     if (!normed) return (float)num;
     const double tt = sq * T.templ_norm;
-    float qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
+    float qf = EXACT_DIV ? quotient_as_float(num, tt, rsq * T.rtempl_norm) : (float)(num * (rsq * T.rtempl_norm));
     asm volatile("" : "+v"(qf));
     const double an = fabs(num);
     const float satf = (num > 0.0) ? 1.0f : -1.0f;
@@ -149,7 +166,7 @@ __device__ __forceinline__ float finish_rt(int method, double corr, double s1, d
     if (method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
     if (!normed) return (float)num;
     const double tt = sq * T.templ_norm;
-    float qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
+    float qf = EXACT_DIV ? quotient_as_float(num, tt, rsq * T.rtempl_norm) : (float)(num * (rsq * T.rtempl_norm));
     asm volatile("" : "+v"(qf));
     const double an = fabs(num);
     const float satf = (num > 0.0) ? 1.0f : -1.0f;
@@ -1532,9 +1549,9 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                 for (int cc = 1; cc < CH; ++cc) s1all += ps1[i][cc];
                 pp1[i] = 128.0 * s1all;
-                // (IEEE-division builds of the unmasked normalised methods need no reciprocal at all - kExactNoRcp below:
-                // four float64 divisions per lane and row, and the registers that made the epilogue spill, saved)
-                prsq[i] = (kNormed && !(EXACT_DIV && !MASKED) && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+                // (1 / sq once per pixel, shared by the work item's templates: the reciprocal path's factor and, in IEEE-division
+                // builds, quotient_as_float's; the hits-only pre-test of those builds - kExactNoRcp below - needs none)
+                prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
         };

@@ -952,7 +952,7 @@ def test_float32_on_bf16_matrix_cores(mtm, ctx, coins, monkeypatch):
     bf16 matrix cores; the maps must stay within 5e-5 of the float64 oracle (north_star allows 1e-4) whatever the
     brightness offset, scale or gradient of the image - the centring of both operands is what makes 16 significant
     bits enough - and the hit lists must be those of the exact float64 kernel (MTM_F32_MFMA=0)."""
-    if os.environ.get("MTM_F32_MFMA"):
+    if os.environ.get("MTM_F32_MFMA") or os.environ.get("MTM_KERNEL", "auto") != "auto":
         pytest.skip("the float32 route is forced by the environment")
     from MTM import _lib
     rng = np.random.default_rng(5)
