@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MTM_ABI_VERSION 8
+#define MTM_ABI_VERSION 9
 
 /* pixel types (after the dtype policy of MTM/__init__.py:71-74: uint8 stays, all else float32) */
 #define MTM_U8  0
@@ -190,6 +190,14 @@ int         mtm_get_option(mtm_ctx* ctx, int option, int64_t* value);     /* the
 #define MTM_POISON_LDS     2
 #define MTM_POISON_ARENAS  4
 int         mtm_debug_poison(mtm_ctx* ctx, int pattern_byte, int what);
+/* Test support (ABI 9).  The IEEE-division epilogues of the single-channel uint8 score kernel obtain (float)(num / t) -
+ * the value OpenCV's common_matchTemplate stores, SURVEY 8a-5 - from a reciprocal product plus an integer test that sends the
+ * quotients next to a float32 rounding boundary through the division itself (csrc/mtm_device_util.hip.h,
+ * quotient_as_float).  This call runs that function against the division on n_cases operand triples shaped like the
+ * epilogue's, half of them constructed to straddle a rounding boundary: out4 = {cases run, results that differ in any
+ * bit (must be 0), cases that took the division, largest |num * rr - num / t| seen in ulp(double) (the bound in the
+ * source is 6, the test's margin 32)}. */
+int         mtm_debug_quotient_check(mtm_ctx* ctx, uint64_t n_cases, uint64_t seed, uint64_t* out4);
 /* Page-locked host memory for pixel buffers (optional).  The reference's caller hands over whatever numpy holds
  * (MTM/__init__.py:247 `image`) - pageable memory, which the runtime stages through its own pinned buffers while the
  * upload call blocks.  An image kept in memory from mtm_host_alloc crosses PCIe as a plain DMA transfer behind the call

@@ -28,7 +28,7 @@ POISON_SCRATCH, POISON_LDS, POISON_ARENAS = 1, 2, 4
 E_OVERFLOW = -5
 E_HIP = -2
 COMM_ID_BYTES = 128
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MtmTempl(ctypes.Structure):
@@ -75,6 +75,7 @@ SYMBOLS = {
     "mtm_set_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "mtm_get_option": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _P(ctypes.c_int64)]),
     "mtm_debug_poison": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    "mtm_debug_quotient_check": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, _P(ctypes.c_uint64)]),
     "mtm_set_image": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
     "mtm_set_image_downscaled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -370,6 +371,13 @@ class Context(_RecordMemo):
         """Test support (mtm_debug_poison): a byte pattern into every wave slot's scratch memory (1), every CU's LDS (2) and
         the context's per-call work buffers (4) - memory no result may depend on."""
         check(self._lib.mtm_debug_poison(self._h, int(pattern), int(what)), "mtm_debug_poison")
+
+    def debug_quotient_check(self, n_cases=1 << 28, seed=1):
+        """Test support (mtm_debug_quotient_check): the epilogue's division-free quotient against the IEEE division on
+        n_cases operand triples -> dict(cases, mismatches, took_division, max_ulp_distance)."""
+        out = (ctypes.c_uint64 * 4)()
+        check(self._lib.mtm_debug_quotient_check(self._h, int(n_cases), int(seed), out), "mtm_debug_quotient_check")
+        return {"cases": int(out[0]), "mismatches": int(out[1]), "took_division": int(out[2]), "max_ulp_distance": int(out[3])}
 
     def set_image(self, image, downscale=1):
         """Upload the search image; `downscale` > 1 area-averages it by that integer factor on the

@@ -500,6 +500,87 @@ int mtm_debug_poison(mtm_ctx* c, int pattern_byte, int what) {
     return MTM_OK;
 }
 
+// ---- test support: quotient_as_float against the IEEE division it replaces (mtm_debug_quotient_check) -------------------
+// Operands shaped like the epilogue's: sq = sqrt of an integer-valued window energy, templ_norm = sqrt of one, num an
+// integer-valued or fractional numerator with |num| <~ tt.  Even cases are plain random draws; odd cases are adversarial -
+// the numerator is chosen so that the quotient lands within a few ulp(double) of a float32 rounding boundary (the middle
+// between two neighbouring floats, or - every fourth - between two float32 denormals' neighbours of a tiny quotient), the
+// place where a quotient that is a few ulp off rounds to the other float.  out[0] cases, out[1] results that differ from
+// (float)(num / tt) in any bit, out[2] cases that took the division, out[3] the largest distance in ulp(double) between
+// num * rr and num / tt seen where both are normal.
+__device__ __forceinline__ uint64_t dq_mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void quotient_check_kernel(uint64_t n_per_thread, uint64_t seed, unsigned long long* out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0, div = 0, far = 0;
+    for (uint64_t k = 0; k < n_per_thread; ++k) {
+        const uint64_t idx = gid * n_per_thread + k;
+        const uint64_t r0 = dq_mix(seed ^ (idx * 4u)), r1 = dq_mix(seed ^ (idx * 4u + 1u)), r2 = dq_mix(seed ^ (idx * 4u + 2u)),
+                       r3 = dq_mix(seed ^ (idx * 4u + 3u));
+        // window energy and template energy: integers of 1 .. 44 bits (what 4 channels of 16-bit pixels under 2^14 taps reach)
+        const double e_w = (double)(1ull + (r0 >> (20 + (r3 & 31)))), e_t = (double)(1ull + (r1 >> (20 + ((r3 >> 5) & 31))));
+        const double sq = sqrt(e_w), tn = sqrt(e_t);
+        const double tt = sq * tn;
+        const double rr = (1.0 / sq) * (1.0 / tn);
+        double num;
+        if ((idx & 1u) == 0u) {
+            const double u = (double)(int64_t)(r2 >> 11) * 0x1p-52 - 1.0;                    // [-1, 1)
+            num = u * tt * 1.2;
+            if (r3 & (1ull << 40)) num = rint(num);                                            // integer-valued numerators
+        } else {
+            // a float32 rounding boundary: a random float in [2^-20, 1) and the double half way to its successor
+            uint32_t fb = 0x35800000u + (uint32_t)(r2 % (0x3f800000u - 0x35800000u));
+            if ((idx & 7u) == 7u) fb = 0x00000001u + (uint32_t)(r2 % 0x02000000u);          // denormal / tiny floats
+            const double lo_f = (double)__uint_as_float(fb), hi_f = (double)__uint_as_float(fb + 1u);
+            const double mid = 0.5 * (lo_f + hi_f);
+            num = mid * tt;
+            // a few ulp either side of it (the product above is already rounded: the quotient straddles the boundary)
+            const int step = (int)((r3 >> 44) % 9u) - 4;
+            num = __longlong_as_double(__double_as_longlong(num) + (long long)step);
+            if (r3 & (1ull << 41)) num = -num;
+        }
+        const double q0 = num * rr;
+        const double qr = num / tt;
+        const float ref = (float)qr;
+        const float got = quotient_as_float(num, tt, rr);
+        bad += __float_as_uint(ref) != __float_as_uint(got);
+        div += quotient_needs_division(q0);
+        if (fabs(qr) > 0x1p-1000 && fabs(qr) < 0x1p1000) {
+            const long long d = __double_as_longlong(fabs(q0)) - __double_as_longlong(fabs(qr));
+            const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
+            far = ad > far ? ad : far;
+        }
+    }
+    atomicAdd(&out[1], bad);
+    atomicAdd(&out[2], div);
+    atomicMax(&out[3], far);
+}
+
+int mtm_debug_quotient_check(mtm_ctx* c, uint64_t n_cases, uint64_t seed, uint64_t* out4) {
+    if (!c || !out4) return MTM_E_INVALID;
+    MTM_NOT_IN_FLIGHT(c, "mtm_debug_quotient_check");
+    HIPC(hipSetDevice(c->device));
+    const int blocks = 2048, threads = 256;
+    const uint64_t per = (n_cases + (uint64_t)blocks * threads - 1) / ((uint64_t)blocks * threads);
+    MTMC(c->sched.ensure(sizeof(unsigned int) * (1 + 4096 + 8 * 32)));
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(c->sched.as<uint32_t>() + 4096 + 16);   // (behind mtm_debug_poison's word)
+    HIPC(hipMemsetAsync(acc, 0, 4 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(quotient_check_kernel, dim3(blocks), dim3(threads), 0, c->stream, per, seed, acc);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPC(hipMemcpyAsync(h, acc, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipGetLastError());
+    out4[0] = per * (uint64_t)blocks * threads;
+    out4[1] = h[1];
+    out4[2] = h[2];
+    out4[3] = h[3];
+    return MTM_OK;
+}
+
 int mtm_set_image_downscaled(mtm_ctx* c, const void* px, int rows, int cols, int chans, int dtype,
                              int64_t row_stride_bytes, int factor) {
     if (!c) {

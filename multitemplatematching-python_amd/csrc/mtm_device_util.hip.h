@@ -157,4 +157,26 @@ __device__ __forceinline__ void peaks_finish_row(const PeakRow& r, int lane, boo
     hr = lane == 63 ? s * r.er : right;
 }
 
+
+// The float32 value of the IEEE quotient num / tt without the IEEE division sequence (round 6; the IEEE-division epilogues of
+// the single-channel uint8 score kernel).  Only the float32 rounding of the float64 quotient leaves the kernel, so a float64
+// quotient that is a few ulp off gives the same float unless it lies next to a float32 rounding boundary: q0 = num * rr with
+// rr = RN(RN(1 / sq) * RN(1 / templ_norm)) carries four roundings, the reference RN(num / RN(sq * templ_norm)) two - they
+// differ by <= 6 ulp(double) (mtm_debug_quotient_check measures it).  A float32 rounding boundary is a double whose low 29
+// significand bits read 0x10000000; q0 within 32 ulp of one (1.2e-7 of the outputs), or below 2^-120 where the float is
+// denormal and rounds elsewhere, takes the division itself.  Zero, the 0 * x of a flat window and the unused quotients
+// of |num| >= tt are "far from a boundary" by the same integer test.
+__device__ __forceinline__ bool quotient_needs_division(double q0) {
+    const uint32_t lo = (uint32_t)__double2loint(q0), hi = (uint32_t)__double2hiint(q0);
+    const bool near_boundary = ((lo & 0x1fffffffu) - (0x10000000u - 32u)) <= 64u;
+    const bool tiny = ((hi & 0x7fffffffu) - 1u) < (0x38700000u - 1u);   // 0 < |q0| < 2^-120 (hi == 0: 0 or a double denormal -> +-0)
+    return near_boundary || tiny;
+}
+__device__ __forceinline__ float quotient_as_float(double num, double tt, double rr) {
+    const double q0 = num * rr;
+    float qf = (float)q0;
+    if (quotient_needs_division(q0)) qf = (float)(num / tt);
+    return qf;
+}
+
 }  // namespace mtm

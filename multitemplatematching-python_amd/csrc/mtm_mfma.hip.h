@@ -97,29 +97,16 @@ __device__ __forceinline__ float finish_lean(int a32, double s1, double p1, doub
     return (an < tt) ? qf : ((an < tt * 1.125) ? satf : other);
 }
 
-// The float32 value of the IEEE quotient num / tt without the IEEE division sequence (round 6).  Only the float32
-// rounding of the float64 quotient leaves the kernel, so a float64 quotient that is a few ulp off gives the same
-// float unless it lies next to a float32 rounding boundary: q0 = num * rr with rr = RN(RN(1 / sq) * RN(1 / templ_norm))
-// carries four roundings, the reference RN(num / RN(sq * templ_norm)) two - they differ by <= 6 ulp(double).  A float32
-// rounding boundary is a double whose low 29 significand bits read 0x10000000; q0 within 32 ulp of one (6e-8 of the
-// outputs), or below 2^-120 where the float is denormal and rounds elsewhere, takes the division itself.  Zero, the
-// 0 * x of a flat window and the unused quotients of |num| >= tt are "far from a boundary" by the same integer test.
-__device__ __forceinline__ float quotient_as_float(double num, double tt, double rr) {
-    const double q0 = num * rr;
-    float qf = (float)q0;
-    const uint32_t lo = (uint32_t)__double2loint(q0), hi = (uint32_t)__double2hiint(q0);
-    const bool near_boundary = ((lo & 0x1fffffffu) - (0x10000000u - 32u)) <= 64u;
-    const bool tiny = ((hi & 0x7fffffffu) - 1u) < (0x38700000u - 1u);       // 0 < |q0| < 2^-120 (hi == 0: 0 or a double denormal -> +-0)
-    if (near_boundary || tiny) qf = (float)(num / tt);
-    return qf;
-}
-
+// (quotient_as_float: mtm_device_util.hip.h)
 // finish_lean with the quotient computed unconditionally (the empty asm keeps the compiler from
 // sinking it into a divergent branch): straight-line code, the four pixels of a lane interleave.
 // Same operations in the same order as finish_lean: bit-identical results.
-template <int METHOD, bool EXACT_DIV, int CH = 1>
+// DEFER (IEEE-division builds, one channel): the quotient is quotient_as_float's reciprocal product and *redo says whether
+// it sits next to a float32 rounding boundary - the caller repeats those through the division behind ONE wave-uniform
+// branch for the lane's four pixels (as a per-lane `if` the compiler turned the division into a select and computed both).
+template <int METHOD, bool EXACT_DIV, int CH = 1, bool DEFER = false>
 __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], double p1, double sum2, double sq,
-                                             double rsq, const MfTemplConst& T) {
+                                             double rsq, const MfTemplConst& T, bool* redo = nullptr) {
     constexpr bool normed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                             METHOD == MTM_TM_CCOEFF_NORMED;
     if constexpr (!EXACT_DIV && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
@@ -147,7 +134,16 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
     if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
     if (!normed) return (float)num;
     const double tt = sq * T.templ_norm;
-    float qf = EXACT_DIV ? quotient_as_float(num, tt, rsq * T.rtempl_norm) : (float)(num * (rsq * T.rtempl_norm));
+    // (IEEE-division builds: single-channel instantiations defer; three channels keep the division - the reciprocals' eight
+    // registers next to three channels of statistics made those epilogues spill more)
+    float qf;
+    if constexpr (EXACT_DIV && DEFER) {
+        const double q0 = num * (rsq * T.rtempl_norm);
+        qf = (float)q0;
+        *redo = quotient_needs_division(q0);
+    } else {
+        qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
+    }
     asm volatile("" : "+v"(qf));
     const double an = fabs(num);
     const float satf = (num > 0.0) ? 1.0f : -1.0f;
@@ -166,7 +162,7 @@ __device__ __forceinline__ float finish_rt(int method, double corr, double s1, d
     if (method == MTM_TM_SQDIFF || method == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
     if (!normed) return (float)num;
     const double tt = sq * T.templ_norm;
-    float qf = EXACT_DIV ? quotient_as_float(num, tt, rsq * T.rtempl_norm) : (float)(num * (rsq * T.rtempl_norm));
+    float qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
     asm volatile("" : "+v"(qf));
     const double an = fabs(num);
     const float satf = (num > 0.0) ? 1.0f : -1.0f;
@@ -1117,12 +1113,26 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             if (__builtin_amdgcn_ballot_w64(wanted) == 0ull) continue;       // wave-uniform
                         }
                         float out[4];
+                        constexpr bool kDefer = EXACT_DIV && !MASKED && CH == 1 && kNormed;      // (see the plain tiling's epilogue)
+                        bool redo[4] = {false, false, false, false};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             out[k] = MASKED ? finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], pp1[k], psum2[k],
                                                                                                      prsq[k], T)
-                                            : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, CH>(a32[k], ps1[k], pp1[k], psum2[k],
+                                            : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, CH, kDefer>(a32[k], ps1[k], pp1[k],
+                                                                                                          psum2[k], psq[k], prsq[k],
+                                                                                                          T, &redo[k]);
+                        if constexpr (kDefer) {
+                            if (__builtin_amdgcn_ballot_w64(redo[0] || redo[1] || redo[2] || redo[3]) != 0ull) {   // wave-uniform
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    float e = finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, CH>(a32[k], ps1[k], pp1[k], psum2[k],
                                                                                                   psq[k], prsq[k], T);
+                                    asm volatile("" : "+v"(e));
+                                    out[k] = redo[k] ? e : out[k];
+                                }
+                            }
+                        }
                         const bool ones = !MASKED && T.all_ones != 0;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) out[k] = ones ? 1.0f : out[k];
@@ -1551,7 +1561,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 pp1[i] = 128.0 * s1all;
                 // (1 / sq once per pixel, shared by the work item's templates: the reciprocal path's factor and, in IEEE-division
                 // builds, quotient_as_float's; the hits-only pre-test of those builds - kExactNoRcp below - needs none)
-                prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+                prsq[i] = (kNormed && !(EXACT_DIV && !MASKED && CH > 1) && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
         };
@@ -1635,16 +1645,30 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             if (__builtin_amdgcn_ballot_w64(wanted) == 0ull) continue;
                         }
                         float out[4];
+                        constexpr bool kDefer = EXACT_DIV && !MASKED && CH == 1 && kNormed;
+                        bool redo[4] = {false, false, false, false};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             if (MASKED)
                                 out[i] = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
                             else
-                                out[i] = finish_fast<METHOD, EXACT_DIV, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
-                                                                            prsq[i], T);
+                                out[i] = finish_fast<METHOD, EXACT_DIV, CH, kDefer>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
+                                                                                    prsq[i], T, &redo[i]);
                             // (IEEE division: one quotient after the other - four interleaved division sequences need ~40
                             // registers more than the epilogue has next to 128 accumulators, and spilled)
-                            if constexpr (EXACT_DIV && !MASKED) __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (EXACT_DIV && !MASKED && !kDefer) __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if constexpr (kDefer) {
+                            // 1.2e-7 of the outputs: the quotient next to a float32 rounding boundary, through the division
+                            if (__builtin_amdgcn_ballot_w64(redo[0] || redo[1] || redo[2] || redo[3]) != 0ull) {   // wave-uniform
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float e = finish_fast<METHOD, EXACT_DIV, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i], prsq[i], T);
+                                    asm volatile("" : "+v"(e));       // (keeps the division inside the branch)
+                                    out[i] = redo[i] ? e : out[i];
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
                         }
                         if (!MASKED) {
                             const bool ones = T.all_ones != 0;

@@ -31,7 +31,7 @@ def test_header_symbols_exported(lib):
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().mtm_abi_version() == lib.ABI_VERSION == 8
+    assert lib.load().mtm_abi_version() == lib.ABI_VERSION == 9
 
 
 def test_struct_layout(lib):

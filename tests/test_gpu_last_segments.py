@@ -192,3 +192,27 @@ def test_poison_reaches_what_it_claims(lib):
         assert np.array_equal(b, O.match_template(img, t, 5))
     finally:
         del ctx
+
+
+def test_quotient_without_division(lib):
+    """The IEEE-division epilogues of the single-channel uint8 score kernel take (float)(num / t) - the value OpenCV's
+    common_matchTemplate stores - from a reciprocal product; quotients next to a float32 rounding boundary, and tiny ones, go
+    through the division (csrc/mtm_device_util.hip.h: quotient_as_float).  The function itself against the division, on
+    operand triples shaped like the epilogue's (square roots of integer energies, integer-valued and fractional numerators),
+    half of them constructed to straddle a rounding boundary by a few ulp(double): no result may differ in any bit, the
+    distance between the two float64 quotients must stay inside the bound the source states (6 ulp; the margin is 32), and
+    the adversarial half must really have reached the fall-back."""
+    ctx = lib.Context(0)
+    try:
+        total = 0
+        for seed in (1, 2, 3, 4, 5, 6, 7, 8):
+            r = ctx.debug_quotient_check(1 << 28, seed)
+            assert r["mismatches"] == 0, r
+            assert r["max_ulp_distance"] <= 6, r
+            # adversarial cases (half of all) land within 4 + 6 ulp of a boundary or are tiny: all of them take the division;
+            # of the random half 1.2e-7 do
+            assert 0.49 * r["cases"] < r["took_division"] < 0.51 * r["cases"], r
+            total += r["cases"]
+        assert total >= 1 << 31
+    finally:
+        del ctx
