@@ -106,7 +106,7 @@ __device__ __forceinline__ float finish_lean(int a32, double s1, double p1, doub
 // branch for the lane's four pixels (as a per-lane `if` the compiler turned the division into a select and computed both).
 template <int METHOD, bool EXACT_DIV, int CH = 1, bool DEFER = false>
 __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], double p1, double sum2, double sq,
-                                             double rsq, const MfTemplConst& T, bool* redo = nullptr) {
+                                             double rsq, const MfTemplConst& T, bool* redo = nullptr, bool* sat = nullptr) {
     constexpr bool normed = METHOD == MTM_TM_SQDIFF_NORMED || METHOD == MTM_TM_CCORR_NORMED ||
                             METHOD == MTM_TM_CCOEFF_NORMED;
     if constexpr (!EXACT_DIV && (METHOD == MTM_TM_CCORR_NORMED || METHOD == MTM_TM_CCOEFF_NORMED)) {
@@ -138,9 +138,12 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
     // registers next to three channels of statistics made those epilogues spill more)
     float qf;
     if constexpr (EXACT_DIV && DEFER) {
+        // |num| >= t (a flat window, a saturated quotient: the rules' constants, finish_saturated) is the caller's second
+        // wave-uniform branch - the comparison with 1.125 t and the selects leave the common path as well
         const double q0 = num * (rsq * T.rtempl_norm);
-        qf = (float)q0;
         *redo = quotient_needs_division(q0);
+        *sat = !(fabs(num) < tt);
+        return (float)q0;
     } else {
         qf = EXACT_DIV ? (float)(num / tt) : (float)(num * (rsq * T.rtempl_norm));
     }
@@ -150,6 +153,23 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
     const float other = (METHOD == MTM_TM_SQDIFF_NORMED) ? 1.0f : 0.0f;
     const float r2 = (an < tt * 1.125) ? satf : other;
     return (an < tt) ? qf : r2;
+}
+
+// What finish_fast returns where |num| >= t (same quantities, same order): +-1 below 1.125 t, else the rules' constant.
+template <int METHOD, int CH = 1>
+__device__ __forceinline__ float finish_saturated(int a32, const double (&s1)[CH], double p1, double sum2, double sq,
+                                                  const MfTemplConst& T) {
+    const double corr = (double)a32 + (p1 + T.mfma_k);
+    double num = corr;
+    if (METHOD == MTM_TM_CCOEFF || METHOD == MTM_TM_CCOEFF_NORMED) {
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) num -= s1[cc] * T.mean[cc];
+    }
+    if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
+    const double tt = sq * T.templ_norm;
+    const float satf = (num > 0.0) ? 1.0f : -1.0f;
+    const float other = (METHOD == MTM_TM_SQDIFF_NORMED) ? 1.0f : 0.0f;
+    return (fabs(num) < tt * 1.125) ? satf : other;
 }
 
 // finish_lean with the method chosen at run time (one channel): `corr` is the exact correlation.
@@ -1114,14 +1134,14 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         }
                         float out[4];
                         constexpr bool kDefer = EXACT_DIV && !MASKED && CH == 1 && kNormed;      // (see the plain tiling's epilogue)
-                        bool redo[4] = {false, false, false, false};
+                        bool redo[4] = {false, false, false, false}, sat[4] = {false, false, false, false};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             out[k] = MASKED ? finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], pp1[k], psum2[k],
                                                                                                      prsq[k], T)
                                             : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, CH, kDefer>(a32[k], ps1[k], pp1[k],
                                                                                                           psum2[k], psq[k], prsq[k],
-                                                                                                          T, &redo[k]);
+                                                                                                          T, &redo[k], &sat[k]);
                         if constexpr (kDefer) {
                             if (__builtin_amdgcn_ballot_w64(redo[0] || redo[1] || redo[2] || redo[3]) != 0ull) {   // wave-uniform
 #pragma unroll
@@ -1130,6 +1150,14 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                                                                                   psq[k], prsq[k], T);
                                     asm volatile("" : "+v"(e));
                                     out[k] = redo[k] ? e : out[k];
+                                }
+                            }
+                            if (__builtin_amdgcn_ballot_w64(sat[0] || sat[1] || sat[2] || sat[3]) != 0ull) {     // wave-uniform
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    float e = finish_saturated<(METHOD < 0 ? 0 : METHOD), CH>(a32[k], ps1[k], pp1[k], psum2[k], psq[k], T);
+                                    asm volatile("" : "+v"(e));
+                                    out[k] = sat[k] ? e : out[k];
                                 }
                             }
                         }
@@ -1646,14 +1674,14 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         }
                         float out[4];
                         constexpr bool kDefer = EXACT_DIV && !MASKED && CH == 1 && kNormed;
-                        bool redo[4] = {false, false, false, false};
+                        bool redo[4] = {false, false, false, false}, sat[4] = {false, false, false, false};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             if (MASKED)
                                 out[i] = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
                             else
                                 out[i] = finish_fast<METHOD, EXACT_DIV, CH, kDefer>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
-                                                                                    prsq[i], T, &redo[i]);
+                                                                                    prsq[i], T, &redo[i], &sat[i]);
                             // (IEEE division: one quotient after the other - four interleaved division sequences need ~40
                             // registers more than the epilogue has next to 128 accumulators, and spilled)
                             if constexpr (EXACT_DIV && !MASKED && !kDefer) __builtin_amdgcn_sched_barrier(0);
@@ -1667,6 +1695,15 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                     asm volatile("" : "+v"(e));       // (keeps the division inside the branch)
                                     out[i] = redo[i] ? e : out[i];
                                     __builtin_amdgcn_sched_barrier(0);
+                                }
+                            }
+                            // flat windows, saturated quotients: the rules' constants
+                            if (__builtin_amdgcn_ballot_w64(sat[0] || sat[1] || sat[2] || sat[3]) != 0ull) {     // wave-uniform
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float e = finish_saturated<METHOD, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i], T);
+                                    asm volatile("" : "+v"(e));
+                                    out[i] = sat[i] ? e : out[i];
                                 }
                             }
                         }

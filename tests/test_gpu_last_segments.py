@@ -216,3 +216,49 @@ def test_quotient_without_division(lib):
         assert total >= 1 << 31
     finally:
         del ctx
+
+
+@pytest.mark.parametrize("method", [5, 3, 1])
+@pytest.mark.parametrize("shape", [(20, 70), (24, 64), (24, 40)], ids=["two_row", "64wide", "row_multiplexed"])
+def test_flat_windows_and_saturated_quotients_whole_maps(lib, shape, method):
+    """The IEEE-division epilogues keep three things off their common path (round 6): the division (quotients next to a float32
+    rounding boundary take it), and the rules' constants for |num| >= t - flat windows (t == 0: black or constant regions,
+    whole waves of them and single lanes at their borders), exact copies (|num| == t up to rounding: +-1) and constant
+    templates.  Whole maps, bit for bit against the oracle, on an image that has all of them."""
+    h, w = shape
+    rng = np.random.default_rng(90 + method)
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[10:80, 20:200] = 0                                   # a black region wider than a wave's 256 outputs is not possible at
+    img[90:140, 150:330] = 131                               # W = 333; these cover whole 64-lane runs and their borders
+    img[100:104, 160:170] = 132                              # (almost flat windows: tiny t, quotients of every size)
+    units = []
+    n_units = 5 if shape == (24, 40) else 20
+    for i in range(n_units):
+        y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+        t = np.ascontiguousarray(img[y:y + h, x:x + w])      # exact copies: some of them flat, some straddling a border
+        if i % 4 == 1:
+            t = np.clip(t.astype(np.int32) + rng.integers(-30, 31, t.shape), 0, 255).astype(np.uint8)
+        if i == 2:
+            t = np.full((h, w), 200, np.uint8)               # a constant template
+        if i == 3:
+            t = 255 - t                                      # anti-correlated with its source: -1
+        units.append((t, None))
+    ctx = lib.Context(0)
+    try:
+        ctx.set_option(lib.OPT_KERNEL, 3)
+        ctx.set_option(lib.OPT_EXACT_DIV, 1)
+        ctx.set_option(lib.OPT_HITS_ONLY, 0)
+        ctx.search(units, img, method, lib.PEAKS_LOCAL, 0.5)
+        assert ctx.timing()["kernel_used"] == 3
+        for idx, (t, _) in enumerate(units):
+            got = ctx.last_score_map(idx, (H - h + 1, W - w + 1))
+            exp = O.match_template(img, t, method)
+            bad = np.argwhere(~((got == exp) | (np.isnan(got) & np.isnan(exp))))
+            assert len(bad) == 0, (shape, method, idx, len(bad), bad[:5].tolist(), got[tuple(bad[0])], exp[tuple(bad[0])])
+        # and the lists of the hits-only route are map mode's
+        ref = ctx.search(units, img, method, lib.PEAKS_LOCAL, 0.5).copy()
+        ctx.set_option(lib.OPT_HITS_ONLY, 1)
+        got = ctx.search(units, img, method, lib.PEAKS_LOCAL, 0.5).copy()
+        assert got.tobytes() == ref.tobytes(), (len(got), len(ref))
+    finally:
+        del ctx
