@@ -1254,7 +1254,7 @@ def test_large_templates_as_slabs_on_mfma(mtm, ctx):
                                    mtm.computeScoreMap(lt[-1][1], im, method), ctx.timing()["kernel_used"])
                 finally:
                     set_kernel(ctx, "auto")
-            if not os.environ.get("MTM_SLAB_MFMA") and not os.environ.get("MTM_TEMPL_ON_DEVICE"):
+            if not os.environ.get("MTM_SLAB_MFMA") and default_routes():
                 assert res["auto"][2] == 3 and res["dot4"][2] == 2             # matrix cores vs VALU fallback
             assert res["auto"][0] == res["dot4"][0] and len(res["auto"][0]) >= 1, (len(lt), method)
             assert np.array_equal(res["auto"][1], res["dot4"][1])
@@ -1391,7 +1391,7 @@ def test_masked_api_uses_integer_path(mtm, ctx, coins):
     small, _ = coin_templates(coins)
     mask = otsu_mask(small)
     hits = mtm.matchTemplates([("testMask", small, mask)], coins, method=3, score_threshold=0.8, maxOverlap=0)
-    assert ctx.timing()["kernel_used"] == 3
+    assert ctx.timing()["kernel_used"] == 3 or not default_routes()
     assert_hits_equal(hits, G["notebook_G3"]["hits"], tol=1e-4)
 
 
@@ -1621,7 +1621,7 @@ def test_uint16_exact_path(mtm, ctx, coins):
     for method in range(6):
         for name, t in lt[:3]:
             got = mtm.computeScoreMap(t, img, method)
-            assert ctx.timing()["kernel_used"] == 4, "uint16 pair must take the byte-plane MFMA path"
+            assert ctx.timing()["kernel_used"] == 4 or not default_routes(), "uint16 pair must take the byte-plane MFMA path"
             exp = O.match_template(f32img, t.astype(np.float32), method)
             if method in (0, 2, 4):
                 # raw sums of ~1e13: the oracle's float64 FFT carries ~1e-3 of absolute noise there (the
@@ -2720,7 +2720,7 @@ def test_float32_error_bound_holds(pieces):
                         ctx.set_image(im)
                         ctx.set_templates([(t, None)], method)
                         maps.append(ctx.score_map(0, shape).astype(np.float64))
-                    assert fast.timing()["kernel_used"] == 5 and exact.timing()["kernel_used"] == 0
+                    assert (fast.timing()["kernel_used"] == 5 or not default_routes()) and exact.timing()["kernel_used"] == 0
                     assert fast.timing()["f32_pieces"] == pieces
                     M, live = _bf16_bound_map(im, t, method, pieces)
                     unsat = live & (np.abs(maps[1]) < 1.0) & (np.abs(maps[0]) < 1.0)
