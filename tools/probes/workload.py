@@ -46,6 +46,7 @@ elif name in ("dense_4k32", "dense_4k32_nms"):      # (_nms: search + non-maxima
         ctx.search = lambda tl_, img_, method_, mode_, thr_: ctx.search_nms(tl_, img_, method_, thr_, 0.25)
 else:
     sys.exit("unknown workload " + name)
+thr = float(os.environ.get("WL_THR", thr))       # (probing how a workload's time depends on its threshold)
 ctx.search(tl, img, method, mode, thr)          # placement, allocation
 for _ in range(3):
     ctx.search(tl, img, method, mode, thr)
