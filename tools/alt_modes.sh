@@ -6,5 +6,5 @@ DEFAULT_MODES="X=0 MTM_FUSE_LAYOUT=0 MTM_CAND_PINNED=0 MTM_SEG_SKIP=0 MTM_ROW_MU
 # ALT_MODES: a subset of the switches (space separated) instead of all of them
 for e in ${ALT_MODES:-$DEFAULT_MODES}; do
   # ALT_K: optional pytest -k expression for a quick pass (e.g. ALT_K="not cfg" tools/alt_modes.sh)
-  echo "== $e"; env $e timeout 900 python -m pytest tests -m gpu -x -q ${ALT_K:+-k "$ALT_K"} 2>&1 | grep -E "passed|failed|error" | tail -2
+  echo "== $e"; env $e timeout 900 python -m pytest tests -m gpu -q ${ALT_K:+-k "$ALT_K"} 2>&1 | grep -E "passed|failed|error" | tail -2
 done
