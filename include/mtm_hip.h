@@ -194,7 +194,9 @@ int         mtm_debug_poison(mtm_ctx* ctx, int pattern_byte, int what);
  * the value OpenCV's common_matchTemplate stores, SURVEY 8a-5 - from a reciprocal product plus an integer test that sends the
  * quotients next to a float32 rounding boundary through the division itself (csrc/mtm_device_util.hip.h,
  * quotient_as_float).  This call runs that function against the division on n_cases operand triples shaped like the
- * epilogue's, half of them constructed to straddle a rounding boundary: out4 = {cases run, results that differ in any
+ * epilogue's, half of them constructed to straddle a rounding boundary (both instantiations of the function: the general
+ * one, which also guards quotients in the float32 denormal range, and the epilogues', whose operands cannot produce
+ * those): out4 = {cases run, results that differ in any
  * bit (must be 0), cases that took the division, largest |num * rr - num / t| seen in ulp(double) (the bound in the
  * source is 6, the test's margin 32)}. */
 int         mtm_debug_quotient_check(mtm_ctx* ctx, uint64_t n_cases, uint64_t seed, uint64_t* out4);

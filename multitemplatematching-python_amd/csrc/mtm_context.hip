@@ -504,7 +504,7 @@ int mtm_debug_poison(mtm_ctx* c, int pattern_byte, int what) {
 // Operands shaped like the epilogue's: sq = sqrt of an integer-valued window energy, templ_norm = sqrt of one, num an
 // integer-valued or fractional numerator with |num| <~ tt.  Even cases are plain random draws; odd cases are adversarial -
 // the numerator is chosen so that the quotient lands within a few ulp(double) of a float32 rounding boundary (the middle
-// between two neighbouring floats, or - every fourth - between two float32 denormals' neighbours of a tiny quotient), the
+// between two neighbouring floats, or - every fourth of those - between two float32 denormals' neighbours of a tiny quotient), the
 // place where a quotient that is a few ulp off rounds to the other float.  out[0] cases, out[1] results that differ from
 // (float)(num / tt) in any bit, out[2] cases that took the division, out[3] the largest distance in ulp(double) between
 // num * rr and num / tt seen where both are normal.
@@ -548,6 +548,8 @@ __global__ __launch_bounds__(256) void quotient_check_kernel(uint64_t n_per_thre
         const float ref = (float)qr;
         const float got = quotient_as_float(num, tt, rr);
         bad += __float_as_uint(ref) != __float_as_uint(got);
+        // the epilogues' instantiation (no test for tiny quotients) on everything but the denormal-range cases
+        if ((idx & 7u) != 7u) bad += __float_as_uint(ref) != __float_as_uint(quotient_as_float<false>(num, tt, rr));
         div += quotient_needs_division(q0);
         if (fabs(qr) > 0x1p-1000 && fabs(qr) < 0x1p1000) {
             const long long d = __double_as_longlong(fabs(q0)) - __double_as_longlong(fabs(qr));

@@ -162,20 +162,32 @@ __device__ __forceinline__ void peaks_finish_row(const PeakRow& r, int lane, boo
 // the single-channel uint8 score kernel).  Only the float32 rounding of the float64 quotient leaves the kernel, so a float64
 // quotient that is a few ulp off gives the same float unless it lies next to a float32 rounding boundary: q0 = num * rr with
 // rr = RN(RN(1 / sq) * RN(1 / templ_norm)) carries four roundings, the reference RN(num / RN(sq * templ_norm)) two - they
-// differ by <= 6 ulp(double) (mtm_debug_quotient_check measures it).  A float32 rounding boundary is a double whose low 29
-// significand bits read 0x10000000; q0 within 32 ulp of one (1.2e-7 of the outputs), or below 2^-120 where the float is
-// denormal and rounds elsewhere, takes the division itself.  Zero, the 0 * x of a flat window and the unused quotients
-// of |num| >= tt are "far from a boundary" by the same integer test.
+// differ by <= 6 ulp(double) (mtm_debug_quotient_check measures it: 4).  A float32 rounding boundary is a double whose low 29
+// significand bits read 0x10000000; q0 within 32 ulp of one (1.2e-7 of the outputs) takes the division itself.  Zero, the
+// 0 * x of a flat window and the unused quotients of |num| >= tt are "far from a boundary" by the same integer test.
+// TINY: non-zero quotients below 2^-120 take the division too - there the float is (nearly) denormal and rounds at other
+// bits.  The score kernel's epilogues instantiate TINY = false, because their operands cannot produce such a quotient:
+//   * num is 0 or |num| >= 2^-53.  TM_CCORR_NORMED / TM_SQDIFF_NORMED: an integer.  TM_CCOEFF_NORMED: corr - RN(S1 mean)
+//     with corr and S1 integers; p = RN(S1 mean) is 0 (then corr = 0 too), or an integer, or a double that is not an integer:
+//     for p >= 1 integers are multiples of ulp(p), so |corr - p| >= ulp(p) >= 2^-52; for p < 1 either corr = 0 and
+//     |num| = p >= S1 mean (1 - 2^-53) >= 1 / (2 area), or |corr| >= 1 and |num| >= 1 - p >= 2^-53; the subtraction of two
+//     doubles that far apart does not round below that.
+//   * tt = sq templ_norm <= 255^2 area (both are square roots of sums of at most `area` squares of 8-bit values).
+//   With area < 2^31 (an int32-indexed image): |q| >= min(2^-53, 2^-32) / 2^47 = 2^-100.
+// quotient_check_kernel runs both instantiations, the general one also on quotients in the float32 denormal range.
+template <bool TINY = true>
 __device__ __forceinline__ bool quotient_needs_division(double q0) {
     const uint32_t lo = (uint32_t)__double2loint(q0), hi = (uint32_t)__double2hiint(q0);
     const bool near_boundary = ((lo & 0x1fffffffu) - (0x10000000u - 32u)) <= 64u;
+    if constexpr (!TINY) return near_boundary;
     const bool tiny = ((hi & 0x7fffffffu) - 1u) < (0x38700000u - 1u);   // 0 < |q0| < 2^-120 (hi == 0: 0 or a double denormal -> +-0)
     return near_boundary || tiny;
 }
+template <bool TINY = true>
 __device__ __forceinline__ float quotient_as_float(double num, double tt, double rr) {
     const double q0 = num * rr;
     float qf = (float)q0;
-    if (quotient_needs_division(q0)) qf = (float)(num / tt);
+    if (quotient_needs_division<TINY>(q0)) qf = (float)(num / tt);
     return qf;
 }
 

@@ -141,7 +141,7 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
         // |num| >= t (a flat window, a saturated quotient: the rules' constants, finish_saturated) is the caller's second
         // wave-uniform branch - the comparison with 1.125 t and the selects leave the common path as well
         const double q0 = num * (rsq * T.rtempl_norm);
-        *redo = quotient_needs_division(q0);
+        *redo = quotient_needs_division<false>(q0);      // (no tiny quotients from these operands: mtm_device_util.hip.h)
         *sat = !(fabs(num) < tt);
         return (float)q0;
     } else {

@@ -196,8 +196,9 @@ def test_poison_reaches_what_it_claims(lib):
 
 def test_quotient_without_division(lib):
     """The IEEE-division epilogues of the single-channel uint8 score kernel take (float)(num / t) - the value OpenCV's
-    common_matchTemplate stores - from a reciprocal product; quotients next to a float32 rounding boundary, and tiny ones, go
-    through the division (csrc/mtm_device_util.hip.h: quotient_as_float).  The function itself against the division, on
+    common_matchTemplate stores - from a reciprocal product; quotients next to a float32 rounding boundary go
+    through the division (and, in the function's general form, non-zero ones below 2^-120: the epilogues' operands cannot
+    produce those, and their instantiation leaves that test out - the kernel checks both forms) (csrc/mtm_device_util.hip.h: quotient_as_float).  The function itself against the division, on
     operand triples shaped like the epilogue's (square roots of integer energies, integer-valued and fractional numerators),
     half of them constructed to straddle a rounding boundary by a few ulp(double): no result may differ in any bit, the
     distance between the two float64 quotients must stay inside the bound the source states (6 ulp; the margin is 32), and

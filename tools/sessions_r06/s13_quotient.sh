@@ -23,7 +23,7 @@ print('$1', 'ms', d['ms_per_step'], 'kernel', r['kernel_ms_per_step'], 'frac', r
       '| fresh', g('fresh_templates','median_ms_per_call'), '| resident', g('resident_inputs','pipelined_ms_per_step'))"; }
 for rep in 1 2 3; do
   for t in new base; do
-    d=$R; [ $t != new ] && d=$R/ab_builds/r6base
+    d=$R; [ $t != new ] && d=$R/ab_builds/${AB_BASE:-r6base}
     (cd $d && python bench.py --no-cpu-baseline --steps 200 2>>$O/bench.err | clean | tail -1 | line $t) | tee -a $O/ab.txt
   done
 done
