@@ -134,14 +134,14 @@ __device__ __forceinline__ float finish_fast(int a32, const double (&s1)[CH], do
     if (METHOD == MTM_TM_SQDIFF || METHOD == MTM_TM_SQDIFF_NORMED) num = fmax(sum2 - 2.0 * corr + T.templ_sum2, 0.0);
     if (!normed) return (float)num;
     const double tt = sq * T.templ_norm;
-    // (IEEE-division builds: single-channel instantiations defer; three channels keep the division - the reciprocals' eight
-    // registers next to three channels of statistics made those epilogues spill more)
+    // (IEEE-division builds of the normalised methods defer; three channels with the function's general form - 16-44 B more
+    // scratch in eight of those instantiations, RGB map-mode kernel 2.83 -> 2.68 ms at 4K x 32)
     float qf;
     if constexpr (EXACT_DIV && DEFER) {
         // |num| >= t (a flat window, a saturated quotient: the rules' constants, finish_saturated) is the caller's second
         // wave-uniform branch - the comparison with 1.125 t and the selects leave the common path as well
         const double q0 = num * (rsq * T.rtempl_norm);
-        *redo = quotient_needs_division<false>(q0);      // (no tiny quotients from these operands: mtm_device_util.hip.h)
+        *redo = quotient_needs_division<(CH > 1)>(q0);   // (one channel: no tiny quotients from these operands, mtm_device_util.hip.h)
         *sat = !(fabs(num) < tt);
         return (float)q0;
     } else {
@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             if (__builtin_amdgcn_ballot_w64(wanted) == 0ull) continue;       // wave-uniform
                         }
                         float out[4];
-                        constexpr bool kDefer = EXACT_DIV && !MASKED && CH == 1 && kNormed;      // (see the plain tiling's epilogue)
+                        constexpr bool kDefer = EXACT_DIV && !MASKED && kNormed;      // (see the plain tiling's epilogue)
                         bool redo[4] = {false, false, false, false}, sat[4] = {false, false, false, false};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -1589,7 +1589,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 pp1[i] = 128.0 * s1all;
                 // (1 / sq once per pixel, shared by the work item's templates: the reciprocal path's factor and, in IEEE-division
                 // builds, quotient_as_float's; the hits-only pre-test of those builds - kExactNoRcp below - needs none)
-                prsq[i] = (kNormed && !(EXACT_DIV && !MASKED && CH > 1) && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
+                prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
                 if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
         };
@@ -1673,7 +1673,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                             if (__builtin_amdgcn_ballot_w64(wanted) == 0ull) continue;
                         }
                         float out[4];
-                        constexpr bool kDefer = EXACT_DIV && !MASKED && CH == 1 && kNormed;
+                        constexpr bool kDefer = EXACT_DIV && !MASKED && kNormed;
                         bool redo[4] = {false, false, false, false}, sat[4] = {false, false, false, false};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
