@@ -194,13 +194,23 @@ __device__ __forceinline__ float finish_rt(int method, double corr, double s1, d
 // Masked templates (OpenCV's matchTemplateMask, binary uint8 mask, reference MTM/__init__.py:78,:216):
 // c1 = sum I*(T*M) comes from the MFMA accumulator exactly like an unmasked correlation (the packed
 // template is T*M), c2 = sum I^2*M from the class's raw row-multiplexed pass (MfmaParams::sq_fused; MTM_ROW_MUX=0: the MASKSQ dot4 pass).  No guards, as in OpenCV: 0/0 is NaN.
-template <int METHOD, bool EXACT_DIV>
+// DEFER (IEEE builds, round 6): the float32 value of num / sqrt(tms c2) from num * (RN(1 / sqrt(c2)) * RN(1 / sqrt(tms))) - six
+// roundings against the reference's three, <= 9 ulp(double) apart - with quotient_needs_division's general form; a quotient
+// that is not finite (c2 == 0: inf or the 0 / 0 NaN of OpenCV) takes the reference sequence as well, so that even the NaN's bits
+// are the division's.  *redo: the caller repeats those behind one wave-uniform branch (see finish_fast).
+template <int METHOD, bool EXACT_DIV, bool DEFER = false>
 __device__ __forceinline__ float finish_lean_masked(int a32, double p1, double c2, double rsqrt_c2,
-                                                    const MfTemplConst& T) {
+                                                    const MfTemplConst& T, bool* redo = nullptr) {
     const double c1 = (double)a32 + (p1 + T.mfma_k);
     if (METHOD == MTM_TM_CCORR) return (float)c1;
     if (METHOD == MTM_TM_SQDIFF) return (float)(-2.0 * c1 + c2 + T.tms);
     const double num = (METHOD == MTM_TM_SQDIFF_NORMED) ? (-2.0 * c1 + c2 + T.tms) : c1;
+    if constexpr (EXACT_DIV && DEFER) {
+        const double q0 = num * (rsqrt_c2 * T.rsqrt_tms);
+        const bool finite = ((uint32_t)__double2hiint(q0) & 0x7ff00000u) != 0x7ff00000u;
+        *redo = quotient_needs_division<true>(q0) || !finite;
+        return (float)q0;
+    }
     return EXACT_DIV ? (float)(num / sqrt(T.tms * c2)) : (float)(num * (rsqrt_c2 * T.rsqrt_tms));
 }
 
@@ -1107,7 +1117,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
 #pragma unroll
                                 for (int cc = 1; cc < CH; ++cc) s1all += ps1[k][cc];
                                 pp1[k] = 128.0 * s1all;
-                                if (kMaskedNormed && !EXACT_DIV) prsq[k] = 1.0 / sqrt(psum2[k]);
+                                if (kMaskedNormed) prsq[k] = 1.0 / sqrt(psum2[k]);
                             }
                         }
                         const MfTemplConst T = tcl[t];
@@ -1134,11 +1144,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         }
                         float out[4];
                         constexpr bool kDefer = EXACT_DIV && !MASKED && kNormed;      // (see the plain tiling's epilogue)
+                        constexpr bool kDeferM = EXACT_DIV && kMaskedNormed;
                         bool redo[4] = {false, false, false, false}, sat[4] = {false, false, false, false};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            out[k] = MASKED ? finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], pp1[k], psum2[k],
-                                                                                                     prsq[k], T)
+                            out[k] = MASKED ? finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, kDeferM>(a32[k], pp1[k], psum2[k],
+                                                                                                              prsq[k], T, &redo[k])
                                             : finish_fast<(METHOD < 0 ? 0 : METHOD), EXACT_DIV, CH, kDefer>(a32[k], ps1[k], pp1[k],
                                                                                                           psum2[k], psq[k], prsq[k],
                                                                                                           T, &redo[k], &sat[k]);
@@ -1158,6 +1169,16 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                     float e = finish_saturated<(METHOD < 0 ? 0 : METHOD), CH>(a32[k], ps1[k], pp1[k], psum2[k], psq[k], T);
                                     asm volatile("" : "+v"(e));
                                     out[k] = sat[k] ? e : out[k];
+                                }
+                            }
+                        }
+                        if constexpr (kDeferM) {
+                            if (__builtin_amdgcn_ballot_w64(redo[0] || redo[1] || redo[2] || redo[3]) != 0ull) {   // wave-uniform
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    float e = finish_lean_masked<(METHOD < 0 ? 0 : METHOD), EXACT_DIV>(a32[k], pp1[k], psum2[k], prsq[k], T);
+                                    asm volatile("" : "+v"(e));
+                                    out[k] = redo[k] ? e : out[k];
                                 }
                             }
                         }
@@ -1590,7 +1611,7 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                 // (1 / sq once per pixel, shared by the work item's templates: the reciprocal path's factor and, in IEEE-division
                 // builds, quotient_as_float's; the hits-only pre-test of those builds - kExactNoRcp below - needs none)
                 prsq[i] = (kNormed && psq[i] > 0.0) ? 1.0 / psq[i] : 0.0;
-                if (kMaskedNormed && !EXACT_DIV) prsq[i] = 1.0 / sqrt(psum2[i]);
+                if (kMaskedNormed) prsq[i] = 1.0 / sqrt(psum2[i]);
             }
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1674,11 +1695,12 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                         }
                         float out[4];
                         constexpr bool kDefer = EXACT_DIV && !MASKED && kNormed;
+                        constexpr bool kDeferM = EXACT_DIV && kMaskedNormed;
                         bool redo[4] = {false, false, false, false}, sat[4] = {false, false, false, false};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             if (MASKED)
-                                out[i] = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
+                                out[i] = finish_lean_masked<METHOD, EXACT_DIV, kDeferM>(a32[i], pp1[i], psum2[i], prsq[i], T, &redo[i]);
                             else
                                 out[i] = finish_fast<METHOD, EXACT_DIV, CH, kDefer>(a32[i], ps1[i], pp1[i], psum2[i], psq[i],
                                                                                     prsq[i], T, &redo[i], &sat[i]);
@@ -1704,6 +1726,17 @@ __global__ __launch_bounds__(256, 2) void ncc_mfma_kernel(MfmaParams p, const Te
                                     float e = finish_saturated<METHOD, CH>(a32[i], ps1[i], pp1[i], psum2[i], psq[i], T);
                                     asm volatile("" : "+v"(e));
                                     out[i] = sat[i] ? e : out[i];
+                                }
+                            }
+                        }
+                        if constexpr (kDeferM) {
+                            // masked normalised methods: num / sqrt(tms c2) without the square root and the division
+                            if (__builtin_amdgcn_ballot_w64(redo[0] || redo[1] || redo[2] || redo[3]) != 0ull) {   // wave-uniform
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    float e = finish_lean_masked<METHOD, EXACT_DIV>(a32[i], pp1[i], psum2[i], prsq[i], T);
+                                    asm volatile("" : "+v"(e));
+                                    out[i] = redo[i] ? e : out[i];
                                 }
                             }
                         }

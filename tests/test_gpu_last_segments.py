@@ -263,3 +263,54 @@ def test_flat_windows_and_saturated_quotients_whole_maps(lib, shape, method):
         assert got.tobytes() == ref.tobytes(), (len(got), len(ref))
     finally:
         del ctx
+
+
+@pytest.mark.parametrize("method", [3, 1])
+@pytest.mark.parametrize("shape,n_units", [((24, 32), 20), ((24, 32), 3)], ids=["plain", "row_multiplexed"])
+def test_masked_maps_without_square_root_and_division_equal_the_valu_kernel(lib, shape, n_units, method):
+    """Masked normalised methods, IEEE mode (round 6): the matrix-core epilogue takes (float)(num / sqrt(tms c2)) from a
+    product of reciprocals and sends quotients next to a float32 rounding boundary, tiny ones and non-finite ones (c2 == 0:
+    OpenCV's inf and 0 / 0) through the reference sequence.  Its maps must be the VALU kernel's - which computes that
+    sequence at every output - bit for bit, NaNs at the same pixels, on an image with regions that are zero under the mask."""
+    h, w = shape
+    rng = np.random.default_rng(600 + method)
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[20:90, 30:180] = 0                                   # c2 == 0 over whole windows: NaN (0 / 0)
+    img[100:140, 200:330] = 7                                # constant: quotients of one size over many outputs
+    disc = _disc(h, w)
+    units = []
+    for i in range(n_units):
+        y, x = int(rng.integers(0, H - h)), int(rng.integers(0, W - w))
+        t = np.ascontiguousarray(img[y:y + h, x:x + w])
+        if i % 3 == 1:
+            t = np.clip(t.astype(np.int32) + rng.integers(-30, 31, t.shape), 0, 255).astype(np.uint8)
+        units.append((t, disc))
+    maps = {}
+    for kernel in (3, 2):                                    # matrix cores, v_dot4 VALU kernel
+        ctx = lib.Context(0)
+        try:
+            ctx.set_option(lib.OPT_KERNEL, kernel)
+            ctx.set_option(lib.OPT_EXACT_DIV, 1)
+            ctx.set_option(lib.OPT_HITS_ONLY, 0)
+            ctx.debug_poison(0xFF, 7)
+            ctx.search(units, img, method, lib.PEAKS_LOCAL, 0.8 if method == 3 else 0.2)
+            used = ctx.timing()["kernel_used"]
+            assert (used == 3) == (kernel == 3), used        # (masked classes of the VALU route report the float64 kernel's code)
+            maps[kernel] = [ctx.last_score_map(i, (H - h + 1, W - w + 1)).copy() for i in range(n_units)]
+        finally:
+            del ctx
+    n_nan = 0
+    for i in range(n_units):
+        a, b = maps[3][i], maps[2][i]
+        nan_a, nan_b = np.isnan(a), np.isnan(b)
+        assert np.array_equal(nan_a, nan_b), (i, int(nan_a.sum()), int(nan_b.sum()))
+        assert np.array_equal(a.view(np.uint32)[~nan_a], b.view(np.uint32)[~nan_a]), (i, np.argwhere(a.view(np.uint32) != b.view(np.uint32))[:5])
+        exp = O.match_template(img, units[i][0], method, mask=disc)
+        ok = np.isnan(exp) == nan_a
+        assert ok.all(), i
+        fin = np.isfinite(exp)
+        assert np.array_equal(np.isinf(a), np.isinf(exp)) and np.array_equal(a[np.isinf(a)] > 0, exp[np.isinf(exp)] > 0), i     # x / 0
+        if fin.any():                                        # (a template cut from the zero region: tms == 0, x / 0 everywhere)
+            assert np.abs(a[fin].astype(np.float64) - exp[fin]).max() <= 1e-6 * max(1.0, float(np.abs(exp[fin]).max()))
+        n_nan += int(nan_a.sum())
+    assert n_nan > 0                                         # the zero region really produced 0 / 0
